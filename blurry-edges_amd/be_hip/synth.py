@@ -1,0 +1,242 @@
+"""Portable deterministic generators for weights and synthetic patch pairs.
+
+Everything here is a pure function of (seed, tensor name, element index) built on a
+counter-based 64-bit integer hash (splitmix64), evaluated with numpy in float64 and
+rounded once to float32.  No torch RNG, no numpy RNG state: the container that makes
+the golden vectors and the GPU box regenerate bit-identical tensors from the seed alone
+(SURVEY.md §7 step 1, §8d "synthetic patch-pair generator").
+
+Shapes / parameter ranges follow the reference's own conventions:
+  * LocalStage state-dict layout ........ models/local_stage.py:30-50 (100 entries)
+  * camera constants .................... utils/args.py:14-15
+  * thin-lens blur radius per aperture .. utils/data_generator.py:16-17
+  * photon / read noise model ........... train_val_data_generator.py:173-181
+"""
+from __future__ import annotations
+
+import math
+import zlib
+from collections import OrderedDict
+
+import numpy as np
+from scipy.special import erf as _erf
+
+SEED_DEFAULT = 1869  # echoes local_training.py:73
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+_GAMMA = np.uint64(0x9E3779B97F4A7C15)
+_C1 = np.uint64(0xBF58476D1CE4E5B9)
+_C2 = np.uint64(0x94D049BB133111EB)
+
+
+def _mix(x: np.ndarray) -> np.ndarray:
+    """splitmix64 finaliser on a uint64 array (wrap-around arithmetic)."""
+    with np.errstate(over="ignore"):
+        z = x + _GAMMA
+        z = (z ^ (z >> np.uint64(30))) * _C1
+        z = (z ^ (z >> np.uint64(27))) * _C2
+        return z ^ (z >> np.uint64(31))
+
+
+def _stream_key(seed: int, name: str, lane: int = 0) -> np.uint64:
+    tag = zlib.crc32(name.encode("utf-8")) & 0xFFFFFFFF
+    k = (int(seed) & 0xFFFFFFFF) | (tag << 32)
+    k ^= (lane * 0xD1B54A32D192ED03) & 0xFFFFFFFFFFFFFFFF
+    return _mix(np.array([k], dtype=np.uint64))[0]
+
+
+def hash_uniform(seed: int, name: str, shape, lane: int = 0) -> np.ndarray:
+    """float64 uniforms in [0,1), one per element, addressable by (seed, name, index)."""
+    n = int(np.prod(shape)) if len(shape) else 1
+    idx = np.arange(n, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        h = _mix(_mix(idx + _stream_key(seed, name, lane)))
+    u = (h >> np.uint64(11)).astype(np.float64) * (1.0 / 9007199254740992.0)
+    return u.reshape(shape)
+
+
+def hash_normal(seed: int, name: str, shape) -> np.ndarray:
+    """float64 standard normals (Box-Muller on two hashed uniform streams)."""
+    u1 = hash_uniform(seed, name, shape, lane=1)
+    u2 = hash_uniform(seed, name, shape, lane=2)
+    r = np.sqrt(-2.0 * np.log(1.0 - u1))  # 1-u1 in (0,1]
+    return r * np.cos(2.0 * math.pi * u2)
+
+
+def f32(a: np.ndarray) -> np.ndarray:
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+# ---------------------------------------------------------------------------------------
+# LocalStage weights (state-dict layout of models/local_stage.py:30-62)
+# ---------------------------------------------------------------------------------------
+
+# (prefix, Cout, Cin, k) of every conv+BN pair, in state-dict order.
+LOCAL_STAGE_CONVS = [
+    ("conv1", 64, 3, 7),
+    ("layer0.0.conv1", 96, 64, 3), ("layer0.0.conv2", 96, 96, 3), ("layer0.0.downsample", 96, 64, 1),
+    ("layer1.0.conv1", 256, 96, 3), ("layer1.0.conv2", 256, 256, 3), ("layer1.0.downsample", 256, 96, 1),
+    ("layer2.0.conv1", 384, 256, 3), ("layer2.0.conv2", 384, 384, 3), ("layer2.0.downsample", 384, 256, 1),
+    ("layer3.0.conv1", 256, 384, 3), ("layer3.0.conv2", 256, 256, 3), ("layer3.0.downsample", 256, 384, 1),
+]
+
+
+def _bn_entries(sd, seed, prefix, c):
+    sd[f"{prefix}.weight"] = f32(0.5 + hash_uniform(seed, f"{prefix}.weight", (c,)))
+    sd[f"{prefix}.bias"] = f32(-0.1 + 0.2 * hash_uniform(seed, f"{prefix}.bias", (c,)))
+    sd[f"{prefix}.running_mean"] = f32(0.1 * hash_normal(seed, f"{prefix}.running_mean", (c,)))
+    sd[f"{prefix}.running_var"] = f32(0.5 + hash_uniform(seed, f"{prefix}.running_var", (c,)))
+    sd[f"{prefix}.num_batches_tracked"] = np.array(0, dtype=np.int64)
+
+
+def local_stage_state_dict(seed: int = SEED_DEFAULT, gain: float = 1.0) -> "OrderedDict[str, np.ndarray]":
+    """Random-but-reproducible LocalStage weights as numpy arrays keyed exactly like the
+    reference's ``state_dict()`` (100 entries, models/local_stage.py:30-50).
+
+    conv / linear weights ~ N(0, gain^2 * 2/(fan_in+fan_out))  (xavier-normal, as the caller in
+    local_training.py:83-85 re-initialises them); biases ~ U[-0.05, 0.05];
+    BN gamma ~ U[0.5,1.5], beta ~ U[-0.1,0.1], running_mean ~ N(0, 0.1^2), running_var ~ U[0.5,1.5].
+    """
+    sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
+    for prefix, co, ci, k in LOCAL_STAGE_CONVS:
+        fan_in, fan_out = ci * k * k, co * k * k
+        std = gain * math.sqrt(2.0 / (fan_in + fan_out))
+        sd[f"{prefix}.0.weight"] = f32(std * hash_normal(seed, f"{prefix}.0.weight", (co, ci, k, k)))
+        sd[f"{prefix}.0.bias"] = f32(-0.05 + 0.1 * hash_uniform(seed, f"{prefix}.0.bias", (co,)))
+        _bn_entries(sd, seed, f"{prefix}.1", co)
+    std = gain * math.sqrt(2.0 / (2304 + 1024))
+    sd["fc.1.weight"] = f32(std * hash_normal(seed, "fc.1.weight", (1024, 2304)))
+    sd["fc.1.bias"] = f32(-0.05 + 0.1 * hash_uniform(seed, "fc.1.bias", (1024,)))
+    _bn_entries(sd, seed, "fc.2", 1024)
+    std = gain * math.sqrt(2.0 / (1024 + 10))
+    sd["fc.4.weight"] = f32(std * hash_normal(seed, "fc.4.weight", (10, 1024)))
+    sd["fc.4.bias"] = f32(-0.05 + 0.1 * hash_uniform(seed, "fc.4.bias", (10,)))
+    return sd
+
+
+# ---------------------------------------------------------------------------------------
+# Inputs
+# ---------------------------------------------------------------------------------------
+
+def uniform_patches(n: int, seed: int = SEED_DEFAULT, name: str = "patches") -> np.ndarray:
+    """[n,3,21,21] float32 in [0,1): pure-parity input."""
+    return f32(hash_uniform(seed, name, (n, 3, 21, 21)))
+
+
+def plausible_params10(n: int, seed: int = SEED_DEFAULT, name: str = "params10") -> np.ndarray:
+    """[n,10] wedge parameters in the range the CNN is trained to emit:
+    vertices in [-1.5,1.5]^2, angles in [0,2pi), eta coefficients ~ N(0.5, 0.5^2)."""
+    p = np.empty((n, 10), dtype=np.float64)
+    p[:, 0:4] = -1.5 + 3.0 * hash_uniform(seed, name + ".xy", (n, 4))
+    p[:, 4:8] = 2.0 * math.pi * hash_uniform(seed, name + ".ang", (n, 4))
+    p[:, 8:10] = 0.5 + 0.5 * hash_normal(seed, name + ".eta", (n, 2))
+    return f32(p)
+
+
+def plausible_params12(n: int, seed: int = SEED_DEFAULT, name: str = "params12") -> np.ndarray:
+    """[n,12]: 8 shared geometry + eta coefficients (w1,img1),(w2,img1),(w1,img2),(w2,img2)
+    (layout of blurry_edges_test.py:36-37,44-45)."""
+    p = np.empty((n, 12), dtype=np.float64)
+    p[:, 0:4] = -1.5 + 3.0 * hash_uniform(seed, name + ".xy", (n, 4))
+    p[:, 4:8] = 2.0 * math.pi * hash_uniform(seed, name + ".ang", (n, 4))
+    p[:, 8:12] = 0.5 + 0.5 * hash_normal(seed, name + ".eta", (n, 4))
+    return f32(p)
+
+
+# camera constants, utils/args.py:14-15
+CAM = dict(s=0.1104, rho_1=10.0, rho_2=10.2, sigma_cam=0.003, pixel_pitch=5.86e-6)
+MAG = 4.0
+Z_RANGE = (0.75, 1.18)   # utils/args.py:23
+ALPHA_RANGE = (180.0, 200.0)
+READ_SIGMA = 2.0
+
+
+def blur_sigma_px(z: np.ndarray) -> np.ndarray:
+    """Per-aperture Gaussian blur radius in pixels for depth z [..] -> [..,2]
+    (thin-lens model of utils/data_generator.py:16-17)."""
+    rhos = np.array([CAM["rho_1"], CAM["rho_2"]])
+    return np.abs((1.0 / z[..., None] - rhos) * CAM["s"] + 1.0) * CAM["sigma_cam"] / CAM["pixel_pitch"] / MAG
+
+
+def synthetic_patch_pairs(p: int, seed: int = SEED_DEFAULT, noise: bool = True):
+    """P two-aperture 21x21 patch pairs of a blurred straight edge / corner scene.
+
+    Returns (x [2P,3,21,21] float32, image-major as blurry_edges_test.py:121 orders them:
+    rows 0..P-1 are aperture 1, rows P..2P-1 aperture 2; z [P] float32 ground-truth depth).
+
+    Scene per pair: one or two half-planes ("wedges" with a 180 deg opening) through the patch with
+    flat colours, at a single depth z ~ U[0.75,1.18] m; each aperture sees it through a Gaussian PSF
+    of radius blur_sigma_px(z) (order-2 PSF of utils/data_generator.py:19-23), i.e. an erf edge;
+    photon scaling alpha ~ U[180,200]; noise = Poisson(img*alpha) approximated by a hashed normal with
+    matching variance + 2*N(0,1) read noise, clipped to [0,alpha], rounded, / alpha
+    (train_val_data_generator.py:173-181).
+    """
+    name = "pairs"
+    z = Z_RANGE[0] + (Z_RANGE[1] - Z_RANGE[0]) * hash_uniform(seed, name + ".z", (p,))
+    sig = blur_sigma_px(z)                                   # [P,2] pixels
+    ang = 2.0 * math.pi * hash_uniform(seed, name + ".ang", (p, 2))
+    off = -6.0 + 12.0 * hash_uniform(seed, name + ".off", (p, 2))   # pixels from centre
+    two = hash_uniform(seed, name + ".two", (p,)) < 0.5
+    col = hash_uniform(seed, name + ".col", (p, 3, 3))          # [P, wedge(bg,w1,w2), rgb]
+    alpha = ALPHA_RANGE[0] + (ALPHA_RANGE[1] - ALPHA_RANGE[0]) * hash_uniform(seed, name + ".alpha", (p,))
+
+    yy, xx = np.meshgrid(np.arange(21) - 10.0, np.arange(21) - 10.0, indexing="ij")
+    out = np.empty((2, p, 3, 21, 21), dtype=np.float64)
+    erf = _erf
+    for a in range(2):
+        s = sig[:, a][:, None, None] * math.sqrt(2.0)
+        d1 = (-np.sin(ang[:, 0])[:, None, None] * xx + np.cos(ang[:, 0])[:, None, None] * yy) - off[:, 0][:, None, None]
+        d2 = (-np.sin(ang[:, 1])[:, None, None] * xx + np.cos(ang[:, 1])[:, None, None] * yy) - off[:, 1][:, None, None]
+        h1 = 0.5 * (1.0 + erf(d1 / s))
+        h2 = np.where(two[:, None, None], 0.5 * (1.0 + erf(d2 / s)), 0.0)
+        u0 = (1 - h1) * (1 - h2)
+        u1 = h1 * (1 - h2)
+        u2 = h2
+        img = (u0[:, None] * col[:, 0, :, None, None] + u1[:, None] * col[:, 1, :, None, None]
+               + u2[:, None] * col[:, 2, :, None, None])
+        if noise:
+            lam = img * alpha[:, None, None, None]
+            g1 = hash_normal(seed, f"{name}.shot{a}", img.shape)
+            g2 = hash_normal(seed, f"{name}.read{a}", img.shape)
+            cnt = np.rint(np.clip(lam + np.sqrt(np.maximum(lam, 0.0)) * g1 + READ_SIGMA * g2,
+                                  0.0, alpha[:, None, None, None]))
+            img = cnt / alpha[:, None, None, None]
+        out[a] = img
+    return f32(out.reshape(2 * p, 3, 21, 21)), f32(z)
+
+
+def synthetic_image_pair(h: int = 147, w: int = 147, seed: int = SEED_DEFAULT, nshape: int = 6):
+    """One two-aperture image pair [2,3,h,w] float32 (+ depth map [h,w]) made of nshape random
+    half-plane / disc layers at random depths, back to front, each blurred per aperture by its own
+    erf edge (the per-layer compositing of train_val_data_generator.py:31-116 restated analytically)."""
+    name = f"img{h}x{w}"
+    yy, xx = np.meshgrid(np.arange(h, dtype=np.float64), np.arange(w, dtype=np.float64), indexing="ij")
+    zs = np.sort(Z_RANGE[0] + (Z_RANGE[1] - Z_RANGE[0]) * hash_uniform(seed, name + ".z", (nshape + 1,)))[::-1]
+    col = hash_uniform(seed, name + ".col", (nshape + 1, 3))
+    cx = hash_uniform(seed, name + ".cx", (nshape,)) * w
+    cy = hash_uniform(seed, name + ".cy", (nshape,)) * h
+    rad = (0.08 + 0.22 * hash_uniform(seed, name + ".r", (nshape,))) * min(h, w)
+    kind = hash_uniform(seed, name + ".k", (nshape,)) < 0.5
+    ang = 2.0 * math.pi * hash_uniform(seed, name + ".a", (nshape,))
+    erf = _erf
+    imgs = np.empty((2, 3, h, w), dtype=np.float64)
+    depth = np.full((h, w), zs[0], dtype=np.float64)
+    for a in range(2):
+        img = np.broadcast_to(col[0][:, None, None], (3, h, w)).copy()
+        for i in range(nshape):
+            z = zs[i + 1]
+            s = blur_sigma_px(np.array(z))[a] * math.sqrt(2.0)
+            if kind[i]:
+                d = rad[i] - np.sqrt((xx - cx[i]) ** 2 + (yy - cy[i]) ** 2)
+            else:
+                d = -math.sin(ang[i]) * (xx - cx[i]) + math.cos(ang[i]) * (yy - cy[i])
+            m = 0.5 * (1.0 + erf(d / s))
+            img = img * (1 - m) + m * col[i + 1][:, None, None]
+            if a == 0:
+                depth = np.where(d > 0, z, depth)
+        imgs[a] = img
+    alpha = 190.0
+    g = hash_normal(seed, name + ".noise", imgs.shape)
+    lam = imgs * alpha
+    imgs = np.rint(np.clip(lam + np.sqrt(np.maximum(lam, 0)) * g, 0, alpha)) / alpha
+    return f32(imgs), f32(depth)

@@ -1,0 +1,189 @@
+"""The CPU oracle (oracle/) against golden vectors captured from the real reference
+(tools/make_golden.py).  This is what pins the oracle; it runs without a GPU."""
+import numpy as np
+import torch
+
+from conftest import load_golden, relmax
+from be_hip import synth
+from oracle import local_stage as ols, render as orr, depth as od, tiling as ot
+
+
+def T(a, dt=torch.float32):
+    return torch.from_numpy(np.asarray(a)).to(dt)
+
+
+def test_g1_local_stage_eval_logits_and_taps():
+    g = load_golden("g1_local_stage_eval")
+    sd = ols.to_torch_sd(synth.local_stage_state_dict())
+    x = T(synth.uniform_patches(16))
+    taps = {}
+    with torch.no_grad():
+        y = ols.local_stage_forward(sd, x, taps=taps)
+    assert relmax(y.numpy(), g["logits"]) <= 1e-6
+    for k in ("pool1", "layer0", "pool2", "layer1", "layer2", "layer3", "pool3", "fc1"):
+        assert relmax(taps[k][:2].numpy(), g["tap_" + k]) <= 1e-6, k
+    assert relmax(taps["conv1"][0].numpy(), g["tap_conv1_patch0"]) <= 1e-6
+    xs, _ = synth.synthetic_patch_pairs(8)
+    with torch.no_grad():
+        ys = ols.local_stage_forward(sd, T(xs))
+    assert relmax(ys.numpy(), g["logits_synth_pairs"]) <= 1e-6
+    # float64 oracle vs float64 reference
+    sd64 = ols.to_torch_sd(synth.local_stage_state_dict(), torch.float64)
+    with torch.no_grad():
+        y64 = ols.local_stage_forward(sd64, x.double())
+    assert relmax(y64.numpy(), g["logits_fp64"]) <= 1e-12
+
+
+def test_g2_local_stage_train_mode():
+    g = load_golden("g2_local_stage_train")
+    sd = ols.to_torch_sd(synth.local_stage_state_dict())
+    for k, v in sd.items():
+        if v.is_floating_point() and "running_" not in k:
+            v.requires_grad_(True)
+    x = T(synth.uniform_patches(64, name="train_patches")).requires_grad_(True)
+    ct = T(synth.f32(synth.hash_normal(synth.SEED_DEFAULT, "train_cotangent", (64, 10))))
+    y = ols.local_stage_forward(sd, x, training=True)
+    (y * ct).sum().backward()
+    assert relmax(y.detach().numpy(), g["logits"]) <= 2e-5
+    for k in g:
+        if k.startswith("grad_") and k != "grad_x_sub":
+            name = k[len("grad_"):]
+            assert relmax(sd[name].grad.numpy(), g[k]) <= 2e-4, name
+    assert relmax(x.grad.flatten()[::101].numpy(), g["grad_x_sub"]) <= 2e-4
+
+
+def test_g3_render_stages_fp32_and_fp64():
+    g = load_golden("g3_render_local")
+    p10 = synth.plausible_params10(8)
+    img = synth.uniform_patches(8, name="render_patches")
+    for tag, dt, tol in (("f32", torch.float32, 2e-6), ("f64", torch.float64, 1e-12)):
+        r = orr.render_pass_a(T(p10, dt), T(img, dt))
+        assert relmax(r["dists"], g[tag + "_dists"]) <= tol
+        assert relmax(r["etas"], g[tag + "_etas"]) <= tol
+        assert relmax(r["wedges"], g[tag + "_wedges"]) <= tol
+        assert relmax(r["G"], g[tag + "_G"]) <= tol
+        assert relmax(r["b"], g[tag + "_b"]) <= tol
+        # the Cayley-Hamilton inverse amplifies fp32 rounding: looser in fp32
+        ctol = 5e-3 if dt == torch.float32 else 1e-9
+        assert relmax(r["colors"], g[tag + "_colors"]) <= ctol
+        assert relmax(r["recon"], g[tag + "_patches"]) <= ctol
+        assert relmax(orr.boundary_map(r["dists"]), g[tag + "_boundary"]) <= tol * 10
+    # the stable solve agrees with the fp64 reference far better than the reference's own fp32 path does
+    r32 = orr.render_pass_a(T(p10), T(img), inverse="solve")
+    assert relmax(r32["colors"], g["f64_colors"]) <= 1e-4
+
+
+def test_g4_local_loss_value_and_gradient():
+    g = load_golden("g4_local_loss")
+    B, S = 64, synth.SEED_DEFAULT
+    p10 = synth.plausible_params10(B, name="loss_params")
+    img = synth.f32(synth.hash_uniform(S, "loss_img", (B, 21, 21, 3)))
+    gt = synth.f32(synth.hash_uniform(S, "loss_gt", (B, 21, 21, 3)))
+    bd = synth.f32(5.0 * synth.hash_uniform(S, "loss_bd", (B, 21, 21)))
+    de = synth.f32(synth.hash_uniform(S, "loss_deri", (B, 19, 19, 3)))
+    est = T(p10, torch.float64).requires_grad_(True)
+    loss, _, _ = orr.local_loss(est, T(img, torch.float64), T(gt, torch.float64), T(bd, torch.float64),
+                                T(de, torch.float64))
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["f64_loss"])) <= 1e-12 * abs(float(g["f64_loss"]))
+    assert relmax(est.grad.numpy(), g["f64_grad"]) <= 1e-9
+    est32 = T(p10).requires_grad_(True)
+    loss32, _, _ = orr.local_loss(est32, T(img), T(gt), T(bd), T(de))
+    loss32.backward()
+    assert abs(float(loss32.detach()) - float(g["f32_loss"])) <= 1e-4 * abs(float(g["f32_loss"]))
+
+
+def test_g5_depth_solve_grid():
+    g = load_golden("g5_depth")
+    c = od.depth_consts()
+    assert np.allclose([c.numerator, c.den_const, c.k, c.k2, c.intercept], g["consts"], rtol=0, atol=0)
+    lin = torch.linspace(1e-4, 1.0, 64)
+    e1, e2 = torch.meshgrid(lin, lin, indexing="ij")
+    z, br = od.etas2depth(c, e1, e2, return_branch=True)
+    assert np.array_equal(z.numpy(), g["z_lin"])            # bit-exact in fp32
+    assert set(np.unique(br.numpy())) == {0, 1, 2, 3}          # all four branches are exercised
+    lg = torch.logspace(-4, 0, 48)
+    l1, l2 = torch.meshgrid(lg, lg, indexing="ij")
+    assert np.array_equal(od.etas2depth(c, l1, l2).numpy(), g["z_log"])
+    depth = torch.linspace(0.6, 2.3, 257)
+    assert np.array_equal(od.depth2sigma(c, depth, 10.39).numpy(), g["sigma_rho_prime"])
+    assert np.array_equal(od.depth2sigma(c, depth, 10.0).numpy(), g["sigma_rho_1"])
+    assert relmax(od.etas2depth(c, e1.double(), e2.double()), g["z_lin_f64"]) <= 1e-7
+
+
+def _g6_inputs():
+    imgs, _ = synth.synthetic_image_pair(147, 147)
+    pat = ot.unfold_patches(T(imgs))                           # [2,4096,3,21,21]
+    return imgs, pat
+
+
+def test_g6_pass_a_colours_global_layout():
+    g = load_golden("g6_postprocess_147")
+    _, pat = _g6_inputs()
+    for i, nm in enumerate(("g6_img1", "g6_img2")):
+        p10 = T(synth.plausible_params10(4096, name=nm))
+        r = orr.render_pass_a(p10, pat[i])
+        ref = g["colors_a"][i].reshape(3, 3, 4096).transpose(2, 0, 1)     # [P,rgb,wedge]
+        assert relmax(r["colors"], ref) <= 2e-2      # fp32 Cayley inverse: both sides are noisy
+        r64 = orr.render_pass_a(p10.double(), pat[i].double())
+        # vs float64 truth, the reference's fp32 colours are only good to a few 1e-3 (App. C)
+        assert relmax(ref, r64["colors"]) <= 2e-2
+
+
+def test_g6_pass_b_subgrid_and_folds():
+    g = load_golden("g6_postprocess_147")
+    _, pat = _g6_inputs()
+    c = od.depth_consts()
+    p12 = T(synth.plausible_params12(4096, name="g6_est"))
+    ii, jj = np.meshgrid(np.arange(20, 24), np.arange(30, 34), indexing="ij")
+    sel = (ii * 64 + jj).ravel()
+    for densify, tag in ((None, ""), ("w", "w_")):
+        r = orr.render_pass_b(c, p12, pat[0], pat[1], densify=densify)
+        def sub(key):      # reference layout [..., 21,21, 4,4] -> [16, ..., 21,21]
+            a = g[tag + key]
+            return np.moveaxis(a.reshape(a.shape[:-2] + (16,)), -1, 0)
+        assert np.array_equal(r["depth_mask"][sel].numpy(), sub("sub_dmask"))
+        assert np.array_equal(np.bincount(r["depth_mask"].numpy().ravel(), minlength=3), g[tag + "mask_hist"])
+        assert relmax(r["depth_map"][sel], sub("sub_dmap")) <= 1e-6
+        assert relmax(r["boundary"][sel], sub("sub_bnd")) <= 1e-5
+        pp = torch.stack([r["patches1"], r["patches2"]], dim=1)[sel]       # [16,2,3,21,21]
+        assert relmax(pp, sub("sub_patches").transpose(0, 1, 2, 3, 4)) <= 2e-2
+        assert relmax(r["shpd"][sel], sub("sub_shpd")) <= 2e-2
+        assert relmax(r["refoc"][sel], sub("sub_refoc")) <= 2e-2
+        # folds
+        fd, conf = ot.fold_depth(r["depth_map"][None], r["depth_mask"][None], 147, 147)
+        assert relmax(conf[0], g[tag + "fold_conf"][0]) <= 1e-6
+        assert relmax(fd[0], g[tag + "fold_depth"][0]) <= 1e-5
+        fb = ot.fold_mean(r["boundary"][None, :, None], 147, 147)
+        assert relmax(fb[0, 0], g[tag + "fold_bndry"][0, 0]) <= 1e-5
+        fi = ot.fold_mean(torch.stack([r["patches1"], r["patches2"]]), 147, 147)
+        assert relmax(fi, g[tag + "fold_image"][0]) <= 5e-3
+        # against the float64 oracle the folded image is tighter (patch-level noise averages out)
+    r64 = orr.render_pass_b(c, p12.double(), pat[0].double(), pat[1].double())
+    fi64 = ot.fold_mean(torch.stack([r64["patches1"], r64["patches2"]]), 147, 147)
+    assert relmax(g["fold_image"][0], fi64) <= 5e-3
+
+
+def test_g7_unfold_order_and_fold_normaliser():
+    g = load_golden("g7_tiling")
+    idx = torch.arange(3 * 147 * 147, dtype=torch.float32).view(1, 3, 147, 147)
+    vec = ot.unfold_patches(idx)[0]
+    assert np.array_equal(vec[g["sel"]].numpy().astype(np.int32), g["vec_sel"])
+    assert np.array_equal(vec.double().sum(dim=(1, 2, 3)).numpy(), g["vec_rowsum"])
+    assert np.array_equal(ot.num_patches(147, 147).numpy(), g["num_patches"])
+    # fold(unfold(x)) / num_patches == x
+    x = T(synth.hash_uniform(3, "foldcheck", (1, 2, 147, 147)).astype(np.float32))
+    assert relmax(ot.fold_mean(ot.unfold_patches(x), 147, 147), x) <= 1e-5   # <=121 fp32 adds per pixel
+
+
+def test_g8_big_tiler_properties():
+    t = ot.big_tiler()
+    assert (t["block_stride"], t["n_block"], t["big_grid"]) == (88, 6, 284)
+    cover = np.zeros((284, 284), dtype=np.int32)
+    for bi, bj, top, left, (vs, ve, hs, he), (Vs, Ve, Hs, He) in t["blocks"]:
+        assert top + 147 <= 587 and left + 147 <= 587
+        # a kept local patch (v,h) of this block is the same pixels as big-grid patch (Vs+v-vs, Hs+h-hs)
+        assert top + 2 * vs == 2 * Vs and left + 2 * hs == 2 * Hs
+        assert Ve - Vs == ve - vs and He - Hs == he - hs
+        cover[Vs:Ve, Hs:He] += 1
+    assert np.all(cover == 1)

@@ -1,0 +1,280 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REAL reference on PyTorch-CPU.
+
+Runs only in the build container (needs /root/reference, read-only).  Nothing here travels to the
+GPU box except the .npz outputs: inputs and weights are regenerated there from
+blurry-edges_amd/be_hip/synth.py (portable integer-hash generator), so the fixtures hold expected
+OUTPUTS only (plus small inputs where that is cheaper than regenerating).
+
+Import recipe: `utils/__init__.py` star-imports visualization.py which needs cv2
+(absent, drawing only) -> register an empty stub module before importing.
+
+usage: python tools/make_golden.py [G1 G2 ...]      (default: all groups)
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+OUT = os.path.join(ROOT, "tests", "golden")
+sys.dont_write_bytecode = True
+sys.path.insert(0, os.path.join(ROOT, "blurry-edges_amd"))
+from be_hip import synth  # noqa: E402
+
+# the reference's top-level packages are called models / utils / data, same as the build's:
+# import the reference ones under their own names from REF, never mixing the two trees.
+sys.path.insert(0, REF)
+sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+for _m in ("models", "utils", "data"):
+    assert _m not in sys.modules
+import models as ref_models      # noqa: E402
+import utils as ref_utils        # noqa: E402
+assert ref_models.__file__.startswith(REF) and ref_utils.__file__.startswith(REF)
+import blurry_edges_test as ref_test     # noqa: E402
+import local_training as ref_local       # noqa: E402
+
+torch.set_num_threads(8)
+
+
+def ref_args(mode):
+    argv, sys.argv = sys.argv, ["x"]
+    try:
+        return ref_utils.get_args(mode)
+    finally:
+        sys.argv = argv
+
+
+def load_local_stage(seed=synth.SEED_DEFAULT):
+    m = ref_models.LocalStage()
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.local_stage_state_dict(seed).items()}
+    m.load_state_dict(sd, strict=True)
+    return m
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: np.asarray(v) for k, v in arrs.items()})
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.1f} KiB)")
+
+
+def n(t):
+    return t.detach().cpu().numpy()
+
+
+# ------------------------------------------------------------------------------------------------
+def G1():
+    """LocalStage eval: logits for 16 uniform patches + intermediate activations for 2."""
+    m = load_local_stage().eval()
+    x = torch.from_numpy(synth.uniform_patches(16))
+    taps = {}
+    pool_calls = []
+    hooks = [m.conv1.register_forward_hook(lambda mod, i, o: taps.__setitem__("conv1", o)),
+             m.maxpool1.register_forward_hook(lambda mod, i, o: pool_calls.append(o)),
+             m.layer0.register_forward_hook(lambda mod, i, o: taps.__setitem__("layer0", o)),
+             m.layer1.register_forward_hook(lambda mod, i, o: taps.__setitem__("layer1", o)),
+             m.layer2.register_forward_hook(lambda mod, i, o: taps.__setitem__("layer2", o)),
+             m.layer3.register_forward_hook(lambda mod, i, o: taps.__setitem__("layer3", o)),
+             m.maxpool2.register_forward_hook(lambda mod, i, o: taps.__setitem__("pool3", o)),
+             m.fc[3].register_forward_hook(lambda mod, i, o: taps.__setitem__("fc1", o))]
+    with torch.no_grad():
+        y = m(x)
+    for h in hooks:
+        h.remove()
+    taps["pool1"], taps["pool2"] = pool_calls
+    # a second input class: realistic blurred-edge pairs (8 pairs -> 16 patches)
+    xs, _ = synth.synthetic_patch_pairs(8)
+    with torch.no_grad():
+        ys = m(torch.from_numpy(xs))
+    m64 = load_local_stage().double().eval()
+    with torch.no_grad():
+        y64 = m64(x.double())
+    save("g1_local_stage_eval", logits=n(y), logits_fp64=n(y64), logits_synth_pairs=n(ys),
+         **{"tap_" + k: n(v[:2]) for k, v in taps.items() if k != "conv1"},
+         tap_conv1_patch0=n(taps["conv1"][0]))
+
+
+def G2():
+    """LocalStage train mode (batch statistics), batch 64: logits, running-stat updates and gradients of
+    representative parameters under loss = sum(logits * cotangent)."""
+    m = load_local_stage().train()
+    x = torch.from_numpy(synth.uniform_patches(64, name="train_patches"))
+    ct = torch.from_numpy(synth.f32(synth.hash_normal(synth.SEED_DEFAULT, "train_cotangent", (64, 10))))
+    x.requires_grad_(True)
+    y = m(x)
+    (y * ct).sum().backward()
+    names = ["conv1.0.weight", "conv1.1.weight", "conv1.1.bias", "layer0.0.downsample.0.weight",
+             "layer1.0.conv1.1.weight", "layer3.0.conv2.0.bias", "fc.1.bias", "fc.2.weight", "fc.4.weight"]
+    params = dict(m.named_parameters())
+    out = {"grad_" + k: n(params[k].grad) for k in names}
+    # large grads: keep a strided subsample + the exact L2 norm
+    for k in ["layer2.0.conv2.0.weight", "fc.1.weight"]:
+        g = params[k].grad.flatten()
+        out["gradsub_" + k] = n(g[::997])
+        out["gradnorm_" + k] = n(g.double().norm())
+    out["grad_x_sub"] = n(x.grad.flatten()[::101])
+    out["total_grad_norm"] = n(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters())))
+    sd = m.state_dict()
+    save("g2_local_stage_train", logits=n(y),
+         run_mean_conv1=n(sd["conv1.1.running_mean"]), run_var_conv1=n(sd["conv1.1.running_var"]),
+         run_mean_fc2=n(sd["fc.2.running_mean"]), run_var_fc2=n(sd["fc.2.running_var"]),
+         nbt=n(sd["conv1.1.num_batches_tracked"]), **out)
+
+
+def _local_helper(dtype, batch):
+    a = ref_args("local_train")
+    a.batch_size = batch
+    h = ref_local.LocalLoss(a, torch.device("cpu"))
+    if dtype == torch.float64:
+        h.x, h.y, h.ridge = h.x.double(), h.y.double(), h.ridge.double()
+        h.sobel_x, h.sobel_y = h.sobel_x.double(), h.sobel_y.double()
+    return h
+
+
+def G3():
+    """Local-layout render stages for 8 patches, float32 and float64 runs of the reference code."""
+    p10 = synth.plausible_params10(8)
+    img = synth.uniform_patches(8, name="render_patches")          # [8,3,21,21]
+    out = {}
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        h = _local_helper(dt, 8)
+        est = torch.from_numpy(p10).to(dt)
+        y = torch.from_numpy(img).to(dt).permute(0, 2, 3, 1).contiguous()   # channels-last, as the dataset gives
+        dists = h.params2dists(est[:, :8])
+        etas = h.params2etas(est[:, 8:])
+        wedges = h.dists2indicators(dists, etas)
+        A = wedges.permute(0, 2, 3, 1).reshape(8, -1, 3)
+        G = A.permute(0, 2, 1) @ A + h.ridge
+        b = A.permute(0, 2, 1) @ y.view(8, -1, 3)
+        inv = h.inverse_3by3(G)
+        patches, bnd = h.get_patches(est.clone(), y)
+        colors = (inv @ b).permute(0, 2, 1)
+        out.update({f"{tag}_dists": n(dists), f"{tag}_etas": n(etas), f"{tag}_wedges": n(wedges),
+                    f"{tag}_G": n(G), f"{tag}_b": n(b), f"{tag}_inv": n(inv), f"{tag}_colors": n(colors),
+                    f"{tag}_patches": n(patches), f"{tag}_boundary": n(bnd)})
+    save("g3_render_local", **out)
+
+
+def G4():
+    """LocalLoss value and d loss / d est for batch 64 at the final beta, float32 and float64."""
+    B = 64
+    S = synth.SEED_DEFAULT
+    p10 = synth.plausible_params10(B, name="loss_params")
+    img = synth.f32(synth.hash_uniform(S, "loss_img", (B, 21, 21, 3)))
+    gt = synth.f32(synth.hash_uniform(S, "loss_gt", (B, 21, 21, 3)))
+    bd = synth.f32(5.0 * synth.hash_uniform(S, "loss_bd", (B, 21, 21)))
+    de = synth.f32(synth.hash_uniform(S, "loss_deri", (B, 19, 19, 3)))
+    out = {}
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        h = _local_helper(dt, B)
+        h.final_beta()
+        est = torch.from_numpy(p10).to(dt).requires_grad_(True)
+        e2 = est * 1.0      # the reference mutates its input in place; keep the leaf intact
+        loss = h(e2, torch.from_numpy(img).to(dt), torch.from_numpy(gt).to(dt),
+                 torch.from_numpy(bd).to(dt), torch.from_numpy(de).to(dt))
+        loss.backward()
+        out[f"{tag}_loss"] = n(loss)
+        out[f"{tag}_grad"] = n(est.grad)
+    save("g4_local_loss", **out)
+
+
+def G5():
+    """etas2depth / depth2sigma on a dense eta grid over [1e-4,1]^2 (+ a log-spaced one)."""
+    a = ref_args("eval")
+    d = ref_utils.DepthEtas(a, torch.device("cpu"))
+    lin = torch.linspace(1e-4, 1.0, 64)
+    e1, e2 = torch.meshgrid(lin, lin, indexing="ij")
+    z = d.etas2depth(e1, e2)
+    lg = torch.logspace(-4, 0, 48)
+    l1, l2 = torch.meshgrid(lg, lg, indexing="ij")
+    zl = d.etas2depth(l1, l2)
+    depth = torch.linspace(0.6, 2.3, 257)
+    sg = d.depth2sigma(depth, a.rho_prime)
+    sg1 = d.depth2sigma(depth, a.cam_params["rho_1"])
+    save("g5_depth", z_lin=n(z), z_log=n(zl), sigma_rho_prime=n(sg), sigma_rho_1=n(sg1),
+         consts=np.array([d.numerator, d.denominator_constant, d.denominator_factor_root,
+                          d.denominator_factor, float(d.intercept)], dtype=np.float64),
+         z_lin_f64=n(_depth64(d, e1.double(), e2.double())))
+
+
+def _depth64(d, e1, e2):
+    import copy
+    d2 = copy.copy(d)
+    d2.intercept = d.intercept.double()
+    d2.theta_mid, d2.theta_wng = d.theta_mid.double(), d.theta_wng.double()
+    return d2.etas2depth(e1, e2)
+
+
+def G6():
+    """Eval-time PostProcess (blurry_edges_test.py:12-100) on one synthetic 147x147 pair with a plausible
+    12-parameter field: pass-A colours, pass-B per-patch outputs on a 4x4 sub-grid, six folded maps."""
+    a = ref_args("eval")
+    dev = torch.device("cpu")
+    imgs, _ = synth.synthetic_image_pair(147, 147)
+    t_img = torch.from_numpy(imgs)                                                # [2,3,147,147]
+    out = {}
+    for densify in (None, "w"):
+        a.densify = densify
+        dcal = ref_utils.DepthEtas(a, dev)
+        helper = ref_test.PostProcess(a, dcal, dev)
+        img_patches = torch.nn.Unfold(a.R, stride=a.stride)(t_img).view(2, 3, a.R, a.R, 64, 64)
+        p10 = torch.from_numpy(np.stack([synth.plausible_params10(4096, name="g6_img1"),
+                                         synth.plausible_params10(4096, name="g6_img2")]))   # [2,4096,10]
+        colors = helper(p10, img_patches, colors_only=True)                       # [2,3,3,64,64]
+        p12 = torch.from_numpy(synth.plausible_params12(4096, name="g6_est"))[None]   # [1,4096,12]
+        etas = helper.params2etas(p12.permute(0, 2, 1).view(1, 12, 64, 64)[:, 8:])
+        helper.img_patches = img_patches.unsqueeze(0)
+        patches, shpd, refoc, bnd, dmap, dmask = helper.get_patches(
+            p12.permute(0, 2, 1).view(1, 12, 64, 64)[:, :8], etas, False)
+        folded = helper(p12, img_patches, colors_only=False)
+        tag = "w_" if densify == "w" else ""
+        sub = (slice(20, 24), slice(30, 34))
+        out.update({
+            tag + "colors_a": n(colors) if densify is None else np.zeros(0),
+            tag + "sub_patches": n(patches[0][..., sub[0], sub[1]]),
+            tag + "sub_shpd": n(shpd[0][..., sub[0], sub[1]]),
+            tag + "sub_refoc": n(refoc[0][..., sub[0], sub[1]]),
+            tag + "sub_bnd": n(bnd[0, 0][..., sub[0], sub[1]]),
+            tag + "sub_dmap": n(dmap[0][..., sub[0], sub[1]]),
+            tag + "sub_dmask": n(dmask[0][..., sub[0], sub[1]]),
+            tag + "mask_hist": np.bincount(n(dmask).ravel(), minlength=3),
+            tag + "fold_image": folded[0], tag + "fold_shpd": folded[1], tag + "fold_refoc": folded[2],
+            tag + "fold_bndry": folded[3], tag + "fold_depth": folded[4], tag + "fold_conf": folded[5],
+        })
+    save("g6_postprocess_147", **out)
+
+
+def G7():
+    """Unfold ordering on an index image + Fold normaliser."""
+    a = ref_args("eval")
+    idx = torch.arange(3 * 147 * 147, dtype=torch.float32).view(1, 3, 147, 147)    # exact in fp32 (< 2^24)
+    ip = torch.nn.Unfold(a.R, stride=a.stride)(idx).view(1, 3, 21, 21, 64, 64)
+    vec = ip.permute(0, 4, 5, 1, 2, 3).reshape(4096, 3, 21, 21)
+    sel = [0, 1, 63, 64, 2047, 4095]
+    helper = ref_test.PostProcess(ref_args("eval"), None, torch.device("cpu"))
+    save("g7_tiling", sel=np.array(sel), vec_sel=n(vec[sel]).astype(np.int32),
+         vec_rowsum=n(vec.double().sum(dim=(1, 2, 3))), num_patches=n(helper.num_patches))
+
+
+def G10():
+    """eval_depth (utils/metrics.py:3-20) on a fixed pair of maps."""
+    S = synth.SEED_DEFAULT
+    pred = 0.7 + 0.6 * synth.hash_uniform(S, "m_pred", (1, 147, 147))
+    gt = 0.75 + 0.43 * synth.hash_uniform(S, "m_gt", (1, 147, 147))
+    msk = synth.hash_uniform(S, "m_msk", (1, 147, 147)) > 0.3
+    pred = np.where(msk, pred, 0.0)
+    r = ref_utils.eval_depth(pred.astype(np.float32), gt.astype(np.float32), pred > 0, crop=10)
+    save("g10_metrics", metrics=np.array(r, dtype=np.float64))
+
+
+GROUPS = dict(G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G10=G10)
+
+if __name__ == "__main__":
+    todo = sys.argv[1:] or list(GROUPS)
+    for g in todo:
+        print("==", g, GROUPS[g].__doc__.strip().splitlines()[0])
+        GROUPS[g]()
