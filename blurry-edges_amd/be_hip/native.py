@@ -1,0 +1,227 @@
+"""ctypes binding of libblurry_edges_hip.so (the C ABI declared in include/blurry_edges_hip.h).
+
+This module is the only place the Python host side touches native code.  There is NO fallback: if the
+shared library is missing or a tensor is not a contiguous fp32 CUDA(HIP) tensor, the call raises.
+PyTorch is used for device memory and the current stream only.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libblurry_edges_hip.so")
+
+BE_R = 21
+NPIX = 441
+NTENSORS = 86
+
+
+class DepthConsts(C.Structure):
+    _fields_ = [(n, C.c_float) for n in
+                ("s", "numerator", "den_const", "k", "k2", "intercept", "sin_w", "cos_w", "sin_m", "cos_m")]
+
+
+class RenderOpts(C.Structure):
+    _fields_ = [("lambda_ridge", C.c_float), ("w", C.c_float), ("delta_sq", C.c_float),
+                ("wrap_angles", C.c_int), ("lin", C.c_float * BE_R)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("n", "h", "w", "cin", "cout", "ksize", "act")]
+
+
+_P = C.c_void_p
+_SIGNATURES = {
+    "be_version": (C.c_int, []),
+    "be_last_error": (C.c_char_p, []),
+    "be_params2etas_f32": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "be_etas2depth_f32": (C.c_int, [C.POINTER(DepthConsts), _P, _P, _P, _P, C.c_int64, _P]),
+    "be_depth2sigma_f32": (C.c_int, [C.POINTER(DepthConsts), _P, C.c_float, _P, C.c_int64, _P]),
+    "be_local_depth_f32": (C.c_int, [C.POINTER(DepthConsts), _P, _P, C.c_int64, _P]),
+    "be_render_colors_f32": (C.c_int, [C.POINTER(RenderOpts), _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
+    "be_local_stage_packed_floats": (C.c_size_t, []),
+    "be_local_stage_pack_f32": (C.c_int, [C.POINTER(_P), C.c_float, _P, _P]),
+    "be_local_stage_workspace_bytes": (C.c_size_t, [C.c_int64]),
+    "be_local_stage_set_chunk": (C.c_int, [C.c_int]),
+    "be_local_stage_forward_f32": (C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_size_t, _P]),
+    "be_conv_packed_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "be_conv_pack_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "be_conv_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, C.c_int, _P]),
+    "be_maxpool_nhwc_f32": (C.c_int, [_P, _P] + [C.c_int] * 7 + [_P]),
+    "be_nchw3_to_nhwc4_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
+}
+EXPORTED = tuple(_SIGNATURES)
+
+_lib = None
+
+
+def lib():
+    """Load the shared library once; fail loudly if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"(or `make -C blurry-edges_amd/csrc`). There is no CPU fallback for the HIP path.")
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(l, name)          # AttributeError here = header / library mismatch
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        raise RuntimeError(f"{what or 'libblurry_edges_hip'} failed ({rc}): {lib().be_last_error().decode()}")
+
+
+def dptr(t: torch.Tensor | None, name: str = "tensor"):
+    """Device pointer of a contiguous fp32 HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name}: expected a tensor on the GPU; the HIP path has no CPU fallback "
+                           f"(got {type(t).__name__} on {getattr(t, 'device', '?')})")
+    if t.dtype != torch.float32 and t.dtype != torch.int32:
+        raise RuntimeError(f"{name}: expected float32, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name}: expected a contiguous tensor")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+# ---------------------------------------------------------------------------------------------- wrappers
+
+def params2etas(p: torch.Tensor) -> torch.Tensor:
+    p = p.contiguous()
+    out = torch.empty_like(p)
+    check(lib().be_params2etas_f32(dptr(p, "params"), dptr(out), p.numel(), stream_ptr(p.device)), "be_params2etas_f32")
+    return out
+
+
+def etas2depth(consts: DepthConsts, eta1: torch.Tensor, eta2: torch.Tensor, want_branch=False):
+    eta1, eta2 = torch.broadcast_tensors(eta1, eta2)
+    eta1, eta2 = eta1.contiguous(), eta2.contiguous()
+    z = torch.empty_like(eta1)
+    br = torch.empty(eta1.shape, dtype=torch.int32, device=eta1.device) if want_branch else None
+    check(lib().be_etas2depth_f32(C.byref(consts), dptr(eta1, "eta1"), dptr(eta2, "eta2"), dptr(z), dptr(br),
+                                  eta1.numel(), stream_ptr(eta1.device)), "be_etas2depth_f32")
+    return (z, br) if want_branch else z
+
+
+def depth2sigma(consts: DepthConsts, depth: torch.Tensor, rho_prime: float) -> torch.Tensor:
+    depth = depth.contiguous()
+    out = torch.empty_like(depth)
+    check(lib().be_depth2sigma_f32(C.byref(consts), dptr(depth, "depth"), float(rho_prime), dptr(out), depth.numel(),
+                                   stream_ptr(depth.device)), "be_depth2sigma_f32")
+    return out
+
+
+def local_depth(consts: DepthConsts, params10: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+    """params10 [2P,10] image-major -> depth [P,2]."""
+    if params10.dim() != 2 or params10.shape[1] != 10 or params10.shape[0] % 2:
+        raise RuntimeError(f"local_depth: params10 must be [2P,10], got {tuple(params10.shape)}")
+    p = params10.shape[0] // 2
+    if out is None:
+        out = torch.empty(p, 2, dtype=torch.float32, device=params10.device)
+    check(lib().be_local_depth_f32(C.byref(consts), dptr(params10, "params10"), dptr(out), p,
+                                   stream_ptr(params10.device)), "be_local_depth_f32")
+    return out
+
+
+def render_colors(opts: RenderOpts, params10: torch.Tensor, patches: torch.Tensor, *, colors=None, want=()):
+    """params10 [N,10], patches [N,3,21,21] -> colors [N,3,3] and the optional outputs named in `want`
+    (any of 'recon','boundary','dists','wedges','gram','aty').  Returns (colors, dict)."""
+    n = params10.shape[0]
+    if tuple(params10.shape) != (n, 10) or tuple(patches.shape) != (n, 3, BE_R, BE_R):
+        raise RuntimeError(f"render_colors: bad shapes {tuple(params10.shape)} / {tuple(patches.shape)}")
+    dev = params10.device
+    if colors is None:
+        colors = torch.empty(n, 3, 3, dtype=torch.float32, device=dev)
+    shapes = dict(recon=(n, 3, BE_R, BE_R), boundary=(n, BE_R, BE_R), dists=(n, 2, BE_R, BE_R),
+                  wedges=(n, 3, BE_R, BE_R), gram=(n, 3, 3), aty=(n, 3, 3))
+    extra = {k: torch.empty(shapes[k], dtype=torch.float32, device=dev) for k in want}
+    g = lambda k: dptr(extra.get(k))
+    check(lib().be_render_colors_f32(C.byref(opts), dptr(params10, "params10"), dptr(patches, "patches"), dptr(colors),
+                                     g("recon"), g("boundary"), g("dists"), g("wedges"), g("gram"), g("aty"), n,
+                                     stream_ptr(dev)), "be_render_colors_f32")
+    return colors, extra
+
+
+def conv_pack(weight, bias, bn=None, eps=1e-5, chw_hw=0):
+    """weight [Cout,Cin,k,k] (or [Cout,Cin] for a Linear), optional bn=(gamma,beta,mean,var) -> (pw, pb)."""
+    cout, cin = weight.shape[0], weight.shape[1]
+    ks = weight.shape[2] if weight.dim() == 4 else 1
+    nfl = lib().be_conv_packed_floats(cout, cin, ks)
+    if nfl == 0:
+        raise RuntimeError(f"conv_pack: unsupported conv shape cout={cout} cin={cin} k={ks}")
+    dev = weight.device
+    pw = torch.empty(nfl, dtype=torch.float32, device=dev)
+    pb = torch.empty((cout + 31) // 32 * 32, dtype=torch.float32, device=dev)
+    g = bn if bn is not None else (None, None, None, None)
+    check(lib().be_conv_pack_f32(dptr(weight.contiguous(), "weight"), dptr(bias), dptr(g[0]), dptr(g[1]), dptr(g[2]),
+                                 dptr(g[3]), eps, cout, cin, ks, chw_hw, dptr(pw), dptr(pb), stream_ptr(dev)),
+          "be_conv_pack_f32")
+    return pw, pb
+
+
+def conv_nhwc(x, pw, pb, cout, ksize, act, residual=None):
+    """x [N,H,W,Cin] NHWC -> [N,H,W,cout]."""
+    n, h, w, cin = x.shape
+    y = torch.empty(n, h, w, cout, dtype=torch.float32, device=x.device)
+    d = ConvDesc(n, h, w, cin, cout, ksize, int(act))
+    check(lib().be_conv_nhwc_f32(C.byref(d), dptr(x, "x"), dptr(pw), dptr(pb), dptr(residual), dptr(y), cout,
+                                 stream_ptr(x.device)), "be_conv_nhwc_f32")
+    return y
+
+
+def maxpool_nhwc(x, k, stride, pad):
+    n, h, w, c = x.shape
+    oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    y = torch.empty(n, oh, ow, c, dtype=torch.float32, device=x.device)
+    check(lib().be_maxpool_nhwc_f32(dptr(x, "x"), dptr(y), n, h, w, c, k, stride, pad, stream_ptr(x.device)),
+          "be_maxpool_nhwc_f32")
+    return y
+
+
+def nchw3_to_nhwc4(x):
+    n, c, h, w = x.shape
+    if c != 3:
+        raise RuntimeError("nchw3_to_nhwc4: expected 3 channels")
+    y = torch.empty(n, h, w, 4, dtype=torch.float32, device=x.device)
+    check(lib().be_nchw3_to_nhwc4_f32(dptr(x, "x"), dptr(y), n, h * w, stream_ptr(x.device)), "be_nchw3_to_nhwc4_f32")
+    return y
+
+
+def local_stage_pack(tensors, eps=1e-5):
+    """tensors: the 86 fp32 state-dict tensors on the GPU, in the order documented in the header."""
+    if len(tensors) != NTENSORS:
+        raise RuntimeError(f"local_stage_pack: expected {NTENSORS} tensors, got {len(tensors)}")
+    keep = [t.contiguous() for t in tensors]
+    arr = (_P * NTENSORS)(*[dptr(t, f"tensor[{i}]") for i, t in enumerate(keep)])
+    dev = keep[0].device
+    packed = torch.empty(lib().be_local_stage_packed_floats(), dtype=torch.float32, device=dev)
+    check(lib().be_local_stage_pack_f32(arr, eps, dptr(packed), stream_ptr(dev)), "be_local_stage_pack_f32")
+    return packed
+
+
+def local_stage_forward(packed, x, out=None, workspace=None):
+    n = x.shape[0]
+    if tuple(x.shape[1:]) != (3, BE_R, BE_R):
+        raise RuntimeError(f"LocalStage input must be [N,3,21,21], got {tuple(x.shape)}")
+    dev = x.device
+    if out is None:
+        out = torch.empty(n, 10, dtype=torch.float32, device=dev)
+    need = lib().be_local_stage_workspace_bytes(n)
+    if workspace is None or workspace.numel() * 4 < need:
+        workspace = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
+    check(lib().be_local_stage_forward_f32(dptr(packed, "packed"), dptr(x, "x"), dptr(out), n, dptr(workspace),
+                                           workspace.numel() * 4, stream_ptr(dev)), "be_local_stage_forward_f32")
+    return out, workspace

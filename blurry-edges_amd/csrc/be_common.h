@@ -1,0 +1,32 @@
+// Shared host-side helpers of libblurry_edges_hip (error reporting, launch checks).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include "../../include/blurry_edges_hip.h"
+
+namespace be {
+
+char* last_error_buf();   // thread-local, 512 bytes
+
+inline int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(last_error_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return fail(BE_ELAUNCH, "%s: %s", what, hipGetErrorString(e));
+    return BE_OK;
+}
+
+inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+#define BE_REQUIRE(cond, ...) do { if (!(cond)) return be::fail(BE_EINVAL, __VA_ARGS__); } while (0)
+
+}  // namespace be

@@ -1,0 +1,368 @@
+// LocalStage convolutions as fp32-MFMA implicit GEMM on gfx950 (v_mfma_f32_32x32x2_f32: exact fp32,
+// bit-for-bit an fmaf chain), with the conv bias + eval-mode BatchNorm folded into the packed weights and
+// bias + optional residual add + Smish fused into the epilogue.
+//
+// Replaces nn.Conv2d + nn.BatchNorm2d (+ Smish, + residual add) of models/local_stage.py:11-17,20-28,34-37,
+// 54-56 and nn.Linear + nn.BatchNorm1d + Smish of :44-50 (a Linear is the 1x1 case on a 1x1 image).
+//
+// GEMM view: D[M = N*H*W output pixels][Cout] = A[M][K] * B[K][Cout].  Activations are NHWC so that a K-chunk of
+// 32 input channels of one tap is 128 contiguous bytes per output pixel: the A tile is gathered straight from
+// the activation tensor (zero-filled outside the image), never materialised (no im2col buffer).
+//   - block tile 128 x BN (BN = 32*WN*NT in {32,64,96,128}), 256 threads = 4 waves, wave tile (32*MT) x (32*NT)
+//   - K-chunk 32 floats; A/B chunks are register-staged (issue loads for chunk k+1, run the 64 MFMAs of chunk k,
+//     then write the staged registers to the other LDS buffer; one barrier per chunk)
+//   - LDS rows padded to 36 floats: the ds_read_b128 fragment reads (16-lane groups) and the ds_write_b128
+//     staging writes are bank-conflict free
+//   - fragment order inside a group of 8 k: lane half h holds k = 4h..4h+3, MFMA j consumes element j of both
+//     operands, so A and B agree on k without any shuffle
+//   - K order = (cin-chunk outer, tap inner): the 9 taps of a 3x3 re-read the same 128 rows x 128 B of
+//     activations back to back (L1/L2 hits), weights are packed in exactly that order so the B stream is linear
+//   - blockIdx -> (m_tile, n_tile): all N tiles of an M tile run on the same XCD (ids congruent mod 8 share an
+//     XCD's L2), so an activation tile is fetched from HBM once
+#include "be_common.h"
+#include "be_device_math.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128;
+constexpr int BK = 32;
+constexpr int LDS_ROW = 36;           // floats per LDS row (32 + 4 pad)
+enum { MODE_TAPS = 0, MODE_ROW8 = 1 };
+
+struct ConvArgs {
+    const float* x;       // NHWC activations [N,H,W,Cin]
+    const float* w;       // packed [Cout_pad][Ktot]
+    const float* bias;    // [Cout_pad]
+    const float* res;     // optional residual, same layout/stride as y
+    float* y;
+    int M, H, W, HW, Cin, Cout, ldy, ks, nchunk, Ktot, act, m_tiles, n_tiles;
+};
+
+template <int WM, int WN, int MT, int NT, int MODE>
+__global__ __launch_bounds__(256)
+void k_conv_igemm(ConvArgs a) {
+    static_assert(WM * WN == 4 && WM * MT * 32 == BM, "4 waves, 128 rows");
+    constexpr int BN = WN * NT * 32;
+    constexpr int NB = BN / 32;                       // B staging float4 per thread
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                                  // [2][BM][LDS_ROW]
+    float* Bs = smem + 2 * BM * LDS_ROW;               // [2][BN][LDS_ROW]
+
+    // ---- block -> tile (XCD-aware: blocks b, b+8, b+16.. share an XCD and walk the N tiles of one M tile)
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int m_tile = (slot / a.n_tiles) * 8 + xcd;
+    const int n_tile = slot % a.n_tiles;
+    if (m_tile >= a.m_tiles) return;
+    const int m0 = m_tile * BM, n0 = n_tile * BN;
+
+    const int tid = threadIdx.x;
+    const int q = tid & 7, r0 = tid >> 3;              // staging: 8 lanes x 16 B = one 128-B row chunk
+
+    // ---- per-thread A rows (4): flat output pixel m -> (y,x) for the border test; base offset m*Cin
+    int a_off[4], a_yx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + r0 + 32 * i;
+        if (m < a.M) {
+            const int pp = m % a.HW;
+            const int yy = pp / a.W, xx = pp - yy * a.W;
+            a_yx[i] = (yy << 16) | xx;
+            a_off[i] = m;                              // multiplied by Cin at use (fits 32 bit: checked on host)
+        } else {
+            a_yx[i] = -1;                              // row outside the problem: always zero
+            a_off[i] = 0;
+        }
+    }
+    const float* wrow = a.w + (size_t)(n0 + r0) * a.Ktot + 4 * q;
+
+    float4 a_st[4], b_st[NB];
+    auto load_chunk = [&](int kc) {
+        int dy, dx, coff;
+        if (MODE == MODE_TAPS) {
+            const int taps = a.ks * a.ks;
+            const int cc = kc / taps, tap = kc - cc * taps;
+            const int half = a.ks >> 1;
+            dy = tap / a.ks - half; dx = tap % a.ks - half;
+            coff = (dy * a.W + dx) * a.Cin + cc * BK + 4 * q;
+        } else {                                       // conv1: chunk = kernel row kh, 8 pixels x 4 channels
+            dy = kc - 3; dx = q - 3;
+            coff = (dy * a.W + dx) * 4;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int yy = (a_yx[i] >> 16) + dy, xx = (a_yx[i] & 0xffff) + dx;
+            const bool ok = a_yx[i] >= 0 && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+            const float4* src = reinterpret_cast<const float4*>(a.x + (size_t)a_off[i] * a.Cin + coff);
+            a_st[i] = ok ? *src : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            b_st[i] = *reinterpret_cast<const float4*>(wrow + (size_t)(32 * i) * a.Ktot + kc * BK);
+    };
+    auto store_chunk = [&](int buf) {
+        float* Ad = As + buf * BM * LDS_ROW;
+        float* Bd = Bs + buf * BN * LDS_ROW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(Ad + (r0 + 32 * i) * LDS_ROW + 4 * q) = a_st[i];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) *reinterpret_cast<float4*>(Bd + (r0 + 32 * i) * LDS_ROW + 4 * q) = b_st[i];
+    };
+
+    // ---- wave / lane roles for the MFMA phase
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave / WN, wn = wave % WN;
+    const int li = lane & 31, lh = lane >> 5;
+    const int a_frag0 = ((wm * MT) * 32 + li) * LDS_ROW + 4 * lh;
+    const int b_frag0 = ((wn * NT) * 32 + li) * LDS_ROW + 4 * lh;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
+
+    for (int kc = 0; kc < a.nchunk; ++kc) {
+        const int buf = kc & 1;
+        const bool more = kc + 1 < a.nchunk;
+        if (more) load_chunk(kc + 1);
+        const float* Ab = As + buf * BM * LDS_ROW + a_frag0;
+        const float* Bb = Bs + buf * BN * LDS_ROW + b_frag0;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 af[MT], bf[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_ROW + 8 * g);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_ROW + 8 * g);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        if (more) store_chunk(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: D[row][col], col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int c = n0 + (wn * NT + j) * 32 + li;
+        const bool c_ok = c < a.Cout;
+        const float bias = c_ok ? a.bias[c] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (c_ok && m < a.M) {
+                    float v = acc[i][j][r] + bias;
+                    if (a.res) v += a.res[(size_t)m * a.ldy + c];
+                    if (a.act) v = be::smish(v);
+                    a.y[(size_t)m * a.ldy + c] = v;
+                }
+            }
+        }
+    }
+}
+
+template <int WM, int WN, int MT, int NT, int MODE>
+int launch_conv(const ConvArgs& a, hipStream_t s) {
+    constexpr int BN = WN * NT * 32;
+    constexpr size_t lds = (size_t)2 * (BM + BN) * LDS_ROW * sizeof(float);
+    static bool attr_set = false;                     // raise the dynamic-LDS cap once per instantiation
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_igemm<WM, WN, MT, NT, MODE>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return be::fail(BE_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    const int per_xcd = (a.m_tiles + 7) / 8;
+    const unsigned grid = (unsigned)(8 * per_xcd * a.n_tiles);
+    hipLaunchKernelGGL((k_conv_igemm<WM, WN, MT, NT, MODE>), dim3(grid), dim3(256), lds, s, a);
+    return be::check_launch("be_conv_nhwc_f32");
+}
+
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+inline int conv_nchunk(int cin, int ksize) { return ksize == 7 ? 7 : (cin / BK) * ksize * ksize; }
+
+// ------------------------------------------------------------------------------------------- weight packing
+struct PackArgs {
+    const float *w, *b, *gamma, *beta, *mean, *var;
+    float eps;
+    int cout, cin, ks, chw_hw, cout_pad, ktot;
+    float *pw, *pb;
+};
+
+__global__ void k_pack(PackArgs p) {
+    const int64_t total = (int64_t)p.cout_pad * p.ktot;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
+        const int co = (int)(idx / p.ktot), k = (int)(idx % p.ktot);
+        float v = 0.0f;
+        if (co < p.cout) {
+            const float scale = p.gamma ? p.gamma[co] / sqrtf(p.var[co] + p.eps) : 1.0f;
+            const int kc = k / BK, e = k % BK;
+            if (p.ks == 7) {                           // conv1: chunk = kernel row, e = pixel*4 + channel
+                const int kh = kc, kw = e >> 2, ci = e & 3;
+                if (kw < 7 && ci < p.cin) v = p.w[((size_t)(co * p.cin + ci) * 7 + kh) * 7 + kw] * scale;
+            } else {
+                const int taps = p.ks * p.ks;
+                const int cc = kc / taps, tap = kc % taps;
+                int ci = cc * BK + e;                  // NHWC channel index of the consumer
+                size_t src;
+                if (p.chw_hw > 0) {                    // features flattened from (C,H,W): ours are (H,W,C)
+                    const int c_real = ci % (p.cin / p.chw_hw), hw = ci / (p.cin / p.chw_hw);
+                    src = (size_t)co * p.cin + (size_t)c_real * p.chw_hw + hw;
+                } else {
+                    src = ((size_t)(co * p.cin + ci)) * taps + tap;
+                }
+                v = p.w[src] * scale;
+            }
+        }
+        p.pw[idx] = v;
+    }
+    // bias: one thread per output channel
+    for (int64_t co = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; co < p.cout_pad; co += stride) {
+        float v = 0.0f;
+        if (co < p.cout) {
+            const float b = p.b ? p.b[co] : 0.0f;
+            if (p.gamma) v = (b - p.mean[co]) * (p.gamma[co] / sqrtf(p.var[co] + p.eps)) + p.beta[co];
+            else v = b;
+        }
+        p.pb[co] = v;
+    }
+}
+
+// ------------------------------------------------------------------------------------------- pooling / layout
+__global__ void k_maxpool_nhwc(const float* __restrict__ x, float* __restrict__ y, int n, int h, int w, int c4,
+                               int oh, int ow, int k, int stride, int pad) {
+    const int64_t total = (int64_t)n * oh * ow * c4;
+    const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gs) {
+        const int cq = (int)(idx % c4);
+        int64_t t = idx / c4;
+        const int ox = (int)(t % ow); t /= ow;
+        const int oy = (int)(t % oh);
+        const int64_t img = t / oh;
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        for (int dy = 0; dy < k; ++dy) {
+            const int yy = oy * stride - pad + dy;
+            if ((unsigned)yy >= (unsigned)h) continue;
+            for (int dx = 0; dx < k; ++dx) {
+                const int xx = ox * stride - pad + dx;
+                if ((unsigned)xx >= (unsigned)w) continue;
+                const float4 v = reinterpret_cast<const float4*>(x)[((img * h + yy) * w + xx) * c4 + cq];
+                m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
+            }
+        }
+        reinterpret_cast<float4*>(y)[idx] = m;
+    }
+}
+
+__global__ void k_nchw3_to_nhwc4(const float* __restrict__ x, float* __restrict__ y, int64_t n, int hw) {
+    const int64_t total = n * hw;
+    const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gs) {
+        const int64_t img = idx / hw;
+        const int p = (int)(idx - img * hw);
+        const float* s = x + img * 3 * hw + p;
+        reinterpret_cast<float4*>(y)[idx] = make_float4(s[0], s[hw], s[2 * hw], 0.0f);
+    }
+}
+
+inline unsigned grid_cap(int64_t total, int block) {
+    int64_t g = (total + block - 1) / block;
+    return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+}  // namespace
+
+extern "C" size_t be_conv_packed_floats(int cout, int cin, int ksize) {
+    if (cout <= 0 || cin <= 0) return 0;
+    if (ksize == 7) return (size_t)round_up(cout, 32) * 7 * BK;
+    if ((ksize != 1 && ksize != 3) || cin % BK) return 0;
+    return (size_t)round_up(cout, 32) * conv_nchunk(cin, ksize) * BK;
+}
+
+extern "C" int be_conv_pack_f32(const float* w, const float* b, const float* g, const float* beta, const float* mean,
+                                const float* var, float eps, int cout, int cin, int ksize, int chw_hw, float* pw,
+                                float* pb, void* stream) {
+    BE_REQUIRE(w && pw && pb, "be_conv_pack_f32: null pointer");
+    BE_REQUIRE(cout > 0 && cin > 0, "be_conv_pack_f32: bad channel counts");
+    BE_REQUIRE((g == nullptr) == (beta == nullptr) && (g == nullptr) == (mean == nullptr) &&
+               (g == nullptr) == (var == nullptr), "be_conv_pack_f32: BatchNorm tensors must be all set or all null");
+    if (ksize == 7) BE_REQUIRE(cin <= 4, "be_conv_pack_f32: the 7x7 row-gather mode takes cin <= 4 (got %d)", cin);
+    else BE_REQUIRE((ksize == 1 || ksize == 3) && cin % BK == 0,
+                    "be_conv_pack_f32: ksize %d / cin %d unsupported (ksize 1|3 with cin %% 32 == 0, or 7)", ksize, cin);
+    BE_REQUIRE(chw_hw == 0 || (ksize == 1 && cin % chw_hw == 0), "be_conv_pack_f32: bad layout_chw_hw");
+    PackArgs p{w, b, g, beta, mean, var, eps, cout, cin, ksize, chw_hw, round_up(cout, 32),
+               conv_nchunk(cin, ksize) * BK, pw, pb};
+    hipLaunchKernelGGL(k_pack, dim3(grid_cap((int64_t)p.cout_pad * p.ktot, 256)), dim3(256), 0, be::as_stream(stream), p);
+    return be::check_launch("be_conv_pack_f32");
+}
+
+extern "C" int be_conv_nhwc_f32(const be_conv_desc* d, const float* x, const float* pw, const float* pb,
+                                const float* res, float* y, int ldy, void* stream) {
+    BE_REQUIRE(d && x && pw && pb && y, "be_conv_nhwc_f32: null pointer");
+    BE_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cout > 0, "be_conv_nhwc_f32: empty shape");
+    BE_REQUIRE(d->h < 32768 && d->w < 32768, "be_conv_nhwc_f32: image too large");
+    const bool row8 = d->ksize == 7;
+    if (row8) BE_REQUIRE(d->cin == 4, "be_conv_nhwc_f32: ksize 7 needs the NHWC4 input (cin = 4)");
+    else BE_REQUIRE((d->ksize == 1 || d->ksize == 3) && d->cin % BK == 0,
+                    "be_conv_nhwc_f32: ksize %d / cin %d unsupported", d->ksize, d->cin);
+    BE_REQUIRE(ldy >= d->cout, "be_conv_nhwc_f32: ldy < cout");
+    BE_REQUIRE(be::aligned16(x) && be::aligned16(pw), "be_conv_nhwc_f32: x / packed_w must be 16-byte aligned");
+    const int64_t M = (int64_t)d->n * d->h * d->w;
+    BE_REQUIRE(M * (int64_t)d->cin < (int64_t)1 << 40 && M < (int64_t)1 << 31, "be_conv_nhwc_f32: batch too large");
+    ConvArgs a;
+    a.x = x; a.w = pw; a.bias = pb; a.res = res; a.y = y;
+    a.M = (int)M; a.H = d->h; a.W = d->w; a.HW = d->h * d->w; a.Cin = d->cin; a.Cout = d->cout; a.ldy = ldy;
+    a.ks = d->ksize; a.nchunk = conv_nchunk(d->cin, d->ksize); a.Ktot = a.nchunk * BK; a.act = d->act;
+    a.m_tiles = (int)((M + BM - 1) / BM);
+    const int cp = round_up(d->cout, 32);
+    hipStream_t s = be::as_stream(stream);
+    if (row8) {
+        BE_REQUIRE(cp == 64, "be_conv_nhwc_f32: ksize 7 is built for cout 64 (got %d)", d->cout);
+        a.n_tiles = 1;
+        return launch_conv<4, 1, 1, 2, MODE_ROW8>(a, s);
+    }
+    if (cp % 128 == 0) { a.n_tiles = cp / 128; return launch_conv<2, 2, 2, 2, MODE_TAPS>(a, s); }
+    if (cp % 96 == 0)  { a.n_tiles = cp / 96;  return launch_conv<4, 1, 1, 3, MODE_TAPS>(a, s); }
+    if (cp % 64 == 0)  { a.n_tiles = cp / 64;  return launch_conv<4, 1, 1, 2, MODE_TAPS>(a, s); }
+    a.n_tiles = cp / 32;
+    return launch_conv<4, 1, 1, 1, MODE_TAPS>(a, s);
+}
+
+extern "C" int be_maxpool_nhwc_f32(const float* x, float* y, int n, int h, int w, int c, int k, int stride, int pad,
+                                   void* stream) {
+    BE_REQUIRE(x && y, "be_maxpool_nhwc_f32: null pointer");
+    BE_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "be_maxpool_nhwc_f32: bad shape (c %% 4 == 0)");
+    BE_REQUIRE(k > 0 && stride > 0 && pad >= 0 && 2 * pad <= k, "be_maxpool_nhwc_f32: bad window");
+    const int oh = (h + 2 * pad - k) / stride + 1, ow = (w + 2 * pad - k) / stride + 1;
+    BE_REQUIRE(oh > 0 && ow > 0, "be_maxpool_nhwc_f32: empty output");
+    const int64_t total = (int64_t)n * oh * ow * (c / 4);
+    hipLaunchKernelGGL(k_maxpool_nhwc, dim3(grid_cap(total, 256)), dim3(256), 0, be::as_stream(stream), x, y, n, h, w,
+                       c / 4, oh, ow, k, stride, pad);
+    return be::check_launch("be_maxpool_nhwc_f32");
+}
+
+extern "C" int be_nchw3_to_nhwc4_f32(const float* x, float* y, int64_t n, int hw, void* stream) {
+    BE_REQUIRE(x && y && n > 0 && hw > 0, "be_nchw3_to_nhwc4_f32: bad arguments");
+    hipLaunchKernelGGL(k_nchw3_to_nhwc4, dim3(grid_cap(n * hw, 256)), dim3(256), 0, be::as_stream(stream), x, y, n, hw);
+    return be::check_launch("be_nchw3_to_nhwc4_f32");
+}

@@ -1,0 +1,63 @@
+// Device-side scalar math shared by the kernels (gfx950, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "../../include/blurry_edges_hip.h"
+
+namespace be {
+
+// eta = 10^(2 erf(p) - 2)                              utils/postprocessing_loss.py:88-89
+__device__ __forceinline__ float param2eta(float p) {
+#pragma clang fp contract(off)
+    return powf(10.0f, erff(p) * 2.0f - 2.0f);
+}
+
+// utils/depth_etas.py:23-34 -- same operation order as the reference, no contraction.
+__device__ __forceinline__ float etas2depth(const be_depth_consts& c, float e1, float e2, int& branch) {
+#pragma clang fp contract(off)
+    const float I = c.intercept;
+    const float c1 = (-c.sin_w) * e1 + c.cos_w * (e2 - I);
+    const float c2 = (-c.sin_m) * (e1 - I) + c.cos_m * e2;
+    const float c3 = (-c.sin_w) * (e1 - I) + c.cos_w * e2;
+    const float sum_h = (e1 + e2 - I) / 2.0f;
+    float e11, e22;
+    if (c1 > 0.0f)      { e11 = sum_h;                        e22 = I + sum_h;              branch = 0; }
+    else if (c2 > 0.0f) { e11 = I + (e1 - e2 - I) / 2.0f;     e22 = (e2 - e1 + I) / 2.0f;   branch = 1; }
+    else if (c3 < 0.0f) { e11 = I + sum_h;                    e22 = sum_h;                  branch = 2; }
+    else                { e11 = e1;                           e22 = e2;                     branch = 3; }
+    return c.numerator / (c.k2 * (e11 * e11 - e22 * e22) + c.den_const);
+}
+
+// utils/depth_etas.py:36-37
+__device__ __forceinline__ float depth2sigma(const be_depth_consts& c, float depth, float rho_prime) {
+#pragma clang fp contract(off)
+    return fabsf((1.0f / depth - rho_prime) * c.s + 1.0f) / c.k;
+}
+
+// torch.remainder(a, 2*pi) for fp32 (result in [0, 2pi)): fmod, then shift negatives up.
+__device__ __forceinline__ float remainder_2pi(float a) {
+#pragma clang fp contract(off)
+    const float two_pi = 6.283185307179586f;
+    float r = fmodf(a, two_pi);
+    if (r != 0.0f && r < 0.0f) r += two_pi;
+    return r;
+}
+
+// Smish(x) = x * tanh(log(1 + sigmoid(x)))            models/local_stage.py:4-6
+// With u = 1 + sigmoid(x): tanh(log u) = (u^2-1)/(u^2+1); in t = exp(-|x|) this is a ratio of two
+// quadratics that never overflows:  x>=0: (3+2t)/(5+6t+2t^2)   x<0: (3t^2+2t)/(5t^2+6t+2).
+__device__ __forceinline__ float smish(float x) {
+    const float t = expf(-fabsf(x));
+    float num, den;
+    if (x >= 0.0f) { num = fmaf(2.0f, t, 3.0f);        den = fmaf(t, fmaf(2.0f, t, 6.0f), 5.0f); }
+    else           { num = t * fmaf(3.0f, t, 2.0f);    den = fmaf(t, fmaf(5.0f, t, 6.0f), 2.0f); }
+    return x * (num / den);
+}
+
+// Sum over the 64 lanes of a wave; every lane gets the total.  Fixed order -> bitwise reproducible.
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+}  // namespace be

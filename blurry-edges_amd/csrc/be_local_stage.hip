@@ -1,0 +1,141 @@
+// LocalStage.forward (eval) as a chain of launches on one stream: models/local_stage.py:63-73.
+//   conv7x7+BN+Smish -> maxpool(3,2,1) -> block 64->96 @11^2 -> maxpool(3,2,1) -> blocks 96->256, 256->384,
+//   384->256 @6^2 -> maxpool(2,2) -> flatten -> Linear 2304->1024 + BN1d + Smish -> Linear 1024->10
+// Activations are NHWC in a caller-provided workspace; the batch is walked in sub-batches so that the
+// activations between two layers (<= 113 MB per 2048 patches) stay in the 256 MiB Infinity Cache and the
+// workspace stays bounded whatever N is.  No allocation, no synchronisation: graph-capturable.
+#include "be_common.h"
+
+namespace {
+
+struct LayerSpec { int cout, cin, ks, chw_hw; };
+// state_dict() order; conv1 consumes the NHWC4 staging of the NCHW input
+constexpr LayerSpec kLayers[15] = {
+    {64, 3, 7, 0},
+    {96, 64, 3, 0},   {96, 96, 3, 0},   {96, 64, 1, 0},
+    {256, 96, 3, 0},  {256, 256, 3, 0}, {256, 96, 1, 0},
+    {384, 256, 3, 0}, {384, 384, 3, 0}, {384, 256, 1, 0},
+    {256, 384, 3, 0}, {256, 256, 3, 0}, {256, 384, 1, 0},
+    {1024, 2304, 1, 9},
+    {10, 1024, 1, 0},
+};
+
+inline size_t cout_pad(int c) { return (size_t)((c + 31) / 32 * 32); }
+
+struct PackedLayout {
+    size_t w_off[15], b_off[15], total;
+    PackedLayout() {
+        size_t o = 0;
+        for (int i = 0; i < 15; ++i) {
+            w_off[i] = o; o += be_conv_packed_floats(kLayers[i].cout, kLayers[i].cin, kLayers[i].ks);
+            b_off[i] = o; o += cout_pad(kLayers[i].cout);
+        }
+        total = o;
+    }
+};
+const PackedLayout& layout() { static PackedLayout l; return l; }
+
+// workspace regions, floats per patch (lifetimes: see be_local_stage_forward_f32)
+constexpr size_t RA = 28224, RB = 13824, RC = 13824;
+constexpr size_t WS_FLOATS_PER_PATCH = RA + RB + RC;
+int g_chunk = 4096;
+
+}  // namespace
+
+extern "C" size_t be_local_stage_packed_floats(void) { return layout().total; }
+
+extern "C" int be_local_stage_set_chunk(int patches) {
+    BE_REQUIRE(patches >= 1, "be_local_stage_set_chunk: chunk must be >= 1");
+    g_chunk = patches;
+    return BE_OK;
+}
+
+extern "C" size_t be_local_stage_workspace_bytes(int64_t n) {
+    if (n <= 0) return 0;
+    const int64_t nb = n < g_chunk ? n : g_chunk;
+    return (size_t)nb * WS_FLOATS_PER_PATCH * sizeof(float);
+}
+
+extern "C" int be_local_stage_pack_f32(const float* const* t, float bn_eps, float* packed, void* stream) {
+    BE_REQUIRE(t && packed, "be_local_stage_pack_f32: null pointer");
+    for (int i = 0; i < BE_LOCAL_STAGE_NTENSORS; ++i) BE_REQUIRE(t[i], "be_local_stage_pack_f32: tensor %d is null", i);
+    const PackedLayout& L = layout();
+    for (int i = 0; i < 13; ++i) {                    // conv + BatchNorm2d pairs
+        const float* const* e = t + 6 * i;            // weight, bias, gamma, beta, mean, var
+        int rc = be_conv_pack_f32(e[0], e[1], e[2], e[3], e[4], e[5], bn_eps, kLayers[i].cout, kLayers[i].cin,
+                                  kLayers[i].ks, 0, packed + L.w_off[i], packed + L.b_off[i], stream);
+        if (rc) return rc;
+    }
+    const float* const* f = t + 78;                   // fc.1.w, fc.1.b, fc.2.{gamma,beta,mean,var}, fc.4.w, fc.4.b
+    int rc = be_conv_pack_f32(f[0], f[1], f[2], f[3], f[4], f[5], bn_eps, 1024, 2304, 1, 9,
+                              packed + L.w_off[13], packed + L.b_off[13], stream);
+    if (rc) return rc;
+    return be_conv_pack_f32(f[6], f[7], nullptr, nullptr, nullptr, nullptr, bn_eps, 10, 1024, 1, 0,
+                            packed + L.w_off[14], packed + L.b_off[14], stream);
+}
+
+namespace {
+
+int conv(const float* packed, int li, const float* x, const float* res, float* y, int n, int hw, int act, int ldy,
+         void* stream) {
+    const PackedLayout& L = layout();
+    be_conv_desc d;
+    d.n = n; d.h = hw; d.w = hw;
+    d.cin = li == 0 ? 4 : kLayers[li].cin;
+    d.cout = kLayers[li].cout; d.ksize = kLayers[li].ks; d.act = act;
+    return be_conv_nhwc_f32(&d, x, packed + L.w_off[li], packed + L.b_off[li], res, y, ldy, stream);
+}
+
+// ResidualBlock (models/local_stage.py:20-28): Smish(BN(conv3(Smish(BN(conv3(x))))) + BN(conv1x1(x)))
+int block(const float* packed, int l0, const float* x, float* t, float* d, float* o, int n, int hw, void* stream) {
+    const int c = kLayers[l0].cout;
+    int rc;
+    if ((rc = conv(packed, l0, x, nullptr, t, n, hw, 1, c, stream))) return rc;
+    if ((rc = conv(packed, l0 + 2, x, nullptr, d, n, hw, 0, c, stream))) return rc;
+    return conv(packed, l0 + 1, t, d, o, n, hw, 1, c, stream);
+}
+
+}  // namespace
+
+extern "C" int be_local_stage_forward_f32(const float* packed, const float* x, float* out, int64_t n,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+    BE_REQUIRE(n >= 0, "be_local_stage_forward_f32: n < 0");
+    if (n == 0) return BE_OK;
+    BE_REQUIRE(packed && x && out && workspace, "be_local_stage_forward_f32: null pointer");
+    BE_REQUIRE(be::aligned16(workspace) && be::aligned16(packed),
+               "be_local_stage_forward_f32: workspace / packed must be 16-byte aligned");
+    if (workspace_bytes < be_local_stage_workspace_bytes(n))
+        return be::fail(BE_EWORKSPACE, "be_local_stage_forward_f32: workspace %zu B < %zu B needed", workspace_bytes,
+                        be_local_stage_workspace_bytes(n));
+    float* ws = static_cast<float*>(workspace);
+    for (int64_t first = 0; first < n; first += g_chunk) {
+        const int nb = (int)((n - first) < g_chunk ? (n - first) : g_chunk);
+        float* ra = ws;
+        float* rb = ra + (size_t)nb * RA;
+        float* rc_ = rb + (size_t)nb * RB;
+        const float* xin = x + first * 3 * BE_NPIX;
+        int rc;
+        // x4 -> RB ; conv1 -> RA ; pool -> RB(after x4 is dead: RB is big enough to hold both side by side)
+        float* x4 = rb;                                   // nb*1764
+        float* p1 = rb + (size_t)nb * 1764 * 2;           // nb*7744, placed behind x4 (1764*2 + 7744 <= 13824)
+        if ((rc = be_nchw3_to_nhwc4_f32(xin, x4, nb, BE_NPIX, stream))) return rc;
+        if ((rc = conv(packed, 0, x4, nullptr, ra, nb, 21, 1, 64, stream))) return rc;
+        if ((rc = be_maxpool_nhwc_f32(ra, p1, nb, 21, 21, 64, 3, 2, 1, stream))) return rc;
+        // layer0 @11x11: t,d in RA, out in RC
+        if ((rc = block(packed, 1, p1, ra, ra + (size_t)nb * 11616, rc_, nb, 11, stream))) return rc;
+        float* p2 = rb;                                   // nb*3456
+        if ((rc = be_maxpool_nhwc_f32(rc_, p2, nb, 11, 11, 96, 3, 2, 1, stream))) return rc;
+        // layer1: in RB, t,d RA, out RC
+        if ((rc = block(packed, 4, p2, ra, ra + (size_t)nb * 9216, rc_, nb, 6, stream))) return rc;
+        // layer2: in RC, t,d RA, out RB
+        if ((rc = block(packed, 7, rc_, ra, ra + (size_t)nb * 13824, rb, nb, 6, stream))) return rc;
+        // layer3: in RB, t,d RA, out RC
+        if ((rc = block(packed, 10, rb, ra, ra + (size_t)nb * 9216, rc_, nb, 6, stream))) return rc;
+        float* p3 = rb;                                   // nb*2304  (H,W,C) flatten
+        if ((rc = be_maxpool_nhwc_f32(rc_, p3, nb, 6, 6, 256, 2, 2, 0, stream))) return rc;
+        float* f1 = ra;                                   // nb*1024
+        if ((rc = conv(packed, 13, p3, nullptr, f1, nb, 1, 1, 1024, stream))) return rc;
+        if ((rc = conv(packed, 14, f1, nullptr, out + first * BE_LOCAL_OUT, nb, 1, 0, BE_LOCAL_OUT, stream))) return rc;
+    }
+    return BE_OK;
+}

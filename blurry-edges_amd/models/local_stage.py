@@ -1,0 +1,112 @@
+"""LocalStage: the per-patch CNN (3x21x21 -> 10 wedge parameters) behind the reference's own interface.
+
+Same constructor signature, module tree and state-dict layout (100 entries, incl. int64 num_batches_tracked)
+as the reference's models/local_stage.py:30-62, so checkpoints written by either load into the other with
+strict=True.  What differs is what runs: forward() hands the raw parameter tensors to libblurry_edges_hip
+(BatchNorm folded, fp32-MFMA implicit-GEMM convs with fused Smish / residual epilogues, NHWC activations)
+through the C ABI in include/blurry_edges_hip.h.  There is no eager / CPU path.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from be_hip import native
+
+# (attribute, out_channels) of the four residual stages, models/local_stage.py:38-41
+_STAGES = (("layer0", 96), ("layer1", 256), ("layer2", 384), ("layer3", 256))
+
+
+class Smish(nn.Module):
+    """x * tanh(log(1 + sigmoid(x))) (models/local_stage.py:4-6).  Inside LocalStage this is fused into the
+    conv epilogues; the module exists for the state-dict / module-tree contract."""
+
+    def forward(self, x):
+        return x * torch.tanh(torch.log(1 + torch.sigmoid(x)))
+
+
+def _conv_bn(cin, cout, k, pad, act):
+    mods = [nn.Conv2d(cin, cout, kernel_size=k, stride=1, padding=pad), nn.BatchNorm2d(cout)]
+    if act:
+        mods.append(Smish())
+    return nn.Sequential(*mods)
+
+
+class ResidualBlock(nn.Module):
+    """Module-tree twin of models/local_stage.py:8-19 (keys conv1.{0,1}, conv2.{0,1}, downsample.{0,1})."""
+
+    def __init__(self, in_channels, out_channels, kernel_size=3, stride=1, padding=1, downsample=None):
+        super().__init__()
+        if stride != 1:
+            raise NotImplementedError("the HIP conv kernels are stride-1 (every block of LocalStage is)")
+        self.conv1 = _conv_bn(in_channels, out_channels, kernel_size, padding, act=True)
+        self.conv2 = _conv_bn(out_channels, out_channels, 3, 1, act=False)
+        self.downsample = downsample
+        self.activation = Smish()
+
+    def forward(self, x):
+        raise RuntimeError("ResidualBlock runs only as part of LocalStage.forward (fused HIP kernels)")
+
+
+class LocalStage(nn.Module):
+    def __init__(self, block=ResidualBlock, layers=[1, 1, 1, 1], output_dim=10):
+        super().__init__()
+        if list(layers) != [1, 1, 1, 1] or output_dim != 10 or block is not ResidualBlock:
+            raise NotImplementedError("the HIP LocalStage is built for the reference configuration "
+                                      "(ResidualBlock, layers=[1,1,1,1], output_dim=10)")
+        self.inplanes = 64
+        self.conv1 = _conv_bn(3, 64, 7, 3, act=True)
+        for name, planes in _STAGES:
+            setattr(self, name, self._make_layer(block, planes, 1))
+        self.maxpool1 = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.maxpool2 = nn.MaxPool2d(kernel_size=2, stride=2)
+        self.fc = nn.Sequential(nn.Flatten(), nn.Linear(3 * 3 * 256, 1024), nn.BatchNorm1d(1024), Smish(),
+                                nn.Linear(1024, output_dim))
+        self._packed = None
+        self._packed_key = None
+        self._workspace = None
+
+    def _make_layer(self, block, planes, blocks, kernel_size=3, stride=1, padding=1):
+        down = None
+        if stride != 1 or self.inplanes != planes:
+            down = _conv_bn(self.inplanes, planes, 1, 0, act=False)
+        stage = [block(self.inplanes, planes, kernel_size, stride, padding, down)]
+        self.inplanes = planes
+        stage += [block(planes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*stage)
+
+    # ------------------------------------------------------------------ native weight hand-off
+    def _tensor_list(self):
+        """The 86 fp32 tensors in the order be_local_stage_pack_f32 documents."""
+        out = []
+
+        def pair(seq):
+            conv, bn = seq[0], seq[1]
+            out.extend([conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var])
+
+        pair(self.conv1)
+        for name, _ in _STAGES:
+            blk = getattr(self, name)[0]
+            pair(blk.conv1); pair(blk.conv2); pair(blk.downsample)
+        fc1, bn1, fc4 = self.fc[1], self.fc[2], self.fc[4]
+        out.extend([fc1.weight, fc1.bias, bn1.weight, bn1.bias, bn1.running_mean, bn1.running_var,
+                    fc4.weight, fc4.bias])
+        return out
+
+    def _packed_weights(self):
+        tensors = [t.detach() for t in self._tensor_list()]
+        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        if self._packed is None or key != self._packed_key:
+            self._packed = native.local_stage_pack(tensors, eps=self.conv1[1].eps)
+            self._packed_key = key
+        return self._packed
+
+    def forward(self, x):
+        if self.training and torch.is_grad_enabled():
+            raise NotImplementedError("LocalStage training forward/backward (batch-statistics BatchNorm, dgrad, "
+                                      "wgrad) is not built yet; call .eval() / torch.no_grad() for inference")
+        if self.training:
+            raise NotImplementedError("LocalStage in train() mode needs batch-statistics BatchNorm (not built yet)")
+        x = x.to(torch.float32).contiguous()
+        out, self._workspace = native.local_stage_forward(self._packed_weights(), x, workspace=self._workspace)
+        return out

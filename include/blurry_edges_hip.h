@@ -1,0 +1,153 @@
+/*
+ * blurry_edges_hip.h -- C ABI of libblurry_edges_hip.so (MI355X / gfx950).
+ *
+ * The drop-in boundary of the Blurry-Edges hot path: local_stage CNN -> blurred-wedge renderer with ridge
+ * colour solve -> DfD depth solve (+ overlap tiling).  The reference has no FFI of its own (100 % Python on
+ * ATen ops); each entry point below replaces the ATen op sequence of the reference function it cites and is
+ * what a binding for that function would call (ctypes stub: INTEGRATION.md; the build's own Python host
+ * side in blurry-edges_amd/{models,utils} binds exactly these symbols).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HBM) unless its name ends in _host; tensors are dense, fp32,
+ *     row-major in the layout written next to the parameter; nothing is allocated or freed by the library
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); all calls are asynchronous on
+ *     it and graph-capturable (no allocation, no synchronisation inside)
+ *   - return value: BE_OK (0) or a negative BE_E* code; be_last_error() gives the message of the last
+ *     failure on the calling thread.  Invalid shapes are refused on the host before anything is launched.
+ */
+#ifndef BLURRY_EDGES_HIP_H
+#define BLURRY_EDGES_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BE_OK            0
+#define BE_EINVAL       -1   /* bad argument (null pointer, size, alignment, unsupported shape) */
+#define BE_EWORKSPACE   -2   /* workspace too small                                          */
+#define BE_ELAUNCH      -3   /* HIP reported an error at launch                              */
+
+#define BE_R             21  /* patch side, utils/args.py:11                                 */
+#define BE_NPIX          441
+#define BE_LOCAL_OUT     10  /* LocalStage output_dim, models/local_stage.py:31              */
+
+int         be_version(void);
+const char* be_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------------
+ * DepthEtas  (utils/depth_etas.py:3-37)
+ * ------------------------------------------------------------------------------------------------- */
+
+/* Constants of DepthEtas.__init__ (utils/depth_etas.py:4-21), computed by the caller exactly as the
+ * reference does (python float64 -> rounded to fp32 on use; intercept / sin / cos are the fp32 tensor
+ * values) so branch decisions agree bit for bit. */
+typedef struct be_depth_consts {
+    float s;            /* cam_params['s']                                   */
+    float numerator;    /* 2 s^2 (rho_2 - rho_1)                        :13 */
+    float den_const;    /* -s (rho_1-rho_2)(rho_1 s + rho_2 s - 2)      :14 */
+    float k;            /* denominator_factor_root                      :15 */
+    float k2;           /* denominator_factor                           :16 */
+    float intercept;    /*                                              :18 */
+    float sin_w, cos_w; /* sin/cos(theta_wng = pi/4)                    :21 */
+    float sin_m, cos_m; /* sin/cos(theta_mid = 3pi/4)                   :20 */
+} be_depth_consts;
+
+/* params2etas (utils/postprocessing_loss.py:88-89): eta = 10^(2 erf(p) - 2), elementwise, n elements. */
+int be_params2etas_f32(const float* p, float* eta, int64_t n, void* stream);
+
+/* DepthEtas.etas2depth (utils/depth_etas.py:23-34), elementwise over n (eta1[i], eta2[i]) pairs.
+ * branch (optional, may be NULL): int32 id 0..3 of the locus segment taken. */
+int be_etas2depth_f32(const be_depth_consts* consts_host, const float* eta1, const float* eta2,
+                      float* depth, int32_t* branch, int64_t n, void* stream);
+
+/* DepthEtas.depth2sigma (utils/depth_etas.py:36-37), elementwise. */
+int be_depth2sigma_f32(const be_depth_consts* consts_host, const float* depth, float rho_prime,
+                       float* eta, int64_t n, void* stream);
+
+/* Config-2 composition: params10 [2P,10] image-major (rows 0..P-1 aperture 1, rows
+ * P..2P-1 aperture 2, the order of blurry_edges_test.py:121); depth [P,2]:
+ *   depth[i][k] = etas2depth(params2etas(params10[i][8+k]), params2etas(params10[P+i][8+k])). */
+int be_local_depth_f32(const be_depth_consts* consts_host, const float* params10, float* depth,
+                       int64_t n_pairs, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Blurred-wedge renderer, colours-only pass ("pass A")
+ *   replaces PostProcess.forward(colors_only=True) -> get_patches -> get_colors
+ *   (blurry_edges_test.py:19-34,81-92) and LocalLoss.get_patches (local_training.py:32-45):
+ *   params2dists :43-86, params2etas :88-89, dists2indicators :91-95, A^T A + lambda I, A^T y,
+ *   3x3 solve (utils/postprocessing_loss.py:104-112), composite.
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct be_render_opts {
+    float lambda_ridge;    /* (alpha_lambda R^2)^2, utils/postprocessing_loss.py:14                 */
+    float w;               /* args.w (1.0), :71-76                                                   */
+    float delta_sq;        /* normalized_gaussian delta^2 = fp32(0.07**2), :97-98                    */
+    int   wrap_angles;     /* 1: params[4:8] <- remainder(., 2pi) first (blurry_edges_test.py:124)   */
+    float lin[BE_R];       /* torch.linspace(-1,1,21) as fp32, :15-16                                */
+} be_render_opts;
+
+/* params10 [N,10], patches [N,3,21,21]  ->  colors [N,3(rgb),3(wedge)].
+ * Optional outputs (NULL to skip): recon [N,3,21,21] composited patch, boundary [N,21,21],
+ * dists [N,2,21,21], wedges [N,3,21,21], gram [N,3,3] (A^T A + lambda I), aty [N,3(wedge),3(rgb)].
+ * The 3x3 system is solved in fp64 by cofactors (numerically better than the reference's fp32
+ * Cayley-Hamilton inverse; parity is judged against the fp64 oracle). */
+int be_render_colors_f32(const be_render_opts* opts_host, const float* params10, const float* patches,
+                         float* colors, float* recon, float* boundary, float* dists, float* wedges,
+                         float* gram, float* aty, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * LocalStage CNN  (models/local_stage.py:30-73), inference (BatchNorm folded into the convs)
+ * ------------------------------------------------------------------------------------------------- */
+
+/* Kernel-layout weights.  Sizes in floats: be_local_stage_packed_floats(). One contiguous device buffer. */
+size_t be_local_stage_packed_floats(void);
+
+/* The reference state-dict (100 entries) as raw device pointers, in state_dict() order,
+ * skipping the int64 num_batches_tracked entries: for each of the 13 conv+BN pairs
+ *   {conv.weight [Cout,Cin,k,k], conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var}
+ * then fc.1.{weight [1024,2304],bias}, fc.2.{weight,bias,running_mean,running_var}, fc.4.{weight [10,1024],bias}
+ * = 13*6 + 2 + 4 + 2 = 86 pointers. */
+#define BE_LOCAL_STAGE_NTENSORS 86
+int be_local_stage_pack_f32(const float* const* tensors_host /* [86] device ptrs */, float bn_eps,
+                            float* packed, void* stream);
+
+/* The batch is walked in sub-batches of `patches` (default 4096) so that inter-layer activations stay in
+ * the Infinity Cache and the workspace is bounded; affects be_local_stage_workspace_bytes(). */
+int be_local_stage_set_chunk(int patches);
+
+/* Workspace (activations) for a batch of n patches, in bytes. */
+size_t be_local_stage_workspace_bytes(int64_t n);
+
+/* LocalStage.forward in eval mode: x [N,3,21,21] (NCHW as the reference feeds it) -> out [N,10]. */
+int be_local_stage_forward_f32(const float* packed, const float* x, float* out, int64_t n,
+                               void* workspace, size_t workspace_bytes, void* stream);
+
+/* Layer-level entry points (used by the layer-by-layer parity tests and by the training path).
+ * Activations are NHWC.  act: 0 none, 1 Smish (models/local_stage.py:4-6). */
+typedef struct be_conv_desc {
+    int n, h, w;          /* batch, spatial size (stride 1, "same" padding)      */
+    int cin, cout;        /* cin % 32 == 0 (conv1: cin = 4, NHWC4 input)         */
+    int ksize;            /* 1, 3, or 7 (7: the conv1 row-gather mode, cin = 4)  */
+    int act;
+} be_conv_desc;
+size_t be_conv_packed_floats(int cout, int cin, int ksize);
+/* Fold conv bias + eval-mode BatchNorm into packed weights/bias.  bn_* may be NULL (plain conv/linear).
+ * layout_chw_hw: 0, or H*W (9) when the input features were flattened from (C,H,W) (fc.1, :45-46). */
+int be_conv_pack_f32(const float* weight_oihw, const float* bias, const float* bn_gamma, const float* bn_beta,
+                     const float* bn_mean, const float* bn_var, float bn_eps, int cout, int cin, int ksize,
+                     int layout_chw_hw, float* packed_w, float* packed_bias, void* stream);
+/* y[n,h,w,cout] = act(conv(x) + bias (+ residual)); residual may be NULL; ldy = row stride of y in floats. */
+int be_conv_nhwc_f32(const be_conv_desc* desc_host, const float* x, const float* packed_w,
+                     const float* packed_bias, const float* residual, float* y, int ldy, void* stream);
+/* nn.MaxPool2d(k, stride, pad) on NHWC (models/local_stage.py:42-43). */
+int be_maxpool_nhwc_f32(const float* x, float* y, int n, int h, int w, int c, int k, int stride, int pad,
+                        void* stream);
+/* [N,3,21,21] NCHW -> [N,21,21,4] NHWC with a zero 4th channel (input staging of conv1). */
+int be_nchw3_to_nhwc4_f32(const float* x, float* y, int64_t n, int hw, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BLURRY_EDGES_HIP_H */

@@ -1,0 +1,233 @@
+"""GPU parity tests: the HIP path (through the C ABI via be_hip.native / the reference-shaped classes)
+against the CPU oracle on identical seeded inputs, and against the committed golden vectors.
+Tolerances are the ones SURVEY.md 8c derives from measurements on the reference (L-inf / L-inf)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, relmax
+from be_hip import synth
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def T(a, dt=torch.float32):
+    return torch.from_numpy(np.asarray(a)).to(dt)
+
+
+@pytest.fixture(scope="module")
+def native():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a GPU")
+    from be_hip import native as n
+    n.lib()
+    return n
+
+
+@pytest.fixture(scope="module")
+def args():
+    import utils
+    return utils.get_args("eval", argv=[])
+
+
+# ------------------------------------------------------------------------------------------ depth solve
+def test_etas2depth_bit_exact_vs_oracle_and_golden(native, args):
+    import utils
+    from oracle import depth as od
+    g = load_golden("g5_depth")
+    d = utils.DepthEtas(args, DEV)
+    lin = torch.linspace(1e-4, 1.0, 64)
+    e1, e2 = torch.meshgrid(lin, lin, indexing="ij")
+    z, br = native.etas2depth(d.consts, e1.to(DEV), e2.to(DEV), want_branch=True)
+    zo, bro = od.etas2depth(od.depth_consts(), e1, e2, return_branch=True)
+    assert np.array_equal(br.cpu().numpy(), bro.numpy())            # same locus segment everywhere
+    assert np.array_equal(z.cpu().numpy(), g["z_lin"])              # bit-exact vs the reference itself
+    lg = torch.logspace(-4, 0, 48)
+    l1, l2 = torch.meshgrid(lg, lg, indexing="ij")
+    assert np.array_equal(d.etas2depth(l1.to(DEV), l2.to(DEV)).cpu().numpy(), g["z_log"])
+    depth = torch.linspace(0.6, 2.3, 257)
+    assert np.array_equal(d.depth2sigma(depth.to(DEV), 10.39).cpu().numpy(), g["sigma_rho_prime"])
+    # broadcasting + empty input (edge cases of the reference API: any-shape tensors)
+    zb = d.etas2depth(lin.to(DEV)[:, None], lin.to(DEV)[None, :])
+    assert np.array_equal(zb.cpu().numpy(), g["z_lin"])
+    assert d.etas2depth(torch.empty(0, device=DEV), torch.empty(0, device=DEV)).numel() == 0
+
+
+def test_params2etas_and_local_depth(native, args):
+    import utils
+    from oracle import render as orr, depth as od
+    p = T(synth.plausible_params10(4096 * 2, name="ld"))
+    eta = native.params2etas(p[:, 8:].contiguous().to(DEV))
+    assert relmax(eta.cpu(), orr.params2etas(p[:, 8:])) <= 2e-6     # powf/erff: 1-2 ulp apart from Sleef
+    d = utils.DepthEtas(args, DEV)
+    z = native.local_depth(d.consts, p.to(DEV))
+    zo = orr.local_depth(od.depth_consts(), p[:4096], p[4096:])
+    # depth is well conditioned (App. C): 1e-6 rel on all but branch-flipped pairs
+    err = (z.cpu() - zo).abs() / zo.abs()
+    assert float((err > 1e-5).float().mean()) <= 1e-3
+    assert float(err.median()) <= 1e-6
+    # depth -> eta -> depth round trip: property that holds at any size
+    zt = torch.tensor([0.75, 0.9, 1.0, 1.18], device=DEV)
+    e1 = d.depth2sigma(zt, args.cam_params["rho_1"])
+    e2 = d.depth2sigma(zt, args.cam_params["rho_2"])
+    assert relmax(d.etas2depth(e1, e2).cpu(), zt.cpu()) <= 2e-6
+
+
+# ------------------------------------------------------------------------------------------ renderer
+def _helper(args):
+    import utils
+    a = utils.get_args("local_train", argv=[])
+    return utils.PostProcessLocalBase(a, DEV)
+
+
+def test_render_pass_a_stage_by_stage_vs_golden_and_oracle(native, args):
+    from oracle import render as orr
+    g = load_golden("g3_render_local")
+    p10 = synth.plausible_params10(8)
+    img = synth.uniform_patches(8, name="render_patches")
+    h = _helper(args)
+    col, ex = h.render_colors(T(p10).to(DEV), T(img).to(DEV), want=("recon", "boundary", "dists", "wedges", "gram", "aty"))
+    c = lambda t: t.cpu().numpy()
+    assert relmax(c(ex["dists"]), g["f32_dists"]) <= 1e-5
+    assert relmax(c(ex["wedges"]), g["f64_wedges"]) <= 3e-4          # eta -> 1e-4 makes erf a step (App. C)
+    assert relmax(c(ex["gram"]), g["f64_G"]) <= 1e-5
+    assert relmax(c(ex["aty"]), g["f64_b"]) <= 1e-5
+    assert relmax(c(ex["boundary"]), g["f32_boundary"]) <= 1e-5
+    # ill-conditioned stages are judged against the float64 run of the reference
+    assert relmax(c(col), g["f64_colors"]) <= 1e-4
+    assert relmax(c(ex["recon"]), g["f64_patches"]) <= 1e-4
+    # reported: our error vs the fp32 reference next to the reference's own fp32-vs-fp64 error
+    print("colors: hip-vs-ref32 %.2e   ref32-vs-ref64 %.2e" %
+          (relmax(c(col), g["f32_colors"]), relmax(g["f32_colors"], g["f64_colors"])))
+
+
+def test_render_pass_a_4096_patches_vs_fp64_oracle(native, args):
+    from oracle import render as orr, tiling as ot
+    imgs, _ = synth.synthetic_image_pair(147, 147)
+    pat = ot.unfold_patches(T(imgs))[0].contiguous()                 # [4096,3,21,21]
+    p10 = T(synth.plausible_params10(4096, name="g6_img1"))
+    h = _helper(args)
+    col, ex = h.render_colors(p10.to(DEV), pat.to(DEV), want=("dists", "recon"))
+    r64 = orr.render_pass_a(p10.double(), pat.double())
+    assert relmax(ex["dists"].cpu(), r64["dists"]) <= 1e-5
+    assert relmax(col.cpu(), r64["colors"]) <= 1e-4
+    assert relmax(ex["recon"].cpu(), r64["recon"]) <= 1e-4
+    # wrap_angles=True on unwrapped angles == wrapping first (blurry_edges_test.py:123-127)
+    shifted = p10.clone()
+    shifted[:, 4:8] += 2 * torch.pi * torch.tensor([1.0, -1.0, 2.0, -3.0])
+    col_w, _ = h.render_colors(shifted.to(DEV), pat.to(DEV), wrap_angles=True)
+    col_o = orr.render_pass_a(orr.wrap_angles10(shifted).double(), pat.double())["colors"]
+    assert relmax(col_w.cpu(), col_o) <= 1e-4
+    # ragged / empty batch
+    assert h.render_colors(p10[:0].to(DEV), pat[:0].to(DEV))[0].shape == (0, 3, 3)
+    col3, _ = h.render_colors(p10[:3].to(DEV), pat[:3].to(DEV))
+    assert torch.equal(col3, col[:3])
+
+
+# ------------------------------------------------------------------------------------------ CNN
+def _nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def test_conv_layers_one_by_one_vs_oracle(native):
+    """Each conv(+BN+Smish / +residual) of LocalStage, fed with the ORACLE's input activation."""
+    from oracle import local_stage as ols
+    sd_np = synth.local_stage_state_dict()
+    sd = ols.to_torch_sd(sd_np)
+    x = T(synth.uniform_patches(16))
+    taps = {}
+    with torch.no_grad():
+        ols.local_stage_forward(sd, x, taps=taps)
+    dev = lambda k: sd[k].to(DEV)
+
+    def pack(prefix):
+        return native.conv_pack(dev(prefix + ".0.weight"), dev(prefix + ".0.bias"),
+                                bn=(dev(prefix + ".1.weight"), dev(prefix + ".1.bias"),
+                                    dev(prefix + ".1.running_mean"), dev(prefix + ".1.running_var")))
+
+    # conv1 (7x7, NHWC4 staging) + Smish
+    pw, pb = pack("conv1")
+    y = native.conv_nhwc(native.nchw3_to_nhwc4(x.to(DEV)), pw, pb, 64, 7, act=1)
+    assert relmax(y.cpu(), _nhwc(taps["conv1"])) <= 1e-5
+    # maxpool(3,2,1)
+    p1 = native.maxpool_nhwc(y, 3, 2, 1)
+    assert relmax(p1.cpu(), _nhwc(taps["pool1"])) <= 1e-5
+    # residual blocks
+    for name, inp, cout in (("layer0.0", "pool1", 96), ("layer1.0", "pool2", 256), ("layer2.0", "layer1", 384),
+                            ("layer3.0", "layer2", 256)):
+        xin = _nhwc(taps[inp]).to(DEV)
+        t = native.conv_nhwc(xin, *pack(name + ".conv1"), cout, 3, act=1)
+        d = native.conv_nhwc(xin, *pack(name + ".downsample"), cout, 1, act=0)
+        o = native.conv_nhwc(t, *pack(name + ".conv2"), cout, 3, act=1, residual=d)
+        assert relmax(o.cpu(), _nhwc(taps[name.split(".")[0]])) <= 1e-5, name
+    p3 = native.maxpool_nhwc(_nhwc(taps["layer3"]).to(DEV), 2, 2, 0)
+    assert relmax(p3.cpu(), _nhwc(taps["pool3"])) <= 1e-6
+    # fc.1 + BN1d + Smish on the (H,W,C)-flattened features
+    pw, pb = native.conv_pack(dev("fc.1.weight"), dev("fc.1.bias"),
+                              bn=(dev("fc.2.weight"), dev("fc.2.bias"), dev("fc.2.running_mean"), dev("fc.2.running_var")),
+                              chw_hw=9)
+    f1 = native.conv_nhwc(p3.reshape(16, 1, 1, 2304), pw, pb, 1024, 1, act=1)
+    assert relmax(f1.reshape(16, 1024).cpu(), taps["fc1"]) <= 1e-5
+
+
+def test_local_stage_logits_vs_golden_and_oracle(native):
+    import models
+    from oracle import local_stage as ols
+    g = load_golden("g1_local_stage_eval")
+    sd_np = synth.local_stage_state_dict()
+    m = models.LocalStage()
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()}, strict=True)
+    m = m.to(DEV).eval()
+    x = T(synth.uniform_patches(16)).to(DEV)
+    with torch.no_grad():
+        y = m(x)
+    assert y.shape == (16, 10)
+    assert relmax(y.cpu(), g["logits"]) <= 1e-5          # vs the fp32 reference
+    assert relmax(y.cpu(), g["logits_fp64"]) <= 1e-5     # vs the fp64 reference
+    xs, _ = synth.synthetic_patch_pairs(8)
+    with torch.no_grad():
+        ys = m(T(xs).to(DEV))
+    assert relmax(ys.cpu(), g["logits_synth_pairs"]) <= 1e-5
+    # config 1: a single pair (N = 2), ragged N, and reloading weights invalidates the packed cache
+    with torch.no_grad():
+        y2 = m(x[:2])
+        y5 = m(x[:5])
+    assert torch.equal(y2, y[:2]) and torch.equal(y5, y[:5])
+    sd2 = synth.local_stage_state_dict(seed=7)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd2.items()})
+    with torch.no_grad():
+        y7 = m(x)
+    o7 = ols.local_stage_forward(ols.to_torch_sd(sd2), x.cpu())
+    assert relmax(y7.cpu(), o7) <= 1e-5
+
+
+def test_local_stage_full_batch_8192_properties(native):
+    """BASELINE config 2 size: results must not depend on where a patch sits in the batch (tile position,
+    sub-batch chunk), and a sampled subset must match the oracle."""
+    import models
+    from oracle import local_stage as ols
+    sd_np = synth.local_stage_state_dict()
+    m = models.LocalStage()
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()})
+    m = m.to(DEV).eval()
+    x, _ = synth.synthetic_patch_pairs(4096)
+    x = T(x).to(DEV)
+    with torch.no_grad():
+        y = m(x)
+        idx = torch.arange(0, 8192, 127, device=DEV)            # 65 patches spread over both chunks
+        ys = m(x[idx].contiguous())
+    assert torch.isfinite(y).all()
+    assert torch.equal(ys, y[idx])                              # bit-identical, batch-position independent
+    with torch.no_grad():
+        yo = ols.local_stage_forward(ols.to_torch_sd(sd_np), x[idx].cpu())
+    assert relmax(ys.cpu(), yo) <= 1e-5
+
+
+def test_product_path_refuses_cpu_tensors(native):
+    import models
+    m = models.LocalStage().eval()
+    with pytest.raises(RuntimeError):
+        with torch.no_grad():
+            m(torch.zeros(2, 3, 21, 21))

@@ -1,0 +1,77 @@
+"""CPU-side tests: the C-ABI library loads and exports every declared symbol, the host classes keep the
+reference's names / state-dict layout, and the product path refuses to run without the GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden
+from be_hip import synth
+
+
+def test_library_exports_every_symbol_in_the_header():
+    from be_hip import native
+    hdr = open(os.path.join(ROOT, "include", "blurry_edges_hip.h")).read()
+    declared = set(re.findall(r"\b(be_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    lib = native.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in the header but not exported"
+    assert declared == set(native.EXPORTED)
+    assert lib.be_version() >= 1
+    assert lib.be_local_stage_workspace_bytes(0) == 0
+    assert lib.be_local_stage_packed_floats() > 7254122          # >= parameter count (padding only adds)
+
+
+def test_host_side_argument_checks_fail_before_any_launch():
+    from be_hip import native
+    lib = native.lib()
+    assert lib.be_params2etas_f32(None, None, -1, None) < 0
+    assert b"n < 0" in lib.be_last_error()
+    assert lib.be_conv_packed_floats(64, 48, 3) == 0               # cin % 32 != 0 is unsupported
+    d = native.ConvDesc(1, 6, 6, 48, 64, 3, 0)
+    assert lib.be_conv_nhwc_f32(d, None, None, None, None, None, 64, None) < 0
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        native.params2etas(torch.zeros(4))
+
+
+def test_local_stage_state_dict_layout_matches_the_reference():
+    import models
+    m = models.LocalStage()
+    sd = m.state_dict()
+    ref = synth.local_stage_state_dict()
+    assert list(sd.keys()) == list(ref.keys()) and len(sd) == 100
+    for k, v in sd.items():
+        assert tuple(v.shape) == tuple(ref[k].shape), k
+        assert (v.dtype == torch.int64) == k.endswith("num_batches_tracked")
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in ref.items()}, strict=True)
+    assert sum(p.numel() for p in m.parameters()) == 7254122
+    assert len(m._tensor_list()) == 86
+    with pytest.raises(RuntimeError):
+        m.eval()(torch.zeros(1, 3, 21, 21))                           # CPU tensor: refused, no fallback
+
+
+def test_args_defaults_and_depth_constants():
+    import utils
+    a = utils.get_args("eval", argv=[])
+    assert (a.R, a.stride, a.img_size, a.rho_prime, a.crop, a.densify) == (21, 2, [147, 147], 10.39, 10, None)
+    assert utils.get_args("eval", big=True, argv=[]).n_margin_patch == 10
+    b = utils.get_args("local_train", argv=[])
+    assert (b.batch_size, b.learning_rate, b.beta_bndry_loc, b.beta_smthns, b.dynamic_epoch) == (64, 6e-5, 1e-3, 5e-4, 200)
+    d = utils.DepthEtas(a, "cpu")
+    g = load_golden("g5_depth")
+    got = [d.numerator, d.denominator_constant, d.denominator_factor_root, d.denominator_factor, float(d.intercept)]
+    assert np.array_equal(np.array(got), g["consts"])
+
+
+def test_eval_depth_metric_matches_golden():
+    import utils
+    S = synth.SEED_DEFAULT
+    pred = 0.7 + 0.6 * synth.hash_uniform(S, "m_pred", (1, 147, 147))
+    gt = 0.75 + 0.43 * synth.hash_uniform(S, "m_gt", (1, 147, 147))
+    msk = synth.hash_uniform(S, "m_msk", (1, 147, 147)) > 0.3
+    pred = np.where(msk, pred, 0.0).astype(np.float32)
+    r = utils.eval_depth(pred, gt.astype(np.float32), pred > 0, crop=10)
+    assert np.allclose(np.array(r, dtype=np.float64), load_golden("g10_metrics")["metrics"], rtol=1e-6)
