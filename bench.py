@@ -1,0 +1,212 @@
+#!/usr/bin/env python3
+"""bench.py -- patch-pairs/s through the Blurry-Edges hot path on MI355X.
+
+One "step" = one pass of the hot path over one batch of synthetic input, BASELINE.json configs[1]:
+a batch of 4096 synthetic 21x21 two-aperture patch pairs (8192 CNN patches) per GPU through
+  LocalStage CNN (fp32-MFMA implicit GEMM)  ->  wedge renderer pass A (colours, ridge solve)  ->  DfD depth solve
+with the input already resident in HBM.  Prints ONE JSON line (rank 0).
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: patch pairs are independent, so every rank runs its own shard of 4096 pairs with NO data-path
+collective (weak scaling); RCCL is used only for the barrier and the MAX-over-ranks of the elapsed time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "blurry-edges_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+PAIRS = 4096                          # configs[1]
+FLOP_PER_PATCH = 387.716e6            # SURVEY.md A.2 (2*MAC, convs + linears)
+FLOP_PER_PAIR = 2 * FLOP_PER_PATCH    # 775.43 MFLOP, SURVEY.md 8d
+PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: dense fp32 matrix peak
+CPU_SAMPLE_PAIRS = 1024
+
+
+def cpu_baseline(x_np, sd_np):
+    """The oracle (CPU port of the reference path) timed on this box's host cores on a bounded sample."""
+    from oracle import local_stage as ols, render as orr, depth as od
+    # the box's CPU share, not the host's core count: affinity mask if set, capped at the 16 cores a 1-GPU box gets
+    try:
+        ncores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncores = os.cpu_count() or 1
+    ncores = max(1, min(ncores, int(os.environ.get("BE_CPU_THREADS", "16"))))
+    torch.set_num_threads(ncores)
+    sd = ols.to_torch_sd(sd_np)
+    p = CPU_SAMPLE_PAIRS
+    x = torch.from_numpy(np.concatenate([x_np[:p], x_np[PAIRS:PAIRS + p]]))
+    c = od.depth_consts()
+
+    def run():
+        with torch.no_grad():
+            est = ols.local_stage_forward(sd, x)
+            q = orr.wrap_angles10(est)
+            col = orr.render_pass_a(q, x)["colors"]
+            z = orr.local_depth(c, est[:p], est[p:])
+        return est, col, z
+    run_small = lambda: ols.local_stage_forward(sd, x[:64])        # warm the thread pool / allocator
+    with torch.no_grad():
+        run_small()
+    t0 = time.perf_counter()
+    est, col, z = run()
+    dt = time.perf_counter() - t0
+    return dict(value=p / dt, unit="patch-pairs/s", cores=ncores, kind="port",
+                sample=f"{p} pairs ({2 * p} CNN patches) of the same synthetic workload, 1 run, {dt:.1f} s, "
+                       f"torch {torch.__version__} CPU, {ncores} threads"), (est, col, z)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chunk", type=int, default=0, help="LocalStage sub-batch (patches); 0 = library default")
+    ap.add_argument("--layers", action="store_true", help="print the per-launch conv timing table to stderr")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from be_hip import native, synth
+    import models, utils
+    native.lib()                                   # fails loudly if the HIP library is missing
+    if args.chunk:
+        native.check(native.lib().be_local_stage_set_chunk(args.chunk))
+
+    # ---- synthetic workload, resident in HBM before the timed region (each rank: its own shard)
+    x_np, z_gt = synth.synthetic_patch_pairs(PAIRS, seed=synth.SEED_DEFAULT + rank)
+    sd_np = synth.local_stage_state_dict()
+    model = models.LocalStage()
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()})
+    model = model.to(dev).eval()
+    helper = utils.PostProcessLocalBase(utils.get_args("local_train", argv=[]), dev)
+    dcal = utils.DepthEtas(utils.get_args("eval", argv=[]), dev)
+    x = torch.from_numpy(x_np).to(dev)
+    colors = torch.empty(2 * PAIRS, 3, 3, device=dev)
+    depth = torch.empty(PAIRS, 2, device=dev)
+    opts = native.RenderOpts.from_buffer_copy(helper._opts)
+    opts.wrap_angles = 1
+
+    def step():
+        with torch.no_grad():
+            est = model(x)                                                   # [8192,10]
+            native.render_colors(opts, est, x, colors=colors)                # [8192,3,3]
+            native.local_depth(dcal.consts, est, out=depth)                  # [4096,2]
+        return est
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        est = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline leg: the same K steps again with a hipEvent pair around every conv launch (on the launch
+    #      stream = torch's current stream); dominant kernel = the 128x128 fp32-MFMA implicit-GEMM conv
+    roof = None
+    if rank == 0:
+        per_step = 15 * ((2 * PAIRS + 4095) // 4096 + 1)
+        cap = per_step * args.steps
+        native.profile_enable(cap)
+        torch.cuda.synchronize()
+        for _ in range(args.steps):
+            step()
+        torch.cuda.synchronize()
+        recs = native.profile_read(cap)
+        native.profile_enable(0)
+        if args.layers and recs:
+            nl = len(recs) // args.steps
+            print("launch  kernel  GFLOP      ms     TFLOP/s", file=sys.stderr)
+            for i in range(nl):
+                rr = recs[i::nl]
+                ms_i = sum(r[3] for r in rr) / len(rr)
+                print(f"{i:4d}  {rr[0][0]:5d}  {rr[0][1] / 1e9:8.2f}  {ms_i:7.4f}  {rr[0][1] / ms_i / 1e9:8.2f}", file=sys.stderr)
+        dom = [r for r in recs if r[0] == 0]
+        conv_ms = sum(r[3] for r in recs) / args.steps
+        if dom:
+            avg_ms = sum(r[3] for r in dom) / len(dom)
+            avg_flop = sum(r[1] for r in dom) / len(dom)
+            ach = avg_flop / (avg_ms * 1e-3) / 1e12
+            roof = dict(bound="mfma", kernel=native.KERNEL_NAMES[0], achieved=round(ach, 2),
+                        peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                        traffic=None, launches_per_step=len(dom) // args.steps,
+                        avg_launch_ms=round(avg_ms, 4), flop_per_launch=avg_flop,
+                        all_conv_ms_per_step=round(conv_ms, 3),
+                        end_to_end_frac=round(PAIRS * args.steps / elapsed * FLOP_PER_PAIR / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4))
+            pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+            if os.path.exists(pmc):                 # HBM bytes per launch from the separate --pmc passes
+                try:
+                    roof["traffic"] = json.load(open(pmc)).get("bytes_per_launch")
+                except Exception:
+                    pass
+
+    cpu = None
+    extra = {}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu, (est_o, col_o, z_o) = cpu_baseline(x_np, sd_np)
+        p = CPU_SAMPLE_PAIRS
+        zh = depth[:p].cpu()
+        d = (zh - z_o)
+        rel = d.abs() / z_o.abs()
+        keep = rel <= 1e-3                                       # branch-flipped pairs are counted, not averaged
+        extra = dict(depth_rmse_vs_oracle_m=float(torch.sqrt((d[keep] ** 2).mean())),
+                     depth_branch_flip_frac=float((~keep).float().mean()),
+                     logits_relmax_vs_oracle=float((torch.cat([est[:p], est[PAIRS:PAIRS + p]]).cpu() - est_o).abs().max()
+                                                   / est_o.abs().max()))
+
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        out = {
+            "metric": "patch-pairs/s (local CNN + render + depth) on 21x21 synth",
+            "value": round(world * PAIRS * args.steps / elapsed, 1), "unit": "patch-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: batch of 4096 synthetic 21x21 two-aperture patch pairs per GPU "
+                                   "(8192 CNN patches): LocalStage inference + pass-A colour solve + depth solve",
+                       "pairs_per_gpu": PAIRS, "weights": "portable-generator random init (no checkpoint offline)",
+                       "sharding": "independent pairs per rank, no data-path collective"},
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+        out.update(extra)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

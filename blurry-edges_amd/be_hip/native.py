@@ -52,6 +52,10 @@ _SIGNATURES = {
     "be_conv_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, C.c_int, _P]),
     "be_maxpool_nhwc_f32": (C.c_int, [_P, _P] + [C.c_int] * 7 + [_P]),
     "be_nchw3_to_nhwc4_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
+    "be_profile_enable": (C.c_int, [C.c_int]),
+    "be_profile_reset": (C.c_int, []),
+    "be_profile_read": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                  C.POINTER(C.c_float), C.c_int]),
 }
 EXPORTED = tuple(_SIGNATURES)
 
@@ -225,3 +229,25 @@ def local_stage_forward(packed, x, out=None, workspace=None):
     check(lib().be_local_stage_forward_f32(dptr(packed, "packed"), dptr(x, "x"), dptr(out), n, dptr(workspace),
                                            workspace.numel() * 4, stream_ptr(dev)), "be_local_stage_forward_f32")
     return out, workspace
+
+
+KERNEL_NAMES = {0: "k_conv_igemm<2,2,2,2,TAPS> (128x128)", 1: "k_conv_igemm<4,1,1,3,TAPS> (128x96)",
+                2: "k_conv_igemm<4,1,1,2,TAPS> (128x64)", 3: "k_conv_igemm<4,1,1,1,TAPS> (128x32)",
+                4: "k_conv_igemm<4,1,1,2,ROW8> (conv1)"}
+
+
+def profile_enable(max_launches: int):
+    check(lib().be_profile_enable(int(max_launches)), "be_profile_enable")
+
+
+def profile_reset():
+    lib().be_profile_reset()
+
+
+def profile_read(cap: int):
+    """-> list of (kernel_id, flops, bytes, ms) in launch order (waits for the events)."""
+    ids = (C.c_int * cap)(); fl = (C.c_double * cap)(); by = (C.c_double * cap)(); ms = (C.c_float * cap)()
+    n = lib().be_profile_read(ids, fl, by, ms, cap)
+    if n < 0:
+        check(n, "be_profile_read")
+    return [(ids[i], fl[i], by[i], ms[i]) for i in range(n)]

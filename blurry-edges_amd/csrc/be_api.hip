@@ -10,3 +10,51 @@ char* last_error_buf() {
 
 extern "C" int be_version(void) { return 1; }
 extern "C" const char* be_last_error(void) { return be::last_error_buf(); }
+
+// ------------------------------------------------------------------------------------------------ profiling
+namespace {
+struct Rec { hipEvent_t a, b; int kernel_id; double flops, bytes; };
+struct Prof { Rec* recs = nullptr; int cap = 0, n = 0; bool on = false; } g_prof;
+}  // namespace
+
+namespace be {
+ProfileScope::ProfileScope(hipStream_t s, int kernel_id, double flops, double bytes) : s_(s), slot_(-1) {
+    if (!g_prof.on || g_prof.n >= g_prof.cap) return;
+    slot_ = g_prof.n++;
+    Rec& r = g_prof.recs[slot_];
+    r.kernel_id = kernel_id; r.flops = flops; r.bytes = bytes;
+    (void)hipEventRecord(r.a, s_);
+}
+ProfileScope::~ProfileScope() {
+    if (slot_ >= 0) (void)hipEventRecord(g_prof.recs[slot_].b, s_);
+}
+}  // namespace be
+
+extern "C" int be_profile_enable(int max_launches) {
+    for (int i = 0; i < g_prof.cap; ++i) { (void)hipEventDestroy(g_prof.recs[i].a); (void)hipEventDestroy(g_prof.recs[i].b); }
+    delete[] g_prof.recs;
+    g_prof = Prof();
+    if (max_launches <= 0) return BE_OK;
+    g_prof.recs = new Rec[max_launches];
+    for (int i = 0; i < max_launches; ++i) {
+        if (hipEventCreate(&g_prof.recs[i].a) != hipSuccess || hipEventCreate(&g_prof.recs[i].b) != hipSuccess)
+            return be::fail(BE_ELAUNCH, "be_profile_enable: hipEventCreate failed");
+    }
+    g_prof.cap = max_launches;
+    g_prof.on = true;
+    return BE_OK;
+}
+
+extern "C" int be_profile_reset(void) { g_prof.n = 0; return BE_OK; }
+
+extern "C" int be_profile_read(int* kernel_id, double* flops, double* bytes, float* ms, int cap) {
+    const int n = g_prof.n < cap ? g_prof.n : cap;
+    for (int i = 0; i < n; ++i) {
+        Rec& r = g_prof.recs[i];
+        if (hipEventSynchronize(r.b) != hipSuccess) return be::fail(BE_ELAUNCH, "be_profile_read: event sync failed");
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return be::fail(BE_ELAUNCH, "be_profile_read: elapsed failed");
+        kernel_id[i] = r.kernel_id; flops[i] = r.flops; bytes[i] = r.bytes; ms[i] = t;
+    }
+    return n;
+}

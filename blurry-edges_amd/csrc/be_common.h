@@ -27,6 +27,14 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
+// Opt-in per-launch timing (be_profile_* in the C ABI): when enabled, every conv launch is bracketed by two
+// pre-created hipEvents recorded on the launch stream (asynchronous; read back later).
+struct ProfileScope {
+    ProfileScope(hipStream_t s, int kernel_id, double flops, double bytes);
+    ~ProfileScope();
+    hipStream_t s_; int slot_;
+};
+
 #define BE_REQUIRE(cond, ...) do { if (!(cond)) return be::fail(BE_EINVAL, __VA_ARGS__); } while (0)
 
 }  // namespace be

@@ -180,7 +180,7 @@ void k_conv_igemm(ConvArgs a) {
 }
 
 template <int WM, int WN, int MT, int NT, int MODE>
-int launch_conv(const ConvArgs& a, hipStream_t s) {
+int launch_conv(const ConvArgs& a, hipStream_t s, int kernel_id) {
     constexpr int BN = WN * NT * 32;
     constexpr size_t lds = (size_t)2 * (BM + BN) * LDS_ROW * sizeof(float);
     static bool attr_set = false;                     // raise the dynamic-LDS cap once per instantiation
@@ -192,7 +192,13 @@ int launch_conv(const ConvArgs& a, hipStream_t s) {
     }
     const int per_xcd = (a.m_tiles + 7) / 8;
     const unsigned grid = (unsigned)(8 * per_xcd * a.n_tiles);
-    hipLaunchKernelGGL((k_conv_igemm<WM, WN, MT, NT, MODE>), dim3(grid), dim3(256), lds, s, a);
+    {   // algorithmic work of this launch: 2*M*K*Cout with the REAL K (no padding); bytes = in + weights + out
+        const double k_real = MODE == MODE_ROW8 ? 3.0 * 49.0 : (double)a.Cin * a.ks * a.ks;
+        const double cin_real = MODE == MODE_ROW8 ? 3.0 : (double)a.Cin;
+        be::ProfileScope prof(s, kernel_id, 2.0 * a.M * k_real * a.Cout,
+                              4.0 * (a.M * cin_real + k_real * a.Cout + (double)a.M * a.Cout * (a.res ? 2 : 1)));
+        hipLaunchKernelGGL((k_conv_igemm<WM, WN, MT, NT, MODE>), dim3(grid), dim3(256), lds, s, a);
+    }
     return be::check_launch("be_conv_nhwc_f32");
 }
 
@@ -339,13 +345,13 @@ extern "C" int be_conv_nhwc_f32(const be_conv_desc* d, const float* x, const flo
     if (row8) {
         BE_REQUIRE(cp == 64, "be_conv_nhwc_f32: ksize 7 is built for cout 64 (got %d)", d->cout);
         a.n_tiles = 1;
-        return launch_conv<4, 1, 1, 2, MODE_ROW8>(a, s);
+        return launch_conv<4, 1, 1, 2, MODE_ROW8>(a, s, BE_KERNEL_CONV_ROW8_128x64);
     }
-    if (cp % 128 == 0) { a.n_tiles = cp / 128; return launch_conv<2, 2, 2, 2, MODE_TAPS>(a, s); }
-    if (cp % 96 == 0)  { a.n_tiles = cp / 96;  return launch_conv<4, 1, 1, 3, MODE_TAPS>(a, s); }
-    if (cp % 64 == 0)  { a.n_tiles = cp / 64;  return launch_conv<4, 1, 1, 2, MODE_TAPS>(a, s); }
+    if (cp % 128 == 0) { a.n_tiles = cp / 128; return launch_conv<2, 2, 2, 2, MODE_TAPS>(a, s, BE_KERNEL_CONV_128x128); }
+    if (cp % 96 == 0)  { a.n_tiles = cp / 96;  return launch_conv<4, 1, 1, 3, MODE_TAPS>(a, s, BE_KERNEL_CONV_128x96); }
+    if (cp % 64 == 0)  { a.n_tiles = cp / 64;  return launch_conv<4, 1, 1, 2, MODE_TAPS>(a, s, BE_KERNEL_CONV_128x64); }
     a.n_tiles = cp / 32;
-    return launch_conv<4, 1, 1, 1, MODE_TAPS>(a, s);
+    return launch_conv<4, 1, 1, 1, MODE_TAPS>(a, s, BE_KERNEL_CONV_128x32);
 }
 
 extern "C" int be_maxpool_nhwc_f32(const float* x, float* y, int n, int h, int w, int c, int k, int stride, int pad,

@@ -24,7 +24,8 @@ __device__ __forceinline__ float etas2depth(const be_depth_consts& c, float e1, 
     else if (c2 > 0.0f) { e11 = I + (e1 - e2 - I) / 2.0f;     e22 = (e2 - e1 + I) / 2.0f;   branch = 1; }
     else if (c3 < 0.0f) { e11 = I + sum_h;                    e22 = sum_h;                  branch = 2; }
     else                { e11 = e1;                           e22 = e2;                     branch = 3; }
-    return c.numerator / (c.k2 * (e11 * e11 - e22 * e22) + c.den_const);
+    // python_float / tensor is tensor.reciprocal() * python_float in PyTorch (Tensor.__rtruediv__): two roundings
+    return (1.0f / (c.k2 * (e11 * e11 - e22 * e22) + c.den_const)) * c.numerator;
 }
 
 // utils/depth_etas.py:36-37

@@ -147,6 +147,21 @@ int be_maxpool_nhwc_f32(const float* x, float* y, int n, int h, int w, int c, in
 /* [N,3,21,21] NCHW -> [N,21,21,4] NHWC with a zero 4th channel (input staging of conv1). */
 int be_nchw3_to_nhwc4_f32(const float* x, float* y, int64_t n, int hw, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------
+ * Measurement hooks (bench.py's roofline leg): opt-in hipEvent pair around every conv launch, recorded on
+ * the launch stream.  be_profile_enable(0) turns it off and frees the events.  Not thread-safe.
+ * ------------------------------------------------------------------------------------------------- */
+#define BE_KERNEL_CONV_128x128      0   /* k_conv_igemm<2,2,2,2,TAPS>: layers 1-3 + fc.1 (the dominant kernel) */
+#define BE_KERNEL_CONV_128x96       1   /* layer0                                                              */
+#define BE_KERNEL_CONV_128x64       2
+#define BE_KERNEL_CONV_128x32       3   /* fc.4                                                                */
+#define BE_KERNEL_CONV_ROW8_128x64  4   /* conv1 (7x7 row-gather)                                              */
+int be_profile_enable(int max_launches);
+int be_profile_reset(void);
+/* Waits for the recorded events; fills up to cap records (launch order); returns the number filled (>= 0)
+ * or a negative error.  flops/bytes = ALGORITHMIC work of the launch (unpadded K, in+weights+out bytes). */
+int be_profile_read(int* kernel_id_host, double* flops_host, double* bytes_host, float* ms_host, int cap);
+
 #ifdef __cplusplus
 }
 #endif
