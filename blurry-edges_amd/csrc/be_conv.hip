@@ -25,6 +25,7 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: HIP's float4 class kept staging arrays in scratch
 
 constexpr int BM = 128;
 constexpr int BK = 32;
@@ -40,8 +41,11 @@ struct ConvArgs {
     int M, H, W, HW, Cin, Cout, ldy, ks, nchunk, Ktot, act, m_tiles, n_tiles;
 };
 
+// __launch_bounds__(256, 2): LDS admits two blocks per CU (= 2 waves per SIMD), so let the register allocator use
+// up to 256 VGPR+AGPR: with the default budget it spilled the staged B chunk to scratch and waited for the global
+// loads BEFORE the MFMA phase (v1: 60 % MFMA-busy).
 template <int WM, int WN, int MT, int NT, int MODE>
-__global__ __launch_bounds__(256)
+__global__ __launch_bounds__(256, 2)
 void k_conv_igemm(ConvArgs a) {
     static_assert(WM * WN == 4 && WM * MT * 32 == BM, "4 waves, 128 rows");
     constexpr int BN = WN * NT * 32;
@@ -78,38 +82,46 @@ void k_conv_igemm(ConvArgs a) {
     }
     const float* wrow = a.w + (size_t)(n0 + r0) * a.Ktot + 4 * q;
 
-    float4 a_st[4], b_st[NB];
-    auto load_chunk = [&](int kc) {
-        int dy, dx, coff;
-        if (MODE == MODE_TAPS) {
-            const int taps = a.ks * a.ks;
-            const int cc = kc / taps, tap = kc - cc * taps;
-            const int half = a.ks >> 1;
-            dy = tap / a.ks - half; dx = tap % a.ks - half;
-            coff = (dy * a.W + dx) * a.Cin + cc * BK + 4 * q;
-        } else {                                       // conv1: chunk = kernel row kh, 8 pixels x 4 channels
-            dy = kc - 3; dx = q - 3;
-            coff = (dy * a.W + dx) * 4;
-        }
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int yy = (a_yx[i] >> 16) + dy, xx = (a_yx[i] & 0xffff) + dx;
-            const bool ok = a_yx[i] >= 0 && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
-            const float4* src = reinterpret_cast<const float4*>(a.x + (size_t)a_off[i] * a.Cin + coff);
-            a_st[i] = ok ? *src : make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-#pragma unroll
-        for (int i = 0; i < NB; ++i)
-            b_st[i] = *reinterpret_cast<const float4*>(wrow + (size_t)(32 * i) * a.Ktot + kc * BK);
-    };
-    auto store_chunk = [&](int buf) {
-        float* Ad = As + buf * BM * LDS_ROW;
-        float* Bd = Bs + buf * BN * LDS_ROW;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(Ad + (r0 + 32 * i) * LDS_ROW + 4 * q) = a_st[i];
-#pragma unroll
-        for (int i = 0; i < NB; ++i) *reinterpret_cast<float4*>(Bd + (r0 + 32 * i) * LDS_ROW + 4 * q) = b_st[i];
-    };
+    // Staging registers for the next K chunk.  Straight-line helpers on array references (no lambdas, no
+    // conditionals around the loads): anything else made hipcc keep b_st in scratch memory.
+    f32x4 a_st[4], b_st[NB];
+    unsigned a_ok = 0;                                 // bit i: a_st[i] is inside the image (else stored as zeros)
+#define BE_LOAD_CHUNK(KC)                                                                                       \
+    do {                                                                                                        \
+        int dy_, dx_, coff_;                                                                                    \
+        if (MODE == MODE_TAPS) {                                                                                \
+            const int taps_ = a.ks * a.ks;                                                                      \
+            const int cc_ = (KC) / taps_, tap_ = (KC) - cc_ * taps_;                                            \
+            const int half_ = a.ks >> 1;                                                                        \
+            dy_ = tap_ / a.ks - half_; dx_ = tap_ % a.ks - half_;                                               \
+            coff_ = (dy_ * a.W + dx_) * a.Cin + cc_ * BK + 4 * q;                                               \
+        } else { /* conv1: chunk = kernel row kh, 8 pixels x 4 channels */                                      \
+            dy_ = (KC) - 3; dx_ = q - 3;                                                                        \
+            coff_ = (dy_ * a.W + dx_) * 4;                                                                      \
+        }                                                                                                       \
+        a_ok = 0;                                                                                               \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                      \
+            const int yy_ = (a_yx[i_] >> 16) + dy_, xx_ = (a_yx[i_] & 0xffff) + dx_;                            \
+            const bool ok_ = a_yx[i_] >= 0 && (unsigned)yy_ < (unsigned)a.H && (unsigned)xx_ < (unsigned)a.W;   \
+            /* branch-free: out-of-image taps read the (valid) first 16 B of the tensor and are zeroed */      \
+            int64_t off_ = ok_ ? (int64_t)a_off[i_] * a.Cin + coff_ : 0;                                        \
+            asm volatile("" : "+v"(off_));  /* opaque: keeps the load unconditional (no exec-mask branch) */    \
+            a_st[i_] = *reinterpret_cast<const f32x4*>(a.x + off_);  /* zeroed at store time: no wait here */   \
+            a_ok |= (ok_ ? 1u : 0u) << i_;                                                                      \
+        }                                                                                                       \
+        _Pragma("unroll") for (int i_ = 0; i_ < NB; ++i_)                                                       \
+            b_st[i_] = *reinterpret_cast<const f32x4*>(wrow  + (size_t)(32 * i_) * a.Ktot + (KC) * BK);         \
+    } while (0)
+#define BE_STORE_CHUNK(BUF)                                                                                     \
+    do {                                                                                                        \
+        float* Ad_ = As + (BUF) * BM * LDS_ROW;                                                                 \
+        float* Bd_ = Bs + (BUF) * BN * LDS_ROW;                                                                 \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                        \
+            *reinterpret_cast<f32x4*>(Ad_  + (r0 + 32 * i_) * LDS_ROW + 4 * q) =                                \
+                ((a_ok >> i_) & 1u) ? a_st[i_] : f32x4{0.f, 0.f, 0.f, 0.f};                                     \
+        _Pragma("unroll") for (int i_ = 0; i_ < NB; ++i_)                                                       \
+            *reinterpret_cast<f32x4*>(Bd_  + (r0 + 32 * i_) * LDS_ROW + 4 * q) = b_st[i_];                      \
+    } while (0)
 
     // ---- wave / lane roles for the MFMA phase
     const int wave = tid >> 6, lane = tid & 63;
@@ -126,23 +138,25 @@ void k_conv_igemm(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    load_chunk(0);
-    store_chunk(0);
+    BE_LOAD_CHUNK(0);
+    BE_STORE_CHUNK(0);
     __syncthreads();
 
     for (int kc = 0; kc < a.nchunk; ++kc) {
         const int buf = kc & 1;
-        const bool more = kc + 1 < a.nchunk;
-        if (more) load_chunk(kc + 1);
+        // always prefetch (the last iteration re-reads its own chunk into the idle buffer: keeps the body branch-free)
+        const int kn = kc + 1 < a.nchunk ? kc + 1 : kc;
+        BE_LOAD_CHUNK(kn);
+        __builtin_amdgcn_sched_barrier(0);            // the loads stay ABOVE the MFMA phase (hipcc sank them below it)
         const float* Ab = As + buf * BM * LDS_ROW + a_frag0;
         const float* Bb = Bs + buf * BN * LDS_ROW + b_frag0;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            float4 af[MT], bf[NT];
+            f32x4 af[MT], bf[NT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const float4*>(Ab + i * 32 * LDS_ROW + 8 * g);
+            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDS_ROW + 8 * g);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const float4*>(Bb + j * 32 * LDS_ROW + 8 * g);
+            for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDS_ROW + 8 * g);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -153,9 +167,12 @@ void k_conv_igemm(ConvArgs a) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
                 }
         }
-        if (more) store_chunk(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);            // ... and the LDS hand-over stays below it
+        BE_STORE_CHUNK(buf ^ 1);
         __syncthreads();
     }
+#undef BE_LOAD_CHUNK
+#undef BE_STORE_CHUNK
 
     // ---- epilogue: D[row][col], col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
