@@ -139,7 +139,7 @@ def main():
     #      stream = torch's current stream); dominant kernel = the 128x128 fp32-MFMA implicit-GEMM conv
     roof = None
     if rank == 0:
-        per_step = 15 * ((2 * PAIRS + 4095) // 4096 + 1)
+        per_step = 15 * ((2 * PAIRS + 1023) // 1024 + 1)
         cap = per_step * args.steps
         native.profile_enable(cap)
         torch.cuda.synchronize()

@@ -113,7 +113,7 @@ size_t be_local_stage_packed_floats(void);
 int be_local_stage_pack_f32(const float* const* tensors_host /* [86] device ptrs */, float bn_eps,
                             float* packed, void* stream);
 
-/* The batch is walked in sub-batches of `patches` (default 4096) so that inter-layer activations stay in
+/* The batch is walked in sub-batches of `patches` (default 8192) so that inter-layer activations stay in
  * the Infinity Cache and the workspace is bounded; affects be_local_stage_workspace_bytes(). */
 int be_local_stage_set_chunk(int patches);
 
