@@ -29,6 +29,14 @@ class RenderOpts(C.Structure):
                 ("wrap_angles", C.c_int), ("lin", C.c_float * BE_R)]
 
 
+class PatchView(C.Structure):
+    _fields_ = [("base", C.c_void_p), ("s_aperture", C.c_int64), ("s_chan", C.c_int64), ("s_row", C.c_int64),
+                ("s_col", C.c_int64), ("s_pi", C.c_int64), ("s_pj", C.c_int64), ("wp", C.c_int)]
+
+
+RECORD_FLOATS = 32
+
+
 class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("n", "h", "w", "cin", "cout", "ksize", "act")]
 
@@ -52,6 +60,12 @@ _SIGNATURES = {
     "be_conv_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, C.c_int, _P]),
     "be_maxpool_nhwc_f32": (C.c_int, [_P, _P] + [C.c_int] * 7 + [_P]),
     "be_nchw3_to_nhwc4_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
+    "be_render_full_f32": (C.c_int, [C.POINTER(RenderOpts), C.POINTER(DepthConsts), C.c_float, C.c_int, _P,
+                                     C.POINTER(PatchView), _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
+    "be_fold_records_f32": (C.c_int, [C.POINTER(RenderOpts), _P] + [C.c_int] * 6 + [_P] * 6 + [_P]),
+    "be_unfold_patches_f32": (C.c_int, [_P, _P] + [C.c_int] * 5 + [_P]),
+    "be_local_features_f32": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
+    "be_global_denorm_f32": (C.c_int, [_P, _P, C.c_int64, _P]),
     "be_profile_enable": (C.c_int, [C.c_int]),
     "be_profile_reset": (C.c_int, []),
     "be_profile_read": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -251,3 +265,95 @@ def profile_read(cap: int):
     if n < 0:
         check(n, "be_profile_read")
     return [(ids[i], fl[i], by[i], ms[i]) for i in range(n)]
+
+
+# ---------------------------------------------------------------------------------------------- pass B / tiling
+
+def view_image_pair(img: torch.Tensor, stride: int = 2) -> PatchView:
+    """img [2,3,H,W] -> gather-on-read view of its (H-21)/stride+1 x (W-21)/stride+1 patch grid."""
+    if img.dim() != 4 or img.shape[0] != 2 or img.shape[1] != 3:
+        raise RuntimeError(f"view_image_pair: expected [2,3,H,W], got {tuple(img.shape)}")
+    dptr(img, "img")
+    _, _, h, w = img.shape
+    return PatchView(img.data_ptr(), 3 * h * w, h * w, w, 1, stride * w, stride, (w - BE_R) // stride + 1)
+
+
+def view_flat_patches(pat: torch.Tensor, wp: int) -> PatchView:
+    """pat [2,P,3,21,21] (what unfold_patches returns for an image pair)."""
+    if pat.dim() != 5 or pat.shape[0] != 2 or tuple(pat.shape[2:]) != (3, BE_R, BE_R):
+        raise RuntimeError(f"view_flat_patches: expected [2,P,3,21,21], got {tuple(pat.shape)}")
+    dptr(pat, "patches")
+    p = pat.shape[1]
+    return PatchView(pat.data_ptr(), 3 * NPIX * p, NPIX, BE_R, 1, 3 * NPIX * wp, 3 * NPIX, wp)
+
+
+def view_unfolded(t: torch.Tensor) -> PatchView:
+    """t [2,3,21,21,Hp,Wp]: the layout nn.Unfold(...).view(...) has in blurry_edges_test.py:120."""
+    if t.dim() != 6 or t.shape[0] != 2 or tuple(t.shape[1:4]) != (3, BE_R, BE_R):
+        raise RuntimeError(f"view_unfolded: expected [2,3,21,21,Hp,Wp], got {tuple(t.shape)}")
+    dptr(t, "img_patches")
+    hp, wp = t.shape[4], t.shape[5]
+    p = hp * wp
+    return PatchView(t.data_ptr(), 3 * NPIX * p, NPIX * p, BE_R * p, p, wp, 1, wp)
+
+
+def render_full(opts, consts, rho_prime, densify_w, params12, view: PatchView, want=()):
+    """params12 [P,12] -> records [P,32] (+ optional per-patch tensors named in `want`:
+    'patches','shpd','refoc','boundary','depth_map','depth_mask')."""
+    n = params12.shape[0]
+    if tuple(params12.shape) != (n, 12):
+        raise RuntimeError(f"render_full: params12 must be [P,12], got {tuple(params12.shape)}")
+    dev = params12.device
+    rec = torch.empty(n, RECORD_FLOATS, dtype=torch.float32, device=dev)
+    shapes = dict(patches=(n, 2, 3, BE_R, BE_R), shpd=(n, 3, BE_R, BE_R), refoc=(n, 3, BE_R, BE_R),
+                  boundary=(n, BE_R, BE_R), depth_map=(n, BE_R, BE_R), depth_mask=(n, BE_R, BE_R))
+    extra = {k: torch.empty(shapes[k], dtype=torch.int32 if k == "depth_mask" else torch.float32, device=dev) for k in want}
+    g = lambda k: dptr(extra.get(k))
+    check(lib().be_render_full_f32(C.byref(opts), C.byref(consts), float(rho_prime), int(bool(densify_w)),
+                                   dptr(params12, "params12"), C.byref(view), dptr(rec), g("patches"), g("shpd"),
+                                   g("refoc"), g("boundary"), g("depth_map"), g("depth_mask"), n, stream_ptr(dev)),
+          "be_render_full_f32")
+    return rec, extra
+
+
+FOLD_MAPS = ("image", "shpd", "refoc", "bndry", "depth", "conf")
+
+
+def fold_records(opts, records, hp, wp, H, W, stride=2, densify_w=False, want=FOLD_MAPS):
+    if tuple(records.shape) != (hp * wp, RECORD_FLOATS):
+        raise RuntimeError(f"fold_records: records must be [{hp * wp},{RECORD_FLOATS}], got {tuple(records.shape)}")
+    dev = records.device
+    shapes = dict(image=(2, 3, H, W), shpd=(3, H, W), refoc=(3, H, W), bndry=(H, W), depth=(H, W), conf=(H, W))
+    out = {k: torch.empty(shapes[k], dtype=torch.float32, device=dev) for k in want}
+    g = lambda k: dptr(out.get(k))
+    check(lib().be_fold_records_f32(C.byref(opts), dptr(records, "records"), hp, wp, H, W, stride, int(bool(densify_w)),
+                                    g("image"), g("shpd"), g("refoc"), g("bndry"), g("depth"), g("conf"),
+                                    stream_ptr(dev)), "be_fold_records_f32")
+    return out
+
+
+def unfold_patches(img: torch.Tensor, stride: int = 2) -> torch.Tensor:
+    """img [B,C,H,W] -> [B, Hp*Wp, C, 21, 21]."""
+    b, c, h, w = img.shape
+    hp, wp = (h - BE_R) // stride + 1, (w - BE_R) // stride + 1
+    out = torch.empty(b, hp * wp, c, BE_R, BE_R, dtype=torch.float32, device=img.device)
+    check(lib().be_unfold_patches_f32(dptr(img, "img"), dptr(out), b, c, h, w, stride, stream_ptr(img.device)),
+          "be_unfold_patches_f32")
+    return out
+
+
+def local_features(params10: torch.Tensor, colors: torch.Tensor) -> torch.Tensor:
+    """params10 [2,P,10] (or [2P,10]) + colors [2,P,3,3] (or [2P,3,3]) -> pm [P,38]."""
+    p = params10.numel() // 20
+    pm = torch.empty(p, 38, dtype=torch.float32, device=params10.device)
+    check(lib().be_local_features_f32(dptr(params10, "params10"), dptr(colors, "colors"), dptr(pm), p,
+                                      stream_ptr(params10.device)), "be_local_features_f32")
+    return pm
+
+
+def global_denorm(y: torch.Tensor) -> torch.Tensor:
+    """y [P,12] -> est [P,12]."""
+    y = y.contiguous()
+    est = torch.empty_like(y)
+    check(lib().be_global_denorm_f32(dptr(y, "y"), dptr(est), y.numel() // 12, stream_ptr(y.device)), "be_global_denorm_f32")
+    return est

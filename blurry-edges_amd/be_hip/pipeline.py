@@ -1,0 +1,92 @@
+"""End-to-end depth estimation for one image pair: the build's counterpart of the reference's evaluation
+harness (depth_estimator in blurry_edges_test.py:102-145 and blurry_edges_test_big.py:113-192).
+
+image pair [2,3,H,W]  ->  unfold  ->  LocalStage (HIP)  ->  pass-A colours (HIP)  ->  feature normalisation (HIP)
+  ->  GlobalStage (PyTorch-ROCm, boundary kept)  ->  de-normalisation (HIP)  ->  pass-B records (HIP)
+  ->  owner-computes fold (HIP)  ->  six maps + thresholded depth.
+Nothing here computes on the CPU; tensors stay on the GPU until the caller asks for them.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+
+from . import native
+
+
+class DepthPipeline:
+    def __init__(self, local_module, global_module, helper, depth_cal, rho_prime=10.39, densify=None, stride=2):
+        """helper: a utils.PostProcessGlobalBase (render options); depth_cal: utils.DepthEtas."""
+        if densify not in (None, "w"):
+            raise NotImplementedError("densify='pp' needs the DepthCompletion U-Net (out of scope, SURVEY §8f-4)")
+        self.local, self.globl = local_module, global_module
+        self.helper, self.dcal = helper, depth_cal
+        self.rho_prime, self.densify, self.stride = rho_prime, densify, stride
+        self.depth_thres = 0.0 if densify == "w" else 0.05          # blurry_edges_test.py:109-112
+
+    # ---- stages --------------------------------------------------------------------------------------
+    def local_pass(self, img):
+        """img [2,3,H,W] -> (patches [2,P,3,21,21], est10 [2P,10], colors [2P,3,3], pm [P,38])."""
+        pat = native.unfold_patches(img, self.stride)
+        flat = pat.view(-1, 3, native.BE_R, native.BE_R)
+        est10 = self.local(flat)
+        colors, _ = self.helper.render_colors(est10, flat, wrap_angles=True)
+        pm = native.local_features(est10, colors)
+        return pat, est10, colors, pm
+
+    def global_pass(self, pm):
+        """pm [P,38] -> est12 [P,12] (de-normalised wedge parameters)."""
+        y = self.globl(pm.unsqueeze(0))
+        return native.global_denorm(y[0])
+
+    def records(self, est12, img, want=()):
+        opts = self.helper.render_opts(wrap_angles=False)
+        return native.render_full(opts, self.dcal.consts, self.rho_prime, self.densify == "w", est12,
+                                  native.view_image_pair(img, self.stride), want=want)
+
+    # ---- one 147x147 pair (blurry_edges_test.py:117-145) ---------------------------------------------
+    @torch.no_grad()
+    def __call__(self, img):
+        img = img.contiguous()
+        _, _, H, W = img.shape
+        hp, wp = (H - native.BE_R) // self.stride + 1, (W - native.BE_R) // self.stride + 1
+        _, est10, colors, pm = self.local_pass(img)
+        est12 = self.global_pass(pm)
+        rec, _ = self.records(est12, img)
+        maps = native.fold_records(self.helper.render_opts(False), rec, hp, wp, H, W, self.stride, self.densify == "w")
+        maps["depth_map"] = torch.where(maps["conf"] > self.depth_thres, maps["depth"], torch.zeros_like(maps["depth"]))
+        maps.update(est10=est10, colors_a=colors, est12=est12, records=rec)
+        return maps
+
+    # ---- big image: 147x147 blocks with margin patches dropped (blurry_edges_test_big.py:116-189) -----
+    @torch.no_grad()
+    def run_big(self, img, block=147, n_margin=10):
+        img = img.contiguous()
+        _, _, H, W = img.shape
+        s, R = self.stride, native.BE_R
+        bstride = block - R + s - 2 * s * n_margin                                  # 88
+        nb_v = math.ceil((H - R - 2 * s * n_margin + s) / bstride)
+        nb_h = math.ceil((W - R - 2 * s * n_margin + s) / bstride)
+        hp = (block - R) // s + 1                                                   # 64
+        HP, WP = (H - R) // s + 1, (W - R) // s + 1                                 # 284
+        step = bstride // s
+        # every block's patches through the CNN in ONE batch (blocks are independent until the transformer)
+        blocks = [img[:, :, bi * bstride:bi * bstride + block, bj * bstride:bj * bstride + block].contiguous()
+                  for bi in range(nb_v) for bj in range(nb_h)]
+        big = torch.zeros(HP * WP, native.RECORD_FLOATS, dtype=torch.float32, device=img.device).view(HP, WP, -1)
+        k = 0
+        for bi in range(nb_v):
+            for bj in range(nb_h):
+                b = blocks[k]; k += 1
+                _, _, _, pm = self.local_pass(b)
+                est12 = self.global_pass(pm)
+                rec, _ = self.records(est12, b)
+                vs = 0 if bi == 0 else n_margin
+                ve = hp if bi == nb_v - 1 else hp - n_margin
+                hs = 0 if bj == 0 else n_margin
+                he = hp if bj == nb_h - 1 else hp - n_margin
+                big[bi * step + vs:bi * step + ve, bj * step + hs:bj * step + he] = rec.view(hp, hp, -1)[vs:ve, hs:he]
+        maps = native.fold_records(self.helper.render_opts(False), big.view(HP * WP, -1), HP, WP, H, W, s, self.densify == "w")
+        maps["depth_map"] = torch.where(maps["conf"] > 0.05, maps["depth"], torch.zeros_like(maps["depth"]))
+        return maps

@@ -240,3 +240,37 @@ def synthetic_image_pair(h: int = 147, w: int = 147, seed: int = SEED_DEFAULT, n
     lam = imgs * alpha
     imgs = np.rint(np.clip(lam + np.sqrt(np.maximum(lam, 0)) * g, 0, alpha)) / alpha
     return f32(imgs), f32(depth)
+
+
+# ---------------------------------------------------------------------------------------
+# GlobalStage weights (state-dict layout of models/global_stage.py:23-33; SURVEY §8b, 102 entries)
+# ---------------------------------------------------------------------------------------
+
+def global_stage_state_dict(seed: int = SEED_DEFAULT, d_model=128, nlayers=8, d_ff=256, d_in=38, d_out=12):
+    sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
+
+    def lin(name, o, i, gain=1.0):
+        std = gain * math.sqrt(2.0 / (i + o))
+        sd[name + ".weight" if not name.endswith("_weight") else name] = f32(std * hash_normal(seed, "g." + name + ".w", (o, i)))
+
+    def vec(name, n, lo, hi):
+        sd[name] = f32(lo + (hi - lo) * hash_uniform(seed, "g." + name, (n,)))
+
+    lin("in_src_projection", d_model, d_in); vec("in_src_projection.bias", d_model, -0.05, 0.05)
+    for l in range(nlayers):
+        p = f"encoder.layers.{l}."
+        sd[p + "self_attn.in_proj_weight"] = f32(math.sqrt(2.0 / (4 * d_model)) * hash_normal(seed, "g." + p + "inw", (3 * d_model, d_model)))
+        vec(p + "self_attn.in_proj_bias", 3 * d_model, -0.05, 0.05)
+        lin(p + "self_attn.out_proj", d_model, d_model); vec(p + "self_attn.out_proj.bias", d_model, -0.05, 0.05)
+        lin(p + "linear1", d_ff, d_model); vec(p + "linear1.bias", d_ff, -0.05, 0.05)
+        lin(p + "linear2", d_model, d_ff); vec(p + "linear2.bias", d_model, -0.05, 0.05)
+        vec(p + "norm1.weight", d_model, 0.8, 1.2); vec(p + "norm1.bias", d_model, -0.1, 0.1)
+        vec(p + "norm2.weight", d_model, 0.8, 1.2); vec(p + "norm2.bias", d_model, -0.1, 0.1)
+    vec("encoder.norm.weight", d_model, 0.8, 1.2); vec("encoder.norm.bias", d_model, -0.1, 0.1)
+    lin("generator", d_out, d_model, gain=0.5); vec("generator.bias", d_out, -0.05, 0.05)
+    return sd
+
+
+def global_features(p: int = 4096, seed: int = SEED_DEFAULT, name: str = "pm") -> np.ndarray:
+    """[1,P,38] normalised features in the range blurry_edges_test.py:129-132 produces ([-1,1]-ish)."""
+    return f32(-1.0 + 2.0 * hash_uniform(seed, name, (1, p, 38)))

@@ -1,1 +1,2 @@
 from .local_stage import LocalStage
+from .global_stage import GlobalStage

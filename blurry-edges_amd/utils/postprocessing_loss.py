@@ -47,13 +47,16 @@ class PostProcessBase(nn.Module, ABC):
         return torch.exp(-x ** 2 / delta ** 2)
 
     # ---- fused passes (flat layout)
+    def render_opts(self, wrap_angles=False):
+        opts = native.RenderOpts.from_buffer_copy(self._opts)
+        opts.wrap_angles = int(bool(wrap_angles))
+        return opts
+
     def render_colors(self, params10, patches, wrap_angles=False, want=()):
         """Colours-only pass: params10 [N,10], patches [N,3,21,21] -> (colors [N,3(rgb),3(wedge)], extras).
         One launch replaces params2dists + params2etas + dists2indicators + the ridge solve
         (utils/postprocessing_loss.py:43-112; blurry_edges_test.py:19-34)."""
-        opts = native.RenderOpts.from_buffer_copy(self._opts)
-        opts.wrap_angles = int(bool(wrap_angles))
-        return native.render_colors(opts, params10.contiguous(), patches.contiguous(), want=want)
+        return native.render_colors(self.render_opts(wrap_angles), params10.contiguous(), patches.contiguous(), want=want)
 
 
 class PostProcessLocalBase(PostProcessBase):

@@ -98,6 +98,55 @@ int be_render_colors_f32(const be_render_opts* opts_host, const float* params10,
                          float* gram, float* aty, int64_t n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * Full render pass ("pass B") + overlap aggregation
+ *   replaces PostProcess.get_patches(colors_only=False) (blurry_edges_test.py:36-79) and the six nn.Fold
+ *   aggregations local2global_{color,bndry,depth} (utils/postprocessing_loss.py:151-173; the big-image
+ *   stitching of blurry_edges_test_big.py:166-189 is the same fold over a 284x284 record grid).
+ * ------------------------------------------------------------------------------------------------- */
+
+/* Strided view of the pixel data of a grid of patch positions, so the kernels gather on read from whatever the
+ * caller has: an image pair [2,3,H,W] (s_aperture=3HW, s_chan=HW, s_row=W, s_col=1, s_pi=stride*W, s_pj=stride),
+ * the reference's unfolded tensor [2,3,21,21,Hp,Wp] (s_chan=441*P, s_row=21*P, s_col=P, s_pi=Wp, s_pj=1) or
+ * flat patches [2,P,3,21,21] (s_aperture=1323*P, s_chan=441, s_row=21, s_col=1, s_pi=1323*Wp, s_pj=1323).
+ * Strides are in floats; patch p sits at grid position (p / wp, p % wp). */
+typedef struct be_patch_view {
+    const float* base;
+    int64_t s_aperture, s_chan, s_row, s_col, s_pi, s_pj;
+    int wp;
+} be_patch_view;
+
+#define BE_RECORD_FLOATS 32   /* per-patch state handed from be_render_full_f32 to be_fold_records_f32 (128 B):
+                                 geometry 14, sqrt2*eta for aperture 1 / aperture 2 / refocus 2+2+2, colours 9
+                                 ([rgb][wedge]), wedge depths 2, mask-presence flags 1 */
+
+/* params12 [P,12] = 8 shared geometry + eta coefficients (w1,img1),(w2,img1),(w1,img2),(w2,img2), de-normalised
+ * (blurry_edges_test.py:135-138); records [P,32] out.  Optional per-patch tensors in the reference's pixel order
+ * (NULL to skip): patches [P,2,3,21,21], shpd [P,3,21,21], refoc [P,3,21,21], boundary [P,21,21],
+ * depth_map [P,21,21], depth_mask int32 [P,21,21].  densify_w: 1 = the '--densify w' mask rule (:47-50).
+ * opts->wrap_angles is honoured (0 for de-normalised parameters, which are already in [0,2pi)). */
+int be_render_full_f32(const be_render_opts* opts_host, const be_depth_consts* consts_host, float rho_prime,
+                       int densify_w, const float* params12, const be_patch_view* view_host, float* records,
+                       float* patches, float* shpd, float* refoc, float* boundary, float* depth_map,
+                       int32_t* depth_mask, int64_t n, void* stream);
+
+/* Owner-computes fold of a hp x wp record grid onto an H x W image (stride = patch stride, 2).  Outputs (NULL to
+ * skip): image [2,3,H,W], shpd [3,H,W], refoc [3,H,W], bndry [H,W] (all / overlap count), depth [H,W] (mean
+ * over patches whose mask covers the pixel) and conf [H,W] (that count / overlap count). */
+int be_fold_records_f32(const be_render_opts* opts_host, const float* records, int hp, int wp, int H, int W,
+                        int stride, int densify_w, float* image, float* shpd, float* refoc, float* bndry,
+                        float* depth, float* conf, void* stream);
+
+/* nn.Unfold(21, stride) in the order blurry_edges_test.py:120-121 consumes it:
+ * img [B,C,H,W] -> out [B, Hp*Wp, C, 21, 21], patch (i,j) = rows stride*i.., cols stride*j.., index i*Wp+j. */
+int be_unfold_patches_f32(const float* img, float* out, int B, int C, int H, int W, int stride, void* stream);
+
+/* Feature normalisation between the two stages (blurry_edges_test.py:123-132):
+ * params10 [2,P,10] (raw CNN output, image-major) + colors [2,P,9] -> pm [P,38]. */
+int be_local_features_f32(const float* params10, const float* colors, float* pm, int64_t P, void* stream);
+/* De-normalisation of the GlobalStage output (blurry_edges_test.py:134-138): y [P,12] -> est [P,12]. */
+int be_global_denorm_f32(const float* y, float* est, int64_t P, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * LocalStage CNN  (models/local_stage.py:30-73), inference (BatchNorm folded into the convs)
  * ------------------------------------------------------------------------------------------------- */
 

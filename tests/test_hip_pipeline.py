@@ -1,0 +1,213 @@
+"""GPU parity tests for the full render pass, the fold, the tiling glue and the end-to-end pipeline
+(BASELINE.json configs[3]: 147x147 image tiled into overlapping patches + GlobalStage aggregation)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, relmax
+from be_hip import synth
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def T(a, dt=torch.float32):
+    return torch.from_numpy(np.asarray(a)).to(dt)
+
+
+@pytest.fixture(scope="module")
+def env():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a GPU")
+    import utils
+    from be_hip import native
+    native.lib()
+    a = utils.get_args("eval", argv=[])
+    return dict(native=native, args=a, helper=utils.PostProcessGlobalBase(a, DEV), dcal=utils.DepthEtas(a, DEV))
+
+
+def test_unfold_order_bit_exact(env):
+    g = load_golden("g7_tiling")
+    idx = torch.arange(3 * 147 * 147, dtype=torch.float32).view(1, 3, 147, 147)
+    vec = env["native"].unfold_patches(idx.to(DEV))[0].cpu()
+    assert np.array_equal(vec[g["sel"]].numpy().astype(np.int32), g["vec_sel"])
+    assert np.array_equal(vec.double().sum(dim=(1, 2, 3)).numpy(), g["vec_rowsum"])
+
+
+def test_feature_glue_vs_oracle(env):
+    from oracle import glue
+    n = env["native"]
+    p10 = T(synth.plausible_params10(8192, name="glue")).view(2, 4096, 10)
+    p10[:, :, 4:8] += 7.0 * T(synth.hash_normal(1, "glue_shift", (2, 4096, 4)))      # unwrapped angles, both signs
+    col = T(synth.hash_uniform(2, "glue_col", (2, 4096, 3, 3)).astype(np.float32))
+    pm = n.local_features(p10.to(DEV), col.to(DEV))
+    assert relmax(pm.cpu(), glue.local_features(p10, col)) <= 1e-6
+    y = T((-1 + 2 * synth.hash_uniform(3, "glue_y", (4096, 12))).astype(np.float32))
+    assert relmax(n.global_denorm(y.to(DEV)).cpu(), glue.global_denorm(y)) <= 1e-6
+
+
+def _pass_b(env, densify, want):
+    n = env["native"]
+    imgs, _ = synth.synthetic_image_pair(147, 147)
+    img = T(imgs).to(DEV)
+    p12 = T(synth.plausible_params12(4096, name="g6_est")).to(DEV)
+    opts = env["helper"].render_opts(False)
+    rec, ex = n.render_full(opts, env["dcal"].consts, 10.39, densify == "w", p12, n.view_image_pair(img), want=want)
+    return img, p12, opts, rec, ex
+
+
+@pytest.mark.parametrize("densify,tag", [(None, ""), ("w", "w_")])
+def test_pass_b_per_patch_outputs_vs_golden_and_fp64_oracle(env, densify, tag):
+    from oracle import render as orr, depth as od, tiling as ot
+    g = load_golden("g6_postprocess_147")
+    img, p12, opts, rec, ex = _pass_b(env, densify, ("patches", "shpd", "refoc", "boundary", "depth_map", "depth_mask"))
+    ii, jj = np.meshgrid(np.arange(20, 24), np.arange(30, 34), indexing="ij")
+    sel = (ii * 64 + jj).ravel()
+
+    def sub(key):
+        a = g[tag + key]
+        return np.moveaxis(a.reshape(a.shape[:-2] + (16,)), -1, 0)
+    c = lambda k: ex[k].cpu().numpy()
+    # hard decisions: identical to the reference on identical inputs
+    assert np.array_equal(c("depth_mask")[sel], sub("sub_dmask"))
+    assert np.array_equal(np.bincount(c("depth_mask").ravel(), minlength=3), g[tag + "mask_hist"])
+    assert relmax(c("depth_map")[sel], sub("sub_dmap")) <= 1e-6
+    assert relmax(c("boundary")[sel], sub("sub_bnd")) <= 1e-5
+    # colour-dependent outputs against the float64 oracle
+    pat = ot.unfold_patches(img.cpu())
+    r64 = orr.render_pass_b(od.depth_consts(), p12.cpu().double(), pat[0].double(), pat[1].double(), densify=densify)
+    assert relmax(rec[:, 20:29].cpu(), r64["colors"].reshape(-1, 9)) <= 1e-4
+    assert relmax(c("patches"), torch.stack([r64["patches1"], r64["patches2"]], dim=1)) <= 1e-4
+    # sharpened render: eta = 1e-4 turns erf into a step, so a pixel within ~1e-4 of an edge is sensitive to the
+    # fp32 rounding of its own distance (App. C: wedges differ by up to 3e-4 between fp32 and fp64 reference runs)
+    es = np.abs(c("shpd") - r64["shpd"].numpy()) / float(r64["shpd"].abs().max())
+    assert float((es > 1e-4).mean()) <= 1e-4 and float(es.max()) <= 5e-3
+    # refocus: eta_refoc = depth2sigma(fp32 depth) can be as small as ~1e-3 near the refocus plane: same sensitivity
+    er = np.abs(c("refoc") - r64["refoc"].numpy()) / float(r64["refoc"].abs().max())
+    assert float((er > 1e-4).mean()) <= 1e-5 and float(er.max()) <= 1e-3
+    assert relmax(rec[:, 29:31].cpu(), torch.stack([r64["depth1"], r64["depth2"]], dim=1)) <= 1e-6
+    # the reference's own fp32 patches are within its fp32-vs-fp64 noise of ours
+    assert relmax(c("patches")[sel], sub("sub_patches")) <= 2e-2
+
+
+@pytest.mark.parametrize("densify,tag", [(None, ""), ("w", "w_")])
+def test_fold_maps_vs_golden(env, densify, tag):
+    g = load_golden("g6_postprocess_147")
+    n = env["native"]
+    img, p12, opts, rec, _ = _pass_b(env, densify, ())
+    m = n.fold_records(opts, rec, 64, 64, 147, 147, 2, densify == "w")
+    c = lambda k: m[k].cpu().numpy()
+    assert relmax(c("conf"), g[tag + "fold_conf"][0]) <= 1e-6
+    assert relmax(c("depth"), g[tag + "fold_depth"][0]) <= 1e-5
+    assert relmax(c("bndry"), g[tag + "fold_bndry"][0, 0]) <= 1e-5
+    # colour maps: the reference's fp32 Cayley-Hamilton noise averages down in the fold (App. C: 3.3e-4)
+    assert relmax(c("image"), g[tag + "fold_image"][0]) <= 5e-3
+    assert relmax(c("shpd"), g[tag + "fold_shpd"][0]) <= 1e-2
+    assert relmax(c("refoc"), g[tag + "fold_refoc"][0]) <= 5e-3
+    # tighter: against the float64 oracle fold of the float64 oracle render
+    from oracle import render as orr, depth as od, tiling as ot
+    pat = ot.unfold_patches(img.cpu())
+    r64 = orr.render_pass_b(od.depth_consts(), p12.cpu().double(), pat[0].double(), pat[1].double(), densify=densify)
+    fi = ot.fold_mean(torch.stack([r64["patches1"], r64["patches2"]]), 147, 147)
+    assert relmax(c("image"), fi) <= 1e-4
+    assert relmax(c("refoc"), ot.fold_mean(r64["refoc"][None], 147, 147)[0]) <= 1e-4
+    # a view over materialised patches gives the same records as the image view (gather-on-read is layout-blind)
+    pats = n.unfold_patches(img)
+    rec2, _ = n.render_full(opts, env["dcal"].consts, 10.39, densify == "w", p12, n.view_flat_patches(pats, 64))
+    assert torch.equal(rec, rec2)
+    unf = pats.view(2, 64, 64, 3, 21, 21).permute(0, 3, 4, 5, 1, 2).contiguous()     # reference layout [2,3,21,21,Hp,Wp]
+    rec3, _ = n.render_full(opts, env["dcal"].consts, 10.39, densify == "w", p12, n.view_unfolded(unf))
+    assert torch.equal(rec, rec3)
+
+
+def test_global_stage_on_gpu_vs_golden(env):
+    import models
+    g = load_golden("g9_global_stage")
+    m = models.GlobalStage(device=DEV).to(DEV).eval()
+    assert list(m.state_dict().keys()) == list(g["keys"])
+    m.load_state_dict({k: T(v) for k, v in synth.global_stage_state_dict().items()}, strict=True)
+    x = T(synth.global_features()).to(DEV)
+    with torch.no_grad():
+        y = m(x.clone())
+    assert relmax(y[0, ::37].cpu(), g["out_sub"]) <= 1e-4
+    assert relmax(y[0].double().sum(dim=1).cpu(), g["out_rowsum"]) <= 1e-4
+
+
+def _pipeline(env, densify=None):
+    import models, utils
+    from be_hip.pipeline import DepthPipeline
+    lm = models.LocalStage()
+    lm.load_state_dict({k: T(v) for k, v in synth.local_stage_state_dict().items()})
+    gm = models.GlobalStage(device=DEV)
+    gm.load_state_dict({k: T(v) for k, v in synth.global_stage_state_dict().items()})
+    return DepthPipeline(lm.to(DEV).eval(), gm.to(DEV).eval(), env["helper"], env["dcal"], densify=densify)
+
+
+def test_pipeline_147_stage_by_stage_vs_oracle(env):
+    """configs[3]: every stage is checked against the oracle fed with the HIP output of the stage before."""
+    import models
+    from oracle import render as orr, depth as od, tiling as ot, glue, local_stage as ols
+    pipe = _pipeline(env)
+    imgs, _ = synth.synthetic_image_pair(147, 147)
+    img = T(imgs).to(DEV)
+    out = pipe(img)
+    pat = ot.unfold_patches(img.cpu())                               # [2,4096,3,21,21]
+    est10 = out["est10"].cpu()
+    # CNN on a sample of the 8192 patches
+    idx = torch.arange(0, 8192, 131)
+    ref = ols.local_stage_forward(ols.to_torch_sd(synth.local_stage_state_dict()), pat.reshape(-1, 3, 21, 21)[idx])
+    assert relmax(est10[idx], ref) <= 1e-5
+    # pass A colours from the HIP logits
+    col64 = orr.render_pass_a(orr.wrap_angles10(est10).double(), pat.reshape(-1, 3, 21, 21).double())["colors"]
+    assert relmax(out["colors_a"].cpu(), col64) <= 1e-4
+    # features + transformer (same module on the CPU) + de-normalisation
+    pm = glue.local_features(est10.view(2, 4096, 10), out["colors_a"].cpu().view(2, 4096, 3, 3))
+    gm_cpu = models.GlobalStage(device="cpu")
+    gm_cpu.load_state_dict({k: T(v) for k, v in synth.global_stage_state_dict().items()})
+    with torch.no_grad():
+        y = gm_cpu.eval()(pm[None].clone())[0]
+    est12 = glue.global_denorm(y)
+    d = (out["est12"].cpu() - est12).abs()
+    d[:, 4:8] = torch.minimum(d[:, 4:8], 2 * torch.pi - d[:, 4:8])   # angles live on a circle
+    assert float(d.max()) <= 2e-3 and float(d.median()) <= 2e-5
+    # pass B + fold from the HIP est12
+    r64 = orr.render_pass_b(od.depth_consts(), out["est12"].cpu().double(), pat[0].double(), pat[1].double())
+    fi = ot.fold_mean(torch.stack([r64["patches1"], r64["patches2"]]), 147, 147)
+    assert relmax(out["image"].cpu(), fi) <= 1e-4
+    fd, conf = ot.fold_depth(r64["depth_map"][None], r64["depth_mask"][None], 147, 147)
+    flips = (out["conf"].cpu() - conf[0]).abs() > 1e-6
+    assert float(flips.float().mean()) <= 1e-3                        # branch-flipped pixels are counted
+    ok = ~flips
+    rmse = float(torch.sqrt(((out["depth"].cpu() - fd[0])[ok] ** 2).mean()))
+    assert rmse <= 1e-4, rmse
+    thr = torch.where(conf[0] > 0.05, fd[0], torch.zeros_like(fd[0]))
+    assert float(((out["depth_map"].cpu() - thr).abs() > 1e-4).float().mean()) <= 1e-3
+
+
+def test_big_image_tiler_and_fold_587(env):
+    """587x587: 36 blocks through the pipeline; the stitched record grid folded on the GPU must equal the oracle
+    fold of the oracle render of the same stitched parameters (tiler windows from oracle.tiling.big_tiler)."""
+    from oracle import render as orr, depth as od, tiling as ot
+    pipe = _pipeline(env)
+    imgs, _ = synth.synthetic_image_pair(587, 587, nshape=14)
+    img = T(imgs).to(DEV)
+    maps = pipe.run_big(img)
+    assert tuple(maps["image"].shape) == (2, 3, 587, 587) and torch.isfinite(maps["image"]).all()
+    # rebuild the stitched parameter grid block by block with the oracle's window table
+    t = ot.big_tiler()
+    big12 = torch.zeros(284, 284, 12)
+    for bi, bj, top, left, (vs, ve, hs, he), (Vs, Ve, Hs, He) in t["blocks"]:
+        b = img[:, :, top:top + 147, left:left + 147].contiguous()
+        _, _, _, pm = pipe.local_pass(b)
+        est12 = pipe.global_pass(pm).cpu().view(64, 64, 12)
+        big12[Vs:Ve, Hs:He] = est12[vs:ve, hs:he]
+    pat = ot.unfold_patches(img.cpu())
+    # oracle render on a horizontal band of the big grid (rows 100..139) keeps the CPU cost bounded
+    rows = slice(100, 140)
+    sel = (torch.arange(284 * 284).view(284, 284)[rows]).reshape(-1)
+    r = orr.render_pass_b(od.depth_consts(), big12.view(-1, 12)[sel].double(), pat[0][sel].double(), pat[1][sel].double())
+    # pixels covered ONLY by patches of that band: image rows 2*100+20 .. 2*139  -> [220, 278]
+    full = torch.zeros(2, 284 * 284, 3, 21, 21, dtype=torch.float64)
+    full[0, sel], full[1, sel] = r["patches1"], r["patches2"]
+    fi = ot.fold_mean(full, 587, 587)
+    assert relmax(maps["image"].cpu()[:, :, 220:279], fi[:, :, 220:279]) <= 1e-4

@@ -75,3 +75,33 @@ def test_eval_depth_metric_matches_golden():
     pred = np.where(msk, pred, 0.0).astype(np.float32)
     r = utils.eval_depth(pred, gt.astype(np.float32), pred > 0, crop=10)
     assert np.allclose(np.array(r, dtype=np.float64), load_golden("g10_metrics")["metrics"], rtol=1e-6)
+
+
+def test_global_stage_boundary_state_dict_and_cpu_forward_match_golden():
+    """GlobalStage is stock PyTorch (boundary kept): identical to the reference on the CPU."""
+    import models
+    g = load_golden("g9_global_stage")
+    m = models.GlobalStage(device="cpu")
+    sd = m.state_dict()
+    assert list(sd.keys()) == list(g["keys"]) and len(sd) == 102
+    assert [str(tuple(v.shape)) for v in sd.values()] == list(g["shapes"])
+    assert "positional_encoding.pe" not in sd                         # PE is not in the state-dict
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in synth.global_stage_state_dict().items()}, strict=True)
+    with torch.no_grad():
+        y = m.eval()(torch.from_numpy(synth.global_features()).clone())
+    assert np.allclose(y[0, ::37].numpy(), g["out_sub"], atol=2e-6)
+    assert np.array_equal(m.positional_encoding.pe[0, ::61].numpy(), g["pe_sub"])
+    assert sum(p.numel() for p in m.parameters()) == 1066636         # SURVEY 8e
+
+
+def test_oracle_glue_round_trip():
+    from oracle import glue
+    p10 = torch.from_numpy(synth.plausible_params10(64)).view(2, 32, 10)
+    col = torch.rand(2, 32, 3, 3)
+    pm = glue.local_features(p10, col)
+    assert pm.shape == (32, 38)
+    # feeding the first 12 normalised features back through the de-normalisation restores image-1 parameters
+    y = torch.cat([pm[:, :8], pm[:, 8:10], pm[:, 8:10]], dim=1)
+    est = glue.global_denorm(y)
+    assert torch.allclose(est[:, :4], p10[0, :, :4], atol=1e-6)
+    assert torch.allclose(est[:, 4:8], torch.remainder(p10[0, :, 4:8], 2 * torch.pi), atol=1e-5)

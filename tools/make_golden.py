@@ -260,6 +260,22 @@ def G7():
          vec_rowsum=n(vec.double().sum(dim=(1, 2, 3))), num_patches=n(helper.num_patches))
 
 
+def G9():
+    """GlobalStage eval on one [1,4096,38] feature tensor: strided subsample + checksums + state-dict key order."""
+    m = ref_models.GlobalStage(in_parameter_size=38, out_parameter_size=12, device=torch.device("cpu"))
+    keys = list(m.state_dict().keys())
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.global_stage_state_dict().items()}
+    assert sorted(keys) == sorted(sd.keys()), set(keys) ^ set(sd.keys())
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    x = torch.from_numpy(synth.global_features())
+    with torch.no_grad():
+        y = m(x.clone())
+    save("g9_global_stage", keys=np.array(keys), shapes=np.array([str(tuple(v.shape)) for v in m.state_dict().values()]),
+         out_sub=n(y[0, ::37]), out_rowsum=n(y[0].double().sum(dim=1)), out_abs_mean=n(y.abs().mean()),
+         pe_sub=n(m.positional_encoding.pe[0, ::61]))
+
+
 def G10():
     """eval_depth (utils/metrics.py:3-20) on a fixed pair of maps."""
     S = synth.SEED_DEFAULT
@@ -271,7 +287,7 @@ def G10():
     save("g10_metrics", metrics=np.array(r, dtype=np.float64))
 
 
-GROUPS = dict(G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G10=G10)
+GROUPS = dict(G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G9=G9, G10=G10)
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)
