@@ -1,0 +1,59 @@
+"""N > 1 path on the CPU: two gloo ranks shard a pair batch, each computes its shard (with the oracle standing in
+for the GPU path, which cannot run here) and the gathered result must equal the unsharded computation."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT, PKG
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, n_pairs, q):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from be_hip import shard, synth
+    from oracle import render as orr, depth as od
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    params = torch.from_numpy(synth.plausible_params10(2 * n_pairs, name="shard"))        # stands in for CNN output
+    mine = shard.shard_pairs(params, rank, world)
+    p = mine.shape[0] // 2
+    z = orr.local_depth(od.depth_consts(), mine[:p], mine[p:])
+    full = shard.gather_pairs(z, n_pairs)
+    if rank == 0:
+        q.put(full.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_pairs", [8, 7])          # even and ragged split
+def test_two_rank_shard_and_gather_matches_single_process(n_pairs):
+    from be_hip import shard, synth
+    from oracle import render as orr, depth as od
+    assert shard.pair_range(7, 0, 2) == (0, 4) and shard.pair_range(7, 1, 2) == (4, 7)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, n_pairs, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    params = torch.from_numpy(synth.plausible_params10(2 * n_pairs, name="shard"))
+    ref = orr.local_depth(od.depth_consts(), params[:n_pairs], params[n_pairs:]).numpy()
+    assert np.array_equal(got, ref)
