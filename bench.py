@@ -30,7 +30,7 @@ PAIRS = 4096                          # configs[1]
 FLOP_PER_PATCH = 387.716e6            # SURVEY.md A.2 (2*MAC, convs + linears)
 FLOP_PER_PAIR = 2 * FLOP_PER_PATCH    # 775.43 MFLOP, SURVEY.md 8d
 PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: dense fp32 matrix peak
-CPU_SAMPLE_PAIRS = 1024
+CPU_SAMPLE_PAIRS = 4096                 # the whole batch: ~10 s on 16 threads
 
 
 def cpu_baseline(x_np, sd_np):
@@ -165,6 +165,7 @@ def main():
                         peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
                         traffic=None, launches_per_step=len(dom) // args.steps,
                         avg_launch_ms=round(avg_ms, 4), flop_per_launch=avg_flop,
+                        algo_bytes_per_launch=sum(r[2] for r in dom) / len(dom),
                         all_conv_ms_per_step=round(conv_ms, 3),
                         end_to_end_frac=round(PAIRS * args.steps / elapsed * FLOP_PER_PAIR / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4))
             pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")

@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Summarise the rocprofv3 --pmc passes written by tools/pmc_passes.sh into profiles/<tag>_pmc_summary.json and
+profiles/r01_pmc_traffic.json (HBM bytes per launch of the dominant kernel, corrected as MI355X_MICROARCH.md's HBM
+section prescribes: FETCH_SIZE is in KiB and reads exactly half of a wide coalesced stream on gfx950 -> x2;
+WRITE_SIZE in KiB is exact for 16-B streaming stores; our epilogue stores are 4-B per lane, 128-B segments, so the
+write side is 'uncalibrated width' and reported as is)."""
+import collections
+import csv
+import glob
+import json
+import sys
+
+src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
+NAMES = {"k_conv_igemm<2, 2, 2, 2, 0>": "conv128x128", "k_conv_igemm<4, 1, 1, 3, 0>": "conv128x96",
+         "k_conv_igemm<4, 1, 1, 2, 1>": "conv1_row8", "k_render_colors": "render_pass_a"}
+
+
+def short(name):
+    for k, v in NAMES.items():
+        if k in name:
+            return v
+    return None
+
+
+summary = collections.defaultdict(lambda: collections.defaultdict(list))
+for d in sorted(glob.glob(f"{src}/*/")):
+    for f in glob.glob(f"{d}/*/*_counter_collection.csv"):
+        for r in csv.DictReader(open(f)):
+            k = short(r["Kernel_Name"])
+            if k:
+                summary[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {k: {c: {"mean_per_launch": sum(v) / len(v), "launches": len(v)} for c, v in cs.items()} for k, cs in summary.items()}
+for k, cs in out.items():
+    if "GRBM_GUI_ACTIVE" in cs and "SQ_VALU_MFMA_BUSY_CYCLES" in cs:
+        cyc = cs["GRBM_GUI_ACTIVE"]["mean_per_launch"] / 8
+        cs["derived"] = {"mfma_busy_frac": cs["SQ_VALU_MFMA_BUSY_CYCLES"]["mean_per_launch"] / 1024 / cyc,
+                         "wait_any_frac": cs["SQ_WAIT_ANY"]["mean_per_launch"] / cs["SQ_WAVE_CYCLES"]["mean_per_launch"],
+                         "wait_inst_frac": cs["SQ_WAIT_INST_ANY"]["mean_per_launch"] / cs["SQ_WAVE_CYCLES"]["mean_per_launch"]}
+    if "TCC_HIT_sum" in cs:
+        h, m = cs["TCC_HIT_sum"]["mean_per_launch"], cs["TCC_MISS_sum"]["mean_per_launch"]
+        cs.setdefault("derived", {})["l2_hit_rate"] = h / (h + m)
+json.dump(out, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
+dom = out.get("conv128x128", {})
+if "FETCH_SIZE" in dom and "WRITE_SIZE" in dom:
+    rd = dom["FETCH_SIZE"]["mean_per_launch"] * 1024 * 2
+    wr = dom["WRITE_SIZE"]["mean_per_launch"] * 1024
+    json.dump({"kernel": "k_conv_igemm<2,2,2,2,TAPS>", "bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr,
+               "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 (gfx950), KiB -> B",
+               "launches_averaged": dom["FETCH_SIZE"]["launches"]}, open("profiles/r01_pmc_traffic.json", "w"), indent=1)
+print(json.dumps({k: v.get("derived") for k, v in out.items()}, indent=1))
