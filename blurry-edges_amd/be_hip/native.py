@@ -66,6 +66,8 @@ _SIGNATURES = {
     "be_unfold_patches_f32": (C.c_int, [_P, _P] + [C.c_int] * 5 + [_P]),
     "be_local_features_f32": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
     "be_global_denorm_f32": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "be_local_loss_f32": (C.c_int, [C.POINTER(RenderOpts), _P, _P, _P, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P,
+                                    C.c_int64, _P]),
     "be_profile_enable": (C.c_int, [C.c_int]),
     "be_profile_reset": (C.c_int, []),
     "be_profile_read": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -357,3 +359,21 @@ def global_denorm(y: torch.Tensor) -> torch.Tensor:
     est = torch.empty_like(y)
     check(lib().be_global_denorm_f32(dptr(y, "y"), dptr(est), y.numel() // 12, stream_ptr(y.device)), "be_global_denorm_f32")
     return est
+
+
+def local_loss(opts, est, img_fit, gt, bdist, deri, beta_bndry, beta_smooth, want_grad=True, want=()):
+    """-> (partial [B,3], grad_est [B,10] or None, extras {'patches','boundary'})."""
+    b = est.shape[0]
+    if tuple(est.shape) != (b, 10) or tuple(img_fit.shape) != (b, BE_R, BE_R, 3) or tuple(gt.shape) != (b, BE_R, BE_R, 3) \
+            or tuple(bdist.shape) != (b, BE_R, BE_R) or tuple(deri.shape) != (b, 19, 19, 3):
+        raise RuntimeError("local_loss: bad shapes (est [B,10], img/gt [B,21,21,3], bdist [B,21,21], deri [B,19,19,3])")
+    dev = est.device
+    partial = torch.empty(b, 3, dtype=torch.float32, device=dev)
+    grad = torch.empty(b, 10, dtype=torch.float32, device=dev) if want_grad else None
+    shapes = dict(patches=(b, 3, BE_R, BE_R), boundary=(b, BE_R, BE_R))
+    extra = {k: torch.empty(shapes[k], dtype=torch.float32, device=dev) for k in want}
+    check(lib().be_local_loss_f32(C.byref(opts), dptr(est, "est"), dptr(img_fit, "img_fit"), dptr(gt, "gt"),
+                                  dptr(bdist, "bdist"), dptr(deri, "deri"), float(beta_bndry), float(beta_smooth),
+                                  dptr(partial), dptr(grad), dptr(extra.get("patches")), dptr(extra.get("boundary")), b,
+                                  stream_ptr(dev)), "be_local_loss_f32")
+    return partial, grad, extra

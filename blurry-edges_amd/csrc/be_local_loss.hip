@@ -1,0 +1,320 @@
+// LocalLoss forward + analytic backward in one launch, one wavefront per patch (gfx950).
+//
+// Replaces LocalLoss.get_patches + LocalLoss.forward (local_training.py:32-52) and everything autograd records
+// under them (params2dists, params2etas, dists2indicators, the ridge solve through inverse_3by3, the composite,
+// the boundary map, get_image_derivative: utils/postprocessing_loss.py:43-117) plus their backward.
+//
+//   loss = mean_px sum_c (gt - patch)^2  +  beta_b * mean_px (bdist * B)^2  +  beta_s * mean_q sum_c (deri - Sobel(patch))^2
+//
+// The gradient d loss / d est [B,10] is derived by hand (chain: Sobel^T -> composite -> normal equations
+// (dC -> v = G^-1 dC -> db = v, dG = -v C^T) -> indicators -> erf -> wedge distances -> vertices / angles / eta).
+// Hard selections (min, where, sign) take the derivative of the selected branch, as autograd does.
+// Per patch the kernel reads 441*3*2 + 441 + 361*3 floats and writes 10 + 3 floats; LDS holds the rendered patch
+// and the two Sobel adjoint images of the wave (14 KB per wave).
+#include "be_common.h"
+#include "be_wedge.h"
+
+namespace {
+
+constexpr int NPIX = BE_NPIX, R = BE_R, PASSES = 7, WAVES = 4;
+constexpr int Q = 19, NQ = Q * Q;                 // valid-Sobel output 19x19
+constexpr float kInvSqrtPi = 0.56418958354775628695f;
+
+struct LossArgs {
+    const float* est;        // [B,10] raw CNN output
+    const float* img_fit;    // [B,21,21,3] channels-last: pixels the colours are regressed on
+    const float* gt;         // [B,21,21,3]
+    const float* bdist;      // [B,21,21]
+    const float* deri;       // [B,19,19,3]
+    float* partial;          // [B,3]: sum_px sum_c (gt-patch)^2, sum_px (bdist*B)^2, sum_q sum_c (deri-S)^2
+    float* grad;             // [B,10] d loss / d est (already scaled by the three means and betas), or null
+    float* patches;          // [B,3,21,21] or null
+    float* boundary;         // [B,21,21] or null
+    float w1, w2, w3;        // 1/(B*441), beta_b/(B*441), beta_s/(B*361)
+    int64_t n;
+};
+
+// d(ray distance)/d(edge, axial) for the selected branch of utils/postprocessing_loss.py:67-76
+__device__ __forceinline__ void ray_dist_grad(float px, float py, float vx, float vy, float s, float c, float w,
+                                              float& dist, float& edge, float& axial, float& d_edge, float& d_axial) {
+    const float dx = px - vx, dy = py - vy;
+    edge = (-s) * dx + c * dy;
+    axial = c * dx + s * dy;
+    if (axial < 0.0f) {
+        const float aw = axial * w;
+        const float r = sqrtf(edge * edge + aw * aw);
+        const float sg = edge < 0.0f ? -1.0f : 1.0f;
+        dist = sg * r;
+        const float ir = r > 0.0f ? 1.0f / r : 0.0f;
+        d_edge = sg * edge * ir;
+        d_axial = sg * w * w * axial * ir;
+    } else {
+        dist = edge; d_edge = 1.0f; d_axial = 0.0f;
+    }
+}
+
+// Adjoint of one wedge: accumulates d/d(vx, vy, theta, phi) given dL/d(dist_k) at this pixel.
+__device__ __forceinline__ void wedge_backward(float px, float py, float vx, float vy, float sA, float cA, float sB,
+                                               float cB, float sg, bool closed, float w, float g_dist,
+                                               float& g_vx, float& g_vy, float& g_th, float& g_ph) {
+    float dA, eA, aA, deA, daA, dB, eB, aB, deB, daB;
+    ray_dist_grad(px, py, vx, vy, sA, cA, w, dA, eA, aA, deA, daA);
+    ray_dist_grad(px, py, vx, vy, sB, cB, w, dB, eB, aB, deB, daB);
+    const bool inside = closed ? (sg * dA >= 0.0f && sg * dB <= 0.0f) : (sg * dA > 0.0f && sg * dB < 0.0f);
+    const float ind = inside ? sg : -sg;
+    const float absA = fabsf(dA), absB = fabsf(dB);
+    // dist = min(|dA|,|dB|) * ind ; ties split evenly (torch.min backward)
+    float gA = 0.f, gB = 0.f;
+    const float sA_ = dA > 0.f ? 1.f : (dA < 0.f ? -1.f : 0.f), sB_ = dB > 0.f ? 1.f : (dB < 0.f ? -1.f : 0.f);
+    if (absA < absB) gA = g_dist * ind * sA_;
+    else if (absB < absA) gB = g_dist * ind * sB_;
+    else { gA = 0.5f * g_dist * ind * sA_; gB = 0.5f * g_dist * ind * sB_; }
+    // edge = -s dx + c dy : d/dvx = s, d/dvy = -c, d/dang = -axial ; axial = c dx + s dy : d/dvx = -c, d/dvy = -s, d/dang = edge
+    const float gAe = gA * deA, gAa = gA * daA, gBe = gB * deB, gBa = gB * daB;
+    g_vx += gAe * sA - gAa * cA + gBe * sB - gBa * cB;
+    g_vy += -gAe * cA - gAa * sA - gBe * cB - gBa * sB;
+    const float gangA = -gAe * aA + gAa * eA, gangB = -gBe * aB + gBa * eB;
+    g_th += gangA + gangB;            // theta feeds both rays (theta and theta + phi)
+    g_ph += gangB;                    // phi only the second
+}
+
+__global__ __launch_bounds__(64 * WAVES)
+void k_local_loss(be_render_opts o, LossArgs a) {
+    __shared__ float lin[R];
+    __shared__ float sPatch[WAVES][3][NPIX];
+    __shared__ float sDx[WAVES][3][NQ];
+    __shared__ float sDy[WAVES][3][NQ];
+    if (threadIdx.x < R) lin[threadIdx.x] = o.lin[threadIdx.x];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int64_t patch_raw = (int64_t)blockIdx.x * WAVES + wv;
+    const bool active = patch_raw < a.n;
+    const int64_t patch = active ? patch_raw : a.n - 1;        // idle waves shadow the last patch (no stores)
+
+    const float* p = a.est + patch * 10;
+    const be::WedgeGeom g = be::make_geom(p, true);             // local_training.py:33 wraps the angles first
+    const float eta1 = be::param2eta(p[8]), eta2 = be::param2eta(p[9]);
+    const float r1 = be::kRoot2 * eta1, r2 = be::kRoot2 * eta2;
+    const float* fit = a.img_fit + patch * NPIX * 3;
+    const float* gt = a.gt + patch * NPIX * 3;
+
+    float d1s[PASSES], d2s[PASSES], h1s[PASSES], h2s[PASSES];
+    float gs[6] = {0, 0, 0, 0, 0, 0}, bs[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int it = 0; it < PASSES; ++it) {
+        const int pix = it * 64 + lane;
+        const bool live = pix < NPIX;
+        const int pc = live ? pix : 0;
+        const int row = pc / R, col = pc - row * R;
+        float d1, d2;
+        be::wedge_dists(g, lin[col], lin[row], o.w, d1, d2);
+        const float h1 = 0.5f * (1.0f + erff(d1 / r1)), h2 = 0.5f * (1.0f + erff(d2 / r2));
+        d1s[it] = d1; d2s[it] = d2; h1s[it] = h1; h2s[it] = h2;
+        const float u0 = live ? (1.0f - h1) * (1.0f - h2) : 0.f, u1 = live ? h1 * (1.0f - h2) : 0.f, u2 = live ? h2 : 0.f;
+        const float yr = live ? fit[pc * 3] : 0.f, yg = live ? fit[pc * 3 + 1] : 0.f, yb = live ? fit[pc * 3 + 2] : 0.f;
+        gs[0] = fmaf(u0, u0, gs[0]); gs[1] = fmaf(u0, u1, gs[1]); gs[2] = fmaf(u0, u2, gs[2]);
+        gs[3] = fmaf(u1, u1, gs[3]); gs[4] = fmaf(u1, u2, gs[4]); gs[5] = fmaf(u2, u2, gs[5]);
+        bs[0] = fmaf(u0, yr, bs[0]); bs[1] = fmaf(u0, yg, bs[1]); bs[2] = fmaf(u0, yb, bs[2]);
+        bs[3] = fmaf(u1, yr, bs[3]); bs[4] = fmaf(u1, yg, bs[4]); bs[5] = fmaf(u1, yb, bs[5]);
+        bs[6] = fmaf(u2, yr, bs[6]); bs[7] = fmaf(u2, yg, bs[7]); bs[8] = fmaf(u2, yb, bs[8]);
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) gs[k] = be::wave_sum(gs[k]);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) bs[k] = be::wave_sum(bs[k]);
+    // G (with ridge), its inverse by cofactors (fp64), colours C[c][k]
+    const double A00 = (double)gs[0] + o.lambda_ridge, A01 = gs[1], A02 = gs[2], A11 = (double)gs[3] + o.lambda_ridge,
+                 A12 = gs[4], A22 = (double)gs[5] + o.lambda_ridge;
+    double inv[3][3];
+    {
+        const double C00 = A11 * A22 - A12 * A12, C01 = A02 * A12 - A01 * A22, C02 = A01 * A12 - A02 * A11;
+        const double C11 = A00 * A22 - A02 * A02, C12 = A01 * A02 - A00 * A12, C22 = A00 * A11 - A01 * A01;
+        const double idet = 1.0 / (A00 * C00 + A01 * C01 + A02 * C02);
+        inv[0][0] = C00 * idet; inv[0][1] = inv[1][0] = C01 * idet; inv[0][2] = inv[2][0] = C02 * idet;
+        inv[1][1] = C11 * idet; inv[1][2] = inv[2][1] = C12 * idet; inv[2][2] = C22 * idet;
+    }
+    float Cc[3][3];                                           // [channel][wedge]
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            Cc[c][k] = (float)(inv[k][0] * bs[c] + inv[k][1] * bs[3 + c] + inv[k][2] * bs[6 + c]);
+
+    // ---- composite -> LDS, colour loss and its adjoint
+    float gP[PASSES][3];
+    float L1 = 0.f;
+#pragma unroll
+    for (int it = 0; it < PASSES; ++it) {
+        const int pix = it * 64 + lane;
+        const bool live = pix < NPIX;
+        const float h1 = h1s[it], h2 = h2s[it];
+        const float u0 = (1.0f - h1) * (1.0f - h2), u1 = h1 * (1.0f - h2), u2 = h2;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const float v = u0 * Cc[c][0] + u1 * Cc[c][1] + u2 * Cc[c][2];
+            float r = 0.f;
+            if (live) {
+                sPatch[wv][c][pix] = v;
+                r = v - gt[pix * 3 + c];
+                if (a.patches && active) a.patches[(patch * 3 + c) * NPIX + pix] = v;
+            }
+            L1 = fmaf(r, r, L1);
+            gP[it][c] = 2.0f * r * a.w1;
+        }
+    }
+    __syncthreads();
+    // ---- Sobel magnitude on the 19x19 interior, smoothness loss and its adjoint images
+    float L3 = 0.f;
+    const float* dr = a.deri + patch * NQ * 3;
+    for (int q0 = 0; q0 < NQ; q0 += 64) {
+        const int q = q0 + lane;
+        if (q < NQ) {
+            const int qy = q / Q, qx = q - qy * Q;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float* P = sPatch[wv][c] + qy * R + qx;
+                const float p00 = P[0], p01 = P[1], p02 = P[2], p10 = P[R], p12 = P[R + 2], p20 = P[2 * R], p21 = P[2 * R + 1],
+                            p22 = P[2 * R + 2];
+                const float gx = (p02 - p00) + 2.0f * (p12 - p10) + (p22 - p20);      // [[-1,0,1],[-2,0,2],[-1,0,1]]
+                const float gy = (p00 - p20) + 2.0f * (p01 - p21) + (p02 - p22);      // [[1,2,1],[0,0,0],[-1,-2,-1]]
+                const float s = sqrtf(gx * gx + gy * gy + 1e-8f);
+                const float t = dr[q * 3 + c] - s;
+                L3 = fmaf(t, t, L3);
+                const float k = -2.0f * t * a.w3 / s;
+                sDx[wv][c][q] = k * gx;
+                sDy[wv][c][q] = k * gy;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- gather the Sobel adjoint back onto the 21x21 grid
+#pragma unroll
+    for (int it = 0; it < PASSES; ++it) {
+        const int pix = it * 64 + lane;
+        if (pix < NPIX) {
+            const int row = pix / R, col = pix - row * R;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float acc = 0.f;
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int qy = row - dy;
+                    if (qy < 0 || qy >= Q) continue;
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int qx = col - dx;
+                        if (qx < 0 || qx >= Q) continue;
+                        const float kx = (dx == 0 ? -1.f : (dx == 2 ? 1.f : 0.f)) * (dy == 1 ? 2.f : 1.f);
+                        const float ky = (dy == 0 ? 1.f : (dy == 2 ? -1.f : 0.f)) * (dx == 1 ? 2.f : 1.f);
+                        acc += kx * sDx[wv][c][qy * Q + qx] + ky * sDy[wv][c][qy * Q + qx];
+                    }
+                }
+                gP[it][c] += acc;
+            }
+        }
+    }
+    // ---- dC[c][k] = sum_px gP_c u_k ; v_c = G^-1 dC[c] ; S = dG + dG^T with dG = -sum_c v_c C[c]^T
+    float dC[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int it = 0; it < PASSES; ++it) {
+        const bool live = it * 64 + lane < NPIX;
+        const float h1 = h1s[it], h2 = h2s[it];
+        const float u[3] = {live ? (1.0f - h1) * (1.0f - h2) : 0.f, live ? h1 * (1.0f - h2) : 0.f, live ? h2 : 0.f};
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) dC[c * 3 + k] = fmaf(gP[it][c], u[k], dC[c * 3 + k]);
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) dC[k] = be::wave_sum(dC[k]);
+    float V[3][3], S[3][3];                                   // V[c][k]
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            V[c][k] = (float)(inv[k][0] * dC[c * 3] + inv[k][1] * dC[c * 3 + 1] + inv[k][2] * dC[c * 3 + 2]);
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            float dkj = 0.f, djk = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) { dkj -= V[c][k] * Cc[c][j]; djk -= V[c][j] * Cc[c][k]; }
+            S[k][j] = dkj + djk;
+        }
+    // ---- per-pixel adjoints down to the ten parameters
+    float gx0 = 0, gy0 = 0, gt1 = 0, gf1 = 0, gx1 = 0, gy1 = 0, gt2 = 0, gf2 = 0, gr1 = 0, gr2 = 0, L2 = 0;
+#pragma unroll
+    for (int it = 0; it < PASSES; ++it) {
+        const int pix = it * 64 + lane;
+        if (pix < NPIX) {
+            const int row = pix / R, col = pix - row * R;
+            const float px = lin[col], py = lin[row];
+            const float d1 = d1s[it], d2 = d2s[it], h1 = h1s[it], h2 = h2s[it];
+            const float u[3] = {(1.0f - h1) * (1.0f - h2), h1 * (1.0f - h2), h2};
+            const float y[3] = {fit[pix * 3], fit[pix * 3 + 1], fit[pix * 3 + 2]};
+            float du[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                float acc = 0.f;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) acc += gP[it][c] * Cc[c][k] + V[c][k] * y[c];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) acc += S[k][j] * u[j];
+                du[k] = acc;
+            }
+            const float dh1 = (du[1] - du[0]) * (1.0f - h2);
+            const float dh2 = -du[0] * (1.0f - h1) - du[1] * h1 + du[2];
+            const float z1 = d1 / r1, z2 = d2 / r2;
+            const float e1 = expf(-z1 * z1) * kInvSqrtPi, e2 = expf(-z2 * z2) * kInvSqrtPi;
+            float gd1 = dh1 * e1 / r1, gd2 = dh2 * e2 / r2;
+            gr1 -= dh1 * e1 * d1 / (r1 * r1);
+            gr2 -= dh2 * e2 * d2 / (r2 * r2);
+            // boundary localisation term (local_training.py:42-44,50)
+            const float a1 = fabsf(d1), a2 = fabsf(d2);
+            const float db = d2 >= 0.0f ? d2 : (a1 < a2 ? a1 : a2);
+            const float Bv = expf(-(db * db) / o.delta_sq);
+            const float bd = a.bdist[patch * NPIX + pix];
+            L2 = fmaf(bd * Bv, bd * Bv, L2);
+            const float gdb = 2.0f * bd * bd * Bv * a.w2 * Bv * (-2.0f * db / o.delta_sq);
+            if (d2 >= 0.0f) gd2 += gdb;
+            else if (a1 < a2) gd1 += gdb * (d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f));
+            else gd2 += gdb * (d2 > 0.f ? 1.f : (d2 < 0.f ? -1.f : 0.f));
+            if (a.boundary && active) a.boundary[patch * NPIX + pix] = Bv;
+            wedge_backward(px, py, g.x0, g.y0, g.s11, g.c11, g.s12, g.c12, g.sg1, false, o.w, gd1, gx0, gy0, gt1, gf1);
+            wedge_backward(px, py, g.x1, g.y1, g.s21, g.c21, g.s22, g.c22, g.sg2, true, o.w, gd2, gx1, gy1, gt2, gf2);
+        }
+    }
+    gx0 = be::wave_sum(gx0); gy0 = be::wave_sum(gy0); gx1 = be::wave_sum(gx1); gy1 = be::wave_sum(gy1);
+    gt1 = be::wave_sum(gt1); gf1 = be::wave_sum(gf1); gt2 = be::wave_sum(gt2); gf2 = be::wave_sum(gf2);
+    gr1 = be::wave_sum(gr1); gr2 = be::wave_sum(gr2);
+    L1 = be::wave_sum(L1); L2 = be::wave_sum(L2); L3 = be::wave_sum(L3);
+    if (lane == 0 && active) {
+        a.partial[patch * 3] = L1; a.partial[patch * 3 + 1] = L2; a.partial[patch * 3 + 2] = L3;
+        if (a.grad) {
+            float* go = a.grad + patch * 10;
+            go[0] = gx0; go[1] = gy0; go[2] = gx1; go[3] = gy1; go[4] = gt1; go[5] = gf1; go[6] = gt2; go[7] = gf2;
+            // r = sqrt2 * eta, eta = 10^(2 erf(p) - 2): d eta / d p = eta * ln10 * 4/sqrt(pi) * exp(-p^2)
+            const float c10 = 2.302585092994046f * 4.0f * kInvSqrtPi;
+            go[8] = gr1 * be::kRoot2 * eta1 * c10 * expf(-p[8] * p[8]);
+            go[9] = gr2 * be::kRoot2 * eta2 * c10 * expf(-p[9] * p[9]);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int be_local_loss_f32(const be_render_opts* o, const float* est, const float* img_fit, const float* gt,
+                                 const float* bdist, const float* deri, float beta_bndry, float beta_smooth,
+                                 float* partial, float* grad_est, float* patches, float* boundary, int64_t n,
+                                 void* stream) {
+    BE_REQUIRE(n >= 0, "be_local_loss_f32: n < 0");
+    if (n == 0) return BE_OK;
+    BE_REQUIRE(o && est && img_fit && gt && bdist && deri && partial, "be_local_loss_f32: null pointer");
+    LossArgs a{est, img_fit, gt, bdist, deri, partial, grad_est, patches, boundary,
+               1.0f / ((float)n * NPIX), beta_bndry / ((float)n * NPIX), beta_smooth / ((float)n * NQ), n};
+    const int64_t blocks = (n + WAVES - 1) / WAVES;
+    BE_REQUIRE(blocks <= 0x7fffffff, "be_local_loss_f32: n too large");
+    hipLaunchKernelGGL(k_local_loss, dim3((unsigned)blocks), dim3(64 * WAVES), 0, be::as_stream(stream), *o, a);
+    return be::check_launch("be_local_loss_f32");
+}

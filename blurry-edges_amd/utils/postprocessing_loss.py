@@ -79,3 +79,28 @@ class PostProcessGlobalBase(PostProcessBase):
 
     def get_xy_mat(self, xx, yy):
         return (xx.view(1, self.R, self.R, 1, 1).to(self.device), yy.view(1, self.R, self.R, 1, 1).to(self.device))
+
+
+class _LocalLossFn(torch.autograd.Function):
+    """loss(est) with the analytic gradient computed in the same HIP launch (be_local_loss_f32)."""
+
+    @staticmethod
+    def forward(ctx, est, helper, img_fit, gt, bdist, deri, beta_b, beta_s):
+        b = est.shape[0]
+        partial, grad, _ = native.local_loss(helper.render_opts(False), est.detach().contiguous(), img_fit.contiguous(),
+                                             gt.contiguous(), bdist.contiguous(), deri.contiguous(), beta_b, beta_s,
+                                             want_grad=True)
+        ctx.save_for_backward(grad)
+        s = partial.sum(dim=0)                                  # three scalars; deterministic reduction
+        return s[0] / (b * 441) + beta_b * s[1] / (b * 441) + beta_s * s[2] / (b * 361)
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return g * grad, None, None, None, None, None, None, None
+
+
+def local_loss(helper, est, img_fit, gt_img, bndry_dist, deri, beta_bndry_loc, beta_smthns):
+    """LocalLoss.forward (local_training.py:47-52) as one fused HIP forward+backward; differentiable w.r.t. est.
+    Unlike the reference it does NOT write the wrapped angles back into est."""
+    return _LocalLossFn.apply(est, helper, img_fit, gt_img, bndry_dist, deri, float(beta_bndry_loc), float(beta_smthns))

@@ -147,6 +147,19 @@ int be_local_features_f32(const float* params10, const float* colors, float* pm,
 int be_global_denorm_f32(const float* y, float* est, int64_t P, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * LocalLoss forward + backward (training)
+ *   replaces LocalLoss.get_patches + LocalLoss.forward (local_training.py:32-52) and the autograd graph under
+ *   them.  est [B,10] raw CNN output (angles are wrapped inside, :33), img_fit / gt [B,21,21,3] channels-last
+ *   (the dataset layout; local_training.py:105 passes the clean image as both), bdist [B,21,21],
+ *   deri [B,19,19,3].  partial [B,3] = per-patch sums of the three terms:
+ *     loss = sum(partial[:,0])/(B*441) + beta_bndry*sum(partial[:,1])/(B*441) + beta_smooth*sum(partial[:,2])/(B*361)
+ *   grad_est [B,10] = d loss / d est (NULL to skip); patches [B,3,21,21], boundary [B,21,21] optional.
+ * ------------------------------------------------------------------------------------------------- */
+int be_local_loss_f32(const be_render_opts* opts_host, const float* est, const float* img_fit, const float* gt,
+                      const float* bdist, const float* deri, float beta_bndry, float beta_smooth, float* partial,
+                      float* grad_est, float* patches, float* boundary, int64_t n, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * LocalStage CNN  (models/local_stage.py:30-73), inference (BatchNorm folded into the convs)
  * ------------------------------------------------------------------------------------------------- */
 

@@ -231,3 +231,31 @@ def test_product_path_refuses_cpu_tensors(native):
     with pytest.raises(RuntimeError):
         with torch.no_grad():
             m(torch.zeros(2, 3, 21, 21))
+
+
+# ------------------------------------------------------------------------------------------ training loss
+def test_local_loss_value_and_gradient_vs_fp64_golden(native, args):
+    """be_local_loss_f32 (forward + hand-derived backward) against the reference's LocalLoss under autograd (G4)."""
+    import utils
+    g = load_golden("g4_local_loss")
+    B, S = 64, synth.SEED_DEFAULT
+    est = T(synth.plausible_params10(B, name="loss_params")).to(DEV).requires_grad_(True)
+    img = T(synth.f32(synth.hash_uniform(S, "loss_img", (B, 21, 21, 3)))).to(DEV)
+    gt = T(synth.f32(synth.hash_uniform(S, "loss_gt", (B, 21, 21, 3)))).to(DEV)
+    bd = T(synth.f32(5.0 * synth.hash_uniform(S, "loss_bd", (B, 21, 21)))).to(DEV)
+    de = T(synth.f32(synth.hash_uniform(S, "loss_deri", (B, 19, 19, 3)))).to(DEV)
+    a = utils.get_args("local_train", argv=[])
+    h = utils.PostProcessLocalBase(a, DEV)
+    loss = utils.local_loss(h, est, img, gt, bd, de, a.beta_bndry_loc, a.beta_smthns)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(g["f64_loss"])) <= 1e-5 * abs(float(g["f64_loss"]))
+    assert relmax(est.grad.cpu(), g["f64_grad"]) <= 2e-4
+    # for reference: how far the reference's own fp32 autograd gradient is from its fp64 one
+    print("grad: hip-vs-ref64 %.2e   ref32-vs-ref64 %.2e" % (relmax(est.grad.cpu(), g["f64_grad"]),
+                                                             relmax(g["f32_grad"], g["f64_grad"])))
+    # patches / boundary outputs equal the pass-A renderer's
+    _, _, ex = native.local_loss(h.render_opts(False), est.detach(), img, gt, bd, de, 1e-3, 5e-4, want=("patches", "boundary"))
+    q = est.detach().clone()
+    col, ex2 = h.render_colors(q, img.permute(0, 3, 1, 2).contiguous(), wrap_angles=True, want=("recon", "boundary"))
+    assert relmax(ex["patches"].cpu(), ex2["recon"].cpu()) <= 1e-5
+    assert relmax(ex["boundary"].cpu(), ex2["boundary"].cpu()) <= 1e-6
