@@ -68,6 +68,16 @@ _SIGNATURES = {
     "be_global_denorm_f32": (C.c_int, [_P, _P, C.c_int64, _P]),
     "be_local_loss_f32": (C.c_int, [C.POINTER(RenderOpts), _P, _P, _P, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P,
                                     C.c_int64, _P]),
+    "be_train_scratch_bytes": (C.c_size_t, []),
+    "be_bn_train_fwd_f32": (C.c_int, [_P, _P, _P, _P, C.c_float, C.c_float, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int,
+                                      C.c_int, _P, C.c_size_t, _P]),
+    "be_bn_train_bwd_f32": (C.c_int, [_P] * 10 + [C.c_int, C.c_int, _P, C.c_size_t, _P]),
+    "be_col_sum_f32": (C.c_int, [_P, _P, C.c_int, C.c_int, _P, C.c_size_t, _P]),
+    "be_maxpool_nhwc_bwd_f32": (C.c_int, [_P, _P, _P] + [C.c_int] * 7 + [_P]),
+    "be_conv_wgrad_f32": (C.c_int, [_P, _P, _P] + [C.c_int] * 7 + [_P, C.c_size_t, _P]),
+    "be_conv_dgrad_packed_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "be_conv_pack_dgrad_f32": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "be_linear_small_bwd_f32": (C.c_int, [_P] * 6 + [C.c_int] * 3 + [_P]),
     "be_profile_enable": (C.c_int, [C.c_int]),
     "be_profile_reset": (C.c_int, []),
     "be_profile_read": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),

@@ -1,0 +1,214 @@
+"""LocalStage training step on the GPU: train-mode forward (batch-statistics BatchNorm) and the full backward,
+orchestrated layer by layer over the training kernels of libblurry_edges_hip (be_train.hip, be_conv.hip).
+
+Counterpart of `est = model(x); loss.backward()` in local_training.py:103-106: `LocalStageTrainFn.apply(x, *tensors)`
+is a torch.autograd.Function whose backward returns the gradient of every parameter in the reference's layout,
+so torch.optim.AdamW / clip_grad_norm_ / a gradient all-reduce work on it unchanged.  No torch math is involved:
+torch allocates buffers and supplies the stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import native
+from .native import check, dptr, lib, stream_ptr
+
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+
+# (name, cout, cin, k) in state-dict order; index into the 86-tensor list = 6*i
+CONVS = [("conv1", 64, 3, 7),
+         ("layer0.conv1", 96, 64, 3), ("layer0.conv2", 96, 96, 3), ("layer0.ds", 96, 64, 1),
+         ("layer1.conv1", 256, 96, 3), ("layer1.conv2", 256, 256, 3), ("layer1.ds", 256, 96, 1),
+         ("layer2.conv1", 384, 256, 3), ("layer2.conv2", 384, 384, 3), ("layer2.ds", 384, 256, 1),
+         ("layer3.conv1", 256, 384, 3), ("layer3.conv2", 256, 256, 3), ("layer3.ds", 256, 384, 1)]
+
+
+class _Scratch:
+    buf = None
+
+    @classmethod
+    def get(cls, dev):
+        if cls.buf is None or cls.buf.device != dev:
+            cls.buf = torch.empty(lib().be_train_scratch_bytes() // 4, dtype=torch.float32, device=dev)
+        return cls.buf
+
+
+def _new(shape, dev):
+    return torch.empty(shape, dtype=torch.float32, device=dev)
+
+
+def _conv_fwd(x, w, b, cout, ks, chw_hw=0):
+    """plain conv / linear + bias (no BatchNorm fold): x NHWC -> y NHWC."""
+    pw, pb = native.conv_pack(w, b, bn=None, chw_hw=chw_hw)
+    return native.conv_nhwc(x, pw, pb, cout, ks, act=0)
+
+
+def _bn_fwd(y, gamma, beta, rm, rv, res, act):
+    m, c = y.numel() // y.shape[-1], y.shape[-1]
+    dev = y.device
+    mean, invstd = _new(c, dev), _new(c, dev)
+    s_in = torch.empty_like(y) if act else None
+    out = torch.empty_like(y)
+    sc = _Scratch.get(dev)
+    check(lib().be_bn_train_fwd_f32(dptr(y), dptr(gamma), dptr(beta), dptr(res), BN_EPS, BN_MOMENTUM, dptr(rm), dptr(rv),
+                                    dptr(mean), dptr(invstd), dptr(s_in), dptr(out), m, c, int(act), dptr(sc),
+                                    sc.numel() * 4, stream_ptr(dev)), "be_bn_train_fwd_f32")
+    return out, (y, mean, invstd, s_in)
+
+
+def _bn_bwd(dout, saved, gamma):
+    y, mean, invstd, s_in = saved
+    m, c = y.numel() // y.shape[-1], y.shape[-1]
+    dev = y.device
+    ds, dy = torch.empty_like(y), torch.empty_like(y)
+    dgamma, dbeta = _new(c, dev), _new(c, dev)
+    sc = _Scratch.get(dev)
+    check(lib().be_bn_train_bwd_f32(dptr(dout), dptr(s_in), dptr(y), dptr(mean), dptr(invstd), dptr(gamma), dptr(ds),
+                                    dptr(dy), dptr(dgamma), dptr(dbeta), m, c, dptr(sc), sc.numel() * 4, stream_ptr(dev)),
+          "be_bn_train_bwd_f32")
+    return ds, dy, dgamma, dbeta
+
+
+def _col_sum(a):
+    m, c = a.numel() // a.shape[-1], a.shape[-1]
+    out = _new(c, a.device)
+    sc = _Scratch.get(a.device)
+    check(lib().be_col_sum_f32(dptr(a), dptr(out), m, c, dptr(sc), sc.numel() * 4, stream_ptr(a.device)), "be_col_sum_f32")
+    return out
+
+
+def _wgrad(x, dy, w_shape, ks, chw_hw=0):
+    n, h, w, cin = x.shape
+    cout = dy.shape[-1]
+    dw = _new(w_shape, x.device)
+    sc = _Scratch.get(x.device)
+    check(lib().be_conv_wgrad_f32(dptr(x), dptr(dy), dptr(dw), n, h, w, cin, cout, ks, chw_hw, dptr(sc), sc.numel() * 4,
+                                  stream_ptr(x.device)), "be_conv_wgrad_f32")
+    return dw
+
+
+def _dgrad(dy, w, cin, ks, chw_hw=0):
+    """dy NHWC [.., cout] -> dx NHWC [.., cin] through the transposed / mirrored pack."""
+    cout = w.shape[0]
+    dev = dy.device
+    pw = _new(lib().be_conv_dgrad_packed_floats(cout, cin, ks), dev)
+    pb = _new((cin + 31) // 32 * 32, dev)
+    check(lib().be_conv_pack_dgrad_f32(dptr(w.contiguous()), cout, cin, ks, chw_hw, dptr(pw), dptr(pb), stream_ptr(dev)),
+          "be_conv_pack_dgrad_f32")
+    return native.conv_nhwc(dy, pw, pb, cin, ks, act=0)
+
+
+def _pool_bwd(x, dout, k, stride, pad):
+    n, h, w, c = x.shape
+    dx = torch.empty_like(x)
+    check(lib().be_maxpool_nhwc_bwd_f32(dptr(x), dptr(dout), dptr(dx), n, h, w, c, k, stride, pad, stream_ptr(x.device)),
+          "be_maxpool_nhwc_bwd_f32")
+    return dx
+
+
+def forward_train(x, t):
+    """x [N,3,21,21]; t = the 86 tensors (native.local_stage_pack order).  Returns (logits [N,10], saved)."""
+    n = x.shape[0]
+    S = {}
+
+    def unit(name, i, xin, res=None, act=True):
+        _, cout, cin, ks = CONVS[i]
+        w, b, g, be_, rm, rv = t[6 * i:6 * i + 6]
+        y = _conv_fwd(xin, w, b, cout, ks)
+        out, saved = _bn_fwd(y, g, be_, rm, rv, res, act)
+        S[name] = (xin, saved)
+        return out
+
+    x4 = native.nchw3_to_nhwc4(x)
+    a1 = unit("conv1", 0, x4)
+    p1 = native.maxpool_nhwc(a1, 3, 2, 1)
+    S["pool1"] = a1
+
+    def block(tag, base, xin):
+        tt = unit(tag + ".conv1", base, xin)
+        d = unit(tag + ".ds", base + 2, xin, act=False)
+        return unit(tag + ".conv2", base + 1, tt, res=d)
+
+    l0 = block("layer0", 1, p1)
+    p2 = native.maxpool_nhwc(l0, 3, 2, 1)
+    S["pool2"] = l0
+    l1 = block("layer1", 4, p2)
+    l2 = block("layer2", 7, l1)
+    l3 = block("layer3", 10, l2)
+    p3 = native.maxpool_nhwc(l3, 2, 2, 0)
+    S["pool3"] = l3
+    f_in = p3.reshape(n, 1, 1, 2304)
+    w1, b1, g1, be1, rm1, rv1, w4, b4 = t[78:86]
+    y1 = _conv_fwd(f_in, w1, b1, 1024, 1, chw_hw=9)
+    f1, saved1 = _bn_fwd(y1, g1, be1, rm1, rv1, None, True)
+    S["fc1"] = (f_in, saved1)
+    pw4, pb4 = native.conv_pack(w4, b4)
+    out = native.conv_nhwc(f1, pw4, pb4, 10, 1, act=0).reshape(n, 10)
+    S["fc4"] = f1
+    return out, S
+
+
+def backward_train(dlogits, t, S):
+    """Returns the list of 86 gradients (None for running statistics) in the order of t."""
+    n = dlogits.shape[0]
+    dev = dlogits.device
+    grads = [None] * 86
+    w1, b1, g1, be1, rm1, rv1, w4, b4 = t[78:86]
+    # fc.4
+    f1 = S["fc4"].reshape(n, 1024)
+    dx, dw4, db4 = _new((n, 1024), dev), torch.empty_like(w4), torch.empty_like(b4)
+    check(lib().be_linear_small_bwd_f32(dptr(f1), dptr(w4.contiguous()), dptr(dlogits.contiguous()), dptr(dx), dptr(dw4),
+                                        dptr(db4), n, 1024, 10, stream_ptr(dev)), "be_linear_small_bwd_f32")
+    grads[84], grads[85] = dw4, db4
+    # fc.1 + BN1d + Smish
+    f_in, saved1 = S["fc1"]
+    ds, dy, dg, dbt = _bn_bwd(dx.reshape(n, 1, 1, 1024), saved1, g1)
+    grads[80], grads[81] = dg, dbt
+    grads[78] = _wgrad(f_in, dy, tuple(w1.shape), 1, chw_hw=9)
+    grads[79] = _col_sum(dy)
+    d = _dgrad(dy, w1, 2304, 1, chw_hw=9).reshape(n, 3, 3, 256)
+    d = _pool_bwd(S["pool3"], d, 2, 2, 0)
+
+    def unit_bwd(name, i, dout, need_dx=True):
+        """dout = gradient w.r.t. the unit's OUTPUT (after Smish if any).  Returns (ds, dx)."""
+        _, cout, cin, ks = CONVS[i]
+        w, b, g = t[6 * i], t[6 * i + 1], t[6 * i + 2]
+        xin, saved = S[name]
+        ds_, dy_, dg_, db_ = _bn_bwd(dout, saved, g)
+        grads[6 * i + 2], grads[6 * i + 3] = dg_, db_
+        grads[6 * i] = _wgrad(xin, dy_, tuple(w.shape), ks)
+        grads[6 * i + 1] = _col_sum(dy_)
+        dxi = _dgrad(dy_, w, cin, ks) if need_dx else None
+        return ds_, dxi
+
+    def block_bwd(tag, base, dout):
+        ds_, dt = unit_bwd(tag + ".conv2", base + 1, dout)            # ds_ = dout * smish'(.) = grad of the residual too
+        _, dx_ds = unit_bwd(tag + ".ds", base + 2, ds_)
+        _, dx_c1 = unit_bwd(tag + ".conv1", base, dt)
+        return dx_c1 + dx_ds                                           # elementwise add: torch op on GPU buffers
+
+    d = block_bwd("layer3", 10, d)
+    d = block_bwd("layer2", 7, d)
+    d = block_bwd("layer1", 4, d)
+    d = _pool_bwd(S["pool2"], d, 3, 2, 1)
+    d = block_bwd("layer0", 1, d)
+    d = _pool_bwd(S["pool1"], d, 3, 2, 1)
+    unit_bwd("conv1", 0, d, need_dx=False)
+    return grads
+
+
+class LocalStageTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, *tensors):
+        t = [v.detach() for v in tensors]
+        out, S = forward_train(x.detach().to(torch.float32).contiguous(), t)
+        ctx.S, ctx.t = S, t
+        return out
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        grads = backward_train(dlogits.contiguous(), ctx.t, ctx.S)
+        ctx.S = None
+        return (None,) + tuple(grads)

@@ -229,6 +229,7 @@ struct PackArgs {
     float eps;
     int cout, cin, ks, chw_hw, cout_pad, ktot;
     float *pw, *pb;
+    int dgrad;      // 1: pack W^T with mirrored taps: rows = input channels, K = (cout chunk, tap) -> data-gradient conv
 };
 
 __global__ void k_pack(PackArgs p) {
@@ -237,6 +238,18 @@ __global__ void k_pack(PackArgs p) {
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
         const int co = (int)(idx / p.ktot), k = (int)(idx % p.ktot);
         float v = 0.0f;
+        if (p.dgrad) {
+            // row = channel of the gradient being produced (an INPUT channel of the forward conv, in our NHWC order)
+            const int row = co, taps = p.ks * p.ks;
+            if (row < p.cin) {
+                const int kc = k / BK, e = k % BK, cc = kc / taps, tap = kc % taps;
+                const int oc = cc * BK + e;                                   // forward output channel
+                const int ci_ref = p.chw_hw > 0 ? (row % (p.cin / p.chw_hw)) * p.chw_hw + row / (p.cin / p.chw_hw) : row;
+                if (oc < p.cout) v = p.w[((size_t)oc * p.cin + ci_ref) * taps + (taps - 1 - tap)];
+            }
+            p.pw[idx] = v;
+            continue;
+        }
         if (co < p.cout) {
             const float scale = p.gamma ? p.gamma[co] / sqrtf(p.var[co] + p.eps) : 1.0f;
             const int kc = k / BK, e = k % BK;
@@ -262,7 +275,7 @@ __global__ void k_pack(PackArgs p) {
     // bias: one thread per output channel
     for (int64_t co = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; co < p.cout_pad; co += stride) {
         float v = 0.0f;
-        if (co < p.cout) {
+        if (!p.dgrad && co < p.cout) {
             const float b = p.b ? p.b[co] : 0.0f;
             if (p.gamma) v = (b - p.mean[co]) * (p.gamma[co] / sqrtf(p.var[co] + p.eps)) + p.beta[co];
             else v = b;
@@ -334,9 +347,26 @@ extern "C" int be_conv_pack_f32(const float* w, const float* b, const float* g, 
                     "be_conv_pack_f32: ksize %d / cin %d unsupported (ksize 1|3 with cin %% 32 == 0, or 7)", ksize, cin);
     BE_REQUIRE(chw_hw == 0 || (ksize == 1 && cin % chw_hw == 0), "be_conv_pack_f32: bad layout_chw_hw");
     PackArgs p{w, b, g, beta, mean, var, eps, cout, cin, ksize, chw_hw, round_up(cout, 32),
-               conv_nchunk(cin, ksize) * BK, pw, pb};
+               conv_nchunk(cin, ksize) * BK, pw, pb, 0};
     hipLaunchKernelGGL(k_pack, dim3(grid_cap((int64_t)p.cout_pad * p.ktot, 256)), dim3(256), 0, be::as_stream(stream), p);
     return be::check_launch("be_conv_pack_f32");
+}
+
+extern "C" size_t be_conv_dgrad_packed_floats(int cout, int cin, int ksize) {
+    if (cout <= 0 || cin <= 0 || cout % BK || (ksize != 1 && ksize != 3)) return 0;
+    return (size_t)round_up(cin, 32) * (cout / BK) * ksize * ksize * BK;
+}
+
+extern "C" int be_conv_pack_dgrad_f32(const float* w, int cout, int cin, int ksize, int chw_hw, float* pw, float* pb,
+                                      void* stream) {
+    BE_REQUIRE(w && pw && pb, "be_conv_pack_dgrad_f32: null pointer");
+    BE_REQUIRE(cout > 0 && cin > 0 && cout % BK == 0 && (ksize == 1 || ksize == 3),
+               "be_conv_pack_dgrad_f32: needs cout %% 32 == 0 and ksize 1|3 (got cout %d, ksize %d)", cout, ksize);
+    BE_REQUIRE(chw_hw == 0 || (ksize == 1 && cin % chw_hw == 0), "be_conv_pack_dgrad_f32: bad layout_chw_hw");
+    PackArgs p{w, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, cout, cin, ksize, chw_hw, round_up(cin, 32),
+               (cout / BK) * ksize * ksize * BK, pw, pb, 1};
+    hipLaunchKernelGGL(k_pack, dim3(grid_cap((int64_t)p.cout_pad * p.ktot, 256)), dim3(256), 0, be::as_stream(stream), p);
+    return be::check_launch("be_conv_pack_dgrad_f32");
 }
 
 extern "C" int be_conv_nhwc_f32(const be_conv_desc* d, const float* x, const float* pw, const float* pb,

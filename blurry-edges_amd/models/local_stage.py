@@ -102,11 +102,18 @@ class LocalStage(nn.Module):
         return self._packed
 
     def forward(self, x):
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("LocalStage training forward/backward (batch-statistics BatchNorm, dgrad, "
-                                      "wgrad) is not built yet; call .eval() / torch.no_grad() for inference")
         if self.training:
-            raise NotImplementedError("LocalStage in train() mode needs batch-statistics BatchNorm (not built yet)")
+            # batch-statistics BatchNorm + full backward on the HIP training kernels (be_hip/train.py);
+            # running statistics and num_batches_tracked are updated in place, as nn.BatchNorm does.
+            from be_hip.train import LocalStageTrainFn
+            if not x.is_cuda:
+                raise RuntimeError("LocalStage: expected a tensor on the GPU; the HIP path has no CPU fallback")
+            out = LocalStageTrainFn.apply(x, *self._tensor_list())
+            self._packed_key = None          # running statistics changed under the packed (BN-folded) weights
+            for m in self.modules():
+                if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):
+                    m.num_batches_tracked += 1
+            return out
         x = x.to(torch.float32).contiguous()
         out, self._workspace = native.local_stage_forward(self._packed_weights(), x, workspace=self._workspace)
         return out

@@ -210,6 +210,42 @@ int be_maxpool_nhwc_f32(const float* x, float* y, int n, int h, int w, int c, in
 int be_nchw3_to_nhwc4_f32(const float* x, float* y, int64_t n, int hw, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * LocalStage training kernels (models/local_stage.py under autograd; local_training.py:103-108)
+ *   Activations are NHWC matrices [M = N*H*W][C].  scratch: be_train_scratch_bytes() bytes, 16-byte aligned,
+ *   reused by every call (stream-ordered).  All reductions are two-stage in a fixed order (no float atomics).
+ * ------------------------------------------------------------------------------------------------- */
+size_t be_train_scratch_bytes(void);
+/* nn.BatchNorm2d/1d in train mode (+ optional residual add, + optional Smish): batch mean / biased variance per
+ * channel, running stats updated with `momentum` and the unbiased variance (run_* may be NULL).
+ * out = act((y-mean)*invstd*gamma + beta (+res)); s_in (may be NULL) receives the Smish input for the backward. */
+int be_bn_train_fwd_f32(const float* y, const float* gamma, const float* beta, const float* res, float eps,
+                        float momentum, float* run_mean, float* run_var, float* mean, float* invstd, float* s_in,
+                        float* out, int M, int C, int act, void* scratch, size_t scratch_bytes, void* stream);
+/* Backward of the above: ds = dout * smish'(s_in) (s_in NULL: ds = dout), dgamma = sum ds*xhat, dbeta = sum ds,
+ * dy = gamma*invstd*(ds - dbeta/M - xhat*dgamma/M).  ds may alias dout; ds is also the gradient of `res`. */
+int be_bn_train_bwd_f32(const float* dout, const float* s_in, const float* y, const float* mean, const float* invstd,
+                        const float* gamma, float* ds, float* dy, float* dgamma, float* dbeta, int M, int C,
+                        void* scratch, size_t scratch_bytes, void* stream);
+/* out[c] = sum_r a[r][c] (conv / linear bias gradients). */
+int be_col_sum_f32(const float* a, float* out, int M, int C, void* scratch, size_t scratch_bytes, void* stream);
+/* Backward of nn.MaxPool2d on NHWC: the gradient goes to the first maximum of each window (PyTorch's rule). */
+int be_maxpool_nhwc_bwd_f32(const float* x, const float* dout, float* dx, int n, int h, int w, int c, int k, int stride,
+                            int pad, void* stream);
+/* Weight gradient of a stride-1 "same" conv / a Linear (ksize 1 on a 1x1 image), fp32 MFMA, written in the
+ * reference's parameter layout dw [cout][cin][k][k] (ksize 7: x is the NHWC4 staging, dw is [cout][3][7][7];
+ * layout_chw_hw as in be_conv_pack_f32). */
+int be_conv_wgrad_f32(const float* x, const float* dy, float* dw, int n, int h, int w, int cin, int cout, int ksize,
+                      int layout_chw_hw, void* scratch, size_t scratch_bytes, void* stream);
+/* Data gradient = be_conv_nhwc_f32 with the transposed, tap-mirrored weights packed by this function
+ * (dx has `cin` channels; run the conv with desc.cin = cout, desc.cout = cin, act 0).  packed_bias: cin_pad32 zeros. */
+size_t be_conv_dgrad_packed_floats(int cout, int cin, int ksize);
+int be_conv_pack_dgrad_f32(const float* weight_oihw, int cout, int cin, int ksize, int layout_chw_hw, float* packed_w,
+                           float* packed_bias, void* stream);
+/* Last Linear (K -> J, J small): dx [M,K], dw [J,K], db [J] from x [M,K], w [J,K], dy [M,J]. */
+int be_linear_small_bwd_f32(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int M,
+                            int K, int J, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py's roofline leg): opt-in hipEvent pair around every conv launch, recorded on
  * the launch stream.  be_profile_enable(0) turns it off and frees the events.  Not thread-safe.
  * ------------------------------------------------------------------------------------------------- */

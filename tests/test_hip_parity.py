@@ -259,3 +259,57 @@ def test_local_loss_value_and_gradient_vs_fp64_golden(native, args):
     col, ex2 = h.render_colors(q, img.permute(0, 3, 1, 2).contiguous(), wrap_angles=True, want=("recon", "boundary"))
     assert relmax(ex["patches"].cpu(), ex2["recon"].cpu()) <= 1e-5
     assert relmax(ex["boundary"].cpu(), ex2["boundary"].cpu()) <= 1e-6
+
+
+# ------------------------------------------------------------------------------------------ training step
+def _load_train_model():
+    import models
+    m = models.LocalStage()
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.local_stage_state_dict().items()})
+    return m.to(DEV)
+
+
+def test_local_stage_train_forward_backward_vs_golden(native):
+    """Train-mode forward (batch statistics) and the full backward against the reference under autograd (G2)."""
+    g = load_golden("g2_local_stage_train")
+    m = _load_train_model().train()
+    x = T(synth.uniform_patches(64, name="train_patches")).to(DEV)
+    ct = T(synth.f32(synth.hash_normal(synth.SEED_DEFAULT, "train_cotangent", (64, 10)))).to(DEV)
+    y = m(x)
+    assert relmax(y.detach().cpu(), g["logits"]) <= 2e-5
+    (y * ct).sum().backward()
+    params = dict(m.named_parameters())
+    worst = 0.0
+    for k in g:
+        if k.startswith("grad_") and k != "grad_x_sub":
+            name = k[len("grad_"):]
+            if name.endswith(".0.bias") or name == "fc.1.bias":
+                # a conv / linear bias in front of a BatchNorm has an analytically ZERO gradient: both sides are
+                # round-off noise, so only its size can be compared
+                assert float(params[name].grad.abs().max()) < 1e-4 and np.abs(g[k]).max() < 1e-4, name
+                continue
+            e = relmax(params[name].grad.cpu(), g[k])
+            worst = max(worst, e)
+            assert e <= 5e-4, (name, e)
+    for name in ("layer2.0.conv2.0.weight", "fc.1.weight"):
+        gr = params[name].grad.flatten()
+        assert relmax(gr[::997].cpu(), g["gradsub_" + name]) <= 5e-4, name
+        assert abs(float(gr.double().norm()) - float(g["gradnorm_" + name])) <= 1e-4 * float(g["gradnorm_" + name])
+    tot = float(torch.sqrt(sum((p.grad.double() ** 2).sum() for p in m.parameters())))
+    assert abs(tot - float(g["total_grad_norm"])) <= 1e-4 * float(g["total_grad_norm"])
+    sd = m.state_dict()
+    assert relmax(sd["conv1.1.running_mean"].cpu(), g["run_mean_conv1"]) <= 1e-5
+    assert relmax(sd["conv1.1.running_var"].cpu(), g["run_var_conv1"]) <= 1e-5
+    assert relmax(sd["fc.2.running_mean"].cpu(), g["run_mean_fc2"]) <= 1e-5
+    assert relmax(sd["fc.2.running_var"].cpu(), g["run_var_fc2"]) <= 1e-5
+    assert int(sd["conv1.1.num_batches_tracked"]) == int(g["nbt"]) == 1
+    print("worst listed-parameter gradient error %.2e" % worst)
+    # eval after a training step uses the UPDATED running statistics (packed cache invalidated)
+    from oracle import local_stage as ols
+    m.eval()
+    with torch.no_grad():
+        ye = m(x[:8])
+    sd_cpu = {k: v.detach().cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        yo = ols.local_stage_forward(sd_cpu, x[:8].cpu())
+    assert relmax(ye.cpu(), yo) <= 1e-5
