@@ -274,3 +274,43 @@ def global_stage_state_dict(seed: int = SEED_DEFAULT, d_model=128, nlayers=8, d_
 def global_features(p: int = 4096, seed: int = SEED_DEFAULT, name: str = "pm") -> np.ndarray:
     """[1,P,38] normalised features in the range blurry_edges_test.py:129-132 produces ([-1,1]-ish)."""
     return f32(-1.0 + 2.0 * hash_uniform(seed, name, (1, p, 38)))
+
+
+# ---------------------------------------------------------------------------------------
+# Synthetic local-training set (the tensors data/dataset.py:40-47 hands to local_training.py:102-105)
+# ---------------------------------------------------------------------------------------
+
+def synthetic_training_patches(n: int, seed: int = SEED_DEFAULT):
+    """n single-aperture 21x21 training patches of blurred edge / corner scenes, already divided by alpha:
+    dict(img_ny [n,21,21,3], img_gt [n,21,21,3] (noise-free), bndry_dist [n,21,21] (pixels to the nearest true
+    boundary), deri [n,19,19,3] (Sobel magnitude of the clean image, border cropped)) -- float32, channels-last,
+    the layouts of train_val_data_generator.py:267-275 / data/dataset.py:11-19."""
+    name = "trainset"
+    z = Z_RANGE[0] + (Z_RANGE[1] - Z_RANGE[0]) * hash_uniform(seed, name + ".z", (n,))
+    sig = blur_sigma_px(z)[:, 0]
+    ang = 2.0 * math.pi * hash_uniform(seed, name + ".ang", (n, 2))
+    off = -6.0 + 12.0 * hash_uniform(seed, name + ".off", (n, 2))
+    two = hash_uniform(seed, name + ".two", (n,)) < 0.5
+    col = hash_uniform(seed, name + ".col", (n, 3, 3))
+    alpha = ALPHA_RANGE[0] + (ALPHA_RANGE[1] - ALPHA_RANGE[0]) * hash_uniform(seed, name + ".alpha", (n,))
+    yy, xx = np.meshgrid(np.arange(21) - 10.0, np.arange(21) - 10.0, indexing="ij")
+    s = sig[:, None, None] * math.sqrt(2.0)
+    d1 = (-np.sin(ang[:, 0])[:, None, None] * xx + np.cos(ang[:, 0])[:, None, None] * yy) - off[:, 0][:, None, None]
+    d2 = (-np.sin(ang[:, 1])[:, None, None] * xx + np.cos(ang[:, 1])[:, None, None] * yy) - off[:, 1][:, None, None]
+    h1 = 0.5 * (1.0 + _erf(d1 / s))
+    h2 = np.where(two[:, None, None], 0.5 * (1.0 + _erf(d2 / s)), 0.0)
+    u = np.stack([(1 - h1) * (1 - h2), h1 * (1 - h2), h2], axis=-1)            # [n,21,21,3 wedges]
+    gt = np.einsum("nhwk,nkc->nhwc", u, col)                                   # [n,21,21,3 rgb]
+    lam = gt * alpha[:, None, None, None]
+    g1 = hash_normal(seed, name + ".shot", gt.shape)
+    g2 = hash_normal(seed, name + ".read", gt.shape)
+    ny = np.rint(np.clip(lam + np.sqrt(np.maximum(lam, 0.0)) * g1 + READ_SIGMA * g2, 0.0, alpha[:, None, None, None]))
+    ny = ny / alpha[:, None, None, None]
+    # boundary distance: |d1| where wedge 2 does not cover, |d2| on its edge; nearest of the visible edges
+    bd = np.where(two[:, None, None], np.minimum(np.where(d2 < 0, np.abs(d1), 1e3), np.abs(d2)), np.abs(d1))
+    kx = np.array([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]], dtype=np.float64)
+    ky = np.array([[1, 2, 1], [0, 0, 0], [-1, -2, -1]], dtype=np.float64)
+    gx = sum(kx[a, b] * gt[:, a:a + 19, b:b + 19, :] for a in range(3) for b in range(3))
+    gy = sum(ky[a, b] * gt[:, a:a + 19, b:b + 19, :] for a in range(3) for b in range(3))
+    deri = np.sqrt(gx ** 2 + gy ** 2)
+    return dict(img_ny=f32(ny), img_gt=f32(gt), bndry_dist=f32(bd), deri=f32(deri))

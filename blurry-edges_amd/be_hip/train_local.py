@@ -1,0 +1,91 @@
+"""Local-stage training loop: the build's counterpart of local_training.py:68-118 (epoch loop, beta schedule,
+AdamW lr 6e-5, clip-norm 1, ReduceLROnPlateau) on the HIP training kernels, optionally data-parallel.
+
+    python -m be_hip.train_local --steps 200            (single GPU, synthetic basic-shapes patches)
+    torchrun --nproc-per-node 8 -m be_hip.train_local   (per-GPU batch 64, RCCL gradient all-reduce)
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import time
+
+import numpy as np
+import torch
+
+from . import dp, synth
+
+
+class BetaSchedule:
+    """LocalLoss.update_beta / final_beta (local_training.py:18-30): linear 0 -> max over dynamic_epoch epochs."""
+
+    def __init__(self, max_bndry, max_smooth, dynamic_epoch):
+        self.max_b, self.max_s, self.dyn, self.idx = max_bndry, max_smooth, dynamic_epoch, -1
+        self.beta_b = self.beta_s = 0.0
+
+    def step(self):
+        self.idx += 1
+        rate = self.idx / (self.dyn - 1) if self.idx < self.dyn else 1.0
+        self.beta_b, self.beta_s = rate * self.max_b, rate * self.max_s
+
+    def final(self):
+        self.beta_b, self.beta_s = self.max_b, self.max_s
+
+
+def train_step(model, helper, opt, batch, beta_b, beta_s, flat=None, world=1, clip=1.0):
+    """One iteration of local_training.py:103-108.  batch: dict of GPU tensors (dataset layouts)."""
+    import utils
+    est = model(batch["img_ny"].permute(0, 3, 1, 2))
+    opt.zero_grad(set_to_none=False)
+    loss = utils.local_loss(helper, est, batch["img_gt"], batch["img_gt"], batch["bndry_dist"], batch["deri"], beta_b, beta_s)
+    loss.backward()
+    if flat is not None:
+        dp.copy_grads_into(flat, list(model.parameters()))
+        dp.allreduce_mean_(flat, world)
+    torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=clip, norm_type=2)
+    opt.step()
+    return loss.detach()
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--patches", type=int, default=16000)       # 8000 images x 2 (train_val_data_generator.py:188)
+    ap.add_argument("--lr", type=float, default=6e-5)
+    a = ap.parse_args(argv)
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    lr_ = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", lr_))
+    torch.cuda.set_device(lr_)
+    dev = torch.device("cuda", lr_)
+    import models, utils
+    args = utils.get_args("local_train", argv=[])
+    model = models.LocalStage().to(dev)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)).to(dev) for k, v in synth.local_stage_state_dict().items()})
+    helper = utils.PostProcessLocalBase(args, dev)
+    opt = torch.optim.AdamW(model.parameters(), lr=a.lr)
+    flat = dp.flat_grad_buffer(model.parameters()) if world > 1 else None
+    data = {k: torch.from_numpy(v).to(dev) for k, v in synth.synthetic_training_patches(a.patches, seed=1869 + rank).items()}
+    sched = BetaSchedule(args.beta_bndry_loc, args.beta_smthns, args.dynamic_epoch)
+    sched.final()
+    model.train()
+    losses = []
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for it in range(a.steps):
+        lo = (it * a.batch) % (a.patches - a.batch + 1)
+        batch = {k: v[lo:lo + a.batch] for k, v in data.items()}
+        losses.append(train_step(model, helper, opt, batch, sched.beta_b, sched.beta_s, flat, world))
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if rank == 0:
+        print(json.dumps({"metric": "local training patches/s", "value": world * a.batch * a.steps / dt, "n_gpus": world,
+                          "ms_per_step": dt / a.steps * 1e3, "first_loss": float(losses[0]), "last_loss": float(losses[-1])}))
+
+
+if __name__ == "__main__":
+    main()

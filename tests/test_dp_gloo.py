@@ -1,0 +1,66 @@
+"""Gradient exchange of data-parallel training on two gloo ranks (CPU): averaging the per-rank gradients of a
+half batch each through be_hip.dp equals the gradient of the mean loss over the full batch."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT, PKG
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _model():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Linear(12, 32), torch.nn.Tanh(), torch.nn.Linear(32, 5))
+
+
+def _worker(rank, world, port, q):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from be_hip import dp
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(1)
+    m = _model()
+    flat = dp.flat_grad_buffer(m.parameters())
+    g = torch.Generator().manual_seed(1)
+    x, y = torch.randn(16, 12, generator=g), torch.randn(16, 5, generator=g)
+    xs, ys = x[rank * 8:(rank + 1) * 8], y[rank * 8:(rank + 1) * 8]
+    for p in m.parameters():
+        p.grad = None                                   # autograd then allocates fresh grads, as after the HIP backward
+    ((m(xs) - ys) ** 2).mean().backward()
+    dp.copy_grads_into(flat, list(m.parameters()))
+    dp.allreduce_mean_(flat, world, bucket_bytes=256)   # tiny buckets: exercises the bucketing
+    if rank == 0:
+        q.put(flat.clone().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gradient_average_equals_full_batch_gradient():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    m = _model()
+    g = torch.Generator().manual_seed(1)
+    x, y = torch.randn(16, 12, generator=g), torch.randn(16, 5, generator=g)
+    ((m(x) - y) ** 2).mean().backward()
+    ref = torch.cat([p.grad.flatten() for p in m.parameters()]).numpy()
+    assert np.allclose(got, ref, rtol=1e-5, atol=1e-7)
