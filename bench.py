@@ -86,7 +86,14 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # rehearsal knobs (a 1-GPU box): BE_DIST_BACKEND=gloo BE_LOCAL_DEVICE=0 runs every rank on one device
+        backend = os.environ.get("BE_DIST_BACKEND", "nccl")
+        if "BE_LOCAL_DEVICE" in os.environ:
+            local_rank = int(os.environ["BE_LOCAL_DEVICE"])
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -131,7 +138,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 

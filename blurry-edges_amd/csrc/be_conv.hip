@@ -21,6 +21,7 @@
 //     XCD's L2), so an activation tile is fetched from HBM once
 #include "be_common.h"
 #include "be_device_math.h"
+#include <cstdlib>
 
 namespace {
 
@@ -29,7 +30,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: HIP
 
 constexpr int BM = 128;
 constexpr int BK = 32;
-constexpr int LDS_ROW = 36;           // floats per LDS row (32 + 4 pad)
 enum { MODE_TAPS = 0, MODE_ROW8 = 1 };
 
 struct ConvArgs {
@@ -44,15 +44,22 @@ struct ConvArgs {
 // __launch_bounds__(256, 2): LDS admits two blocks per CU (= 2 waves per SIMD), so let the register allocator use
 // up to 256 VGPR+AGPR: with the default budget it spilled the staged B chunk to scratch and waited for the global
 // loads BEFORE the MFMA phase (v1: 60 % MFMA-busy).
-template <int WM, int WN, int MT, int NT, int MODE>
-__global__ __launch_bounds__(256, 2)
+// BKT = K-chunk in floats (32, or 16: 41 KB of LDS -> three blocks per CU); PRIO: s_setprio around the MFMA phase.
+template <int WM, int WN, int MT, int NT, int MODE, int BKT, int PRIO>
+__global__ __launch_bounds__(256, BKT == 16 ? (PRIO == 2 ? 4 : 3) : (BKT == 8 ? 4 : 2))
 void k_conv_igemm(ConvArgs a) {
     static_assert(WM * WN == 4 && WM * MT * 32 == BM, "4 waves, 128 rows");
+    static_assert(BKT == 32 || BKT == 16 || BKT == 8, "K chunk");
     constexpr int BN = WN * NT * 32;
-    constexpr int NB = BN / 32;                       // B staging float4 per thread
+    constexpr int LROW = BKT + 4;                      // floats per LDS row (pad 4: conflict-free b128 reads/writes)
+    constexpr int QL = BKT / 4;                        // lanes per staged row (16 B each)
+    constexpr int RP = 256 / QL;                       // rows staged per pass
+    constexpr int NA = BM / RP, NB = (BN + RP - 1) / RP;   // staging vectors per thread (last B pass may be partial)
+    constexpr bool B_PARTIAL = BN % RP != 0;
+    constexpr int SUB = 32 / BKT;                      // chunks per 32-channel packing unit
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* As = smem;                                  // [2][BM][LDS_ROW]
-    float* Bs = smem + 2 * BM * LDS_ROW;               // [2][BN][LDS_ROW]
+    float* As = smem;                                  // [2][BM][LROW]
+    float* Bs = smem + 2 * BM * LROW;                  // [2][BN][LROW]
 
     // ---- block -> tile (XCD-aware: blocks b, b+8, b+16.. share an XCD and walk the N tiles of one M tile)
     const int bid = blockIdx.x;
@@ -63,13 +70,13 @@ void k_conv_igemm(ConvArgs a) {
     const int m0 = m_tile * BM, n0 = n_tile * BN;
 
     const int tid = threadIdx.x;
-    const int q = tid & 7, r0 = tid >> 3;              // staging: 8 lanes x 16 B = one 128-B row chunk
+    const int q = tid % QL, r0 = tid / QL;             // staging: QL lanes x 16 B = one row chunk
 
-    // ---- per-thread A rows (4): flat output pixel m -> (y,x) for the border test; base offset m*Cin
-    int a_off[4], a_yx[4];
+    // ---- per-thread A rows: flat output pixel m -> (y,x) for the border test; base offset m*Cin
+    int a_off[NA], a_yx[NA];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + r0 + 32 * i;
+    for (int i = 0; i < NA; ++i) {
+        const int m = m0 + r0 + RP * i;
         if (m < a.M) {
             const int pp = m % a.HW;
             const int yy = pp / a.W, xx = pp - yy * a.W;
@@ -84,23 +91,24 @@ void k_conv_igemm(ConvArgs a) {
 
     // Staging registers for the next K chunk.  Straight-line helpers on array references (no lambdas, no
     // conditionals around the loads): anything else made hipcc keep b_st in scratch memory.
-    f32x4 a_st[4], b_st[NB];
+    f32x4 a_st[NA], b_st[NB];
     unsigned a_ok = 0;                                 // bit i: a_st[i] is inside the image (else stored as zeros)
 #define BE_LOAD_CHUNK(KC)                                                                                       \
     do {                                                                                                        \
         int dy_, dx_, coff_;                                                                                    \
         if (MODE == MODE_TAPS) {                                                                                \
+            const int k32_ = (KC) / SUB, sub_ = (KC) - k32_ * SUB;                                              \
             const int taps_ = a.ks * a.ks;                                                                      \
-            const int cc_ = (KC) / taps_, tap_ = (KC) - cc_ * taps_;                                            \
+            const int cc_ = k32_ / taps_, tap_ = k32_ - cc_ * taps_;                                            \
             const int half_ = a.ks >> 1;                                                                        \
             dy_ = tap_ / a.ks - half_; dx_ = tap_ % a.ks - half_;                                               \
-            coff_ = (dy_ * a.W + dx_) * a.Cin + cc_ * BK + 4 * q;                                               \
+            coff_ = (dy_ * a.W + dx_) * a.Cin + cc_ * 32 + sub_ * BKT + 4 * q;                                  \
         } else { /* conv1: chunk = kernel row kh, 8 pixels x 4 channels */                                      \
             dy_ = (KC) - 3; dx_ = q - 3;                                                                        \
             coff_ = (dy_ * a.W + dx_) * 4;                                                                      \
         }                                                                                                       \
         a_ok = 0;                                                                                               \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                      \
+        _Pragma("unroll") for (int i_ = 0; i_ < NA; ++i_) {                                                     \
             const int yy_ = (a_yx[i_] >> 16) + dy_, xx_ = (a_yx[i_] & 0xffff) + dx_;                            \
             const bool ok_ = a_yx[i_] >= 0 && (unsigned)yy_ < (unsigned)a.H && (unsigned)xx_ < (unsigned)a.W;   \
             /* branch-free: out-of-image taps read the (valid) first 16 B of the tensor and are zeroed */      \
@@ -109,26 +117,30 @@ void k_conv_igemm(ConvArgs a) {
             a_st[i_] = *reinterpret_cast<const f32x4*>(a.x + off_);  /* zeroed at store time: no wait here */   \
             a_ok |= (ok_ ? 1u : 0u) << i_;                                                                      \
         }                                                                                                       \
-        _Pragma("unroll") for (int i_ = 0; i_ < NB; ++i_)                                                       \
-            b_st[i_] = *reinterpret_cast<const f32x4*>(wrow  + (size_t)(32 * i_) * a.Ktot + (KC) * BK);         \
+        _Pragma("unroll") for (int i_ = 0; i_ < NB; ++i_) {                                                     \
+            /* a partial last pass re-reads the thread's first row (always inside the tile); it is not stored */ \
+            const int rowoff_ = (B_PARTIAL && RP * i_ + r0 >= BN) ? 0 : RP * i_;                                \
+            b_st[i_] = *reinterpret_cast<const f32x4*>(wrow + (size_t)rowoff_ * a.Ktot + (KC) * BKT);           \
+        }                                                                                                       \
     } while (0)
 #define BE_STORE_CHUNK(BUF)                                                                                     \
     do {                                                                                                        \
-        float* Ad_ = As + (BUF) * BM * LDS_ROW;                                                                 \
-        float* Bd_ = Bs + (BUF) * BN * LDS_ROW;                                                                 \
-        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_)                                                        \
-            *reinterpret_cast<f32x4*>(Ad_  + (r0 + 32 * i_) * LDS_ROW + 4 * q) =                                \
+        float* Ad_ = As + (BUF) * BM * LROW;                                                                    \
+        float* Bd_ = Bs + (BUF) * BN * LROW;                                                                    \
+        _Pragma("unroll") for (int i_ = 0; i_ < NA; ++i_)                                                       \
+            *reinterpret_cast<f32x4*>(Ad_ + (r0 + RP * i_) * LROW + 4 * q) =                                    \
                 ((a_ok >> i_) & 1u) ? a_st[i_] : f32x4{0.f, 0.f, 0.f, 0.f};                                     \
         _Pragma("unroll") for (int i_ = 0; i_ < NB; ++i_)                                                       \
-            *reinterpret_cast<f32x4*>(Bd_  + (r0 + 32 * i_) * LDS_ROW + 4 * q) = b_st[i_];                      \
+            if (!B_PARTIAL || RP * i_ + r0 < BN)                                                                \
+                *reinterpret_cast<f32x4*>(Bd_ + (r0 + RP * i_) * LROW + 4 * q) = b_st[i_];                      \
     } while (0)
 
     // ---- wave / lane roles for the MFMA phase
     const int wave = tid >> 6, lane = tid & 63;
     const int wm = wave / WN, wn = wave % WN;
     const int li = lane & 31, lh = lane >> 5;
-    const int a_frag0 = ((wm * MT) * 32 + li) * LDS_ROW + 4 * lh;
-    const int b_frag0 = ((wn * NT) * 32 + li) * LDS_ROW + 4 * lh;
+    const int a_frag0 = ((wm * MT) * 32 + li) * LROW + 4 * lh;
+    const int b_frag0 = ((wn * NT) * 32 + li) * LROW + 4 * lh;
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -138,25 +150,27 @@ void k_conv_igemm(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
+    const int nchunk = a.nchunk * SUB;
     BE_LOAD_CHUNK(0);
     BE_STORE_CHUNK(0);
     __syncthreads();
 
-    for (int kc = 0; kc < a.nchunk; ++kc) {
+    for (int kc = 0; kc < nchunk; ++kc) {
         const int buf = kc & 1;
         // always prefetch (the last iteration re-reads its own chunk into the idle buffer: keeps the body branch-free)
-        const int kn = kc + 1 < a.nchunk ? kc + 1 : kc;
+        const int kn = kc + 1 < nchunk ? kc + 1 : kc;
         BE_LOAD_CHUNK(kn);
         __builtin_amdgcn_sched_barrier(0);            // the loads stay ABOVE the MFMA phase (hipcc sank them below it)
-        const float* Ab = As + buf * BM * LDS_ROW + a_frag0;
-        const float* Bb = Bs + buf * BN * LDS_ROW + b_frag0;
+        const float* Ab = As + buf * BM * LROW + a_frag0;
+        const float* Bb = Bs + buf * BN * LROW + b_frag0;
+        if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < BKT / 8; ++g) {
             f32x4 af[MT], bf[NT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDS_ROW + 8 * g);
+            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LROW + 8 * g);
 #pragma unroll
-            for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDS_ROW + 8 * g);
+            for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LROW + 8 * g);
 #pragma unroll
             for (int i = 0; i < MT; ++i)
 #pragma unroll
@@ -167,6 +181,7 @@ void k_conv_igemm(ConvArgs a) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
                 }
         }
+        if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);            // ... and the LDS hand-over stays below it
         BE_STORE_CHUNK(buf ^ 1);
         __syncthreads();
@@ -196,13 +211,13 @@ void k_conv_igemm(ConvArgs a) {
     }
 }
 
-template <int WM, int WN, int MT, int NT, int MODE>
+template <int WM, int WN, int MT, int NT, int MODE, int BKT = 32, int PRIO = 0>
 int launch_conv(const ConvArgs& a, hipStream_t s, int kernel_id) {
     constexpr int BN = WN * NT * 32;
-    constexpr size_t lds = (size_t)2 * (BM + BN) * LDS_ROW * sizeof(float);
+    constexpr size_t lds = (size_t)2 * (BM + BN) * (BKT + 4) * sizeof(float);
     static bool attr_set = false;                     // raise the dynamic-LDS cap once per instantiation
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_igemm<WM, WN, MT, NT, MODE>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_igemm<WM, WN, MT, NT, MODE, BKT, PRIO>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return be::fail(BE_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
@@ -214,9 +229,15 @@ int launch_conv(const ConvArgs& a, hipStream_t s, int kernel_id) {
         const double cin_real = MODE == MODE_ROW8 ? 3.0 : (double)a.Cin;
         be::ProfileScope prof(s, kernel_id, 2.0 * a.M * k_real * a.Cout,
                               4.0 * (a.M * cin_real + k_real * a.Cout + (double)a.M * a.Cout * (a.res ? 2 : 1)));
-        hipLaunchKernelGGL((k_conv_igemm<WM, WN, MT, NT, MODE>), dim3(grid), dim3(256), lds, s, a);
+        hipLaunchKernelGGL((k_conv_igemm<WM, WN, MT, NT, MODE, BKT, PRIO>), dim3(grid), dim3(256), lds, s, a);
     }
     return be::check_launch("be_conv_nhwc_f32");
+}
+
+// tuning knob for A/B runs: BE_CONV_VARIANT=32 selects the K-chunk-32 instantiations
+inline int conv_variant() {
+    static const int v = getenv("BE_CONV_VARIANT") ? atoi(getenv("BE_CONV_VARIANT")) : 0;
+    return v;
 }
 
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
@@ -394,8 +415,18 @@ extern "C" int be_conv_nhwc_f32(const be_conv_desc* d, const float* x, const flo
         a.n_tiles = 1;
         return launch_conv<4, 1, 1, 2, MODE_ROW8>(a, s, BE_KERNEL_CONV_ROW8_128x64);
     }
-    if (cp % 128 == 0) { a.n_tiles = cp / 128; return launch_conv<2, 2, 2, 2, MODE_TAPS>(a, s, BE_KERNEL_CONV_128x128); }
-    if (cp % 96 == 0)  { a.n_tiles = cp / 96;  return launch_conv<4, 1, 1, 3, MODE_TAPS>(a, s, BE_KERNEL_CONV_128x96); }
+    if (cp % 128 == 0) {
+        a.n_tiles = cp / 128;
+        // K-chunk 16 (40 KB of LDS, three workgroups per CU) measured 8 % faster than 32 (two per CU); 8 is slower
+        // again (barrier per 16 MFMAs); s_setprio around the MFMA phase and a 4th workgroup per CU change nothing.
+        if (conv_variant() == 32) return launch_conv<2, 2, 2, 2, MODE_TAPS, 32, 0>(a, s, BE_KERNEL_CONV_128x128);
+        return launch_conv<2, 2, 2, 2, MODE_TAPS, 16, 0>(a, s, BE_KERNEL_CONV_128x128);
+    }
+    if (cp % 96 == 0) {
+        a.n_tiles = cp / 96;
+        if (conv_variant() == 32) return launch_conv<4, 1, 1, 3, MODE_TAPS, 32, 0>(a, s, BE_KERNEL_CONV_128x96);
+        return launch_conv<4, 1, 1, 3, MODE_TAPS, 16, 0>(a, s, BE_KERNEL_CONV_128x96);
+    }
     if (cp % 64 == 0)  { a.n_tiles = cp / 64;  return launch_conv<4, 1, 1, 2, MODE_TAPS>(a, s, BE_KERNEL_CONV_128x64); }
     a.n_tiles = cp / 32;
     return launch_conv<4, 1, 1, 1, MODE_TAPS>(a, s, BE_KERNEL_CONV_128x32);
