@@ -78,6 +78,11 @@ _SIGNATURES = {
     "be_conv_dgrad_packed_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "be_conv_pack_dgrad_f32": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "be_linear_small_bwd_f32": (C.c_int, [_P] * 6 + [C.c_int] * 3 + [_P]),
+    "be_params2dists_f32": (C.c_int, [C.POINTER(RenderOpts), _P, _P, C.c_int64, _P]),
+    "be_dists2indicators_f32": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
+    "be_inverse3x3_f32": (C.c_int, [_P, _P, C.c_int64, _P]),
+    "be_image_derivative_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, _P]),
+    "be_fold_patches_f32": (C.c_int, [_P, _P, _P] + [C.c_int] * 7 + [C.c_int64] * 6 + [C.c_int, _P]),
     "be_profile_enable": (C.c_int, [C.c_int]),
     "be_profile_reset": (C.c_int, []),
     "be_profile_read": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),

@@ -39,12 +39,67 @@ class PostProcessBase(nn.Module, ABC):
     def get_xy_mat(self, xx, yy):
         raise NotImplementedError
 
-    # ---- elementwise pieces of the reference API that map 1:1 onto a kernel
+    # ---- the reference's fine-grained methods (utils/postprocessing_loss.py:43-117), each one HIP kernel.
+    #      Both layouts of the reference are accepted: local [N,K,...] and global [B,K,...,Hp,Wp] (patch index fastest);
+    #      the global one is permuted to the kernels' flat one-row-per-patch layout and back (views + one copy).
+    @staticmethod
+    def _flat_params(t):
+        """[N,K] stays; [B,K,Hp,Wp] -> ([B*Hp*Wp,K], (B,Hp,Wp))."""
+        if t.dim() == 2:
+            return t.contiguous(), None
+        b, k, hp, wp = t.shape
+        return t.permute(0, 2, 3, 1).reshape(-1, k).contiguous(), (b, hp, wp)
+
+    @staticmethod
+    def _unflat_pixels(t, grid):
+        """[N,K,21,21] -> as is, or back to [B,K,21,21,Hp,Wp]."""
+        if grid is None:
+            return t
+        b, hp, wp = grid
+        return t.view(b, hp, wp, t.shape[1], t.shape[2], t.shape[3]).permute(0, 3, 4, 5, 1, 2)
+
     def params2etas(self, params):
         return native.params2etas(params)
 
+    def params2dists(self, params):
+        p, grid = self._flat_params(params)
+        n = p.shape[0]
+        out = torch.empty(n, 2, self.R, self.R, dtype=torch.float32, device=p.device)
+        native.check(native.lib().be_params2dists_f32(native.C.byref(self.render_opts(False)), native.dptr(p, "params"),
+                                                      native.dptr(out), n, native.stream_ptr(p.device)), "be_params2dists_f32")
+        return self._unflat_pixels(out, grid)
+
+    def dists2indicators(self, dists, etas):
+        if dists.dim() == 6:                                   # global layout [B,2,21,21,Hp,Wp]
+            b, _, _, _, hp, wp = dists.shape
+            d = dists.permute(0, 4, 5, 1, 2, 3).reshape(-1, 2, self.R, self.R).contiguous()
+            grid = (b, hp, wp)
+        else:
+            d, grid = dists.contiguous(), None
+        e, _ = self._flat_params(etas)
+        n = d.shape[0]
+        out = torch.empty(n, 3, self.R, self.R, dtype=torch.float32, device=d.device)
+        native.check(native.lib().be_dists2indicators_f32(native.dptr(d, "dists"), native.dptr(e, "etas"), native.dptr(out),
+                                                          n, native.stream_ptr(d.device)), "be_dists2indicators_f32")
+        return self._unflat_pixels(out, grid)
+
     def normalized_gaussian(self, x, delta=0.07):
         return torch.exp(-x ** 2 / delta ** 2)
+
+    def inverse_3by3(self, A):
+        a = A.contiguous()
+        out = torch.empty_like(a)
+        native.check(native.lib().be_inverse3x3_f32(native.dptr(a, "A"), native.dptr(out), a.numel() // 9,
+                                                    native.stream_ptr(a.device)), "be_inverse3x3_f32")
+        return out
+
+    def get_image_derivative(self, img):
+        x = img.contiguous()
+        n, c, h, w = x.shape
+        out = torch.empty(n, c, h - 2, w - 2, dtype=torch.float32, device=x.device)
+        native.check(native.lib().be_image_derivative_f32(native.dptr(x, "img"), native.dptr(out), n * c, h, w,
+                                                          native.stream_ptr(x.device)), "be_image_derivative_f32")
+        return out
 
     # ---- fused passes (flat layout)
     def render_opts(self, wrap_angles=False):
@@ -77,8 +132,44 @@ class PostProcessGlobalBase(PostProcessBase):
         self.H_patches = int(np.floor((self.H - self.R) / self.stride) + 1)
         self.W_patches = int(np.floor((self.W - self.R) / self.stride) + 1)
 
+        cy = torch.tensor([sum(1 for i in range(self.H_patches) if self.stride * i <= y <= self.stride * i + self.R - 1)
+                           for y in range(self.H)], dtype=torch.float32)
+        cx = torch.tensor([sum(1 for j in range(self.W_patches) if self.stride * j <= x <= self.stride * j + self.R - 1)
+                           for x in range(self.W)], dtype=torch.float32)
+        self.num_patches = (cy[:, None] * cx[None, :]).to(self.device)          # = nn.Fold(ones), :139-143
+
     def get_xy_mat(self, xx, yy):
         return (xx.view(1, self.R, self.R, 1, 1).to(self.device), yy.view(1, self.R, self.R, 1, 1).to(self.device))
+
+    # ---- nn.Fold aggregations of the reference (:151-173) on materialised patch tensors [.., 21,21,Hp,Wp]
+    def _fold(self, t, lead, mode, int_src=False):
+        """t viewed as [lead, C, 21, 21, Hp, Wp] contiguous -> [lead, C, H, W]."""
+        p = self.H_patches * self.W_patches
+        c = t.numel() // (lead * self.R * self.R * p)
+        t = t.contiguous()
+        out = torch.empty(lead, c, self.H, self.W, dtype=torch.float32, device=t.device)
+        src, src_i = (None, native.dptr(t, "mask")) if int_src else (native.dptr(t, "patches"), None)
+        native.check(native.lib().be_fold_patches_f32(src, src_i, native.dptr(out), lead, c, self.H_patches, self.W_patches,
+                                                      self.H, self.W, self.stride, c * self.R * self.R * p,
+                                                      self.R * self.R * p, self.R * p, p, self.W_patches, 1, mode,
+                                                      native.stream_ptr(t.device)), "be_fold_patches_f32")
+        return out
+
+    def local2global_color(self, patches, pair=True):
+        if pair:
+            return self._fold(patches, self.batch_size * 2, 1).view(self.batch_size, 2, 3, self.H, self.W)
+        return self._fold(patches, self.batch_size, 1).view(self.batch_size, 3, self.H, self.W)
+
+    def local2global_bndry(self, bndry_patches):
+        return self._fold(bndry_patches, self.batch_size, 1).view(self.batch_size, 1, self.H, self.W)
+
+    def local2global_depth(self, depth_map, depth_mask):
+        is_int = depth_mask.dtype == torch.int32
+        cnt = self._fold(depth_mask if is_int else depth_mask.to(torch.float32), self.batch_size, 2, int_src=is_int)
+        cnt = cnt.view(self.batch_size, self.H, self.W)
+        tot = self._fold(depth_map.to(torch.float32), self.batch_size, 0).view(self.batch_size, self.H, self.W)
+        conf = cnt / self.num_patches.unsqueeze(0)
+        return tot / torch.where(cnt > 0, cnt, torch.ones_like(cnt)), conf
 
 
 class _LocalLossFn(torch.autograd.Function):

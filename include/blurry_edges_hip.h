@@ -147,6 +147,25 @@ int be_local_features_f32(const float* params10, const float* colors, float* pm,
 int be_global_denorm_f32(const float* y, float* est, int64_t P, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * The base-class methods of PostProcessBase one by one (for callers that subclass the reference's
+ * PostProcessLocalBase / PostProcessGlobalBase and chain them themselves), flat layout:
+ * ------------------------------------------------------------------------------------------------- */
+/* params2dists (utils/postprocessing_loss.py:43-86): params8 [N,8] -> dists [N,2,21,21]. */
+int be_params2dists_f32(const be_render_opts* opts_host, const float* params8, float* dists, int64_t n, void* stream);
+/* dists2indicators (:91-95): dists [N,2,21,21], etas [N,2] -> wedges [N,3,21,21]. */
+int be_dists2indicators_f32(const float* dists, const float* etas, float* wedges, int64_t n, void* stream);
+/* inverse_3by3 (:104-112): n row-major 3x3 matrices (cofactor inverse, fp64 inside). */
+int be_inverse3x3_f32(const float* a, float* out, int64_t n, void* stream);
+/* get_image_derivative (:114-117): per-plane Sobel magnitude, valid padding: [planes,H,W] -> [planes,H-2,W-2]. */
+int be_image_derivative_f32(const float* img, float* out, int64_t planes, int H, int W, void* stream);
+/* nn.Fold of a strided patch tensor (local2global_*, :151-173), owner computes.  Element (b,c,r,col,i,j) of the
+ * source sits at b*s_b + c*s_c + r*s_r + col*s_col + i*s_pi + j*s_pj (floats).  mode 0: overlap sum, 1: sum /
+ * overlap count, 2: number of covering patches whose entry is > 0 (src_int, if not NULL, is read instead of src). */
+int be_fold_patches_f32(const float* src, const int32_t* src_int, float* out, int B, int C, int hp, int wp, int H, int W,
+                        int stride, int64_t s_b, int64_t s_c, int64_t s_r, int64_t s_col, int64_t s_pi, int64_t s_pj,
+                        int mode, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * LocalLoss forward + backward (training)
  *   replaces LocalLoss.get_patches + LocalLoss.forward (local_training.py:32-52) and the autograd graph under
  *   them.  est [B,10] raw CNN output (angles are wrapped inside, :33), img_fit / gt [B,21,21,3] channels-last

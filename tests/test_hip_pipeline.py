@@ -211,3 +211,46 @@ def test_big_image_tiler_and_fold_587(env):
     full[0, sel], full[1, sel] = r["patches1"], r["patches2"]
     fi = ot.fold_mean(full, 587, 587)
     assert relmax(maps["image"].cpu()[:, :, 220:279], fi[:, :, 220:279]) <= 1e-4
+
+
+def test_base_class_methods_both_layouts_vs_oracle(env):
+    """The reference's fine-grained PostProcess methods (what a subclass written against the reference calls)."""
+    import utils
+    from oracle import render as orr, tiling as ot, depth as od
+    h = env["helper"]                                             # PostProcessGlobalBase, batch_size 1
+    p12 = T(synth.plausible_params12(4096, name="g6_est"))
+    est = p12.t().reshape(1, 12, 64, 64).contiguous().to(DEV)     # reference global layout [B,12,Hp,Wp]
+    dists = h.params2dists(est[:, :8])
+    assert tuple(dists.shape) == (1, 2, 21, 21, 64, 64)
+    d_or = orr.params2dists(p12[:, :8])                           # [P,2,21,21]
+    assert relmax(dists[0].permute(3, 4, 0, 1, 2).reshape(4096, 2, 21, 21).cpu(), d_or) <= 1e-5
+    etas = h.params2etas(est[:, 8:10].contiguous())
+    wed = h.dists2indicators(dists, etas)
+    w_or = orr.dists2indicators(d_or.double(), orr.params2etas(p12[:, 8:10].double()))
+    assert relmax(wed[0].permute(3, 4, 0, 1, 2).reshape(4096, 3, 21, 21).cpu(), w_or) <= 3e-4
+    # local layout
+    a = utils.get_args("local_train", argv=[])
+    hl = utils.PostProcessLocalBase(a, DEV)
+    dl = hl.params2dists(p12[:64, :8].to(DEV))
+    assert relmax(dl.cpu(), d_or[:64]) <= 1e-5
+    # inverse_3by3 on ridge-regularised Gram matrices, derivative of an image
+    r = orr.render_pass_a(T(synth.plausible_params10(64)), T(synth.uniform_patches(64)))
+    inv = hl.inverse_3by3(r["G"].to(DEV))
+    assert relmax(inv.cpu(), torch.linalg.inv(r["G"].double())) <= 1e-5
+    img = T(synth.uniform_patches(8, name="deriv"))
+    assert relmax(hl.get_image_derivative(img.to(DEV)).cpu(), orr.image_derivative(img)) <= 1e-5
+    # folds of materialised tensors in the reference layout
+    imgs, _ = synth.synthetic_image_pair(147, 147)
+    pat = ot.unfold_patches(T(imgs))                              # [2,P,3,21,21]
+    ref_layout = pat.view(2, 64, 64, 3, 21, 21).permute(0, 3, 4, 5, 1, 2).contiguous().to(DEV)   # [2,3,21,21,Hp,Wp]
+    back = h.local2global_color(ref_layout.unsqueeze(0))          # fold(unfold(x)) / count == x
+    assert relmax(back[0].cpu(), T(imgs)) <= 1e-5
+    assert torch.equal(h.num_patches.cpu(), ot.num_patches(147, 147))
+    rb = orr.render_pass_b(od.depth_consts(), p12, pat[0], pat[1])
+    dm = rb["depth_map"].view(64, 64, 21, 21).permute(2, 3, 0, 1)[None].contiguous().to(DEV)
+    mk = rb["depth_mask"].view(64, 64, 21, 21).permute(2, 3, 0, 1)[None].contiguous().to(DEV)
+    depth, conf = h.local2global_depth(dm, mk)
+    fd, fc = ot.fold_depth(rb["depth_map"][None], rb["depth_mask"][None], 147, 147)
+    assert relmax(conf.cpu(), fc) <= 1e-6 and relmax(depth.cpu(), fd) <= 1e-5
+    bp = rb["boundary"].view(64, 64, 21, 21).permute(2, 3, 0, 1)[None, None].contiguous().to(DEV)
+    assert relmax(h.local2global_bndry(bp).cpu()[0, 0], ot.fold_mean(rb["boundary"][None, :, None], 147, 147)[0, 0]) <= 1e-5
