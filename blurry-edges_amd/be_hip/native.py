@@ -264,7 +264,7 @@ def local_stage_forward(packed, x, out=None, workspace=None):
 
 KERNEL_NAMES = {0: "k_conv_igemm<2,2,2,2,TAPS> (128x128)", 1: "k_conv_igemm<4,1,1,3,TAPS> (128x96)",
                 2: "k_conv_igemm<4,1,1,2,TAPS> (128x64)", 3: "k_conv_igemm<4,1,1,1,TAPS> (128x32)",
-                4: "k_conv_igemm<4,1,1,2,ROW8> (conv1)"}
+                4: "k_conv_igemm<4,1,1,2,ROW8> (conv1)", 5: "k_conv_igemm small-M tiles (64x64 / 128x32)"}
 
 
 def profile_enable(max_launches: int):

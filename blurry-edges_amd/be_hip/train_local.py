@@ -54,6 +54,7 @@ def main(argv=None):
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--patches", type=int, default=16000)       # 8000 images x 2 (train_val_data_generator.py:188)
     ap.add_argument("--lr", type=float, default=6e-5)
+    ap.add_argument("--graph", action="store_true", help="capture the whole step (fwd + loss + bwd + clip + AdamW) in a hipGraph")
     a = ap.parse_args(argv)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     lr_ = int(os.environ.get("LOCAL_RANK", "0"))
@@ -67,24 +68,44 @@ def main(argv=None):
     model = models.LocalStage().to(dev)
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)).to(dev) for k, v in synth.local_stage_state_dict().items()})
     helper = utils.PostProcessLocalBase(args, dev)
-    opt = torch.optim.AdamW(model.parameters(), lr=a.lr)
+    opt = torch.optim.AdamW(model.parameters(), lr=a.lr, capturable=a.graph)
     flat = dp.flat_grad_buffer(model.parameters()) if world > 1 else None
     data = {k: torch.from_numpy(v).to(dev) for k, v in synth.synthetic_training_patches(a.patches, seed=1869 + rank).items()}
     sched = BetaSchedule(args.beta_bndry_loc, args.beta_smthns, args.dynamic_epoch)
     sched.final()
     model.train()
     losses = []
+    if a.graph:
+        # ~150 short launches per step at batch 64: replaying one captured hipGraph removes the host launch cost.
+        # Static input buffers; every kernel of the step runs on the capture stream (the library takes the stream
+        # from torch and never allocates or synchronises).
+        static = {k: v[:a.batch].clone() for k, v in data.items()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                train_step(model, helper, opt, static, sched.beta_b, sched.beta_s, flat, world)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            static_loss = train_step(model, helper, opt, static, sched.beta_b, sched.beta_s, flat, world)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for it in range(a.steps):
         lo = (it * a.batch) % (a.patches - a.batch + 1)
         batch = {k: v[lo:lo + a.batch] for k, v in data.items()}
-        losses.append(train_step(model, helper, opt, batch, sched.beta_b, sched.beta_s, flat, world))
+        if a.graph:
+            for k in static:
+                static[k].copy_(batch[k])
+            graph.replay()
+            losses.append(static_loss.clone())
+        else:
+            losses.append(train_step(model, helper, opt, batch, sched.beta_b, sched.beta_s, flat, world))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if rank == 0:
         print(json.dumps({"metric": "local training patches/s", "value": world * a.batch * a.steps / dt, "n_gpus": world,
-                          "ms_per_step": dt / a.steps * 1e3, "first_loss": float(losses[0]), "last_loss": float(losses[-1])}))
+                          "ms_per_step": dt / a.steps * 1e3, "graph": bool(a.graph), "first_loss": float(losses[0]), "last_loss": float(losses[-1])}))
 
 
 if __name__ == "__main__":

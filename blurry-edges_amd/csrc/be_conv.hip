@@ -28,7 +28,6 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));   // native vector: HIP's float4 class kept staging arrays in scratch
 
-constexpr int BM = 128;
 constexpr int BK = 32;
 enum { MODE_TAPS = 0, MODE_ROW8 = 1 };
 
@@ -48,7 +47,8 @@ struct ConvArgs {
 template <int WM, int WN, int MT, int NT, int MODE, int BKT, int PRIO>
 __global__ __launch_bounds__(256, BKT == 16 ? (PRIO == 2 ? 4 : 3) : (BKT == 8 ? 4 : 2))
 void k_conv_igemm(ConvArgs a) {
-    static_assert(WM * WN == 4 && WM * MT * 32 == BM, "4 waves, 128 rows");
+    static_assert(WM * WN == 4, "4 waves");
+    constexpr int BM = WM * MT * 32;                   // 128 (inference tiles) or 64 (small-M training tile)
     static_assert(BKT == 32 || BKT == 16 || BKT == 8, "K chunk");
     constexpr int BN = WN * NT * 32;
     constexpr int LROW = BKT + 4;                      // floats per LDS row (pad 4: conflict-free b128 reads/writes)
@@ -87,7 +87,7 @@ void k_conv_igemm(ConvArgs a) {
             a_off[i] = 0;
         }
     }
-    const float* wrow = a.w + (size_t)(n0 + r0) * a.Ktot + 4 * q;
+    const float* wbase = a.w + (size_t)n0 * a.Ktot + 4 * q;   // + row * Ktot + chunk offset
 
     // Staging registers for the next K chunk.  Straight-line helpers on array references (no lambdas, no
     // conditionals around the loads): anything else made hipcc keep b_st in scratch memory.
@@ -118,9 +118,9 @@ void k_conv_igemm(ConvArgs a) {
             a_ok |= (ok_ ? 1u : 0u) << i_;                                                                      \
         }                                                                                                       \
         _Pragma("unroll") for (int i_ = 0; i_ < NB; ++i_) {                                                     \
-            /* a partial last pass re-reads the thread's first row (always inside the tile); it is not stored */ \
-            const int rowoff_ = (B_PARTIAL && RP * i_ + r0 >= BN) ? 0 : RP * i_;                                \
-            b_st[i_] = *reinterpret_cast<const f32x4*>(wrow + (size_t)rowoff_ * a.Ktot + (KC) * BKT);           \
+            /* rows past the tile (partial pass, or BN < RP) read row 0 of the tile instead and are never stored */ \
+            const int row_ = (B_PARTIAL && RP * i_ + r0 >= BN) ? 0 : RP * i_ + r0;                              \
+            b_st[i_] = *reinterpret_cast<const f32x4*>(wbase + (size_t)row_ * a.Ktot + (KC) * BKT);             \
         }                                                                                                       \
     } while (0)
 #define BE_STORE_CHUNK(BUF)                                                                                     \
@@ -214,6 +214,7 @@ void k_conv_igemm(ConvArgs a) {
 template <int WM, int WN, int MT, int NT, int MODE, int BKT = 32, int PRIO = 0>
 int launch_conv(const ConvArgs& a, hipStream_t s, int kernel_id) {
     constexpr int BN = WN * NT * 32;
+    constexpr int BM = WM * MT * 32;
     constexpr size_t lds = (size_t)2 * (BM + BN) * (BKT + 4) * sizeof(float);
     static bool attr_set = false;                     // raise the dynamic-LDS cap once per instantiation
     if (!attr_set) {
@@ -407,9 +408,20 @@ extern "C" int be_conv_nhwc_f32(const be_conv_desc* d, const float* x, const flo
     a.x = x; a.w = pw; a.bias = pb; a.res = res; a.y = y;
     a.M = (int)M; a.H = d->h; a.W = d->w; a.HW = d->h * d->w; a.Cin = d->cin; a.Cout = d->cout; a.ldy = ldy;
     a.ks = d->ksize; a.nchunk = conv_nchunk(d->cin, d->ksize); a.Ktot = a.nchunk * BK; a.act = d->act;
-    a.m_tiles = (int)((M + BM - 1) / BM);
+    a.m_tiles = (int)((M + 127) / 128);
     const int cp = round_up(d->cout, 32);
     hipStream_t s = be::as_stream(stream);
+    // Small-M regime (training at batch 64: M = 2304 rows at 6x6): the 128-row tiles give a few dozen workgroups on
+    // 256 CUs and one launch lasts as long as ONE workgroup's serial K loop.  Below ~1.5 workgroups per CU switch to
+    // 64x64 (or 128x32) tiles: 4x the workgroups, each with a quarter of the work.
+    if (!row8 && (int64_t)a.m_tiles * ((cp + 127) / 128) < 384) {
+        if (cp % 64 == 0) {
+            a.m_tiles = (int)((M + 63) / 64); a.n_tiles = cp / 64;
+            return launch_conv<2, 2, 1, 1, MODE_TAPS, 16, 0>(a, s, BE_KERNEL_CONV_SMALL);
+        }
+        a.n_tiles = cp / 32;
+        return launch_conv<4, 1, 1, 1, MODE_TAPS, 16, 0>(a, s, BE_KERNEL_CONV_SMALL);
+    }
     if (row8) {
         BE_REQUIRE(cp == 64, "be_conv_nhwc_f32: ksize 7 is built for cout 64 (got %d)", d->cout);
         a.n_tiles = 1;

@@ -34,48 +34,93 @@ struct LossArgs {
     int64_t n;
 };
 
+// The training loss is evaluated with fp64 geometry.  An edge can be far sharper than the pixel pitch
+// (eta down to 1e-4 against a pitch of 0.1), so the few pixels within ~eta of it carry the whole erf gradient with a
+// sensitivity of 1/eta to their own distance: in fp32 the gradient of such a patch is only good to ~1e-3 (the
+// reference's own fp32-vs-fp64 autograd gradients differ by that much); fp64 here costs nothing (64 x 441 pixels per
+// step) and puts the gradient on the fp64 reference to ~1e-6.
+typedef double real;
+
+struct GeomD { real x0, y0, x1, y1, s11, c11, s12, c12, s21, c21, s22, c22, sg1, sg2; };
+
+__device__ __forceinline__ real wrap_2pi_d(real a) {
+    const real two_pi = 6.283185307179586476925286766559;
+    real r = fmod(a, two_pi);
+    if (r < 0.0) r += two_pi;
+    return r;
+}
+
+__device__ __forceinline__ GeomD make_geom_d(const float* p8) {
+    // local_training.py:33 wraps the angles first.  Done in fp64 here: the fp32 wrap (modulus float32(2*pi), off by
+    // 1.7e-7) moves a wrapped angle by ~2e-7 rad, which a razor-sharp edge turns into a 1e-3 gradient change.
+    const real t1 = wrap_2pi_d(p8[4]), f1 = wrap_2pi_d(p8[5]), t2 = wrap_2pi_d(p8[6]), f2 = wrap_2pi_d(p8[7]);
+    GeomD g;
+    g.x0 = p8[0]; g.y0 = p8[1]; g.x1 = p8[2]; g.y1 = p8[3];
+    g.sg1 = f1 < 3.14159265358979323846 ? 1.0 : -1.0;
+    g.sg2 = f2 < 3.14159265358979323846 ? 1.0 : -1.0;
+    const real a1 = t1, a1p = t1 + f1, a2 = t2, a2p = t2 + f2;
+    g.s11 = sin(a1); g.c11 = cos(a1); g.s12 = sin(a1p); g.c12 = cos(a1p);
+    g.s21 = sin(a2); g.c21 = cos(a2); g.s22 = sin(a2p); g.c22 = cos(a2p);
+    return g;
+}
+
 // d(ray distance)/d(edge, axial) for the selected branch of utils/postprocessing_loss.py:67-76
-__device__ __forceinline__ void ray_dist_grad(float px, float py, float vx, float vy, float s, float c, float w,
-                                              float& dist, float& edge, float& axial, float& d_edge, float& d_axial) {
-    const float dx = px - vx, dy = py - vy;
+__device__ __forceinline__ void ray_dist_grad(real px, real py, real vx, real vy, real s, real c, real w,
+                                              real& dist, real& edge, real& axial, real& d_edge, real& d_axial) {
+    const real dx = px - vx, dy = py - vy;
     edge = (-s) * dx + c * dy;
     axial = c * dx + s * dy;
-    if (axial < 0.0f) {
-        const float aw = axial * w;
-        const float r = sqrtf(edge * edge + aw * aw);
-        const float sg = edge < 0.0f ? -1.0f : 1.0f;
+    if (axial < 0.0) {
+        const real aw = axial * w;
+        const real r = sqrt(edge * edge + aw * aw);
+        const real sg = edge < 0.0 ? -1.0 : 1.0;
         dist = sg * r;
-        const float ir = r > 0.0f ? 1.0f / r : 0.0f;
+        const real ir = r > 0.0 ? 1.0 / r : 0.0;
         d_edge = sg * edge * ir;
         d_axial = sg * w * w * axial * ir;
     } else {
-        dist = edge; d_edge = 1.0f; d_axial = 0.0f;
+        dist = edge; d_edge = 1.0; d_axial = 0.0;
     }
 }
 
-// Adjoint of one wedge: accumulates d/d(vx, vy, theta, phi) given dL/d(dist_k) at this pixel.
-__device__ __forceinline__ void wedge_backward(float px, float py, float vx, float vy, float sA, float cA, float sB,
-                                               float cB, float sg, bool closed, float w, float g_dist,
-                                               float& g_vx, float& g_vy, float& g_th, float& g_ph) {
-    float dA, eA, aA, deA, daA, dB, eB, aB, deB, daB;
+__device__ __forceinline__ real wedge_dist_d(real px, real py, real vx, real vy, real sA, real cA, real sB, real cB,
+                                             real sg, bool closed, real w) {
+    real dA, eA, aA, deA, daA, dB, eB, aB, deB, daB;
     ray_dist_grad(px, py, vx, vy, sA, cA, w, dA, eA, aA, deA, daA);
     ray_dist_grad(px, py, vx, vy, sB, cB, w, dB, eB, aB, deB, daB);
-    const bool inside = closed ? (sg * dA >= 0.0f && sg * dB <= 0.0f) : (sg * dA > 0.0f && sg * dB < 0.0f);
-    const float ind = inside ? sg : -sg;
-    const float absA = fabsf(dA), absB = fabsf(dB);
+    const bool inside = closed ? (sg * dA >= 0.0 && sg * dB <= 0.0) : (sg * dA > 0.0 && sg * dB < 0.0);
+    return fmin(fabs(dA), fabs(dB)) * (inside ? sg : -sg);
+}
+
+// Adjoint of one wedge: accumulates d/d(vx, vy, theta, phi) given dL/d(dist_k) at this pixel.
+__device__ __forceinline__ void wedge_backward(real px, real py, real vx, real vy, real sA, real cA, real sB,
+                                               real cB, real sg, bool closed, real w, real g_dist,
+                                               real& g_vx, real& g_vy, real& g_th, real& g_ph) {
+    real dA, eA, aA, deA, daA, dB, eB, aB, deB, daB;
+    ray_dist_grad(px, py, vx, vy, sA, cA, w, dA, eA, aA, deA, daA);
+    ray_dist_grad(px, py, vx, vy, sB, cB, w, dB, eB, aB, deB, daB);
+    const bool inside = closed ? (sg * dA >= 0.0 && sg * dB <= 0.0) : (sg * dA > 0.0 && sg * dB < 0.0);
+    const real ind = inside ? sg : -sg;
+    const real absA = fabs(dA), absB = fabs(dB);
     // dist = min(|dA|,|dB|) * ind ; ties split evenly (torch.min backward)
-    float gA = 0.f, gB = 0.f;
-    const float sA_ = dA > 0.f ? 1.f : (dA < 0.f ? -1.f : 0.f), sB_ = dB > 0.f ? 1.f : (dB < 0.f ? -1.f : 0.f);
+    real gA = 0., gB = 0.;
+    const real sA_ = dA > 0. ? 1. : (dA < 0. ? -1. : 0.), sB_ = dB > 0. ? 1. : (dB < 0. ? -1. : 0.);
     if (absA < absB) gA = g_dist * ind * sA_;
     else if (absB < absA) gB = g_dist * ind * sB_;
-    else { gA = 0.5f * g_dist * ind * sA_; gB = 0.5f * g_dist * ind * sB_; }
+    else { gA = 0.5 * g_dist * ind * sA_; gB = 0.5 * g_dist * ind * sB_; }
     // edge = -s dx + c dy : d/dvx = s, d/dvy = -c, d/dang = -axial ; axial = c dx + s dy : d/dvx = -c, d/dvy = -s, d/dang = edge
-    const float gAe = gA * deA, gAa = gA * daA, gBe = gB * deB, gBa = gB * daB;
+    const real gAe = gA * deA, gAa = gA * daA, gBe = gB * deB, gBa = gB * daB;
     g_vx += gAe * sA - gAa * cA + gBe * sB - gBa * cB;
     g_vy += -gAe * cA - gAa * sA - gBe * cB - gBa * sB;
-    const float gangA = -gAe * aA + gAa * eA, gangB = -gBe * aB + gBa * eB;
+    const real gangA = -gAe * aA + gAa * eA, gangB = -gBe * aB + gBa * eB;
     g_th += gangA + gangB;            // theta feeds both rays (theta and theta + phi)
     g_ph += gangB;                    // phi only the second
+}
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
 }
 
 __global__ __launch_bounds__(64 * WAVES)
@@ -92,13 +137,14 @@ void k_local_loss(be_render_opts o, LossArgs a) {
     const int64_t patch = active ? patch_raw : a.n - 1;        // idle waves shadow the last patch (no stores)
 
     const float* p = a.est + patch * 10;
-    const be::WedgeGeom g = be::make_geom(p, true);             // local_training.py:33 wraps the angles first
-    const float eta1 = be::param2eta(p[8]), eta2 = be::param2eta(p[9]);
-    const float r1 = be::kRoot2 * eta1, r2 = be::kRoot2 * eta2;
+    const GeomD g = make_geom_d(p);                             // local_training.py:33 wraps the angles first
+    const real eta1 = pow(10.0, 2.0 * erf((real)p[8]) - 2.0), eta2 = pow(10.0, 2.0 * erf((real)p[9]) - 2.0);
+    const real r1 = (real)be::kRoot2 * eta1, r2 = (real)be::kRoot2 * eta2;
     const float* fit = a.img_fit + patch * NPIX * 3;
     const float* gt = a.gt + patch * NPIX * 3;
 
-    float d1s[PASSES], d2s[PASSES], h1s[PASSES], h2s[PASSES];
+    real d1s[PASSES], d2s[PASSES];
+    float h1s[PASSES], h2s[PASSES];
     float gs[6] = {0, 0, 0, 0, 0, 0}, bs[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int it = 0; it < PASSES; ++it) {
@@ -106,9 +152,9 @@ void k_local_loss(be_render_opts o, LossArgs a) {
         const bool live = pix < NPIX;
         const int pc = live ? pix : 0;
         const int row = pc / R, col = pc - row * R;
-        float d1, d2;
-        be::wedge_dists(g, lin[col], lin[row], o.w, d1, d2);
-        const float h1 = 0.5f * (1.0f + erff(d1 / r1)), h2 = 0.5f * (1.0f + erff(d2 / r2));
+        const real d1 = wedge_dist_d(lin[col], lin[row], g.x0, g.y0, g.s11, g.c11, g.s12, g.c12, g.sg1, false, o.w);
+        const real d2 = wedge_dist_d(lin[col], lin[row], g.x1, g.y1, g.s21, g.c21, g.s22, g.c22, g.sg2, true, o.w);
+        const float h1 = (float)(0.5 * (1.0 + erf(d1 / r1))), h2 = (float)(0.5 * (1.0 + erf(d2 / r2)));
         d1s[it] = d1; d2s[it] = d2; h1s[it] = h1; h2s[it] = h2;
         const float u0 = live ? (1.0f - h1) * (1.0f - h2) : 0.f, u1 = live ? h1 * (1.0f - h2) : 0.f, u2 = live ? h2 : 0.f;
         const float yr = live ? fit[pc * 3] : 0.f, yg = live ? fit[pc * 3 + 1] : 0.f, yb = live ? fit[pc * 3 + 2] : 0.f;
@@ -243,14 +289,16 @@ void k_local_loss(be_render_opts o, LossArgs a) {
             S[k][j] = dkj + djk;
         }
     // ---- per-pixel adjoints down to the ten parameters
-    float gx0 = 0, gy0 = 0, gt1 = 0, gf1 = 0, gx1 = 0, gy1 = 0, gt2 = 0, gf2 = 0, gr1 = 0, gr2 = 0, L2 = 0;
+    real gx0 = 0, gy0 = 0, gt1 = 0, gf1 = 0, gx1 = 0, gy1 = 0, gt2 = 0, gf2 = 0, gr1 = 0, gr2 = 0;
+    float L2 = 0;
 #pragma unroll
     for (int it = 0; it < PASSES; ++it) {
         const int pix = it * 64 + lane;
         if (pix < NPIX) {
             const int row = pix / R, col = pix - row * R;
-            const float px = lin[col], py = lin[row];
-            const float d1 = d1s[it], d2 = d2s[it], h1 = h1s[it], h2 = h2s[it];
+            const real px = lin[col], py = lin[row];
+            const real d1 = d1s[it], d2 = d2s[it];
+            const float h1 = h1s[it], h2 = h2s[it];
             const float u[3] = {(1.0f - h1) * (1.0f - h2), h1 * (1.0f - h2), h2};
             const float y[3] = {fit[pix * 3], fit[pix * 3 + 1], fit[pix * 3 + 2]};
             float du[3];
@@ -265,39 +313,40 @@ void k_local_loss(be_render_opts o, LossArgs a) {
             }
             const float dh1 = (du[1] - du[0]) * (1.0f - h2);
             const float dh2 = -du[0] * (1.0f - h1) - du[1] * h1 + du[2];
-            const float z1 = d1 / r1, z2 = d2 / r2;
-            const float e1 = expf(-z1 * z1) * kInvSqrtPi, e2 = expf(-z2 * z2) * kInvSqrtPi;
-            float gd1 = dh1 * e1 / r1, gd2 = dh2 * e2 / r2;
+            const real z1 = d1 / r1, z2 = d2 / r2;
+            const real e1 = exp(-z1 * z1) * (real)kInvSqrtPi, e2 = exp(-z2 * z2) * (real)kInvSqrtPi;
+            real gd1 = dh1 * e1 / r1, gd2 = dh2 * e2 / r2;
             gr1 -= dh1 * e1 * d1 / (r1 * r1);
             gr2 -= dh2 * e2 * d2 / (r2 * r2);
             // boundary localisation term (local_training.py:42-44,50)
-            const float a1 = fabsf(d1), a2 = fabsf(d2);
-            const float db = d2 >= 0.0f ? d2 : (a1 < a2 ? a1 : a2);
-            const float Bv = expf(-(db * db) / o.delta_sq);
-            const float bd = a.bdist[patch * NPIX + pix];
-            L2 = fmaf(bd * Bv, bd * Bv, L2);
-            const float gdb = 2.0f * bd * bd * Bv * a.w2 * Bv * (-2.0f * db / o.delta_sq);
-            if (d2 >= 0.0f) gd2 += gdb;
-            else if (a1 < a2) gd1 += gdb * (d1 > 0.f ? 1.f : (d1 < 0.f ? -1.f : 0.f));
-            else gd2 += gdb * (d2 > 0.f ? 1.f : (d2 < 0.f ? -1.f : 0.f));
-            if (a.boundary && active) a.boundary[patch * NPIX + pix] = Bv;
+            const real a1 = fabs(d1), a2 = fabs(d2);
+            const real db = d2 >= 0.0 ? d2 : (a1 < a2 ? a1 : a2);
+            const real Bv = exp(-(db * db) / (real)o.delta_sq);
+            const real bd = a.bdist[patch * NPIX + pix];
+            L2 += (float)((bd * Bv) * (bd * Bv));
+            const real gdb = 2.0 * bd * bd * Bv * a.w2 * Bv * (-2.0 * db / (real)o.delta_sq);
+            if (d2 >= 0.0) gd2 += gdb;
+            else if (a1 < a2) gd1 += gdb * (d1 > 0. ? 1. : (d1 < 0. ? -1. : 0.));
+            else gd2 += gdb * (d2 > 0. ? 1. : (d2 < 0. ? -1. : 0.));
+            if (a.boundary && active) a.boundary[patch * NPIX + pix] = (float)Bv;
             wedge_backward(px, py, g.x0, g.y0, g.s11, g.c11, g.s12, g.c12, g.sg1, false, o.w, gd1, gx0, gy0, gt1, gf1);
             wedge_backward(px, py, g.x1, g.y1, g.s21, g.c21, g.s22, g.c22, g.sg2, true, o.w, gd2, gx1, gy1, gt2, gf2);
         }
     }
-    gx0 = be::wave_sum(gx0); gy0 = be::wave_sum(gy0); gx1 = be::wave_sum(gx1); gy1 = be::wave_sum(gy1);
-    gt1 = be::wave_sum(gt1); gf1 = be::wave_sum(gf1); gt2 = be::wave_sum(gt2); gf2 = be::wave_sum(gf2);
-    gr1 = be::wave_sum(gr1); gr2 = be::wave_sum(gr2);
+    gx0 = wave_sum_d(gx0); gy0 = wave_sum_d(gy0); gx1 = wave_sum_d(gx1); gy1 = wave_sum_d(gy1);
+    gt1 = wave_sum_d(gt1); gf1 = wave_sum_d(gf1); gt2 = wave_sum_d(gt2); gf2 = wave_sum_d(gf2);
+    gr1 = wave_sum_d(gr1); gr2 = wave_sum_d(gr2);
     L1 = be::wave_sum(L1); L2 = be::wave_sum(L2); L3 = be::wave_sum(L3);
     if (lane == 0 && active) {
         a.partial[patch * 3] = L1; a.partial[patch * 3 + 1] = L2; a.partial[patch * 3 + 2] = L3;
         if (a.grad) {
             float* go = a.grad + patch * 10;
-            go[0] = gx0; go[1] = gy0; go[2] = gx1; go[3] = gy1; go[4] = gt1; go[5] = gf1; go[6] = gt2; go[7] = gf2;
+            go[0] = (float)gx0; go[1] = (float)gy0; go[2] = (float)gx1; go[3] = (float)gy1;
+            go[4] = (float)gt1; go[5] = (float)gf1; go[6] = (float)gt2; go[7] = (float)gf2;
             // r = sqrt2 * eta, eta = 10^(2 erf(p) - 2): d eta / d p = eta * ln10 * 4/sqrt(pi) * exp(-p^2)
-            const float c10 = 2.302585092994046f * 4.0f * kInvSqrtPi;
-            go[8] = gr1 * be::kRoot2 * eta1 * c10 * expf(-p[8] * p[8]);
-            go[9] = gr2 * be::kRoot2 * eta2 * c10 * expf(-p[9] * p[9]);
+            const real c10 = 2.302585092994046 * 4.0 * (real)kInvSqrtPi;
+            go[8] = (float)(gr1 * (real)be::kRoot2 * eta1 * c10 * exp(-(real)p[8] * p[8]));
+            go[9] = (float)(gr2 * (real)be::kRoot2 * eta2 * c10 * exp(-(real)p[9] * p[9]));
         }
     }
 }

@@ -275,22 +275,25 @@ __global__ void k_sum_splits(const float* partial, float* out, int64_t n, int S)
 }
 
 // conv1 weight gradient (Cin = 3, 7x7): dW[co][ci][kh][kw] = sum_m dy[m][co] * x4[pixel m + (kh-3,kw-3)][ci].
-// 0.5 GFLOP per step at batch 64: a plain FMA kernel, one thread per (co, ci, kh, kw) and M slice.
-__global__ void k_wgrad_conv1(const float* __restrict__ x4, const float* __restrict__ dy, float* __restrict__ partial, int M,
-                              int H, int W, int Cout, int rows_per_split) {
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;          // co fastest: coalesced dy reads
+// 0.5 GFLOP per step at batch 64: a plain FMA kernel, one thread per (co, ci, kh, kw), one grid slice per group of
+// whole images so the pixel loops run over the valid window only (no per-row div/mod, no bounds tests).
+__global__ void k_wgrad_conv1(const float* __restrict__ x4, const float* __restrict__ dy, float* __restrict__ partial, int N,
+                              int H, int W, int Cout, int imgs_per_split) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;          // co fastest: coalesced dy reads, broadcast x4 reads
     const int total = Cout * 3 * 49;
     if (e >= total) return;
     const int co = e % Cout, rest = e / Cout;
     const int ci = rest % 3, t = rest / 3, kh = t / 7, kw = t % 7;
-    const int m0 = blockIdx.y * rows_per_split, m1 = min(M, m0 + rows_per_split);
-    const int HW = H * W;
+    const int n0 = blockIdx.y * imgs_per_split, n1 = min(N, n0 + imgs_per_split);
+    const int y_lo = max(0, 3 - kh), y_hi = min(H, H + 3 - kh);   // output rows whose tap (kh) falls inside the image
+    const int x_lo = max(0, 3 - kw), x_hi = min(W, W + 3 - kw);
     float s = 0.f;
-    for (int m = m0; m < m1; ++m) {
-        const int pp = m % HW, yy = pp / W + kh - 3, xx = pp % W + kw - 3;
-        if ((unsigned)yy < (unsigned)H && (unsigned)xx < (unsigned)W)
-            s = fmaf(dy[(size_t)m * Cout + co], x4[((int64_t)m + (kh - 3) * W + (kw - 3)) * 4 + ci], s);
-    }
+    for (int n = n0; n < n1; ++n)
+        for (int y = y_lo; y < y_hi; ++y) {
+            const float* dyp = dy + ((size_t)(n * H + y) * W) * Cout + co;
+            const float* xp = x4 + ((size_t)(n * H + y + kh - 3) * W + (kw - 3)) * 4 + ci;
+            for (int x = x_lo; x < x_hi; ++x) s = fmaf(dyp[(size_t)x * Cout], xp[x * 4], s);
+        }
     partial[(size_t)blockIdx.y * total + ((co * 3 + ci) * 7 + kh) * 7 + kw] = s;
 }
 
@@ -323,7 +326,9 @@ inline unsigned cap_grid(int64_t total, int block, int64_t cap = 4096) {
 }
 
 inline int pick_splits(int M, int col_blocks, int max_splits) {
-    // enough blocks to cover the chip (~512) without making slices shorter than 32 rows
+    // enough blocks to cover the chip (~512) without making slices shorter than 32 rows; the finalize kernels walk
+    // the splits serially (fixed order), so more than 32 of them costs more there than it gains here
+    if (max_splits > 32) max_splits = 32;
     int s = (512 + col_blocks - 1) / col_blocks;
     const int by_rows = (M + 31) / 32;
     if (s > by_rows) s = by_rows;
@@ -404,10 +409,11 @@ extern "C" int be_conv_wgrad_f32(const float* x, const float* dy, float* dw, int
     if (ksize == 7) {
         BE_REQUIRE(cin == 4, "be_conv_wgrad_f32: ksize 7 takes the NHWC4 input (cin = 4); dW has 3 input channels");
         const int total = cout * 3 * 49;
-        int S = 64; if (S > (M + 63) / 64) S = (M + 63) / 64;
+        const int per = (n + 63) / 64;                       // images per grid slice (<= 64 slices)
+        const int S = (n + per - 1) / per;
         BE_REQUIRE((size_t)S * total * sizeof(float) <= scratch_bytes, "be_conv_wgrad_f32: scratch too small");
-        hipLaunchKernelGGL(k_wgrad_conv1, dim3((total + 255) / 256, S), dim3(256), 0, s, x, dy, static_cast<float*>(scratch), M,
-                           h, w, cout, (M + S - 1) / S);
+        hipLaunchKernelGGL(k_wgrad_conv1, dim3((total + 255) / 256, S), dim3(256), 0, s, x, dy, static_cast<float*>(scratch), n,
+                           h, w, cout, per);
         hipLaunchKernelGGL(k_sum_splits, dim3(cap_grid(total, 256)), dim3(256), 0, s, static_cast<const float*>(scratch), dw,
                            (int64_t)total, S);
         return be::check_launch("be_conv_wgrad_f32(conv1)");

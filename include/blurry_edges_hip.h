@@ -273,6 +273,7 @@ int be_linear_small_bwd_f32(const float* x, const float* w, const float* dy, flo
 #define BE_KERNEL_CONV_128x64       2
 #define BE_KERNEL_CONV_128x32       3   /* fc.4                                                                */
 #define BE_KERNEL_CONV_ROW8_128x64  4   /* conv1 (7x7 row-gather)                                              */
+#define BE_KERNEL_CONV_SMALL        5   /* 64x64 / 128x32 tiles for small M (training batches)                 */
 int be_profile_enable(int max_launches);
 int be_profile_reset(void);
 /* Waits for the recorded events; fills up to cap records (launch order); returns the number filled (>= 0)

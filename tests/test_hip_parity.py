@@ -258,7 +258,7 @@ def test_local_loss_value_and_gradient_vs_fp64_golden(native, args):
     q = est.detach().clone()
     col, ex2 = h.render_colors(q, img.permute(0, 3, 1, 2).contiguous(), wrap_angles=True, want=("recon", "boundary"))
     assert relmax(ex["patches"].cpu(), ex2["recon"].cpu()) <= 1e-5
-    assert relmax(ex["boundary"].cpu(), ex2["boundary"].cpu()) <= 1e-6
+    assert relmax(ex["boundary"].cpu(), ex2["boundary"].cpu()) <= 5e-5      # fp64 geometry here, fp32 in pass A
 
 
 # ------------------------------------------------------------------------------------------ training step
