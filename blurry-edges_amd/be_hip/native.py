@@ -83,6 +83,10 @@ _SIGNATURES = {
     "be_inverse3x3_f32": (C.c_int, [_P, _P, C.c_int64, _P]),
     "be_image_derivative_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, _P]),
     "be_fold_patches_f32": (C.c_int, [_P, _P, _P] + [C.c_int] * 7 + [C.c_int64] * 6 + [C.c_int, _P]),
+    "be_attention_workspace_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "be_attention_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "be_add_layernorm_f32": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_float, _P]),
+    "be_add_pe_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
     "be_profile_enable": (C.c_int, [C.c_int]),
     "be_profile_reset": (C.c_int, []),
     "be_profile_read": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -392,3 +396,37 @@ def local_loss(opts, est, img_fit, gt, bdist, deri, beta_bndry, beta_smooth, wan
                                   dptr(partial), dptr(grad), dptr(extra.get("patches")), dptr(extra.get("boundary")), b,
                                   stream_ptr(dev)), "be_local_loss_f32")
     return partial, grad, extra
+
+
+# ---------------------------------------------------------------------------------------------- GlobalStage pieces
+
+def linear(x2d, pw, pb, cout, act=0, residual=None):
+    """x2d [T, Cin] (Cin % 32 == 0) -> [T, cout] on the implicit-GEMM kernel (a Linear is a 1x1 conv on a 1x1 image)."""
+    t, cin = x2d.shape
+    y = conv_nhwc(x2d.view(t, 1, 1, cin), pw, pb, cout, 1, act, residual=residual)
+    return y.view(t, cout)
+
+
+def attention(qkv, B, L, H, workspace=None):
+    """qkv [B*L, 3*H*16] -> [B*L, H*16]."""
+    dev = qkv.device
+    need = lib().be_attention_workspace_floats(B, L, H)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.float32, device=dev)
+    out = torch.empty(B * L, H * 16, dtype=torch.float32, device=dev)
+    check(lib().be_attention_f32(dptr(qkv, "qkv"), dptr(out), dptr(workspace), B, L, H, stream_ptr(dev)), "be_attention_f32")
+    return out, workspace
+
+
+def add_layernorm(x, res, gamma, beta, eps=1e-5, out=None):
+    rows, d = x.shape
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().be_add_layernorm_f32(dptr(x, "x"), dptr(res), dptr(gamma), dptr(beta), dptr(out), rows, d, eps,
+                                     stream_ptr(x.device)), "be_add_layernorm_f32")
+    return out
+
+
+def add_pe_(x, pe, batches):
+    check(lib().be_add_pe_f32(dptr(x, "x"), dptr(pe, "pe"), batches, x.numel() // batches, stream_ptr(x.device)), "be_add_pe_f32")
+    return x

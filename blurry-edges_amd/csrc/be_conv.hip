@@ -203,7 +203,8 @@ void k_conv_igemm(ConvArgs a) {
                 if (c_ok && m < a.M) {
                     float v = acc[i][j][r] + bias;
                     if (a.res) v += a.res[(size_t)m * a.ldy + c];
-                    if (a.act) v = be::smish(v);
+                    if (a.act == 1) v = be::smish(v);
+                    else if (a.act == 2) v = fmaxf(v, 0.0f);
                     a.y[(size_t)m * a.ldy + c] = v;
                 }
             }

@@ -2,9 +2,10 @@
 
 Boundary kept exactly (constructor signature, forward(src [B,L,38]) -> [B,L,12], 102-entry state-dict, the 2-D
 sinusoidal position table held as a plain tensor that is NOT part of the state-dict): models/global_stage.py:6-38
-of the reference.  Per SURVEY.md §2 row 4 / §8f-1 this stage runs on stock PyTorch-ROCm ops in this round
-(the math SDPA backend: the flash / mem-efficient backends on ROCm are Triton-built); a hand-written HIP
-attention is the next row.  It is ~2.4 % of the FLOPs of the path (18.9 of 794 MFLOP per pair).
+of the reference.  Inference on the GPU runs on libblurry_edges_hip: the linears on the implicit-GEMM kernel, a
+flash-style fp32-MFMA attention kernel whose scores never leave registers, fused residual + LayerNorm.
+Training and CPU use stock PyTorch ops (math SDPA backend: the flash / mem-efficient backends on ROCm are
+Triton-built).  The stage is ~2.4 % of the FLOPs of the path (18.9 of 794 MFLOP per pair).
 """
 import math
 
@@ -50,7 +51,62 @@ class GlobalStage(nn.Module):
         self.generator = nn.Linear(d_model, out_parameter_size)
 
     def forward(self, src):
+        if src.is_cuda and not (self.training and torch.is_grad_enabled()) and src.shape[1] % 128 == 0:
+            return self._forward_hip(src)
+        # training / CPU: stock PyTorch ops (boundary kept; no Triton-built attention kernels)
         from torch.nn.attention import sdpa_kernel, SDPBackend
-        with sdpa_kernel(SDPBackend.MATH):                     # no Triton-built attention kernels
+        with sdpa_kernel(SDPBackend.MATH):
             h = self.positional_encoding(self.in_src_projection(src))
             return self.generator(self.encoder(h))
+
+    # ------------------------------------------------------------------ inference on the HIP library
+    def _packed(self):
+        """Linear weights in the implicit-GEMM layout, re-packed when a parameter changes."""
+        from be_hip import native
+        ps = list(self.parameters())
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, "_pk_key", None) == key:
+            return self._pk
+        dev = ps[0].device
+
+        def pack(w, b, pad_in=0):
+            w = w.detach()
+            if pad_in:                                       # in-projection: 38 input features padded to 64
+                w = torch.cat([w, w.new_zeros(w.shape[0], pad_in)], dim=1)
+            return native.conv_pack(w.contiguous(), b.detach().contiguous())
+        cin = self.in_src_projection.in_features
+        self._pad_in = (-cin) % 32
+        pk = dict(inp=pack(self.in_src_projection.weight, self.in_src_projection.bias, self._pad_in),
+                  gen=pack(self.generator.weight, self.generator.bias), layers=[])
+        for lyr in self.encoder.layers:
+            a = lyr.self_attn
+            pk["layers"].append(dict(qkv=pack(a.in_proj_weight, a.in_proj_bias), out=pack(a.out_proj.weight, a.out_proj.bias),
+                                     l1=pack(lyr.linear1.weight, lyr.linear1.bias), l2=pack(lyr.linear2.weight, lyr.linear2.bias)))
+        self._pk, self._pk_key = pk, key
+        return pk
+
+    def _forward_hip(self, src):
+        from be_hip import native
+        B, L, cin = src.shape
+        pk = self._packed()
+        d = self.in_src_projection.out_features
+        H = self.encoder.layers[0].self_attn.num_heads
+        x = src.reshape(B * L, cin).to(torch.float32)
+        if self._pad_in:
+            x = torch.cat([x, x.new_zeros(B * L, self._pad_in)], dim=1)
+        h = native.linear(x.contiguous(), *pk["inp"], d)
+        native.add_pe_(h, self.positional_encoding.pe[0, :L].contiguous(), B)
+        ws = getattr(self, "_attn_ws", None)
+        for lyr, p in zip(self.encoder.layers, pk["layers"]):
+            qkv = native.linear(h, *p["qkv"], 3 * d)
+            a, ws = native.attention(qkv, B, L, H, ws)
+            y = native.linear(a, *p["out"], d, residual=h)                       # x + SA(x)
+            h = native.add_layernorm(y, None, lyr.norm1.weight.detach(), lyr.norm1.bias.detach(), lyr.norm1.eps)
+            f = native.linear(h, *p["l1"], lyr.linear1.out_features, act=2)      # ReLU
+            y = native.linear(f, *p["l2"], d, residual=h)                        # x + FFN(x)
+            h = native.add_layernorm(y, None, lyr.norm2.weight.detach(), lyr.norm2.bias.detach(), lyr.norm2.eps)
+        self._attn_ws = ws
+        n = self.encoder.norm
+        h = native.add_layernorm(h, None, n.weight.detach(), n.bias.detach(), n.eps)
+        out = native.linear(h, *pk["gen"], self.generator.out_features)
+        return out.view(B, L, -1)

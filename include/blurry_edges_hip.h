@@ -206,7 +206,7 @@ int be_local_stage_forward_f32(const float* packed, const float* x, float* out, 
                                void* workspace, size_t workspace_bytes, void* stream);
 
 /* Layer-level entry points (used by the layer-by-layer parity tests and by the training path).
- * Activations are NHWC.  act: 0 none, 1 Smish (models/local_stage.py:4-6). */
+ * Activations are NHWC.  act: 0 none, 1 Smish (models/local_stage.py:4-6), 2 ReLU (GlobalStage FFN). */
 typedef struct be_conv_desc {
     int n, h, w;          /* batch, spatial size (stride 1, "same" padding)      */
     int cin, cout;        /* cin % 32 == 0 (conv1: cin = 4, NHWC4 input)         */
@@ -263,6 +263,21 @@ int be_conv_pack_dgrad_f32(const float* weight_oihw, int cout, int cin, int ksiz
 /* Last Linear (K -> J, J small): dx [M,K], dw [J,K], db [J] from x [M,K], w [J,K], dy [M,J]. */
 int be_linear_small_bwd_f32(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int M,
                             int K, int J, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * GlobalStage encoder pieces, inference (nn.TransformerEncoderLayer of models/global_stage.py:28-32; the linears
+ * run on be_conv_nhwc_f32 as 1x1 convs)
+ * ------------------------------------------------------------------------------------------------- */
+/* Multi-head self-attention with head dim 16: qkv [B*L, 3*H*16] (rows = tokens, columns q|k|v as
+ * nn.MultiheadAttention's in_proj produces them) -> out [B*L, H*16] = softmax(q k^T / 4) v per head.
+ * workspace: be_attention_workspace_floats(B,L,H) floats.  L % 128 == 0. */
+size_t be_attention_workspace_floats(int B, int L, int H);
+int be_attention_f32(const float* qkv, float* out, float* workspace, int B, int L, int H, void* stream);
+/* y = LayerNorm(x + res) over the last dimension D in {64,128,192,256}; res may be NULL; y may alias x. */
+int be_add_layernorm_f32(const float* x, const float* res, const float* gamma, const float* beta, float* y,
+                         int64_t rows, int D, float eps, void* stream);
+/* x[b] += pe for b < batches (PositionalEncoding.forward, models/global_stage.py:18-20); per_batch = L*D floats. */
+int be_add_pe_f32(float* x, const float* pe, int64_t batches, int64_t per_batch, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py's roofline leg): opt-in hipEvent pair around every conv launch, recorded on

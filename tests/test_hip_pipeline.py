@@ -254,3 +254,28 @@ def test_base_class_methods_both_layouts_vs_oracle(env):
     assert relmax(conf.cpu(), fc) <= 1e-6 and relmax(depth.cpu(), fd) <= 1e-5
     bp = rb["boundary"].view(64, 64, 21, 21).permute(2, 3, 0, 1)[None, None].contiguous().to(DEV)
     assert relmax(h.local2global_bndry(bp).cpu()[0, 0], ot.fold_mean(rb["boundary"][None, :, None], 147, 147)[0, 0]) <= 1e-5
+
+
+def test_attention_and_layernorm_kernels_vs_torch(env):
+    """be_attention_f32 / be_add_layernorm_f32 against plain PyTorch fp32 (and fp64) on the CPU."""
+    n = env["native"]
+    B, L, H = 2, 256, 8
+    g = torch.Generator().manual_seed(3)
+    qkv = torch.randn(B * L, 3 * H * 16, generator=g) * 1.5
+    out, _ = n.attention(qkv.to(DEV), B, L, H)
+    q, k, v = (t.view(B, L, H, 16).permute(0, 2, 1, 3).double() for t in qkv.split(H * 16, dim=1))
+    ref = torch.softmax(q @ k.transpose(-1, -2) / 4.0, dim=-1) @ v                  # [B,H,L,16]
+    ref = ref.permute(0, 2, 1, 3).reshape(B * L, H * 16)
+    assert relmax(out.cpu(), ref) <= 2e-6
+    # a spiked key (one score far above the rest) exercises the running-max rescale
+    qkv2 = qkv.clone()
+    qkv2[5, H * 16:H * 16 + 16] *= 40.0
+    out2, _ = n.attention(qkv2.to(DEV), B, L, H)
+    q, k, v = (t.view(B, L, H, 16).permute(0, 2, 1, 3).double() for t in qkv2.split(H * 16, dim=1))
+    ref2 = (torch.softmax(q @ k.transpose(-1, -2) / 4.0, dim=-1) @ v).permute(0, 2, 1, 3).reshape(B * L, H * 16)
+    assert relmax(out2.cpu(), ref2) <= 2e-6
+    x, r = torch.randn(300, 128, generator=g), torch.randn(300, 128, generator=g)
+    ga, be_ = torch.rand(128, generator=g) + 0.5, torch.randn(128, generator=g) * 0.1
+    y = n.add_layernorm(x.to(DEV), r.to(DEV), ga.to(DEV), be_.to(DEV))
+    yr = torch.nn.functional.layer_norm((x + r).double(), (128,), ga.double(), be_.double(), 1e-5)
+    assert relmax(y.cpu(), yr) <= 2e-6
