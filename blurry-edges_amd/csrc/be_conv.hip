@@ -38,6 +38,7 @@ struct ConvArgs {
     const float* res;     // optional residual, same layout/stride as y
     float* y;
     int M, H, W, HW, Cin, Cout, ldy, ks, nchunk, Ktot, act, m_tiles, n_tiles;
+    int pixmaj, Nimg;     // pixel-major M tiles: a tile = ONE pixel position of BM consecutive images (see kernel)
 };
 
 // __launch_bounds__(256, 2): LDS admits two blocks per CU (= 2 waves per SIMD), so let the register allocator use
@@ -67,7 +68,28 @@ void k_conv_igemm(ConvArgs a) {
     const int m_tile = (slot / a.n_tiles) * 8 + xcd;
     const int n_tile = slot % a.n_tiles;
     if (m_tile >= a.m_tiles) return;
-    const int m0 = m_tile * BM, n0 = n_tile * BN;
+    const int n0 = n_tile * BN;
+    // Row -> output pixel.  Flat tiles take BM consecutive (image, pixel) rows.  Pixel-major tiles (large batches)
+    // take ONE pixel position of BM consecutive images: every row of the tile then sees the same zero padding, so the
+    // taps that fall outside the image are skipped for the whole tile instead of being multiplied by zeros
+    // (3x3 on 6x6: 256 of 324 pixel-tap pairs are inside: 21 % fewer MFMAs for the same convolution).
+    // pixel order inside a group of images: interior pixels (all taps) first, the border ring (fewer taps) last, so
+    // the short tiles fill the tail of the launch
+    int pix_u = 0;
+    if (a.pixmaj) {
+        const int idx = m_tile % a.HW, ni = (a.H - 2) * (a.W - 2);
+        int py, px;
+        if (idx < ni) { py = 1 + idx / (a.W - 2); px = 1 + idx % (a.W - 2); }
+        else {
+            const int e = idx - ni;
+            if (e < a.W) { py = 0; px = e; }
+            else if (e < 2 * a.W) { py = a.H - 1; px = e - a.W; }
+            else if (e < 2 * a.W + a.H - 2) { px = 0; py = 1 + e - 2 * a.W; }
+            else { px = a.W - 1; py = 1 + e - 2 * a.W - (a.H - 2); }
+        }
+        pix_u = py * a.W + px;
+    }
+    const int row_base = a.pixmaj ? (m_tile / a.HW) * BM : m_tile * BM;      // first image (pixmaj) or first flat row
 
     const int tid = threadIdx.x;
     const int q = tid % QL, r0 = tid / QL;             // staging: QL lanes x 16 B = one row chunk
@@ -76,15 +98,36 @@ void k_conv_igemm(ConvArgs a) {
     int a_off[NA], a_yx[NA];
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-        const int m = m0 + r0 + RP * i;
-        if (m < a.M) {
-            const int pp = m % a.HW;
+        const int rr = row_base + r0 + RP * i;
+        const bool live = a.pixmaj ? rr < a.Nimg : rr < a.M;
+        const int m = a.pixmaj ? rr * a.HW + pix_u : rr;
+        if (live) {
+            const int pp = a.pixmaj ? pix_u : m % a.HW;
             const int yy = pp / a.W, xx = pp - yy * a.W;
             a_yx[i] = (yy << 16) | xx;
             a_off[i] = m;                              // multiplied by Cin at use (fits 32 bit: checked on host)
         } else {
             a_yx[i] = -1;                              // row outside the problem: always zero
             a_off[i] = 0;
+        }
+    }
+    // taps this tile has to visit, 4 bits each (flat tiles: all of them)
+    const int ntap_all = MODE == MODE_TAPS ? a.ks * a.ks : 7;
+    unsigned long long tap_list = 0;
+    int ntap = 0;
+    {
+        const int py = pix_u / a.W, px = pix_u - py * a.W, half = a.ks >> 1;
+        for (int t = 0; t < ntap_all; ++t) {
+            bool ok = true;
+            if (a.pixmaj) {
+                if (MODE == MODE_TAPS) {
+                    const int yy = py + t / a.ks - half, xx = px + t % a.ks - half;
+                    ok = (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
+                } else {
+                    ok = (unsigned)(py + t - 3) < (unsigned)a.H;
+                }
+            }
+            if (ok) { tap_list |= (unsigned long long)t << (4 * ntap); ++ntap; }
         }
     }
     const float* wbase = a.w + (size_t)n0 * a.Ktot + 4 * q;   // + row * Ktot + chunk offset
@@ -96,16 +139,20 @@ void k_conv_igemm(ConvArgs a) {
 #define BE_LOAD_CHUNK(KC)                                                                                       \
     do {                                                                                                        \
         int dy_, dx_, coff_;                                                                                    \
+        int kw_;   /* chunk index into the packed weights, in BKT units */                                     \
         if (MODE == MODE_TAPS) {                                                                                \
             const int k32_ = (KC) / SUB, sub_ = (KC) - k32_ * SUB;                                              \
-            const int taps_ = a.ks * a.ks;                                                                      \
-            const int cc_ = k32_ / taps_, tap_ = k32_ - cc_ * taps_;                                            \
+            const int cc_ = k32_ / ntap, j_ = k32_ - cc_ * ntap;                                                \
+            const int tap_ = (int)((tap_list >> (4 * j_)) & 15ull);                                             \
             const int half_ = a.ks >> 1;                                                                        \
             dy_ = tap_ / a.ks - half_; dx_ = tap_ % a.ks - half_;                                               \
             coff_ = (dy_ * a.W + dx_) * a.Cin + cc_ * 32 + sub_ * BKT + 4 * q;                                  \
+            kw_ = (cc_ * ntap_all + tap_) * SUB + sub_;                                                         \
         } else { /* conv1: chunk = kernel row kh, 8 pixels x 4 channels */                                      \
-            dy_ = (KC) - 3; dx_ = q - 3;                                                                        \
+            const int kh_ = (int)((tap_list >> (4 * (KC))) & 15ull);                                            \
+            dy_ = kh_ - 3; dx_ = q - 3;                                                                         \
             coff_ = (dy_ * a.W + dx_) * 4;                                                                      \
+            kw_ = kh_;                                                                                          \
         }                                                                                                       \
         a_ok = 0;                                                                                               \
         _Pragma("unroll") for (int i_ = 0; i_ < NA; ++i_) {                                                     \
@@ -120,7 +167,7 @@ void k_conv_igemm(ConvArgs a) {
         _Pragma("unroll") for (int i_ = 0; i_ < NB; ++i_) {                                                     \
             /* rows past the tile (partial pass, or BN < RP) read row 0 of the tile instead and are never stored */ \
             const int row_ = (B_PARTIAL && RP * i_ + r0 >= BN) ? 0 : RP * i_ + r0;                              \
-            b_st[i_] = *reinterpret_cast<const f32x4*>(wbase + (size_t)row_ * a.Ktot + (KC) * BKT);             \
+            b_st[i_] = *reinterpret_cast<const f32x4*>(wbase + (size_t)row_ * a.Ktot + kw_ * BKT);              \
         }                                                                                                       \
     } while (0)
 #define BE_STORE_CHUNK(BUF)                                                                                     \
@@ -150,7 +197,7 @@ void k_conv_igemm(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int nchunk = a.nchunk * SUB;
+    const int nchunk = (MODE == MODE_TAPS ? (a.nchunk / ntap_all) * ntap : ntap) * SUB;   // only the taps this tile visits
     BE_LOAD_CHUNK(0);
     BE_STORE_CHUNK(0);
     __syncthreads();
@@ -199,8 +246,9 @@ void k_conv_igemm(ConvArgs a) {
         for (int i = 0; i < MT; ++i) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = m0 + (wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (c_ok && m < a.M) {
+                const int rr = row_base + (wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int m = a.pixmaj ? rr * a.HW + pix_u : rr;
+                if (c_ok && (a.pixmaj ? rr < a.Nimg : rr < a.M)) {
                     float v = acc[i][j][r] + bias;
                     if (a.res) v += a.res[(size_t)m * a.ldy + c];
                     if (a.act == 1) v = be::smish(v);
@@ -410,6 +458,7 @@ extern "C" int be_conv_nhwc_f32(const be_conv_desc* d, const float* x, const flo
     a.M = (int)M; a.H = d->h; a.W = d->w; a.HW = d->h * d->w; a.Cin = d->cin; a.Cout = d->cout; a.ldy = ldy;
     a.ks = d->ksize; a.nchunk = conv_nchunk(d->cin, d->ksize); a.Ktot = a.nchunk * BK; a.act = d->act;
     a.m_tiles = (int)((M + 127) / 128);
+    a.pixmaj = 0; a.Nimg = d->n;
     const int cp = round_up(d->cout, 32);
     hipStream_t s = be::as_stream(stream);
     // Small-M regime (training at batch 64: M = 2304 rows at 6x6): the 128-row tiles give a few dozen workgroups on
@@ -422,6 +471,11 @@ extern "C" int be_conv_nhwc_f32(const be_conv_desc* d, const float* x, const flo
         }
         a.n_tiles = cp / 32;
         return launch_conv<4, 1, 1, 1, MODE_TAPS, 16, 0>(a, s, BE_KERNEL_CONV_SMALL);
+    }
+    // large batches of small images: pixel-major tiles skip the taps that fall into the zero padding
+    if (d->ksize > 1 && d->n >= 512 && conv_variant() != 99) {
+        a.pixmaj = 1;
+        a.m_tiles = a.HW * ((d->n + 127) / 128);
     }
     if (row8) {
         BE_REQUIRE(cp == 64, "be_conv_nhwc_f32: ksize 7 is built for cout 64 (got %d)", d->cout);

@@ -46,12 +46,14 @@ __device__ __forceinline__ float remainder_2pi(float a) {
 // Smish(x) = x * tanh(log(1 + sigmoid(x)))            models/local_stage.py:4-6
 // With u = 1 + sigmoid(x): tanh(log u) = (u^2-1)/(u^2+1); in t = exp(-|x|) this is a ratio of two
 // quadratics that never overflows:  x>=0: (3+2t)/(5+6t+2t^2)   x<0: (3t^2+2t)/(5t^2+6t+2).
+// exp through v_exp_f32 and the quotient through v_rcp_f32 (1 ulp each): the epilogue evaluates this once per output
+// element, and with the IEEE expf + correctly-rounded division it was a quarter of the short-K launches.
 __device__ __forceinline__ float smish(float x) {
-    const float t = expf(-fabsf(x));
+    const float t = __expf(-fabsf(x));
     float num, den;
     if (x >= 0.0f) { num = fmaf(2.0f, t, 3.0f);        den = fmaf(t, fmaf(2.0f, t, 6.0f), 5.0f); }
     else           { num = t * fmaf(3.0f, t, 2.0f);    den = fmaf(t, fmaf(5.0f, t, 6.0f), 2.0f); }
-    return x * (num / den);
+    return x * (num * __frcp_rn(den));
 }
 
 // Sum over the 64 lanes of a wave; every lane gets the total.  Fixed order -> bitwise reproducible.
