@@ -87,6 +87,8 @@ _SIGNATURES = {
     "be_attention_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
     "be_add_layernorm_f32": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_float, _P]),
     "be_add_pe_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
+    "be_global_loss_f32": (C.c_int, [C.POINTER(RenderOpts), C.POINTER(DepthConsts)] + [_P] * 9 + [C.POINTER(C.c_float)]
+                           + [_P] * 3 + [C.c_int] * 6 + [_P]),
     "be_profile_enable": (C.c_int, [C.c_int]),
     "be_profile_reset": (C.c_int, []),
     "be_profile_read": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
@@ -430,3 +432,30 @@ def add_layernorm(x, res, gamma, beta, eps=1e-5, out=None):
 def add_pe_(x, pe, batches):
     check(lib().be_add_pe_f32(dptr(x, "x"), dptr(pe, "pe"), batches, x.numel() // batches, stream_ptr(x.device)), "be_add_pe_f32")
     return x
+
+
+# ---------------------------------------------------------------------------------------------- global-stage training
+
+def view_image_pair_nhwc(img: torch.Tensor, stride: int = 2) -> PatchView:
+    """img [2,H,W,3] channels-last (the dataset layout of data/dataset.py:52) -> gather-on-read patch view."""
+    if img.dim() != 4 or img.shape[0] != 2 or img.shape[3] != 3:
+        raise RuntimeError(f"view_image_pair_nhwc: expected [2,H,W,3], got {tuple(img.shape)}")
+    dptr(img, "img")
+    _, h, w, _ = img.shape
+    return PatchView(img.data_ptr(), h * w * 3, 1, w * 3, 3, stride * w * 3, stride * 3, (w - BE_R) // stride + 1)
+
+
+def global_loss(opts, consts, est, img_fit, img_gt, G, Gd, Gb, bdist, deri, bdepth, gamma6, hp, wp, stride=2):
+    """-> (partial [B*P,8], grad [B*P,12], grad_depth [B*P,4])."""
+    B, P = est.shape[0], est.shape[1]
+    H, W = img_gt.shape[2], img_gt.shape[3]
+    dev = est.device
+    partial = torch.empty(B * P, 8, dtype=torch.float32, device=dev)
+    grad = torch.empty(B * P, 12, dtype=torch.float32, device=dev)
+    gdep = torch.empty(B * P, 4, dtype=torch.float32, device=dev)
+    g6 = (C.c_float * 6)(*[float(v) for v in gamma6])
+    check(lib().be_global_loss_f32(C.byref(opts), C.byref(consts), dptr(est, "est"), dptr(img_fit, "img_fit"),
+                                   dptr(img_gt, "img_gt"), dptr(G, "G"), dptr(Gd, "Gderi"), dptr(Gb, "Gbndry"),
+                                   dptr(bdist, "bdist"), dptr(deri, "deri"), dptr(bdepth, "bdepth"), g6, dptr(partial),
+                                   dptr(grad), dptr(gdep), B, hp, wp, H, W, stride, stream_ptr(dev)), "be_global_loss_f32")
+    return partial, grad, gdep

@@ -314,3 +314,71 @@ def synthetic_training_patches(n: int, seed: int = SEED_DEFAULT):
     gy = sum(ky[a, b] * gt[:, a:a + 19, b:b + 19, :] for a in range(3) for b in range(3))
     deri = np.sqrt(gx ** 2 + gy ** 2)
     return dict(img_ny=f32(ny), img_gt=f32(gt), bndry_dist=f32(bd), deri=f32(deri))
+
+
+# ---------------------------------------------------------------------------------------
+# Synthetic global-stage sample (the tensors data/dataset.py:48-55 hands to global_training.py:204-209)
+# ---------------------------------------------------------------------------------------
+
+def synthetic_global_sample(h: int = 147, w: int = 147, seed: int = SEED_DEFAULT, nshape: int = 6):
+    """One training sample of the global stage, dataset layouts (channels-last, already / alpha):
+    img_ny [2,h,w,3], img_gt [2,h,w,3] (noise-free), bndry_dist [h,w] (pixels to the nearest occlusion boundary),
+    deri [2,h-2,w-2,3] (Sobel magnitude of the clean images), bndry_depth [h,w] (depth of the front surface at
+    boundary pixels, 0 elsewhere), depth [h,w].  Scene = the layered discs / half-planes of synthetic_image_pair."""
+    from scipy.ndimage import distance_transform_edt
+    name = f"glob{h}x{w}"
+    yy, xx = np.meshgrid(np.arange(h, dtype=np.float64), np.arange(w, dtype=np.float64), indexing="ij")
+    zs = np.sort(Z_RANGE[0] + (Z_RANGE[1] - Z_RANGE[0]) * hash_uniform(seed, name + ".z", (nshape + 1,)))[::-1]
+    col = hash_uniform(seed, name + ".col", (nshape + 1, 3))
+    cx = hash_uniform(seed, name + ".cx", (nshape,)) * w
+    cy = hash_uniform(seed, name + ".cy", (nshape,)) * h
+    rad = (0.08 + 0.22 * hash_uniform(seed, name + ".r", (nshape,))) * min(h, w)
+    kind = hash_uniform(seed, name + ".k", (nshape,)) < 0.5
+    ang = 2.0 * math.pi * hash_uniform(seed, name + ".a", (nshape,))
+    clean = np.empty((2, 3, h, w), dtype=np.float64)
+    depth = np.full((h, w), zs[0], dtype=np.float64)
+    layer = np.zeros((h, w), dtype=np.int64)
+    for a in range(2):
+        img = np.broadcast_to(col[0][:, None, None], (3, h, w)).copy()
+        for i in range(nshape):
+            z = zs[i + 1]
+            s = blur_sigma_px(np.array(z))[a] * math.sqrt(2.0)
+            if kind[i]:
+                d = rad[i] - np.sqrt((xx - cx[i]) ** 2 + (yy - cy[i]) ** 2)
+            else:
+                d = -math.sin(ang[i]) * (xx - cx[i]) + math.cos(ang[i]) * (yy - cy[i])
+            m = 0.5 * (1.0 + _erf(d / s))
+            img = img * (1 - m) + m * col[i + 1][:, None, None]
+            if a == 0:
+                depth = np.where(d > 0, z, depth)
+                layer = np.where(d > 0, i + 1, layer)
+        clean[a] = img
+    alpha = 190.0
+    g = hash_normal(seed, name + ".noise", clean.shape)
+    lam = clean * alpha
+    noisy = np.rint(np.clip(lam + np.sqrt(np.maximum(lam, 0)) * g, 0, alpha)) / alpha
+    edge = np.zeros((h, w), dtype=bool)
+    edge[:, 1:] |= layer[:, 1:] != layer[:, :-1]
+    edge[1:, :] |= layer[1:, :] != layer[:-1, :]
+    bdist = distance_transform_edt(~edge) if edge.any() else np.full((h, w), float(max(h, w)))
+    front = depth.copy()                                       # nearer surface of the two sides of a boundary
+    front[:, 1:] = np.minimum(front[:, 1:], depth[:, :-1])
+    front[1:, :] = np.minimum(front[1:, :], depth[:-1, :])
+    bdepth = np.where(edge, front, 0.0)
+    kx = np.array([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]], dtype=np.float64)
+    ky = np.array([[1, 2, 1], [0, 0, 0], [-1, -2, -1]], dtype=np.float64)
+    gx = sum(kx[a_, b_] * clean[:, :, a_:a_ + h - 2, b_:b_ + w - 2] for a_ in range(3) for b_ in range(3))
+    gy = sum(ky[a_, b_] * clean[:, :, a_:a_ + h - 2, b_:b_ + w - 2] for a_ in range(3) for b_ in range(3))
+    deri = np.sqrt(gx ** 2 + gy ** 2)
+    return dict(img_ny=f32(noisy.transpose(0, 2, 3, 1)), img_gt=f32(clean.transpose(0, 2, 3, 1)), bndry_dist=f32(bdist),
+                deri=f32(deri.transpose(0, 2, 3, 1)), bndry_depth=f32(bdepth), depth=f32(depth))
+
+
+def plausible_global_output(p: int = 4096, seed: int = SEED_DEFAULT, name: str = "gout") -> np.ndarray:
+    """[P,12] raw GlobalStage outputs whose de-normalisation (global_training.py:141-145) gives plausible wedges."""
+    q = plausible_params12(p, seed, name).astype(np.float64)
+    out = np.empty_like(q)
+    out[:, :4] = q[:, :4] / 3.0
+    out[:, 4:8] = q[:, 4:8] / math.pi - 1.0
+    out[:, 8:] = q[:, 8:] - 0.5
+    return f32(out)

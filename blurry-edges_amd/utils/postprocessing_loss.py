@@ -195,3 +195,48 @@ def local_loss(helper, est, img_fit, gt_img, bndry_dist, deri, beta_bndry_loc, b
     """LocalLoss.forward (local_training.py:47-52) as one fused HIP forward+backward; differentiable w.r.t. est.
     Unlike the reference it does NOT write the wrapped angles back into est."""
     return _LocalLossFn.apply(est, helper, img_fit, gt_img, bndry_dist, deri, float(beta_bndry_loc), float(beta_smthns))
+
+
+class _GlobalLossFn(torch.autograd.Function):
+    """GlobalLoss(est) with the analytic gradient from the same HIP launch (be_global_loss_f32)."""
+
+    @staticmethod
+    def forward(ctx, est, helper, dcal, img_fit, img_gt, bndry_dist, deri, bndry_depth, gam):
+        e = est.detach().to(torch.float32).contiguous()
+        B, P = e.shape[:2]
+        H, W = img_gt.shape[2], img_gt.shape[3]
+        hp, wp, st = helper.H_patches, helper.W_patches, helper.stride
+        opts = helper.render_opts(False)
+        img_fit, img_gt = img_fit.contiguous(), img_gt.contiguous()
+        # the CURRENT folded image / boundary (the reference detaches them before the consistency terms)
+        G = torch.empty(B, 2, 3, H, W, dtype=torch.float32, device=e.device)
+        Gb = torch.empty(B, H, W, dtype=torch.float32, device=e.device)
+        for b in range(B):
+            rec, _ = native.render_full(opts, dcal.consts, 0.0, False, native.global_denorm(e[b]),
+                                        native.view_image_pair_nhwc(img_fit[b], st))
+            m = native.fold_records(opts, rec, hp, wp, H, W, st, False, want=("image", "bndry"))
+            G[b], Gb[b] = m["image"], m["bndry"]
+        Gd = helper.get_image_derivative(G.view(B * 2, 3, H, W)).view(B, 2, 3, H - 2, W - 2)
+        g6 = [gam[k] for k in ("color", "color_cons", "bndry_cons", "smthns", "smthns_cons", "bndry_loc")]
+        partial, grad, gdep = native.global_loss(opts, dcal.consts, e, img_fit, img_gt, G, Gd, Gb, bndry_dist.contiguous(),
+                                                 deri.contiguous(), bndry_depth.contiguous(), g6, hp, wp, st)
+        t = partial.double().sum(dim=0)
+        n1, n3, n4 = B * 2 * 441 * P, B * 441 * P, B * 2 * 361 * P
+        msum = torch.clamp(t[7], min=1.0)
+        loss = (g6[0] * t[0] + g6[1] * t[1]) / n1 + (g6[2] * t[2] + g6[5] * t[5]) / n3 + (g6[3] * t[3] + g6[4] * t[4]) / n4 \
+            + gam["depth"] * t[6] / msum
+        grad[:, 8:12] += (gam["depth"] / msum).to(torch.float32) * gdep
+        ctx.save_for_backward(grad.view(B, P, 12))
+        ctx.terms = t
+        return loss.to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return (g * grad,) + (None,) * 8
+
+
+def global_loss(helper, depth_cal, est, img_ny, img_gt, bndry_dist, deri, bndry_depth, gamma):
+    """GlobalLoss.forward (global_training.py:147-157) as fused HIP launches; differentiable w.r.t. est [B,P,12].
+    helper: a PostProcessGlobalBase; gamma: dict with the seven keys of oracle/global_loss.GAMMA_FINAL."""
+    return _GlobalLossFn.apply(est, helper, depth_cal, img_ny, img_gt, bndry_dist, deri, bndry_depth, dict(gamma))

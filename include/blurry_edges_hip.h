@@ -179,6 +179,24 @@ int be_local_loss_f32(const be_render_opts* opts_host, const float* est, const f
                       float* grad_est, float* patches, float* boundary, int64_t n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * GlobalLoss forward + backward (global-stage training)
+ *   replaces GlobalLoss.get_patches + get_loss (global_training.py:69-139) and the autograd graph under them.
+ *   est [B,P,12] raw GlobalStage output; img_fit / img_gt [B,2,H,W,3] channels-last (dataset layout);
+ *   G [B,2,3,H,W], Gderi [B,2,3,H-2,W-2], Gbndry [B,H,W]: the CURRENT folded image, its Sobel magnitude and the
+ *   folded boundary map (the reference detaches them, :94,:100,:106; produce them with be_render_full_f32 +
+ *   be_fold_records_f32 + be_image_derivative_f32); bdist [B,H,W]; deri [B,2,H-2,W-2,3]; bdepth [B,H,W];
+ *   gamma6 (host) = gamma_{color, color_cons, bndry_cons, smthns, smthns_cons, bndry_loc}.
+ *   partial [B*P,8] = per-patch sums of the six mean terms, the depth numerator and the depth-mask count;
+ *   grad [B*P,12] = gradient of  sum_k gamma_k * mean_k  w.r.t. est;  grad_depth [B*P,4] = gradient of the depth
+ *   NUMERATOR w.r.t. est[:,8:12] (the caller adds gamma_depth / total_mask_count * grad_depth).
+ * ------------------------------------------------------------------------------------------------- */
+int be_global_loss_f32(const be_render_opts* opts_host, const be_depth_consts* consts_host, const float* est,
+                       const float* img_fit, const float* img_gt, const float* G, const float* Gderi,
+                       const float* Gbndry, const float* bdist, const float* deri, const float* bdepth,
+                       const float* gamma6_host, float* partial, float* grad, float* grad_depth, int B, int hp, int wp,
+                       int H, int W, int stride, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * LocalStage CNN  (models/local_stage.py:30-73), inference (BatchNorm folded into the convs)
  * ------------------------------------------------------------------------------------------------- */
 

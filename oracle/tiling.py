@@ -13,20 +13,21 @@ import torch
 R = 21
 
 
-def grid_dims(H, W, stride=2):
-    return (H - R) // stride + 1, (W - R) // stride + 1            # postprocessing_loss.py:137-138
+def grid_dims(H, W, stride=2, r=R):
+    return (H - r) // stride + 1, (W - r) // stride + 1            # postprocessing_loss.py:137-138
 
 
-def unfold_patches(img: torch.Tensor, stride=2) -> torch.Tensor:
-    """img [B,C,H,W] -> [B, Hp*Wp, C, 21, 21]; patch (i,j) covers rows stride*i.., cols stride*j..,
-    flat index i*Wp+j  (the ordering blurry_edges_test.py:120-121 gets from nn.Unfold)."""
+def unfold_patches(img: torch.Tensor, stride=2, r=R) -> torch.Tensor:
+    """img [B,C,H,W] -> [B, Hp*Wp, C, r, r]; patch (i,j) covers rows stride*i.., cols stride*j..,
+    flat index i*Wp+j  (the ordering blurry_edges_test.py:120-121 gets from nn.Unfold); r = 21, or 19 for the
+    derivative maps of global_training.py:113-116."""
     B, C, H, W = img.shape
-    Hp, Wp = grid_dims(H, W, stride)
-    out = img.new_empty(B, Hp, Wp, C, R, R)
-    for r in range(R):
-        for c in range(R):
-            out[:, :, :, :, r, c] = img[:, :, r:r + stride * Hp:stride, c:c + stride * Wp:stride].permute(0, 2, 3, 1)
-    return out.reshape(B, Hp * Wp, C, R, R)
+    Hp, Wp = grid_dims(H, W, stride, r)
+    out = img.new_empty(B, Hp, Wp, C, r, r)
+    for a in range(r):
+        for c in range(r):
+            out[:, :, :, :, a, c] = img[:, :, a:a + stride * Hp:stride, c:c + stride * Wp:stride].permute(0, 2, 3, 1)
+    return out.reshape(B, Hp * Wp, C, r, r)
 
 
 def fold_sum(patches: torch.Tensor, H, W, stride=2) -> torch.Tensor:

@@ -187,3 +187,21 @@ def test_g8_big_tiler_properties():
         assert Ve - Vs == ve - vs and He - Hs == he - hs
         cover[Vs:Ve, Hs:He] += 1
     assert np.all(cover == 1)
+
+
+def test_g11_global_loss_value_and_gradient():
+    """oracle.global_loss against the reference's GlobalLoss (batch 1, final gammas), float64 and float32."""
+    from oracle import global_loss as ogl
+    g = load_golden("g11_global_loss")
+    smp = synth.synthetic_global_sample(147, 147)
+    est_np = synth.plausible_global_output(4096)
+    c = od.depth_consts()
+    for tag, dt, ltol, gtol in (("f64", torch.float64, 1e-9, 1e-7), ("f32", torch.float32, 2e-3, None)):
+        est = T(est_np, dt)[None].requires_grad_(True)
+        S = lambda k: T(smp[k], dt)[None]
+        loss, terms = ogl.global_loss(c, est, S("img_gt"), S("img_gt"), S("bndry_dist"), S("deri"), S("bndry_depth"))
+        loss.backward()
+        ref = float(g[tag + "_loss"])
+        assert abs(float(loss.detach()) - ref) <= ltol * abs(ref), (tag, float(loss.detach()), ref)
+        if gtol is not None:
+            assert relmax(est.grad[0].numpy(), g[tag + "_grad"]) <= gtol

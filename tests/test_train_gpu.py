@@ -69,3 +69,29 @@ def test_training_loss_curve_matches_oracle_for_the_first_steps():
         assert abs(h - r) <= 0.10 * abs(r), (hip, ref, ref32)
     assert hip[-1] < hip[0] and ref[-1] < ref[0]
     assert all(np.isfinite(hip))
+
+
+def test_global_loss_value_and_gradient_vs_fp64_golden():
+    """be_global_loss_f32 (+ records / fold / Sobel of the current global image) against the reference's GlobalLoss
+    under autograd, batch 1, final gammas (G11)."""
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a GPU")
+    import utils
+    from conftest import load_golden, relmax
+    from oracle import global_loss as ogl
+    g = load_golden("g11_global_loss")
+    a = utils.get_args("global_train", argv=[])
+    a.batch_size = 1
+    helper = utils.PostProcessGlobalBase(a, DEV)
+    dcal = utils.DepthEtas(a, DEV)
+    smp = {k: torch.from_numpy(v)[None].to(DEV) for k, v in synth.synthetic_global_sample(147, 147).items()}
+    est = torch.from_numpy(synth.plausible_global_output(4096))[None].to(DEV).requires_grad_(True)
+    loss = utils.global_loss(helper, dcal, est, smp["img_gt"], smp["img_gt"], smp["bndry_dist"], smp["deri"],
+                             smp["bndry_depth"], ogl.GAMMA_FINAL)
+    loss.backward()
+    ref = float(g["f64_loss"])
+    print("loss hip %.9f ref64 %.9f ref32 %.9f" % (float(loss), ref, float(g["f32_loss"])))
+    assert abs(float(loss.detach()) - ref) <= 2e-5 * abs(ref)
+    e = relmax(est.grad[0].cpu(), g["f64_grad"])
+    print("grad: hip-vs-ref64 %.2e   ref32-vs-ref64 %.2e" % (e, relmax(g["f32_grad"], g["f64_grad"])))
+    assert e <= 2e-4

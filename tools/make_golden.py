@@ -36,6 +36,7 @@ import utils as ref_utils        # noqa: E402
 assert ref_models.__file__.startswith(REF) and ref_utils.__file__.startswith(REF)
 import blurry_edges_test as ref_test     # noqa: E402
 import local_training as ref_local       # noqa: E402
+import global_training as ref_global     # noqa: E402
 
 torch.set_num_threads(8)
 
@@ -276,6 +277,31 @@ def G9():
          pe_sub=n(m.positional_encoding.pe[0, ::61]))
 
 
+def G11():
+    """GlobalLoss (global_training.py:11-157) value, its seven terms and d loss / d est on one synthetic 147x147
+    sample (batch 1) at the final gammas, float32 and float64 runs of the reference code."""
+    a = ref_args("global_train")
+    a.batch_size = 1
+    smp = synth.synthetic_global_sample(147, 147)
+    est_np = synth.plausible_global_output(4096)
+    out = {}
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        dcal = ref_utils.DepthEtas(a, torch.device("cpu"))
+        crit = ref_global.GlobalLoss(a, dcal, torch.device("cpu"))
+        crit.final_gamma()
+        if dt == torch.float64:
+            crit.x, crit.y, crit.ridge = crit.x.double(), crit.y.double(), crit.ridge.double()
+            crit.sobel_x, crit.sobel_y, crit.num_patches = crit.sobel_x.double(), crit.sobel_y.double(), crit.num_patches.double()
+            dcal.intercept, dcal.theta_mid, dcal.theta_wng = dcal.intercept.double(), dcal.theta_mid.double(), dcal.theta_wng.double()
+        est = torch.from_numpy(est_np).to(dt)[None].requires_grad_(True)
+        T = lambda k: torch.from_numpy(smp[k]).to(dt)[None]
+        loss = crit(est, T("img_gt"), T("img_gt"), T("bndry_dist"), T("deri"), T("bndry_depth"))
+        loss.backward()
+        out[tag + "_loss"] = n(loss)
+        out[tag + "_grad"] = n(est.grad[0])
+    save("g11_global_loss", **out)
+
+
 def G10():
     """eval_depth (utils/metrics.py:3-20) on a fixed pair of maps."""
     S = synth.SEED_DEFAULT
@@ -287,7 +313,7 @@ def G10():
     save("g10_metrics", metrics=np.array(r, dtype=np.float64))
 
 
-GROUPS = dict(G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G9=G9, G10=G10)
+GROUPS = dict(G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G9=G9, G10=G10, G11=G11)
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)
