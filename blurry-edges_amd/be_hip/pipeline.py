@@ -18,12 +18,13 @@ from . import native
 class DepthPipeline:
     def __init__(self, local_module, global_module, helper, depth_cal, rho_prime=10.39, densify=None, stride=2):
         """helper: a utils.PostProcessGlobalBase (render options); depth_cal: utils.DepthEtas."""
-        if densify not in (None, "w"):
+        if densify not in (None, "w"):  # noqa: E129
             raise NotImplementedError("densify='pp' needs the DepthCompletion U-Net (out of scope, SURVEY §8f-4)")
         self.local, self.globl = local_module, global_module
         self.helper, self.dcal = helper, depth_cal
         self.rho_prime, self.densify, self.stride = rho_prime, densify, stride
         self.depth_thres = 0.0 if densify == "w" else 0.05          # blurry_edges_test.py:109-112
+        # global_module / depth_cal may be None when only local_pass is used (global_data_pre_cal.py counterpart)
 
     # ---- stages --------------------------------------------------------------------------------------
     def local_pass(self, img):

@@ -95,3 +95,33 @@ def test_global_loss_value_and_gradient_vs_fp64_golden():
     e = relmax(est.grad[0].cpu(), g["f64_grad"])
     print("grad: hip-vs-ref64 %.2e   ref32-vs-ref64 %.2e" % (e, relmax(g["f32_grad"], g["f64_grad"])))
     assert e <= 2e-4
+
+
+def test_global_training_loop_runs_and_descends():
+    """configs[4], global half: GlobalStage under torch autograd + the fused HIP GlobalLoss, a few AdamW steps."""
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a GPU")
+    import models, utils
+    from be_hip import train_global
+    from oracle import global_loss as ogl
+    args = utils.get_args("global_train", argv=[])
+    args.batch_size = 1
+    local = models.LocalStage().to(DEV)
+    local.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.local_stage_state_dict().items()})
+    local.eval()
+    helper, dcal = utils.PostProcessGlobalBase(args, DEV), utils.DepthEtas(args, DEV)
+    data = train_global.make_dataset(1, DEV, local, helper)
+    torch.manual_seed(0)
+    model = models.GlobalStage(device=DEV).to(DEV)
+    for lyr in model.encoder.layers:                        # deterministic run: no dropout
+        lyr.dropout.p = lyr.dropout1.p = lyr.dropout2.p = 0.0
+        lyr.self_attn.dropout = 0.0
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4)
+    model.train()
+    batch = {k: data[0][k][None] for k in ("pm", "img_gt", "bndry_dist", "deri", "bndry_depth")}
+    losses = [float(train_global.train_step(model, helper, dcal, opt, batch, ogl.GAMMA_FINAL)) for _ in range(8)]
+    print("global loss", ["%.5f" % v for v in losses])
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    sched = train_global.GammaSchedule(args)
+    g0 = sched.step()
+    assert abs(g0["color"] - 1.0) < 1e-12 and abs(sched.final()["depth"] - 0.5) < 1e-12
