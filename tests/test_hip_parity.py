@@ -225,6 +225,26 @@ def test_local_stage_full_batch_8192_properties(native):
     assert relmax(ys.cpu(), yo) <= 1e-5
 
 
+@pytest.mark.parametrize("n", [1, 3, 513, 1000])
+def test_local_stage_ragged_batches_are_position_independent(native, n):
+    """Edge sizes: a single patch, a ragged small batch, and ragged LARGE batches (pixel-major conv tiles with a
+    partly empty last tile) give bit-identical logits to the same patches run in another batch."""
+    import models
+    m = models.LocalStage()
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.local_stage_state_dict().items()})
+    m = m.to(DEV).eval()
+    x = T(synth.uniform_patches(1000, name="ragged")).to(DEV)
+    with torch.no_grad():
+        ref = m(x[:16])
+        y = m(x[:n].contiguous())
+    k = min(n, 16)
+    assert torch.equal(y[:k], ref[:k]) and torch.isfinite(y).all()
+    if n > 16:
+        with torch.no_grad():
+            tail = m(x[n - 7:n].contiguous())
+        assert torch.equal(y[n - 7:], tail)
+
+
 def test_product_path_refuses_cpu_tensors(native):
     import models
     m = models.LocalStage().eval()
