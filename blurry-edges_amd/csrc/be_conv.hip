@@ -65,8 +65,18 @@ void k_conv_igemm(ConvArgs a) {
     // ---- block -> tile (XCD-aware: blocks b, b+8, b+16.. share an XCD and walk the N tiles of one M tile)
     const int bid = blockIdx.x;
     const int xcd = bid & 7, slot = bid >> 3;
-    const int m_tile = (slot / a.n_tiles) * 8 + xcd;
     const int n_tile = slot % a.n_tiles;
+    int m_tile;
+    if (a.pixmaj) {
+        // pixel-major: ALL pixel tiles of one group of BM images run on the same XCD, one after the other (the taps of
+        // neighbouring pixels re-read the same input lines: with the tiles of a group spread over the 8 XCDs the L2
+        // hit rate fell from 94 % to 69 % and HBM reads rose 6x)
+        const int t = slot / a.n_tiles;
+        const int grp = (t / a.HW) * 8 + xcd;
+        m_tile = grp * a.HW + t % a.HW;
+    } else {
+        m_tile = (slot / a.n_tiles) * 8 + xcd;
+    }
     if (m_tile >= a.m_tiles) return;
     const int n0 = n_tile * BN;
     // Row -> output pixel.  Flat tiles take BM consecutive (image, pixel) rows.  Pixel-major tiles (large batches)
@@ -272,7 +282,8 @@ int launch_conv(const ConvArgs& a, hipStream_t s, int kernel_id) {
         if (e != hipSuccess) return be::fail(BE_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set = true;
     }
-    const int per_xcd = (a.m_tiles + 7) / 8;
+    // slots per XCD: flat tiles are dealt round-robin; pixel-major tiles keep a group of images on one XCD
+    const int per_xcd = a.pixmaj ? ((a.m_tiles / a.HW + 7) / 8) * a.HW : (a.m_tiles + 7) / 8;
     const unsigned grid = (unsigned)(8 * per_xcd * a.n_tiles);
     {   // algorithmic work of this launch: 2*M*K*Cout with the REAL K (no padding); bytes = in + weights + out
         const double k_real = MODE == MODE_ROW8 ? 3.0 * 49.0 : (double)a.Cin * a.ks * a.ks;
