@@ -105,3 +105,37 @@ def test_oracle_glue_round_trip():
     est = glue.global_denorm(y)
     assert torch.allclose(est[:, :4], p10[0, :, :4], atol=1e-6)
     assert torch.allclose(est[:, 4:8], torch.remainder(p10[0, :, 4:8], 2 * torch.pi), atol=1e-5)
+
+
+def test_training_schedules_match_the_reference_formulas():
+    """LocalLoss.update_beta (local_training.py:18-26) and GlobalLoss.update_gamma (global_training.py:28-51)."""
+    import utils
+    from be_hip.train_local import BetaSchedule
+    from be_hip.train_global import GammaSchedule
+    b = BetaSchedule(1e-3, 5e-4, 200)
+    b.step()
+    assert (b.beta_b, b.beta_s) == (0.0, 0.0)
+    for _ in range(199):
+        b.step()
+    assert abs(b.beta_b - 1e-3) < 1e-15 and abs(b.beta_s - 5e-4) < 1e-15          # epoch index 199 -> rate 1
+    b.step()
+    assert abs(b.beta_b - 1e-3) < 1e-15
+    g = GammaSchedule(utils.get_args("global_train", argv=[]))
+    first = g.step()                                      # epoch 0: rate 0 of the first segment
+    assert first["color"] == 1.0 and first["depth"] == 0.0001
+    for _ in range(29):
+        g.step()                                          # epoch 29: rate 1 of the first segment
+    assert abs(g.gamma["color"] - 0.1) < 1e-12 and abs(g.gamma["depth"] - 0.05) < 1e-12
+    for _ in range(71):
+        g.step()                                          # epoch 100: start of the second segment
+    assert abs(g.gamma["color"] - 0.1) < 1e-12
+    for _ in range(99):
+        g.step()                                          # epoch 199: rate 1 of the second segment
+    assert abs(g.gamma["depth"] - 0.5) < 1e-12 and abs(g.gamma["smthns"] - 0.002) < 1e-12
+    assert g.final() == {k: v[-1] for k, v in g.rng.items()}
+
+
+def test_depth_completion_name_is_importable_but_not_built():
+    import models
+    with pytest.raises(NotImplementedError):
+        models.DepthCompletion()
