@@ -173,6 +173,10 @@ def main():
                         traffic=None, launches_per_step=len(dom) // args.steps,
                         avg_launch_ms=round(avg_ms, 4), flop_per_launch=avg_flop,
                         algo_bytes_per_launch=sum(r[2] for r in dom) / len(dom),
+                        # MFMA work actually issued (pixel-major tiles skip the zero-padding taps the algorithmic
+                        # count includes; tile padding counted): the busy fraction of the matrix pipe at nominal clock
+                        mfma_executed_tflops=round(sum(r[4] for r in dom) / sum(r[3] for r in dom) / 1e9, 2),
+                        mfma_executed_frac=round(sum(r[4] for r in dom) / sum(r[3] for r in dom) / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4),
                         all_conv_ms_per_step=round(conv_ms, 3),
                         end_to_end_frac=round(PAIRS * args.steps / elapsed * FLOP_PER_PAIR / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4))
             pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")

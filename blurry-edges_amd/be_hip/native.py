@@ -58,6 +58,9 @@ _SIGNATURES = {
     "be_conv_packed_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "be_conv_pack_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "be_conv_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, C.c_int, _P]),
+    "be_conv_fused2_packed_floats": (C.c_size_t, [C.c_int] * 4),
+    "be_conv_pack_fused2_f32": (C.c_int, [_P] * 12 + [C.c_float] + [C.c_int] * 4 + [_P, _P, _P]),
+    "be_conv_nhwc_fused2_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, C.c_int, _P, _P, _P, C.c_int, _P]),
     "be_maxpool_nhwc_f32": (C.c_int, [_P, _P] + [C.c_int] * 7 + [_P]),
     "be_nchw3_to_nhwc4_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
     "be_render_full_f32": (C.c_int, [C.POINTER(RenderOpts), C.POINTER(DepthConsts), C.c_float, C.c_int, _P,
@@ -92,7 +95,7 @@ _SIGNATURES = {
     "be_profile_enable": (C.c_int, [C.c_int]),
     "be_profile_reset": (C.c_int, []),
     "be_profile_read": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_double), C.POINTER(C.c_double),
-                                  C.POINTER(C.c_float), C.c_int]),
+                                  C.POINTER(C.c_double), C.POINTER(C.c_float), C.c_int]),
 }
 EXPORTED = tuple(_SIGNATURES)
 
@@ -282,12 +285,13 @@ def profile_reset():
 
 
 def profile_read(cap: int):
-    """-> list of (kernel_id, flops, bytes, ms) in launch order (waits for the events)."""
+    """-> list of (kernel_id, flops, bytes, ms, flops_executed) in launch order (waits for the events)."""
     ids = (C.c_int * cap)(); fl = (C.c_double * cap)(); by = (C.c_double * cap)(); ms = (C.c_float * cap)()
-    n = lib().be_profile_read(ids, fl, by, ms, cap)
+    fx = (C.c_double * cap)()
+    n = lib().be_profile_read(ids, fl, by, fx, ms, cap)
     if n < 0:
         check(n, "be_profile_read")
-    return [(ids[i], fl[i], by[i], ms[i]) for i in range(n)]
+    return [(ids[i], fl[i], by[i], ms[i], fx[i]) for i in range(n)]
 
 
 # ---------------------------------------------------------------------------------------------- pass B / tiling
@@ -459,3 +463,32 @@ def global_loss(opts, consts, est, img_fit, img_gt, G, Gd, Gb, bdist, deri, bdep
                                    dptr(bdist, "bdist"), dptr(deri, "deri"), dptr(bdepth, "bdepth"), g6, dptr(partial),
                                    dptr(grad), dptr(gdep), B, hp, wp, H, W, stride, stream_ptr(dev)), "be_global_loss_f32")
     return partial, grad, gdep
+
+
+def conv_pack_fused2(w, b, bn, w2, b2, bn2, eps=1e-5):
+    """conv kxk (w,b,bn) + 1x1 branch (w2,b2,bn2) packed for conv_nhwc_fused2 -> (pw, pb)."""
+    cout, cin = w.shape[0], w.shape[1]
+    ks = w.shape[2]
+    cin2 = w2.shape[1]
+    nfl = lib().be_conv_fused2_packed_floats(cout, cin, ks, cin2)
+    if nfl == 0:
+        raise RuntimeError("conv_pack_fused2: unsupported shapes")
+    dev = w.device
+    pw = torch.empty(nfl, dtype=torch.float32, device=dev)
+    pb = torch.empty((cout + 31) // 32 * 32, dtype=torch.float32, device=dev)
+    g, g2 = (bn or (None,) * 4), (bn2 or (None,) * 4)
+    check(lib().be_conv_pack_fused2_f32(dptr(w.contiguous()), dptr(b), dptr(g[0]), dptr(g[1]), dptr(g[2]), dptr(g[3]),
+                                        dptr(w2.contiguous()), dptr(b2), dptr(g2[0]), dptr(g2[1]), dptr(g2[2]), dptr(g2[3]),
+                                        eps, cout, cin, ks, cin2, dptr(pw), dptr(pb), stream_ptr(dev)),
+          "be_conv_pack_fused2_f32")
+    return pw, pb
+
+
+def conv_nhwc_fused2(x, x2, pw, pb, cout, ksize, act):
+    """y = act(conv_kxk(x) + conv_1x1(x2) + bias): x [N,H,W,Cin], x2 [N,H,W,Cin2]."""
+    n, h, w, cin = x.shape
+    y = torch.empty(n, h, w, cout, dtype=torch.float32, device=x.device)
+    d = ConvDesc(n, h, w, cin, cout, ksize, int(act))
+    check(lib().be_conv_nhwc_fused2_f32(C.byref(d), dptr(x, "x"), dptr(x2, "x2"), x2.shape[-1], dptr(pw), dptr(pb), dptr(y),
+                                        cout, stream_ptr(x.device)), "be_conv_nhwc_fused2_f32")
+    return y

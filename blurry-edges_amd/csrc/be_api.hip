@@ -13,16 +13,17 @@ extern "C" const char* be_last_error(void) { return be::last_error_buf(); }
 
 // ------------------------------------------------------------------------------------------------ profiling
 namespace {
-struct Rec { hipEvent_t a, b; int kernel_id; double flops, bytes; };
+struct Rec { hipEvent_t a, b; int kernel_id; double flops, bytes, flops_exec; };
 struct Prof { Rec* recs = nullptr; int cap = 0, n = 0; bool on = false; } g_prof;
 }  // namespace
 
 namespace be {
-ProfileScope::ProfileScope(hipStream_t s, int kernel_id, double flops, double bytes) : s_(s), slot_(-1) {
+ProfileScope::ProfileScope(hipStream_t s, int kernel_id, double flops, double bytes, double flops_executed)
+    : s_(s), slot_(-1) {
     if (!g_prof.on || g_prof.n >= g_prof.cap) return;
     slot_ = g_prof.n++;
     Rec& r = g_prof.recs[slot_];
-    r.kernel_id = kernel_id; r.flops = flops; r.bytes = bytes;
+    r.kernel_id = kernel_id; r.flops = flops; r.bytes = bytes; r.flops_exec = flops_executed;
     (void)hipEventRecord(r.a, s_);
 }
 ProfileScope::~ProfileScope() {
@@ -47,7 +48,7 @@ extern "C" int be_profile_enable(int max_launches) {
 
 extern "C" int be_profile_reset(void) { g_prof.n = 0; return BE_OK; }
 
-extern "C" int be_profile_read(int* kernel_id, double* flops, double* bytes, float* ms, int cap) {
+extern "C" int be_profile_read(int* kernel_id, double* flops, double* bytes, double* flops_executed, float* ms, int cap) {
     const int n = g_prof.n < cap ? g_prof.n : cap;
     for (int i = 0; i < n; ++i) {
         Rec& r = g_prof.recs[i];
@@ -55,6 +56,7 @@ extern "C" int be_profile_read(int* kernel_id, double* flops, double* bytes, flo
         float t = 0.f;
         if (hipEventElapsedTime(&t, r.a, r.b) != hipSuccess) return be::fail(BE_ELAUNCH, "be_profile_read: elapsed failed");
         kernel_id[i] = r.kernel_id; flops[i] = r.flops; bytes[i] = r.bytes; ms[i] = t;
+        if (flops_executed) flops_executed[i] = r.flops_exec;
     }
     return n;
 }

@@ -30,7 +30,7 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 // Opt-in per-launch timing (be_profile_* in the C ABI): when enabled, every conv launch is bracketed by two
 // pre-created hipEvents recorded on the launch stream (asynchronous; read back later).
 struct ProfileScope {
-    ProfileScope(hipStream_t s, int kernel_id, double flops, double bytes);
+    ProfileScope(hipStream_t s, int kernel_id, double flops, double bytes, double flops_executed);
     ~ProfileScope();
     hipStream_t s_; int slot_;
 };

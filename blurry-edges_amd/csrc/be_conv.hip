@@ -39,6 +39,8 @@ struct ConvArgs {
     float* y;
     int M, H, W, HW, Cin, Cout, ldy, ks, nchunk, Ktot, act, m_tiles, n_tiles;
     int pixmaj, Nimg;     // pixel-major M tiles: a tile = ONE pixel position of BM consecutive images (see kernel)
+    const float* x2;      // optional second input [N,H,W,Cin2]: its 1x1 conv is appended to the K loop (the residual
+    int Cin2;             //   block's downsample branch fused into conv2: out = act(conv3x3(x) + conv1x1(x2) + bias))
 };
 
 // __launch_bounds__(256, 2): LDS admits two blocks per CU (= 2 waves per SIMD), so let the register allocator use
@@ -150,7 +152,13 @@ void k_conv_igemm(ConvArgs a) {
     do {                                                                                                        \
         int dy_, dx_, coff_;                                                                                    \
         int kw_;   /* chunk index into the packed weights, in BKT units */                                     \
-        if (MODE == MODE_TAPS) {                                                                                \
+        const bool second_ = MODE == MODE_TAPS && (KC) >= n1;   /* fused 1x1 branch on x2 */                    \
+        if (second_) {                                                                                          \
+            const int k2_ = (KC) - n1;                                                                          \
+            dy_ = 0; dx_ = 0;                                                                                   \
+            coff_ = k2_ * BKT + 4 * q;                                                                          \
+            kw_ = a.nchunk * SUB + k2_;                                                                         \
+        } else if (MODE == MODE_TAPS) {                                                                         \
             const int k32_ = (KC) / SUB, sub_ = (KC) - k32_ * SUB;                                              \
             const int cc_ = k32_ / ntap, j_ = k32_ - cc_ * ntap;                                                \
             const int tap_ = (int)((tap_list >> (4 * j_)) & 15ull);                                             \
@@ -169,9 +177,9 @@ void k_conv_igemm(ConvArgs a) {
             const int yy_ = (a_yx[i_] >> 16) + dy_, xx_ = (a_yx[i_] & 0xffff) + dx_;                            \
             const bool ok_ = a_yx[i_] >= 0 && (unsigned)yy_ < (unsigned)a.H && (unsigned)xx_ < (unsigned)a.W;   \
             /* branch-free: out-of-image taps read the (valid) first 16 B of the tensor and are zeroed */      \
-            int64_t off_ = ok_ ? (int64_t)a_off[i_] * a.Cin + coff_ : 0;                                        \
+            int64_t off_ = ok_ ? (int64_t)a_off[i_] * (second_ ? a.Cin2 : a.Cin) + coff_ : 0;                   \
             asm volatile("" : "+v"(off_));  /* opaque: keeps the load unconditional (no exec-mask branch) */    \
-            a_st[i_] = *reinterpret_cast<const f32x4*>(a.x + off_);  /* zeroed at store time: no wait here */   \
+            a_st[i_] = *reinterpret_cast<const f32x4*>((second_ ? a.x2 : a.x) + off_);  /* zeroed at store */   \
             a_ok |= (ok_ ? 1u : 0u) << i_;                                                                      \
         }                                                                                                       \
         _Pragma("unroll") for (int i_ = 0; i_ < NB; ++i_) {                                                     \
@@ -207,7 +215,8 @@ void k_conv_igemm(ConvArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-    const int nchunk = (MODE == MODE_TAPS ? (a.nchunk / ntap_all) * ntap : ntap) * SUB;   // only the taps this tile visits
+    const int n1 = (MODE == MODE_TAPS ? (a.nchunk / ntap_all) * ntap : ntap) * SUB;       // only the taps this tile visits
+    const int nchunk = n1 + (a.x2 ? (a.Cin2 / 32) * SUB : 0);                              // + the fused 1x1 branch
     BE_LOAD_CHUNK(0);
     BE_STORE_CHUNK(0);
     __syncthreads();
@@ -288,8 +297,30 @@ int launch_conv(const ConvArgs& a, hipStream_t s, int kernel_id) {
     {   // algorithmic work of this launch: 2*M*K*Cout with the REAL K (no padding); bytes = in + weights + out
         const double k_real = MODE == MODE_ROW8 ? 3.0 * 49.0 : (double)a.Cin * a.ks * a.ks;
         const double cin_real = MODE == MODE_ROW8 ? 3.0 : (double)a.Cin;
-        be::ProfileScope prof(s, kernel_id, 2.0 * a.M * k_real * a.Cout,
-                              4.0 * (a.M * cin_real + k_real * a.Cout + (double)a.M * a.Cout * (a.res ? 2 : 1)));
+        // MFMA work actually issued: every tile runs (its number of K chunks) x (2*BM*BN*BKT) flops, padding included;
+        // pixel-major tiles visit only the taps inside the image
+        double chunks = 0.0;
+        const int ntap_all = MODE == MODE_ROW8 ? 7 : a.ks * a.ks, ncc = MODE == MODE_ROW8 ? 1 : a.nchunk / ntap_all;
+        if (a.pixmaj) {
+            const int half = a.ks >> 1;
+            for (int py = 0; py < a.H; ++py)
+                for (int px = 0; px < a.W; ++px) {
+                    int nt = 0;
+                    for (int t = 0; t < ntap_all; ++t) {
+                        if (MODE == MODE_ROW8) nt += (unsigned)(py + t - 3) < (unsigned)a.H;
+                        else nt += (unsigned)(py + t / a.ks - half) < (unsigned)a.H && (unsigned)(px + t % a.ks - half) < (unsigned)a.W;
+                    }
+                    chunks += (double)nt * ncc;
+                }
+            chunks *= (double)(a.m_tiles / a.HW) * a.n_tiles * (32 / BKT);
+        } else {
+            chunks = (double)a.m_tiles * a.n_tiles * a.nchunk * (32 / BKT);
+        }
+        if (a.x2) chunks += (double)a.m_tiles * a.n_tiles * (a.Cin2 / 32) * (32 / BKT);
+        const double k2_real = a.x2 ? (double)a.Cin2 : 0.0;
+        be::ProfileScope prof(s, kernel_id, 2.0 * a.M * (k_real + k2_real) * a.Cout,
+                              4.0 * (a.M * (cin_real + k2_real) + (k_real + k2_real) * a.Cout + (double)a.M * a.Cout * (a.res ? 2 : 1)),
+                              chunks * 2.0 * BM * BN * BKT);
         hipLaunchKernelGGL((k_conv_igemm<WM, WN, MT, NT, MODE, BKT, PRIO>), dim3(grid), dim3(256), lds, s, a);
     }
     return be::check_launch("be_conv_nhwc_f32");
@@ -311,6 +342,7 @@ struct PackArgs {
     float eps;
     int cout, cin, ks, chw_hw, cout_pad, ktot;
     float *pw, *pb;
+    int row_stride, col_off, bias_add;   // destination row stride / first column (floats); 1: add to the bias instead of set
     int dgrad;      // 1: pack W^T with mirrored taps: rows = input channels, K = (cout chunk, tap) -> data-gradient conv
 };
 
@@ -329,7 +361,7 @@ __global__ void k_pack(PackArgs p) {
                 const int ci_ref = p.chw_hw > 0 ? (row % (p.cin / p.chw_hw)) * p.chw_hw + row / (p.cin / p.chw_hw) : row;
                 if (oc < p.cout) v = p.w[((size_t)oc * p.cin + ci_ref) * taps + (taps - 1 - tap)];
             }
-            p.pw[idx] = v;
+            p.pw[(size_t)co * p.row_stride + p.col_off + k] = v;
             continue;
         }
         if (co < p.cout) {
@@ -352,7 +384,7 @@ __global__ void k_pack(PackArgs p) {
                 v = p.w[src] * scale;
             }
         }
-        p.pw[idx] = v;
+        p.pw[(size_t)co * p.row_stride + p.col_off + k] = v;
     }
     // bias: one thread per output channel
     for (int64_t co = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; co < p.cout_pad; co += stride) {
@@ -362,7 +394,7 @@ __global__ void k_pack(PackArgs p) {
             if (p.gamma) v = (b - p.mean[co]) * (p.gamma[co] / sqrtf(p.var[co] + p.eps)) + p.beta[co];
             else v = b;
         }
-        p.pb[co] = v;
+        if (p.bias_add) p.pb[co] += v; else p.pb[co] = v;
     }
 }
 
@@ -428,10 +460,35 @@ extern "C" int be_conv_pack_f32(const float* w, const float* b, const float* g, 
     else BE_REQUIRE((ksize == 1 || ksize == 3) && cin % BK == 0,
                     "be_conv_pack_f32: ksize %d / cin %d unsupported (ksize 1|3 with cin %% 32 == 0, or 7)", ksize, cin);
     BE_REQUIRE(chw_hw == 0 || (ksize == 1 && cin % chw_hw == 0), "be_conv_pack_f32: bad layout_chw_hw");
-    PackArgs p{w, b, g, beta, mean, var, eps, cout, cin, ksize, chw_hw, round_up(cout, 32),
-               conv_nchunk(cin, ksize) * BK, pw, pb, 0};
+    const int ktot = conv_nchunk(cin, ksize) * BK;
+    PackArgs p{w, b, g, beta, mean, var, eps, cout, cin, ksize, chw_hw, round_up(cout, 32), ktot, pw, pb, ktot, 0, 0, 0};
     hipLaunchKernelGGL(k_pack, dim3(grid_cap((int64_t)p.cout_pad * p.ktot, 256)), dim3(256), 0, be::as_stream(stream), p);
     return be::check_launch("be_conv_pack_f32");
+}
+
+extern "C" size_t be_conv_fused2_packed_floats(int cout, int cin, int ksize, int cin2) {
+    const size_t k1 = be_conv_packed_floats(cout, cin, ksize);
+    if (!k1 || cin2 <= 0 || cin2 % BK) return 0;
+    return k1 + (size_t)round_up(cout, 32) * cin2;
+}
+
+extern "C" int be_conv_pack_fused2_f32(const float* w, const float* b, const float* g, const float* beta, const float* mean,
+                                       const float* var, const float* w2, const float* b2, const float* g2,
+                                       const float* beta2, const float* mean2, const float* var2, float eps, int cout,
+                                       int cin, int ksize, int cin2, float* pw, float* pb, void* stream) {
+    BE_REQUIRE(w && w2 && pw && pb, "be_conv_pack_fused2_f32: null pointer");
+    BE_REQUIRE((ksize == 1 || ksize == 3) && cin % BK == 0 && cin2 > 0 && cin2 % BK == 0 && cout > 0,
+               "be_conv_pack_fused2_f32: ksize 1|3, cin and cin2 %% 32 == 0");
+    BE_REQUIRE((g == nullptr) == (beta == nullptr) && (g == nullptr) == (mean == nullptr) && (g == nullptr) == (var == nullptr) &&
+               (g2 == nullptr) == (beta2 == nullptr) && (g2 == nullptr) == (mean2 == nullptr) && (g2 == nullptr) == (var2 == nullptr),
+               "be_conv_pack_fused2_f32: BatchNorm tensors must be all set or all null per branch");
+    const int k1 = conv_nchunk(cin, ksize) * BK, ktot = k1 + cin2, cp = round_up(cout, 32);
+    hipStream_t s = be::as_stream(stream);
+    PackArgs p1{w, b, g, beta, mean, var, eps, cout, cin, ksize, 0, cp, k1, pw, pb, ktot, 0, 0, 0};
+    hipLaunchKernelGGL(k_pack, dim3(grid_cap((int64_t)cp * k1, 256)), dim3(256), 0, s, p1);
+    PackArgs p2{w2, b2, g2, beta2, mean2, var2, eps, cout, cin2, 1, 0, cp, cin2, pw, pb, ktot, k1, 1, 0};
+    hipLaunchKernelGGL(k_pack, dim3(grid_cap((int64_t)cp * cin2, 256)), dim3(256), 0, s, p2);
+    return be::check_launch("be_conv_pack_fused2_f32");
 }
 
 extern "C" size_t be_conv_dgrad_packed_floats(int cout, int cin, int ksize) {
@@ -445,14 +502,31 @@ extern "C" int be_conv_pack_dgrad_f32(const float* w, int cout, int cin, int ksi
     BE_REQUIRE(cout > 0 && cin > 0 && cout % BK == 0 && (ksize == 1 || ksize == 3),
                "be_conv_pack_dgrad_f32: needs cout %% 32 == 0 and ksize 1|3 (got cout %d, ksize %d)", cout, ksize);
     BE_REQUIRE(chw_hw == 0 || (ksize == 1 && cin % chw_hw == 0), "be_conv_pack_dgrad_f32: bad layout_chw_hw");
-    PackArgs p{w, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, cout, cin, ksize, chw_hw, round_up(cin, 32),
-               (cout / BK) * ksize * ksize * BK, pw, pb, 1};
+    const int kt = (cout / BK) * ksize * ksize * BK;
+    PackArgs p{w, nullptr, nullptr, nullptr, nullptr, nullptr, 0.f, cout, cin, ksize, chw_hw, round_up(cin, 32), kt, pw, pb,
+               kt, 0, 0, 1};
     hipLaunchKernelGGL(k_pack, dim3(grid_cap((int64_t)p.cout_pad * p.ktot, 256)), dim3(256), 0, be::as_stream(stream), p);
     return be::check_launch("be_conv_pack_dgrad_f32");
 }
 
+static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2, int cin2, const float* pw, const float* pb,
+                         const float* res, float* y, int ldy, void* stream);
+
 extern "C" int be_conv_nhwc_f32(const be_conv_desc* d, const float* x, const float* pw, const float* pb,
                                 const float* res, float* y, int ldy, void* stream) {
+    return conv_dispatch(d, x, nullptr, 0, pw, pb, res, y, ldy, stream);
+}
+
+extern "C" int be_conv_nhwc_fused2_f32(const be_conv_desc* d, const float* x, const float* x2, int cin2, const float* pw,
+                                       const float* pb, float* y, int ldy, void* stream) {
+    BE_REQUIRE(x2 && cin2 > 0 && cin2 % BK == 0, "be_conv_nhwc_fused2_f32: x2 / cin2 (%% 32 == 0) required");
+    BE_REQUIRE(d && d->ksize != 7, "be_conv_nhwc_fused2_f32: not available for the 7x7 row-gather mode");
+    BE_REQUIRE(be::aligned16(x2), "be_conv_nhwc_fused2_f32: x2 must be 16-byte aligned");
+    return conv_dispatch(d, x, x2, cin2, pw, pb, nullptr, y, ldy, stream);
+}
+
+static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2, int cin2, const float* pw, const float* pb,
+                         const float* res, float* y, int ldy, void* stream) {
     BE_REQUIRE(d && x && pw && pb && y, "be_conv_nhwc_f32: null pointer");
     BE_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cout > 0, "be_conv_nhwc_f32: empty shape");
     BE_REQUIRE(d->h < 32768 && d->w < 32768, "be_conv_nhwc_f32: image too large");
@@ -467,7 +541,8 @@ extern "C" int be_conv_nhwc_f32(const be_conv_desc* d, const float* x, const flo
     ConvArgs a;
     a.x = x; a.w = pw; a.bias = pb; a.res = res; a.y = y;
     a.M = (int)M; a.H = d->h; a.W = d->w; a.HW = d->h * d->w; a.Cin = d->cin; a.Cout = d->cout; a.ldy = ldy;
-    a.ks = d->ksize; a.nchunk = conv_nchunk(d->cin, d->ksize); a.Ktot = a.nchunk * BK; a.act = d->act;
+    a.ks = d->ksize; a.nchunk = conv_nchunk(d->cin, d->ksize); a.Ktot = a.nchunk * BK + (x2 ? cin2 : 0); a.act = d->act;
+    a.x2 = x2; a.Cin2 = cin2;
     a.m_tiles = (int)((M + 127) / 128);
     a.pixmaj = 0; a.Nimg = d->n;
     const int cp = round_up(d->cout, 32);

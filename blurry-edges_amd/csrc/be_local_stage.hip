@@ -27,8 +27,13 @@ struct PackedLayout {
     PackedLayout() {
         size_t o = 0;
         for (int i = 0; i < 15; ++i) {
-            w_off[i] = o; o += be_conv_packed_floats(kLayers[i].cout, kLayers[i].cin, kLayers[i].ks);
-            b_off[i] = o; o += cout_pad(kLayers[i].cout);
+            const bool conv2 = i == 2 || i == 5 || i == 8 || i == 11;        // carries its block's downsample too
+            const bool ds = i == 3 || i == 6 || i == 9 || i == 12;            // ... which therefore has no slot
+            w_off[i] = o;
+            if (conv2) o += be_conv_fused2_packed_floats(kLayers[i].cout, kLayers[i].cin, kLayers[i].ks, kLayers[i + 1].cin);
+            else if (!ds) o += be_conv_packed_floats(kLayers[i].cout, kLayers[i].cin, kLayers[i].ks);
+            b_off[i] = o;
+            if (!ds) o += cout_pad(kLayers[i].cout);
         }
         total = o;
     }
@@ -62,8 +67,18 @@ extern "C" int be_local_stage_pack_f32(const float* const* t, float bn_eps, floa
     const PackedLayout& L = layout();
     for (int i = 0; i < 13; ++i) {                    // conv + BatchNorm2d pairs
         const float* const* e = t + 6 * i;            // weight, bias, gamma, beta, mean, var
-        int rc = be_conv_pack_f32(e[0], e[1], e[2], e[3], e[4], e[5], bn_eps, kLayers[i].cout, kLayers[i].cin,
+        const bool conv2 = i == 2 || i == 5 || i == 8 || i == 11, ds = i == 3 || i == 6 || i == 9 || i == 12;
+        if (ds) continue;                              // packed together with the block's conv2
+        int rc;
+        if (conv2) {
+            const float* const* d = t + 6 * (i + 1);  // the block's downsample conv + BN
+            rc = be_conv_pack_fused2_f32(e[0], e[1], e[2], e[3], e[4], e[5], d[0], d[1], d[2], d[3], d[4], d[5], bn_eps,
+                                         kLayers[i].cout, kLayers[i].cin, kLayers[i].ks, kLayers[i + 1].cin,
+                                         packed + L.w_off[i], packed + L.b_off[i], stream);
+        } else {
+            rc = be_conv_pack_f32(e[0], e[1], e[2], e[3], e[4], e[5], bn_eps, kLayers[i].cout, kLayers[i].cin,
                                   kLayers[i].ks, 0, packed + L.w_off[i], packed + L.b_off[i], stream);
+        }
         if (rc) return rc;
     }
     const float* const* f = t + 78;                   // fc.1.w, fc.1.b, fc.2.{gamma,beta,mean,var}, fc.4.w, fc.4.b
@@ -86,13 +101,16 @@ int conv(const float* packed, int li, const float* x, const float* res, float* y
     return be_conv_nhwc_f32(&d, x, packed + L.w_off[li], packed + L.b_off[li], res, y, ldy, stream);
 }
 
-// ResidualBlock (models/local_stage.py:20-28): Smish(BN(conv3(Smish(BN(conv3(x))))) + BN(conv1x1(x)))
-int block(const float* packed, int l0, const float* x, float* t, float* d, float* o, int n, int hw, void* stream) {
+// ResidualBlock (models/local_stage.py:20-28): Smish(BN(conv3(Smish(BN(conv3(x))))) + BN(conv1x1(x))) in two launches:
+// the downsample 1x1 rides in the K loop of conv2 (be_conv_nhwc_fused2_f32), no residual tensor in HBM
+int block(const float* packed, int l0, const float* x, float* t, float* o, int n, int hw, void* stream) {
     const int c = kLayers[l0].cout;
     int rc;
     if ((rc = conv(packed, l0, x, nullptr, t, n, hw, 1, c, stream))) return rc;
-    if ((rc = conv(packed, l0 + 2, x, nullptr, d, n, hw, 0, c, stream))) return rc;
-    return conv(packed, l0 + 1, t, d, o, n, hw, 1, c, stream);
+    const PackedLayout& L = layout();
+    be_conv_desc d;
+    d.n = n; d.h = hw; d.w = hw; d.cin = kLayers[l0 + 1].cin; d.cout = c; d.ksize = 3; d.act = 1;
+    return be_conv_nhwc_fused2_f32(&d, t, x, kLayers[l0 + 2].cin, packed + L.w_off[l0 + 1], packed + L.b_off[l0 + 1], o, c, stream);
 }
 
 }  // namespace
@@ -122,15 +140,15 @@ extern "C" int be_local_stage_forward_f32(const float* packed, const float* x, f
         if ((rc = conv(packed, 0, x4, nullptr, ra, nb, 21, 1, 64, stream))) return rc;
         if ((rc = be_maxpool_nhwc_f32(ra, p1, nb, 21, 21, 64, 3, 2, 1, stream))) return rc;
         // layer0 @11x11: t,d in RA, out in RC
-        if ((rc = block(packed, 1, p1, ra, ra + (size_t)nb * 11616, rc_, nb, 11, stream))) return rc;
+        if ((rc = block(packed, 1, p1, ra, rc_, nb, 11, stream))) return rc;
         float* p2 = rb;                                   // nb*3456
         if ((rc = be_maxpool_nhwc_f32(rc_, p2, nb, 11, 11, 96, 3, 2, 1, stream))) return rc;
         // layer1: in RB, t,d RA, out RC
-        if ((rc = block(packed, 4, p2, ra, ra + (size_t)nb * 9216, rc_, nb, 6, stream))) return rc;
+        if ((rc = block(packed, 4, p2, ra, rc_, nb, 6, stream))) return rc;
         // layer2: in RC, t,d RA, out RB
-        if ((rc = block(packed, 7, rc_, ra, ra + (size_t)nb * 13824, rb, nb, 6, stream))) return rc;
+        if ((rc = block(packed, 7, rc_, ra, rb, nb, 6, stream))) return rc;
         // layer3: in RB, t,d RA, out RC
-        if ((rc = block(packed, 10, rb, ra, ra + (size_t)nb * 9216, rc_, nb, 6, stream))) return rc;
+        if ((rc = block(packed, 10, rb, ra, rc_, nb, 6, stream))) return rc;
         float* p3 = rb;                                   // nb*2304  (H,W,C) flatten
         if ((rc = be_maxpool_nhwc_f32(rc_, p3, nb, 6, 6, 256, 2, 2, 0, stream))) return rc;
         float* f1 = ra;                                   // nb*1024

@@ -240,6 +240,17 @@ int be_conv_pack_f32(const float* weight_oihw, const float* bias, const float* b
 /* y[n,h,w,cout] = act(conv(x) + bias (+ residual)); residual may be NULL; ldy = row stride of y in floats. */
 int be_conv_nhwc_f32(const be_conv_desc* desc_host, const float* x, const float* packed_w,
                      const float* packed_bias, const float* residual, float* y, int ldy, void* stream);
+/* ResidualBlock tail in ONE launch (models/local_stage.py:22-27): y = act(conv_kxk(x) + conv_1x1(x2) + bias) where the
+ * second branch is the block's downsample; its 1x1 conv is appended to the K loop of the first (no residual tensor
+ * in HBM).  Weights: both branches (each with its own folded BatchNorm) packed side by side, biases summed. */
+size_t be_conv_fused2_packed_floats(int cout, int cin, int ksize, int cin2);
+int be_conv_pack_fused2_f32(const float* weight_oihw, const float* bias, const float* bn_gamma, const float* bn_beta,
+                            const float* bn_mean, const float* bn_var, const float* weight2_oi, const float* bias2,
+                            const float* bn2_gamma, const float* bn2_beta, const float* bn2_mean, const float* bn2_var,
+                            float bn_eps, int cout, int cin, int ksize, int cin2, float* packed_w, float* packed_bias,
+                            void* stream);
+int be_conv_nhwc_fused2_f32(const be_conv_desc* desc_host, const float* x, const float* x2, int cin2,
+                            const float* packed_w, const float* packed_bias, float* y, int ldy, void* stream);
 /* nn.MaxPool2d(k, stride, pad) on NHWC (models/local_stage.py:42-43). */
 int be_maxpool_nhwc_f32(const float* x, float* y, int n, int h, int w, int c, int k, int stride, int pad,
                         void* stream);
@@ -310,8 +321,11 @@ int be_add_pe_f32(float* x, const float* pe, int64_t batches, int64_t per_batch,
 int be_profile_enable(int max_launches);
 int be_profile_reset(void);
 /* Waits for the recorded events; fills up to cap records (launch order); returns the number filled (>= 0)
- * or a negative error.  flops/bytes = ALGORITHMIC work of the launch (unpadded K, in+weights+out bytes). */
-int be_profile_read(int* kernel_id_host, double* flops_host, double* bytes_host, float* ms_host, int cap);
+ * or a negative error.  flops/bytes = ALGORITHMIC work of the launch (the convolution's 2*MAC with the unpadded K,
+ * zero-padding taps included as the reference counts them; in+weights+out bytes); flops_executed (may be NULL) =
+ * the MFMA work actually issued (tile padding included, taps outside the image skipped). */
+int be_profile_read(int* kernel_id_host, double* flops_host, double* bytes_host, double* flops_executed_host,
+                    float* ms_host, int cap);
 
 #ifdef __cplusplus
 }

@@ -162,6 +162,13 @@ def test_conv_layers_one_by_one_vs_oracle(native):
         d = native.conv_nhwc(xin, *pack(name + ".downsample"), cout, 1, act=0)
         o = native.conv_nhwc(t, *pack(name + ".conv2"), cout, 3, act=1, residual=d)
         assert relmax(o.cpu(), _nhwc(taps[name.split(".")[0]])) <= 1e-5, name
+        # the fused form LocalStage.forward uses: downsample 1x1 appended to conv2's K loop, no residual tensor
+        bnp = lambda pre: (dev(pre + ".1.weight"), dev(pre + ".1.bias"), dev(pre + ".1.running_mean"), dev(pre + ".1.running_var"))
+        pwf, pbf = native.conv_pack_fused2(dev(name + ".conv2.0.weight"), dev(name + ".conv2.0.bias"), bnp(name + ".conv2"),
+                                           dev(name + ".downsample.0.weight"), dev(name + ".downsample.0.bias"),
+                                           bnp(name + ".downsample"))
+        of = native.conv_nhwc_fused2(t, xin, pwf, pbf, cout, 3, act=1)
+        assert relmax(of.cpu(), o.cpu()) <= 2e-6, name
     p3 = native.maxpool_nhwc(_nhwc(taps["layer3"]).to(DEV), 2, 2, 0)
     assert relmax(p3.cpu(), _nhwc(taps["pool3"])) <= 1e-6
     # fc.1 + BN1d + Smish on the (H,W,C)-flattened features
