@@ -69,7 +69,7 @@ void k_conv_igemm(ConvArgs a) {
     const int xcd = bid & 7, slot = bid >> 3;
     const int n_tile = slot % a.n_tiles;
     int m_tile;
-    if (a.pixmaj) {
+    if (a.pixmaj == 1) {
         // pixel-major: ALL pixel tiles of one group of BM images run on the same XCD, one after the other (the taps of
         // neighbouring pixels re-read the same input lines: with the tiles of a group spread over the 8 XCDs the L2
         // hit rate fell from 94 % to 69 % and HBM reads rose 6x)
@@ -292,7 +292,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s, int kernel_id) {
         attr_set = true;
     }
     // slots per XCD: flat tiles are dealt round-robin; pixel-major tiles keep a group of images on one XCD
-    const int per_xcd = a.pixmaj ? ((a.m_tiles / a.HW + 7) / 8) * a.HW : (a.m_tiles + 7) / 8;
+    const int per_xcd = a.pixmaj == 1 ? ((a.m_tiles / a.HW + 7) / 8) * a.HW : (a.m_tiles + 7) / 8;
     const unsigned grid = (unsigned)(8 * per_xcd * a.n_tiles);
     {   // algorithmic work of this launch: 2*M*K*Cout with the REAL K (no padding); bytes = in + weights + out
         const double k_real = MODE == MODE_ROW8 ? 3.0 * 49.0 : (double)a.Cin * a.ks * a.ks;
@@ -553,6 +553,12 @@ static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2,
     if (!row8 && (int64_t)a.m_tiles * ((cp + 127) / 128) < 384) {
         if (cp % 64 == 0) {
             a.m_tiles = (int)((M + 63) / 64); a.n_tiles = cp / 64;
+            if (d->ksize > 1 && d->n >= 64 && d->n % 64 == 0 && conv_variant() != 99) {
+                // full 64-image tiles (the training batch): pixel-major here too, tiles dealt round-robin over the
+                // XCDs because there are only a few image groups
+                a.pixmaj = 2;
+                a.m_tiles = a.HW * (d->n / 64);
+            }
             return launch_conv<2, 2, 1, 1, MODE_TAPS, 16, 0>(a, s, BE_KERNEL_CONV_SMALL);
         }
         a.n_tiles = cp / 32;

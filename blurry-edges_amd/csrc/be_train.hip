@@ -74,12 +74,21 @@ void k_col_reduce(ColArgs a) {
 }
 
 // forward finalize: mean / invstd (biased variance) + running-stat update (momentum, unbiased variance)
+__device__ __forceinline__ double wave_sum_f64(double v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// one wave per channel: lanes stride over the split partials, fixed-order butterfly (bitwise reproducible)
 __global__ void k_bn_finalize_fwd(const double* partial, int S, int C, int M, float eps, float momentum, float* mean,
                                   float* invstd, float* run_mean, float* run_var) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     double s0 = 0.0, s1 = 0.0;
-    for (int s = 0; s < S; ++s) { s0 += partial[((size_t)s * C + c) * 2]; s1 += partial[((size_t)s * C + c) * 2 + 1]; }
+    for (int s = lane; s < S; s += 64) { s0 += partial[((size_t)s * C + c) * 2]; s1 += partial[((size_t)s * C + c) * 2 + 1]; }
+    s0 = wave_sum_f64(s0); s1 = wave_sum_f64(s1);
+    if (lane != 0) return;
     const double mu = s0 / M;
     double var = s1 / M - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -94,10 +103,12 @@ __global__ void k_bn_finalize_fwd(const double* partial, int S, int C, int M, fl
 
 // backward finalize: dgamma = sum ds*xhat, dbeta = sum ds
 __global__ void k_bn_finalize_bwd(const double* partial, int S, int C, float* dgamma, float* dbeta) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     double s0 = 0.0, s1 = 0.0;
-    for (int s = 0; s < S; ++s) { s0 += partial[((size_t)s * C + c) * 2]; s1 += partial[((size_t)s * C + c) * 2 + 1]; }
+    for (int s = lane; s < S; s += 64) { s0 += partial[((size_t)s * C + c) * 2]; s1 += partial[((size_t)s * C + c) * 2 + 1]; }
+    s0 = wave_sum_f64(s0); s1 = wave_sum_f64(s1);
+    if (lane != 0) return;
     dbeta[c] = (float)s0;
     dgamma[c] = (float)s1;
 }
@@ -143,11 +154,12 @@ void k_col_sum(const float* a, double* partial, int M, int C, int rows_per_split
     if (ty == 0 && c < C) partial[(size_t)blockIdx.y * C + c] = red[0][tx] + red[1][tx] + red[2][tx] + red[3][tx];
 }
 __global__ void k_col_sum_final(const double* partial, int S, int C, float* out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     double s = 0.0;
-    for (int k = 0; k < S; ++k) s += partial[(size_t)k * C + c];
-    out[c] = (float)s;
+    for (int k = lane; k < S; k += 64) s += partial[(size_t)k * C + c];
+    s = wave_sum_f64(s);
+    if (lane == 0) out[c] = (float)s;
 }
 
 // ------------------------------------------------------------------------------------------ max-pool backward
@@ -327,8 +339,8 @@ inline unsigned cap_grid(int64_t total, int block, int64_t cap = 4096) {
 
 inline int pick_splits(int M, int col_blocks, int max_splits) {
     // enough blocks to cover the chip (~512) without making slices shorter than 32 rows; the finalize kernels walk
-    // the splits serially (fixed order), so more than 32 of them costs more there than it gains here
-    if (max_splits > 32) max_splits = 32;
+    // the splits with one wave per channel (fixed-order butterfly)
+    if (max_splits > 128) max_splits = 128;
     int s = (512 + col_blocks - 1) / col_blocks;
     const int by_rows = (M + 31) / 32;
     if (s > by_rows) s = by_rows;
@@ -352,7 +364,7 @@ extern "C" int be_bn_train_fwd_f32(const float* y, const float* gamma, const flo
     hipStream_t s = be::as_stream(stream);
     ColArgs a{y, nullptr, nullptr, nullptr, nullptr, nullptr, static_cast<double*>(scratch), M, C, (M + S - 1) / S};
     hipLaunchKernelGGL(k_col_reduce<0>, dim3(cb, S), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_bn_finalize_fwd, dim3((C + 127) / 128), dim3(128), 0, s, static_cast<const double*>(scratch), S, C, M,
+    hipLaunchKernelGGL(k_bn_finalize_fwd, dim3((C + 3) / 4), dim3(256), 0, s, static_cast<const double*>(scratch), S, C, M,
                        eps, momentum, mean, invstd, run_mean, run_var);
     const int64_t total = (int64_t)M * C;
     hipLaunchKernelGGL(k_bn_apply_fwd, dim3(cap_grid(total, 256)), dim3(256), 0, s, y, mean, invstd, gamma, beta, res, s_in,
@@ -371,7 +383,7 @@ extern "C" int be_bn_train_bwd_f32(const float* dout, const float* s_in, const f
     hipStream_t s = be::as_stream(stream);
     ColArgs a{y, dout, s_in, mean, invstd, ds, static_cast<double*>(scratch), M, C, (M + S - 1) / S};
     hipLaunchKernelGGL(k_col_reduce<1>, dim3(cb, S), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_bn_finalize_bwd, dim3((C + 127) / 128), dim3(128), 0, s, static_cast<const double*>(scratch), S, C,
+    hipLaunchKernelGGL(k_bn_finalize_bwd, dim3((C + 3) / 4), dim3(256), 0, s, static_cast<const double*>(scratch), S, C,
                        dgamma, dbeta);
     const int64_t total = (int64_t)M * C;
     hipLaunchKernelGGL(k_bn_apply_bwd, dim3(cap_grid(total, 256)), dim3(256), 0, s, ds, y, mean, invstd, gamma, dgamma, dbeta,
@@ -386,7 +398,7 @@ extern "C" int be_col_sum_f32(const float* a, float* out, int M, int C, void* sc
     BE_REQUIRE((size_t)S * C * sizeof(double) <= scratch_bytes, "be_col_sum_f32: scratch too small");
     hipStream_t s = be::as_stream(stream);
     hipLaunchKernelGGL(k_col_sum, dim3(cb, S), dim3(256), 0, s, a, static_cast<double*>(scratch), M, C, (M + S - 1) / S);
-    hipLaunchKernelGGL(k_col_sum_final, dim3((C + 127) / 128), dim3(128), 0, s, static_cast<const double*>(scratch), S, C, out);
+    hipLaunchKernelGGL(k_col_sum_final, dim3((C + 3) / 4), dim3(256), 0, s, static_cast<const double*>(scratch), S, C, out);
     return be::check_launch("be_col_sum_f32");
 }
 
