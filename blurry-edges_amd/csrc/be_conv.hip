@@ -166,11 +166,12 @@ void k_conv_igemm(ConvArgs a) {
             dy_ = tap_ / a.ks - half_; dx_ = tap_ % a.ks - half_;                                               \
             coff_ = (dy_ * a.W + dx_) * a.Cin + cc_ * 32 + sub_ * BKT + 4 * q;                                  \
             kw_ = (cc_ * ntap_all + tap_) * SUB + sub_;                                                         \
-        } else { /* conv1: chunk = kernel row kh, 8 pixels x 4 channels */                                      \
-            const int kh_ = (int)((tap_list >> (4 * (KC))) & 15ull);                                            \
-            dy_ = kh_ - 3; dx_ = q - 3;                                                                         \
+        } else { /* conv1: 32 floats = kernel row kh, 8 pixels x 4 channels; a chunk is BKT/4 of those pixels */ \
+            const int k32_ = (KC) / SUB, sub_ = (KC) - k32_ * SUB;                                              \
+            const int kh_ = (int)((tap_list >> (4 * k32_)) & 15ull);                                            \
+            dy_ = kh_ - 3; dx_ = q - 3 + (BKT / 4) * sub_;                                                      \
             coff_ = (dy_ * a.W + dx_) * 4;                                                                      \
-            kw_ = kh_;                                                                                          \
+            kw_ = kh_ * SUB + sub_;                                                                             \
         }                                                                                                       \
         a_ok = 0;                                                                                               \
         _Pragma("unroll") for (int i_ = 0; i_ < NA; ++i_) {                                                     \
@@ -572,7 +573,8 @@ static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2,
     if (row8) {
         BE_REQUIRE(cp == 64, "be_conv_nhwc_f32: ksize 7 is built for cout 64 (got %d)", d->cout);
         a.n_tiles = 1;
-        return launch_conv<4, 1, 1, 2, MODE_ROW8>(a, s, BE_KERNEL_CONV_ROW8_128x64);
+        if (conv_variant() == 32) return launch_conv<4, 1, 1, 2, MODE_ROW8, 32, 0>(a, s, BE_KERNEL_CONV_ROW8_128x64);
+        return launch_conv<4, 1, 1, 2, MODE_ROW8, 16, 0>(a, s, BE_KERNEL_CONV_ROW8_128x64);
     }
     if (cp % 128 == 0) {
         a.n_tiles = cp / 128;
