@@ -72,7 +72,8 @@ void k_conv_igemm(ConvArgs a) {
     if (a.pixmaj == 1) {
         // pixel-major: ALL pixel tiles of one group of BM images run on the same XCD, one after the other (the taps of
         // neighbouring pixels re-read the same input lines: with the tiles of a group spread over the 8 XCDs the L2
-        // hit rate fell from 94 % to 69 % and HBM reads rose 6x)
+        // hit rate fell from 94 % to 69 % and L2-miss reads rose 6x).  Tried and rejected: pixel fastest / N tile slower
+        // (one N tile's weights resident at a time): +11 % L2-miss bytes, 1.3 % slower.
         const int t = slot / a.n_tiles;
         const int grp = (t / a.HW) * 8 + xcd;
         m_tile = grp * a.HW + t % a.HW;
