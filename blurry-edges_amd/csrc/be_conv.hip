@@ -6,19 +6,21 @@
 // 54-56 and nn.Linear + nn.BatchNorm1d + Smish of :44-50 (a Linear is the 1x1 case on a 1x1 image).
 //
 // GEMM view: D[M = N*H*W output pixels][Cout] = A[M][K] * B[K][Cout].  Activations are NHWC so that a K-chunk of
-// 32 input channels of one tap is 128 contiguous bytes per output pixel: the A tile is gathered straight from
-// the activation tensor (zero-filled outside the image), never materialised (no im2col buffer).
-//   - block tile 128 x BN (BN = 32*WN*NT in {32,64,96,128}), 256 threads = 4 waves, wave tile (32*MT) x (32*NT)
-//   - K-chunk 32 floats; A/B chunks are register-staged (issue loads for chunk k+1, run the 64 MFMAs of chunk k,
-//     then write the staged registers to the other LDS buffer; one barrier per chunk)
-//   - LDS rows padded to 36 floats: the ds_read_b128 fragment reads (16-lane groups) and the ds_write_b128
-//     staging writes are bank-conflict free
+// input channels of one tap is contiguous per output pixel: the A tile is gathered straight from the activation
+// tensor (zero-filled outside the image), never materialised (no im2col buffer).
+//   - block tile BM x BN (BM 128 or 64, BN = 32*WN*NT in {32,64,96,128}), 256 threads = 4 waves, wave tile
+//     (32*MT) x (32*NT); small-M problems (training batches) take the 64x64 / 128x32 tiles
+//   - K-chunk BKT = 16 floats (templated 8/16/32; 16 measured best: 40 KB of LDS, three workgroups per CU); A/B chunks
+//     are register-staged (issue the loads of chunk k+1, run the MFMAs of chunk k, then write the staged registers
+//     to the other LDS buffer; one barrier per chunk); sched_barriers pin that order
+//   - LDS rows padded by 4 floats: the ds_read_b128 fragment reads (16-lane groups) and the ds_write_b128 staging
+//     writes are bank-conflict free
 //   - fragment order inside a group of 8 k: lane half h holds k = 4h..4h+3, MFMA j consumes element j of both
 //     operands, so A and B agree on k without any shuffle
-//   - K order = (cin-chunk outer, tap inner): the 9 taps of a 3x3 re-read the same 128 rows x 128 B of
-//     activations back to back (L1/L2 hits), weights are packed in exactly that order so the B stream is linear
-//   - blockIdx -> (m_tile, n_tile): all N tiles of an M tile run on the same XCD (ids congruent mod 8 share an
-//     XCD's L2), so an activation tile is fetched from HBM once
+//   - K order = (32-channel chunk outer, tap inner), weights packed in exactly that order so the B stream is linear
+//   - pixel-major M tiles for large batches (a tile = one pixel position of BM images): the taps that fall into the
+//     zero padding are skipped for the whole tile; an image group's tiles share one XCD (see the kernel)
+//   - an optional second input x2 appends a 1x1 conv to the K loop (residual block: downsample branch fused in)
 #include "be_common.h"
 #include "be_device_math.h"
 #include <cstdlib>
@@ -43,10 +45,10 @@ struct ConvArgs {
     int Cin2;             //   block's downsample branch fused into conv2: out = act(conv3x3(x) + conv1x1(x2) + bias))
 };
 
-// __launch_bounds__(256, 2): LDS admits two blocks per CU (= 2 waves per SIMD), so let the register allocator use
-// up to 256 VGPR+AGPR: with the default budget it spilled the staged B chunk to scratch and waited for the global
+// __launch_bounds__(256, w): w = workgroups per CU the LDS admits (= waves per SIMD), so the register allocator may
+// use 512/w registers: with the default budget it spilled the staged B chunk to scratch and waited for the global
 // loads BEFORE the MFMA phase (v1: 60 % MFMA-busy).
-// BKT = K-chunk in floats (32, or 16: 41 KB of LDS -> three blocks per CU); PRIO: s_setprio around the MFMA phase.
+// BKT = K-chunk in floats; PRIO = 1: s_setprio around the MFMA phase (measured: no effect; kept for A/B runs).
 template <int WM, int WN, int MT, int NT, int MODE, int BKT, int PRIO>
 __global__ __launch_bounds__(256, BKT == 16 ? (PRIO == 2 ? 4 : 3) : (BKT == 8 ? 4 : 2))
 void k_conv_igemm(ConvArgs a) {

@@ -1,9 +1,10 @@
 // LocalStage.forward (eval) as a chain of launches on one stream: models/local_stage.py:63-73.
 //   conv7x7+BN+Smish -> maxpool(3,2,1) -> block 64->96 @11^2 -> maxpool(3,2,1) -> blocks 96->256, 256->384,
 //   384->256 @6^2 -> maxpool(2,2) -> flatten -> Linear 2304->1024 + BN1d + Smish -> Linear 1024->10
-// Activations are NHWC in a caller-provided workspace; the batch is walked in sub-batches so that the
-// activations between two layers (<= 113 MB per 2048 patches) stay in the 256 MiB Infinity Cache and the
-// workspace stays bounded whatever N is.  No allocation, no synchronisation: graph-capturable.
+// Activations are NHWC in a caller-provided workspace; the batch is walked in sub-batches (default 8192 patches,
+// measured best) so the workspace stays bounded whatever N is.  11 launches per sub-batch: staging, conv1, 3 pools,
+// 2 per residual block (conv1; conv2 with the downsample fused in), fc.1, fc.4.  No allocation, no synchronisation:
+// graph-capturable.
 #include "be_common.h"
 
 namespace {
@@ -40,7 +41,8 @@ struct PackedLayout {
 };
 const PackedLayout& layout() { static PackedLayout l; return l; }
 
-// workspace regions, floats per patch (lifetimes: see be_local_stage_forward_f32)
+// workspace regions, floats per patch (lifetimes: see be_local_stage_forward_f32; RA holds conv1's output, then
+// each block's intermediate t)
 constexpr size_t RA = 28224, RB = 13824, RC = 13824;
 constexpr size_t WS_FLOATS_PER_PATCH = RA + RB + RC;
 int g_chunk = 8192;   // measured: 8192 > 4096 > 2048 (fewer partial rounds of the 512 resident blocks)
@@ -139,15 +141,15 @@ extern "C" int be_local_stage_forward_f32(const float* packed, const float* x, f
         if ((rc = be_nchw3_to_nhwc4_f32(xin, x4, nb, BE_NPIX, stream))) return rc;
         if ((rc = conv(packed, 0, x4, nullptr, ra, nb, 21, 1, 64, stream))) return rc;
         if ((rc = be_maxpool_nhwc_f32(ra, p1, nb, 21, 21, 64, 3, 2, 1, stream))) return rc;
-        // layer0 @11x11: t,d in RA, out in RC
+        // layer0 @11x11: t in RA, out in RC
         if ((rc = block(packed, 1, p1, ra, rc_, nb, 11, stream))) return rc;
         float* p2 = rb;                                   // nb*3456
         if ((rc = be_maxpool_nhwc_f32(rc_, p2, nb, 11, 11, 96, 3, 2, 1, stream))) return rc;
-        // layer1: in RB, t,d RA, out RC
+        // layer1: in RB, t RA, out RC
         if ((rc = block(packed, 4, p2, ra, rc_, nb, 6, stream))) return rc;
-        // layer2: in RC, t,d RA, out RB
+        // layer2: in RC, t RA, out RB
         if ((rc = block(packed, 7, rc_, ra, rb, nb, 6, stream))) return rc;
-        // layer3: in RB, t,d RA, out RC
+        // layer3: in RB, t RA, out RC
         if ((rc = block(packed, 10, rb, ra, rc_, nb, 6, stream))) return rc;
         float* p3 = rb;                                   // nb*2304  (H,W,C) flatten
         if ((rc = be_maxpool_nhwc_f32(rc_, p3, nb, 6, 6, 256, 2, 2, 0, stream))) return rc;
