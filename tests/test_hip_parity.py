@@ -232,7 +232,7 @@ def test_local_stage_full_batch_8192_properties(native):
     assert relmax(ys.cpu(), yo) <= 1e-5
 
 
-@pytest.mark.parametrize("n", [1, 3, 513, 1000])
+@pytest.mark.parametrize("n", [1, 3, 513, 1000, 8492])
 def test_local_stage_ragged_batches_are_position_independent(native, n):
     """Edge sizes: a single patch, a ragged small batch, and ragged LARGE batches (pixel-major conv tiles with a
     partly empty last tile) give bit-identical logits to the same patches run in another batch."""
@@ -240,7 +240,7 @@ def test_local_stage_ragged_batches_are_position_independent(native, n):
     m = models.LocalStage()
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.local_stage_state_dict().items()})
     m = m.to(DEV).eval()
-    x = T(synth.uniform_patches(1000, name="ragged")).to(DEV)
+    x = T(synth.uniform_patches(max(n, 16), name="ragged")).to(DEV)
     with torch.no_grad():
         ref = m(x[:16])
         y = m(x[:n].contiguous())
@@ -340,3 +340,37 @@ def test_local_stage_train_forward_backward_vs_golden(native):
     with torch.no_grad():
         yo = ols.local_stage_forward(sd_cpu, x[:8].cpu())
     assert relmax(ye.cpu(), yo) <= 1e-5
+
+
+def test_render_edge_case_parameters_vs_oracle(native, args):
+    """Parameters the CNN can emit but the 'plausible' generators do not: zero / pi / 2pi opening angles (exact ties
+    of the two rays), vertices on pixel centres and far outside the patch, saturated eta coefficients (eta = 1e-4
+    and 1), unwrapped negative and large angles.  Hard decisions must match the fp32 oracle; values the fp64 one."""
+    from oracle import render as orr
+    h = _helper(args)
+    pi = np.pi
+    base = synth.plausible_params10(64, name="edge").astype(np.float64)
+    base[0, 5] = 0.0; base[1, 5] = pi; base[2, 7] = 0.0; base[3, 7] = 2 * pi            # degenerate openings
+    base[4, 0:2] = [0.0, 0.0]; base[5, 2:4] = [0.1, -0.1]; base[6, 0:2] = [-1.0, 1.0]    # vertices on pixel centres
+    base[7, 0:4] = [3.0, -3.0, -2.5, 2.5]                                                # far outside
+    base[8, 8:10] = [5.0, -5.0]; base[9, 8:10] = [-5.0, 5.0]                             # eta = 1 / 1e-4
+    base[10, 4:8] = [-7.0, 11.0, 40.0, -0.001]                                           # unwrapped angles
+    base[11, 4:8] = [pi / 2, pi / 2, 3 * pi / 2, pi]                                     # axis-aligned rays
+    p10 = T(base.astype(np.float32))
+    img = T(synth.uniform_patches(64, name="edge_img"))
+    col, ex = h.render_colors(p10.to(DEV), img.to(DEV), wrap_angles=True, want=("dists", "wedges", "recon", "boundary"))
+    q = orr.wrap_angles10(p10)
+    r32 = orr.render_pass_a(q, img)
+    r64 = orr.render_pass_a(q.double(), img.double())
+    d = ex["dists"].cpu()
+    assert torch.isfinite(col).all() and torch.isfinite(d).all()
+    # signs of the wedge distances are the hard decisions (inside tests, ties): identical to the fp32 oracle except
+    # where the oracle's own fp32 and fp64 runs already disagree (a pixel exactly on a ray)
+    flip = (torch.sign(d) != torch.sign(r32["dists"])) & (torch.sign(r32["dists"]) == torch.sign(r64["dists"].float()))
+    assert int(flip.sum()) == 0, int(flip.sum())
+    ok = torch.sign(r32["dists"]) == torch.sign(r64["dists"].float())
+    assert relmax(d[ok], r64["dists"][ok]) <= 1e-5
+    stable = ok.all(dim=1).flatten(1).all(dim=1)                     # patches without an ambiguous pixel
+    assert int(stable.sum()) >= 56
+    assert relmax(col.cpu()[stable], r64["colors"][stable]) <= 1e-4
+    assert relmax(ex["recon"].cpu()[stable], r64["recon"][stable]) <= 1e-4
