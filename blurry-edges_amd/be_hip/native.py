@@ -55,6 +55,10 @@ _SIGNATURES = {
     "be_local_stage_workspace_bytes": (C.c_size_t, [C.c_int64]),
     "be_local_stage_set_chunk": (C.c_int, [C.c_int]),
     "be_local_stage_forward_f32": (C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_size_t, _P]),
+    "be_local_stage_forward_view_f32": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, _P, C.c_size_t, _P]),
+    "be_render_colors_view_f32": (C.c_int, [C.POINTER(RenderOpts), _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P,
+                                            C.c_int64, _P]),
+    "be_view_to_nhwc4_f32": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, _P]),
     "be_conv_packed_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "be_conv_pack_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "be_conv_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, C.c_int, _P]),
@@ -199,6 +203,24 @@ def render_colors(opts: RenderOpts, params10: torch.Tensor, patches: torch.Tenso
     return colors, extra
 
 
+def render_colors_view(opts: RenderOpts, params10: torch.Tensor, view, patches_per_image: int, *, want=()):
+    """render_colors with the pixels gathered through a PatchView: params10 [A*P,10] aperture-major (the order of
+    img_patches.flatten(0,1), blurry_edges_test.py:120-123) -> (colors [A*P,3,3], extras)."""
+    n = params10.shape[0]
+    if tuple(params10.shape) != (n, 10) or n % patches_per_image:
+        raise RuntimeError(f"render_colors_view: bad shapes {tuple(params10.shape)} / P={patches_per_image}")
+    dev = params10.device
+    colors = torch.empty(n, 3, 3, dtype=torch.float32, device=dev)
+    shapes = dict(recon=(n, 3, BE_R, BE_R), boundary=(n, BE_R, BE_R), dists=(n, 2, BE_R, BE_R),
+                  wedges=(n, 3, BE_R, BE_R), gram=(n, 3, 3), aty=(n, 3, 3))
+    extra = {k: torch.empty(shapes[k], dtype=torch.float32, device=dev) for k in want}
+    g = lambda k: dptr(extra.get(k))
+    check(lib().be_render_colors_view_f32(C.byref(opts), dptr(params10, "params10"), C.byref(view), patches_per_image,
+                                          dptr(colors), g("recon"), g("boundary"), g("dists"), g("wedges"), g("gram"),
+                                          g("aty"), n, stream_ptr(dev)), "be_render_colors_view_f32")
+    return colors, extra
+
+
 def conv_pack(weight, bias, bn=None, eps=1e-5, chw_hw=0):
     """weight [Cout,Cin,k,k] (or [Cout,Cin] for a Linear), optional bn=(gamma,beta,mean,var) -> (pw, pb)."""
     cout, cin = weight.shape[0], weight.shape[1]
@@ -271,6 +293,19 @@ def local_stage_forward(packed, x, out=None, workspace=None):
     return out, workspace
 
 
+def local_stage_forward_view(packed, view, patches_per_image: int, n: int, device, out=None, workspace=None):
+    """LocalStage eval forward over the n = A*P patches of a PatchView (no unfolded copy) -> [n,10]."""
+    if out is None:
+        out = torch.empty(n, 10, dtype=torch.float32, device=device)
+    need = lib().be_local_stage_workspace_bytes(n)
+    if workspace is None or workspace.numel() * 4 < need:
+        workspace = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
+    check(lib().be_local_stage_forward_view_f32(dptr(packed, "packed"), C.byref(view), patches_per_image, dptr(out), n,
+                                                dptr(workspace), workspace.numel() * 4, stream_ptr(device)),
+          "be_local_stage_forward_view_f32")
+    return out, workspace
+
+
 KERNEL_NAMES = {0: "k_conv_igemm<2,2,2,2,TAPS> (128x128)", 1: "k_conv_igemm<4,1,1,3,TAPS> (128x96)",
                 2: "k_conv_igemm<4,1,1,2,TAPS> (128x64)", 3: "k_conv_igemm<4,1,1,1,TAPS> (128x32)",
                 4: "k_conv_igemm<4,1,1,2,ROW8> (conv1)", 5: "k_conv_igemm small-M tiles (64x64 / 128x32)"}
@@ -296,13 +331,18 @@ def profile_read(cap: int):
 
 # ---------------------------------------------------------------------------------------------- pass B / tiling
 
-def view_image_pair(img: torch.Tensor, stride: int = 2) -> PatchView:
-    """img [2,3,H,W] -> gather-on-read view of its (H-21)/stride+1 x (W-21)/stride+1 patch grid."""
+def view_image_pair(img: torch.Tensor, stride: int = 2, window=None) -> PatchView:
+    """img [2,3,H,W] -> gather-on-read view of its (H-21)/stride+1 x (W-21)/stride+1 patch grid; window =
+    (top, left, height, width) restricts it to one block of a big image (blurry_edges_test_big.py:142-150) in place."""
     if img.dim() != 4 or img.shape[0] != 2 or img.shape[1] != 3:
         raise RuntimeError(f"view_image_pair: expected [2,3,H,W], got {tuple(img.shape)}")
     dptr(img, "img")
     _, _, h, w = img.shape
-    return PatchView(img.data_ptr(), 3 * h * w, h * w, w, 1, stride * w, stride, (w - BE_R) // stride + 1)
+    top, left, bh, bw = window if window is not None else (0, 0, h, w)
+    if top < 0 or left < 0 or top + bh > h or left + bw > w or bh < BE_R or bw < BE_R:
+        raise RuntimeError(f"view_image_pair: window {window} outside the {h}x{w} image")
+    return PatchView(img.data_ptr() + 4 * (top * w + left), 3 * h * w, h * w, w, 1, stride * w, stride,
+                     (bw - BE_R) // stride + 1)
 
 
 def view_flat_patches(pat: torch.Tensor, wp: int) -> PatchView:

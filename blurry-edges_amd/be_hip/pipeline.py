@@ -27,24 +27,25 @@ class DepthPipeline:
         # global_module / depth_cal may be None when only local_pass is used (global_data_pre_cal.py counterpart)
 
     # ---- stages --------------------------------------------------------------------------------------
-    def local_pass(self, img):
-        """img [2,3,H,W] -> (patches [2,P,3,21,21], est10 [2P,10], colors [2P,3,3], pm [P,38])."""
-        pat = native.unfold_patches(img, self.stride)
-        flat = pat.view(-1, 3, native.BE_R, native.BE_R)
-        est10 = self.local(flat)
-        colors, _ = self.helper.render_colors(est10, flat, wrap_angles=True)
+    def local_pass(self, img, window=None):
+        """img [2,3,H,W] -> (view of the patch grid, est10 [2P,10], colors [2P,3,3], pm [P,38]).  Both kernels gather
+        their 21x21 windows from the image; the unfolded [2,P,3,21,21] tensor of blurry_edges_test.py:120-121 is
+        never written."""
+        view = native.view_image_pair(img, self.stride, window)
+        est10 = self.local.forward_image_pair(img, self.stride, window)
+        colors, _ = native.render_colors_view(self.helper.render_opts(wrap_angles=True), est10, view, est10.shape[0] // 2)
         pm = native.local_features(est10, colors)
-        return pat, est10, colors, pm
+        return view, est10, colors, pm
 
     def global_pass(self, pm):
         """pm [P,38] -> est12 [P,12] (de-normalised wedge parameters)."""
         y = self.globl(pm.unsqueeze(0))
         return native.global_denorm(y[0])
 
-    def records(self, est12, img, want=()):
+    def records(self, est12, img, want=(), window=None):
         opts = self.helper.render_opts(wrap_angles=False)
         return native.render_full(opts, self.dcal.consts, self.rho_prime, self.densify == "w", est12,
-                                  native.view_image_pair(img, self.stride), want=want)
+                                  native.view_image_pair(img, self.stride, window), want=want)
 
     # ---- one 147x147 pair (blurry_edges_test.py:117-145) ---------------------------------------------
     @torch.no_grad()
@@ -72,17 +73,14 @@ class DepthPipeline:
         hp = (block - R) // s + 1                                                   # 64
         HP, WP = (H - R) // s + 1, (W - R) // s + 1                                 # 284
         step = bstride // s
-        # every block's patches through the CNN in ONE batch (blocks are independent until the transformer)
-        blocks = [img[:, :, bi * bstride:bi * bstride + block, bj * bstride:bj * bstride + block].contiguous()
-                  for bi in range(nb_v) for bj in range(nb_h)]
+        # blocks are windows of the big image: no cropped copies, no unfolded copies
         big = torch.zeros(HP * WP, native.RECORD_FLOATS, dtype=torch.float32, device=img.device).view(HP, WP, -1)
-        k = 0
         for bi in range(nb_v):
             for bj in range(nb_h):
-                b = blocks[k]; k += 1
-                _, _, _, pm = self.local_pass(b)
+                win = (bi * bstride, bj * bstride, block, block)
+                _, _, _, pm = self.local_pass(img, win)
                 est12 = self.global_pass(pm)
-                rec, _ = self.records(est12, b)
+                rec, _ = self.records(est12, img, window=win)
                 vs = 0 if bi == 0 else n_margin
                 ve = hp if bi == nb_v - 1 else hp - n_margin
                 hs = 0 if bj == 0 else n_margin

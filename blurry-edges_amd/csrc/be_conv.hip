@@ -439,6 +439,21 @@ __global__ void k_nchw3_to_nhwc4(const float* __restrict__ x, float* __restrict_
     }
 }
 
+// the same staging, but gathering the 21x21 window of patch (first + i) straight from the image pair
+__global__ void k_view_to_nhwc4(be_patch_view v, int64_t P, int64_t first, float* __restrict__ y, int64_t n) {
+    const int64_t total = n * BE_NPIX;
+    const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gs) {
+        const int64_t patch = first + idx / BE_NPIX;
+        const int p = (int)(idx % BE_NPIX);
+        const int row = p / BE_R, col = p - row * BE_R;
+        const int64_t pg = patch % P;
+        const float* s = v.base + (patch / P) * v.s_aperture + (pg / v.wp) * v.s_pi + (pg % v.wp) * v.s_pj +
+                         row * v.s_row + col * v.s_col;
+        reinterpret_cast<float4*>(y)[idx] = make_float4(s[0], s[v.s_chan], s[2 * v.s_chan], 0.0f);
+    }
+}
+
 inline unsigned grid_cap(int64_t total, int block) {
     int64_t g = (total + block - 1) / block;
     return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -607,6 +622,15 @@ extern "C" int be_maxpool_nhwc_f32(const float* x, float* y, int n, int h, int w
     hipLaunchKernelGGL(k_maxpool_nhwc, dim3(grid_cap(total, 256)), dim3(256), 0, be::as_stream(stream), x, y, n, h, w,
                        c / 4, oh, ow, k, stride, pad);
     return be::check_launch("be_maxpool_nhwc_f32");
+}
+
+extern "C" int be_view_to_nhwc4_f32(const be_patch_view* view, int64_t patches_per_image, int64_t first, float* y,
+                                    int64_t n, void* stream) {
+    BE_REQUIRE(view && view->base && y && n > 0 && first >= 0 && patches_per_image > 0 && view->wp > 0,
+               "be_view_to_nhwc4_f32: bad arguments");
+    hipLaunchKernelGGL(k_view_to_nhwc4, dim3(grid_cap(n * BE_NPIX, 256)), dim3(256), 0, be::as_stream(stream), *view,
+                       patches_per_image, first, y, n);
+    return be::check_launch("be_view_to_nhwc4_f32");
 }
 
 extern "C" int be_nchw3_to_nhwc4_f32(const float* x, float* y, int64_t n, int hw, void* stream) {

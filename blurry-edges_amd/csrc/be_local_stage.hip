@@ -117,15 +117,17 @@ int block(const float* packed, int l0, const float* x, float* t, float* o, int n
 
 }  // namespace
 
-extern "C" int be_local_stage_forward_f32(const float* packed, const float* x, float* out, int64_t n,
-                                          void* workspace, size_t workspace_bytes, void* stream) {
-    BE_REQUIRE(n >= 0, "be_local_stage_forward_f32: n < 0");
+namespace {
+
+// x != nullptr: flat patches [n,3,21,21]; else the patches are gathered from `view` (image pair, f2)
+int forward_impl(const float* packed, const float* x, const be_patch_view* view, int64_t P, float* out, int64_t n,
+                 void* workspace, size_t workspace_bytes, void* stream, const char* who) {
+    BE_REQUIRE(n >= 0, "%s: n < 0", who);
     if (n == 0) return BE_OK;
-    BE_REQUIRE(packed && x && out && workspace, "be_local_stage_forward_f32: null pointer");
-    BE_REQUIRE(be::aligned16(workspace) && be::aligned16(packed),
-               "be_local_stage_forward_f32: workspace / packed must be 16-byte aligned");
+    BE_REQUIRE(packed && (x || view) && out && workspace, "%s: null pointer", who);
+    BE_REQUIRE(be::aligned16(workspace) && be::aligned16(packed), "%s: workspace / packed must be 16-byte aligned", who);
     if (workspace_bytes < be_local_stage_workspace_bytes(n))
-        return be::fail(BE_EWORKSPACE, "be_local_stage_forward_f32: workspace %zu B < %zu B needed", workspace_bytes,
+        return be::fail(BE_EWORKSPACE, "%s: workspace %zu B < %zu B needed", who, workspace_bytes,
                         be_local_stage_workspace_bytes(n));
     float* ws = static_cast<float*>(workspace);
     for (int64_t first = 0; first < n; first += g_chunk) {
@@ -133,12 +135,13 @@ extern "C" int be_local_stage_forward_f32(const float* packed, const float* x, f
         float* ra = ws;
         float* rb = ra + (size_t)nb * RA;
         float* rc_ = rb + (size_t)nb * RB;
-        const float* xin = x + first * 3 * BE_NPIX;
         int rc;
         // x4 -> RB ; conv1 -> RA ; pool -> RB(after x4 is dead: RB is big enough to hold both side by side)
         float* x4 = rb;                                   // nb*1764
         float* p1 = rb + (size_t)nb * 1764 * 2;           // nb*7744, placed behind x4 (1764*2 + 7744 <= 13824)
-        if ((rc = be_nchw3_to_nhwc4_f32(xin, x4, nb, BE_NPIX, stream))) return rc;
+        if (x) rc = be_nchw3_to_nhwc4_f32(x + first * 3 * BE_NPIX, x4, nb, BE_NPIX, stream);
+        else rc = be_view_to_nhwc4_f32(view, P, first, x4, nb, stream);
+        if (rc) return rc;
         if ((rc = conv(packed, 0, x4, nullptr, ra, nb, 21, 1, 64, stream))) return rc;
         if ((rc = be_maxpool_nhwc_f32(ra, p1, nb, 21, 21, 64, 3, 2, 1, stream))) return rc;
         // layer0 @11x11: t in RA, out in RC
@@ -158,4 +161,21 @@ extern "C" int be_local_stage_forward_f32(const float* packed, const float* x, f
         if ((rc = conv(packed, 14, f1, nullptr, out + first * BE_LOCAL_OUT, nb, 1, 0, BE_LOCAL_OUT, stream))) return rc;
     }
     return BE_OK;
+}
+
+}  // namespace
+
+extern "C" int be_local_stage_forward_f32(const float* packed, const float* x, float* out, int64_t n,
+                                          void* workspace, size_t workspace_bytes, void* stream) {
+    BE_REQUIRE(x || n == 0, "be_local_stage_forward_f32: null pointer");
+    return forward_impl(packed, x, nullptr, 1, out, n, workspace, workspace_bytes, stream, "be_local_stage_forward_f32");
+}
+
+extern "C" int be_local_stage_forward_view_f32(const float* packed, const be_patch_view* view, int64_t patches_per_image,
+                                               float* out, int64_t n, void* workspace, size_t workspace_bytes,
+                                               void* stream) {
+    BE_REQUIRE((view && view->base && view->wp > 0 && patches_per_image > 0) || n == 0,
+               "be_local_stage_forward_view_f32: bad view");
+    return forward_impl(packed, nullptr, view, patches_per_image, out, n, workspace, workspace_bytes, stream,
+                        "be_local_stage_forward_view_f32");
 }

@@ -22,7 +22,8 @@ constexpr int WAVES_PER_BLOCK = 4;
 
 struct RenderArgs {
     const float* params;    // [N,10]
-    const float* patches;   // [N,3,21,21]
+    be_patch_view v;        // pixel data, gathered on read; patch n = (aperture n / P, grid position n % P)
+    int64_t P;              // patches per aperture image
     float* colors;          // [N,3,3]
     float* recon;           // [N,3,21,21] or null
     float* boundary;        // [N,21,21] or null
@@ -84,7 +85,8 @@ void k_render_colors(be_render_opts o, RenderArgs a) {
         inv2 = root2 * eta2;
     }
 
-    const float* img = a.patches + patch * (3 * NPIX);
+    const int64_t pg = patch % a.P;
+    const float* img = a.v.base + (patch / a.P) * a.v.s_aperture + (pg / a.v.wp) * a.v.s_pi + (pg % a.v.wp) * a.v.s_pj;
     float u0[PASSES], u1[PASSES], u2[PASSES];
     float g00 = 0, g01 = 0, g02 = 0, g11 = 0, g12 = 0, g22 = 0;
     float b0r = 0, b0g = 0, b0b = 0, b1r = 0, b1g = 0, b1b = 0, b2r = 0, b2g = 0, b2b = 0;
@@ -113,9 +115,10 @@ void k_render_colors(be_render_opts o, RenderArgs a) {
             u1[it] = live ? h1 * (1.0f - h2) : 0.0f;
             u2[it] = live ? h2 : 0.0f;
         }
-        const float yr = live ? img[pc] : 0.0f;
-        const float yg = live ? img[NPIX + pc] : 0.0f;
-        const float yb = live ? img[2 * NPIX + pc] : 0.0f;
+        const float* src = img + row * a.v.s_row + col * a.v.s_col;
+        const float yr = live ? src[0] : 0.0f;
+        const float yg = live ? src[a.v.s_chan] : 0.0f;
+        const float yb = live ? src[2 * a.v.s_chan] : 0.0f;
         g00 = fmaf(u0[it], u0[it], g00); g01 = fmaf(u0[it], u1[it], g01); g02 = fmaf(u0[it], u2[it], g02);
         g11 = fmaf(u1[it], u1[it], g11); g12 = fmaf(u1[it], u2[it], g12); g22 = fmaf(u2[it], u2[it], g22);
         b0r = fmaf(u0[it], yr, b0r); b0g = fmaf(u0[it], yg, b0g); b0b = fmaf(u0[it], yb, b0b);
@@ -183,17 +186,36 @@ void k_render_colors(be_render_opts o, RenderArgs a) {
 
 }  // namespace
 
+static int render_colors_impl(const be_render_opts* o, const float* params10, const be_patch_view& v, int64_t P,
+                              float* colors, float* recon, float* boundary, float* dists, float* wedges, float* gram,
+                              float* aty, int64_t n, void* stream, const char* who) {
+    BE_REQUIRE(n >= 0, "%s: n < 0", who);
+    if (n == 0) return BE_OK;
+    BE_REQUIRE(o && params10 && v.base && colors, "%s: null pointer", who);
+    BE_REQUIRE(o->lambda_ridge >= 0.0f && o->delta_sq > 0.0f, "%s: bad options", who);
+    BE_REQUIRE(P > 0 && v.wp > 0, "%s: bad patch grid", who);
+    RenderArgs a{params10, v, P, colors, recon, boundary, dists, wedges, gram, aty, n};
+    const int64_t blocks = (n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
+    BE_REQUIRE(blocks <= 0x7fffffff, "%s: n too large", who);
+    hipLaunchKernelGGL(k_render_colors, dim3((unsigned)blocks), dim3(64 * WAVES_PER_BLOCK), 0, be::as_stream(stream),
+                       *o, a);
+    return be::check_launch(who);
+}
+
 extern "C" int be_render_colors_f32(const be_render_opts* o, const float* params10, const float* patches,
                                     float* colors, float* recon, float* boundary, float* dists, float* wedges,
                                     float* gram, float* aty, int64_t n, void* stream) {
-    BE_REQUIRE(n >= 0, "be_render_colors_f32: n < 0");
-    if (n == 0) return BE_OK;
-    BE_REQUIRE(o && params10 && patches && colors, "be_render_colors_f32: null pointer");
-    BE_REQUIRE(o->lambda_ridge >= 0.0f && o->delta_sq > 0.0f, "be_render_colors_f32: bad options");
-    RenderArgs a{params10, patches, colors, recon, boundary, dists, wedges, gram, aty, n};
-    const int64_t blocks = (n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
-    BE_REQUIRE(blocks <= 0x7fffffff, "be_render_colors_f32: n too large");
-    hipLaunchKernelGGL(k_render_colors, dim3((unsigned)blocks), dim3(64 * WAVES_PER_BLOCK), 0, be::as_stream(stream),
-                       *o, a);
-    return be::check_launch("be_render_colors_f32");
+    BE_REQUIRE(n < ((int64_t)1 << 31), "be_render_colors_f32: n too large");
+    // flat patches [N,3,21,21] as a one-row grid of N positions
+    be_patch_view v{patches, 0, NPIX, R, 1, 0, 3 * NPIX, (int)(n > 0 ? n : 1)};
+    return render_colors_impl(o, params10, v, n > 0 ? n : 1, colors, recon, boundary, dists, wedges, gram, aty, n, stream,
+                              "be_render_colors_f32");
+}
+
+extern "C" int be_render_colors_view_f32(const be_render_opts* o, const float* params10, const be_patch_view* view,
+                                         int64_t patches_per_image, float* colors, float* recon, float* boundary,
+                                         float* dists, float* wedges, float* gram, float* aty, int64_t n, void* stream) {
+    BE_REQUIRE(view, "be_render_colors_view_f32: null view");
+    return render_colors_impl(o, params10, *view, patches_per_image, colors, recon, boundary, dists, wedges, gram, aty, n,
+                              stream, "be_render_colors_view_f32");
 }

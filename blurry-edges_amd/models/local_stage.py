@@ -117,3 +117,17 @@ class LocalStage(nn.Module):
         x = x.to(torch.float32).contiguous()
         out, self._workspace = native.local_stage_forward(self._packed_weights(), x, workspace=self._workspace)
         return out
+
+    @torch.no_grad()
+    def forward_image_pair(self, img, stride=2, window=None):
+        """Eval forward over every 21x21 window of an image pair [2,3,H,W] (or of its block window = (top, left,
+        height, width)) -> [2*P,10], in the order of nn.Unfold + permute + flatten(0,1)
+        (blurry_edges_test.py:120-123) without materialising the windows."""
+        if self.training:
+            raise RuntimeError("LocalStage.forward_image_pair is an inference entry point; call .eval() first")
+        img = img.to(torch.float32).contiguous()
+        view = native.view_image_pair(img, stride, window)
+        P = (((window[2] if window is not None else img.shape[2]) - native.BE_R) // stride + 1) * view.wp
+        out, self._workspace = native.local_stage_forward_view(self._packed_weights(), view, P, 2 * P, img.device,
+                                                               workspace=self._workspace)
+        return out

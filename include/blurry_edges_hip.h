@@ -115,6 +115,13 @@ typedef struct be_patch_view {
     int wp;
 } be_patch_view;
 
+/* be_render_colors_f32 reading its pixels through a view (no [N,3,21,21] copy of the unfolded pair):
+ * patch n is aperture n / patches_per_image at grid position n % patches_per_image, i.e. the order of
+ * img_patches.flatten(0,1) in blurry_edges_test.py:120-123. */
+int be_render_colors_view_f32(const be_render_opts* opts_host, const float* params10, const be_patch_view* view_host,
+                              int64_t patches_per_image, float* colors, float* recon, float* boundary, float* dists,
+                              float* wedges, float* gram, float* aty, int64_t n, void* stream);
+
 #define BE_RECORD_FLOATS 32   /* per-patch state handed from be_render_full_f32 to be_fold_records_f32 (128 B):
                                  geometry 14, sqrt2*eta for aperture 1 / aperture 2 / refocus 2+2+2, colours 9
                                  ([rgb][wedge]), wedge depths 2, mask-presence flags 1 */
@@ -223,6 +230,11 @@ size_t be_local_stage_workspace_bytes(int64_t n);
 int be_local_stage_forward_f32(const float* packed, const float* x, float* out, int64_t n,
                                void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same forward with the 21x21 windows gathered from a view (e.g. straight from the image pair [2,3,H,W]) in
+ * place of nn.Unfold + permute (blurry_edges_test.py:120-121); patch numbering as be_render_colors_view_f32. */
+int be_local_stage_forward_view_f32(const float* packed, const be_patch_view* view_host, int64_t patches_per_image,
+                                    float* out, int64_t n, void* workspace, size_t workspace_bytes, void* stream);
+
 /* Layer-level entry points (used by the layer-by-layer parity tests and by the training path).
  * Activations are NHWC.  act: 0 none, 1 Smish (models/local_stage.py:4-6), 2 ReLU (GlobalStage FFN). */
 typedef struct be_conv_desc {
@@ -256,6 +268,9 @@ int be_maxpool_nhwc_f32(const float* x, float* y, int n, int h, int w, int c, in
                         void* stream);
 /* [N,3,21,21] NCHW -> [N,21,21,4] NHWC with a zero 4th channel (input staging of conv1). */
 int be_nchw3_to_nhwc4_f32(const float* x, float* y, int64_t n, int hw, void* stream);
+/* Patches [first, first+n) of a view -> [n,21,21,4] (the staging be_local_stage_forward_view_f32 uses). */
+int be_view_to_nhwc4_f32(const be_patch_view* view_host, int64_t patches_per_image, int64_t first, float* y,
+                         int64_t n, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * LocalStage training kernels (models/local_stage.py under autograd; local_training.py:103-108)

@@ -143,6 +143,29 @@ def _pipeline(env, densify=None):
     return DepthPipeline(lm.to(DEV).eval(), gm.to(DEV).eval(), env["helper"], env["dcal"], densify=densify)
 
 
+def test_gather_on_read_local_pass_is_bit_identical_to_the_unfolded_one(env):
+    """LocalStage + pass A reading their windows from the image pair (whole image, and a block window of
+    a larger image) must give exactly what they give on the materialised nn.Unfold tensor."""
+    n = env["native"]
+    pipe = _pipeline(env)
+    big = T(synth.synthetic_image_pair(235, 235, nshape=8)[0]).to(DEV)
+    for win in (None, (88, 0, 147, 147), (88, 88, 147, 147)):
+        img = big[:, :, :147, :147].contiguous() if win is None else big
+        crop = img if win is None else big[:, :, win[0]:win[0] + 147, win[1]:win[1] + 147].contiguous()
+        flat = n.unfold_patches(crop).view(-1, 3, 21, 21)
+        est_ref = pipe.local(flat)
+        col_ref, ex_ref = pipe.helper.render_colors(est_ref, flat, wrap_angles=True, want=("boundary", "aty"))
+        view, est10, colors, _ = pipe.local_pass(img, win)
+        assert torch.equal(est10, est_ref) and torch.equal(colors, col_ref)
+        _, ex = n.render_colors_view(pipe.helper.render_opts(True), est10, view, 4096, want=("boundary", "aty"))
+        assert torch.equal(ex["boundary"], ex_ref["boundary"]) and torch.equal(ex["aty"], ex_ref["aty"])
+        x4 = torch.empty(100, 21, 21, 4, device=DEV)
+        n.check(n.lib().be_view_to_nhwc4_f32(n.C.byref(view), 4096, 4090, n.dptr(x4), 100, n.stream_ptr(x4.device)), "stage")
+        assert torch.equal(x4[..., :3], flat[4090:4190].permute(0, 2, 3, 1)) and not x4[..., 3].any()
+    with pytest.raises(RuntimeError):
+        n.view_image_pair(big, 2, (100, 100, 147, 147))                  # window leaves the image
+
+
 def test_pipeline_147_stage_by_stage_vs_oracle(env):
     """configs[3]: every stage is checked against the oracle fed with the HIP output of the stage before."""
     import models

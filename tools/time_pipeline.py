@@ -22,7 +22,7 @@ def timed(f, n=10):
 with torch.no_grad():
     t_all, out = timed(lambda: pipe(img))
     t_loc, (pat, est10, col, pm) = timed(lambda: pipe.local_pass(img))
-    t_cnn, _ = timed(lambda: pipe.local(pat.view(-1, 3, 21, 21)))
+    t_cnn, _ = timed(lambda: pipe.local.forward_image_pair(img))
     t_glb, est12 = timed(lambda: pipe.global_pass(pm))
     t_rec, (rec, _) = timed(lambda: pipe.records(est12, img))
     t_fold, _ = timed(lambda: native.fold_records(pipe.helper.render_opts(False), rec, 64, 64, 147, 147))
