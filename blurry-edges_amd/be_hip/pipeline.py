@@ -62,30 +62,40 @@ class DepthPipeline:
         return maps
 
     # ---- big image: 147x147 blocks with margin patches dropped (blurry_edges_test_big.py:116-189) -----
+    @staticmethod
+    def big_windows(H, W, block=147, n_margin=10, stride=2, R=21):
+        """Block schedule of the big-image tiler (blurry_edges_test_big.py:118-119,166-177): a list of
+        ((top, left, block, block) pixel window, (vs, ve, hs, he) kept rows/cols of the block's patch grid,
+        (Vs, Hs) where that kept window starts in the big patch grid)."""
+        bstride = block - R + stride - 2 * stride * n_margin                        # 88
+        nb_v = math.ceil((H - R - 2 * stride * n_margin + stride) / bstride)
+        nb_h = math.ceil((W - R - 2 * stride * n_margin + stride) / bstride)
+        hp = (block - R) // stride + 1                                              # 64
+        step = hp - 2 * n_margin                                                    # 44 patches = bstride / stride
+        out = []
+        for bi in range(nb_v):
+            for bj in range(nb_h):
+                vs = 0 if bi == 0 else n_margin
+                ve = hp if bi == nb_v - 1 else hp - n_margin
+                hs = 0 if bj == 0 else n_margin
+                he = hp if bj == nb_h - 1 else hp - n_margin
+                out.append(((bi * bstride, bj * bstride, block, block), (vs, ve, hs, he), (bi * step + vs, bj * step + hs)))
+        return out
+
     @torch.no_grad()
     def run_big(self, img, block=147, n_margin=10):
         img = img.contiguous()
         _, _, H, W = img.shape
         s, R = self.stride, native.BE_R
-        bstride = block - R + s - 2 * s * n_margin                                  # 88
-        nb_v = math.ceil((H - R - 2 * s * n_margin + s) / bstride)
-        nb_h = math.ceil((W - R - 2 * s * n_margin + s) / bstride)
-        hp = (block - R) // s + 1                                                   # 64
+        hp = (block - R) // s + 1
         HP, WP = (H - R) // s + 1, (W - R) // s + 1                                 # 284
-        step = bstride // s
         # blocks are windows of the big image: no cropped copies, no unfolded copies
         big = torch.zeros(HP * WP, native.RECORD_FLOATS, dtype=torch.float32, device=img.device).view(HP, WP, -1)
-        for bi in range(nb_v):
-            for bj in range(nb_h):
-                win = (bi * bstride, bj * bstride, block, block)
-                _, _, _, pm = self.local_pass(img, win)
-                est12 = self.global_pass(pm)
-                rec, _ = self.records(est12, img, window=win)
-                vs = 0 if bi == 0 else n_margin
-                ve = hp if bi == nb_v - 1 else hp - n_margin
-                hs = 0 if bj == 0 else n_margin
-                he = hp if bj == nb_h - 1 else hp - n_margin
-                big[bi * step + vs:bi * step + ve, bj * step + hs:bj * step + he] = rec.view(hp, hp, -1)[vs:ve, hs:he]
+        for win, (vs, ve, hs, he), (Vs, Hs) in self.big_windows(H, W, block, n_margin, s, R):
+            _, _, _, pm = self.local_pass(img, win)
+            est12 = self.global_pass(pm)
+            rec, _ = self.records(est12, img, window=win)
+            big[Vs:Vs + ve - vs, Hs:Hs + he - hs] = rec.view(hp, hp, -1)[vs:ve, hs:he]
         maps = native.fold_records(self.helper.render_opts(False), big.view(HP * WP, -1), HP, WP, H, W, s, self.densify == "w")
         maps["depth_map"] = torch.where(maps["conf"] > 0.05, maps["depth"], torch.zeros_like(maps["depth"]))
         return maps

@@ -139,3 +139,19 @@ def test_depth_completion_name_is_importable_but_not_built():
     import models
     with pytest.raises(NotImplementedError):
         models.DepthCompletion()
+
+
+def test_pipeline_big_windows_match_the_reference_block_loop():
+    """DepthPipeline.big_windows (host logic of run_big) against golden g8, i.e. the reference's own block loop."""
+    from conftest import load_golden
+    from be_hip.pipeline import DepthPipeline
+    code = load_golden("g8_big_tiler")["code"]
+    mine = np.zeros((284, 284), dtype=np.int32)
+    local = np.arange(4096, dtype=np.int32).reshape(64, 64) + 1
+    wins = DepthPipeline.big_windows(587, 587)
+    assert len(wins) == 36
+    for k, ((top, left, bh, bw), (vs, ve, hs, he), (Vs, Hs)) in enumerate(wins):
+        assert (bh, bw) == (147, 147) and top + bh <= 587 and left + bw <= 587
+        assert top + 2 * vs == 2 * Vs and left + 2 * hs == 2 * Hs        # same pixels in block and big-image coordinates
+        mine[Vs:Vs + ve - vs, Hs:Hs + he - hs] = k * 4096 + local[vs:ve, hs:he]
+    assert np.array_equal(mine, code)

@@ -189,6 +189,17 @@ def test_g8_big_tiler_properties():
     assert np.all(cover == 1)
 
 
+def test_g8_big_tiler_matches_the_reference_block_loop():
+    """g8: the reference's depth_estimator run with code-carrying stubs tells, for every big-grid position, which
+    (block, local patch) it was copied from; the oracle's window table must reproduce that map exactly."""
+    code = load_golden("g8_big_tiler")["code"]
+    mine = np.zeros((284, 284), dtype=np.int32)
+    local = np.arange(4096, dtype=np.int32).reshape(64, 64) + 1
+    for k, (bi, bj, top, left, (vs, ve, hs, he), (Vs, Ve, Hs, He)) in enumerate(ot.big_tiler()["blocks"]):
+        mine[Vs:Ve, Hs:He] = k * 4096 + local[vs:ve, hs:he]
+    assert np.array_equal(mine, code)
+
+
 def test_g11_global_loss_value_and_gradient():
     """oracle.global_loss against the reference's GlobalLoss (batch 1, final gammas), float64 and float32."""
     from oracle import global_loss as ogl

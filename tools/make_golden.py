@@ -261,6 +261,63 @@ def G7():
          vec_rowsum=n(vec.double().sum(dim=(1, 2, 3))), num_patches=n(helper.num_patches))
 
 
+def G8():
+    """Big-image tiler: which (block, local patch) lands on each of the 284x284 big-grid positions.
+    The reference's depth_estimator (blurry_edges_test_big.py:116-189) is run as is on a 587x587 input with stub
+    modules: the stub helper marks pixel (0,0) of every local patch with the code block*4096 + i*64 + j + 1, so the
+    folded boundary map at image pixel (2I,2J), times the overlap count, is the code of big-grid patch (I,J)."""
+    import shutil
+    import tempfile
+    sys.modules["cv2"].imwrite = lambda *a, **k: True
+    import blurry_edges_test_big as ref_big
+    argv, sys.argv = sys.argv, ["x"]
+    try:
+        a = ref_utils.get_args("eval", big=True)
+    finally:
+        sys.argv = argv
+    a.cuda = "cpu"
+    tmp = tempfile.mkdtemp(dir=os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else ROOT)
+    a.log_path = tmp
+
+    class Helper:
+        device = torch.device("cpu")
+        H_patches = W_patches = 64
+        count = 0
+
+        def __call__(self, params, img_patches, colors_only):
+            if colors_only:
+                return torch.zeros(2, 3, 3, 64, 64)
+            code = (self.count * 4096 + torch.arange(4096, dtype=torch.float32).view(64, 64) + 1)
+            self.count += 1
+            bnd = torch.zeros(1, 1, 21, 21, 64, 64)
+            bnd[0, 0, 0, 0] = code
+            one = torch.zeros(1, 21, 21, 64, 64)
+            one[0, 0, 0] = 1
+            return (torch.zeros(1, 2, 3, 21, 21, 64, 64), torch.zeros(1, 3, 21, 21, 64, 64),
+                    torch.zeros(1, 3, 21, 21, 64, 64), bnd, one.clone(), one)
+
+    seen = {}
+
+    class Vis:
+        def visualize(self, i1, i2, c1, c2, shpd, refoc, conf, bndry, gt, depth):
+            seen.update(conf=conf, bndry=bndry)
+            return np.zeros((2, 2, 3), np.uint8)
+
+    H, W = a.big_img_size
+    loader = [(torch.zeros(1, 2, H, W, 3), torch.ones(1, H, W))]
+    try:
+        with np.errstate(all="ignore"):
+            ref_big.depth_estimator(a, lambda v: torch.zeros(v.shape[0], 10), lambda pm: torch.zeros(1, 4096, 12),
+                                    Helper(), Vis(), loader)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    hp = (H - a.R) // a.stride + 1
+    val = seen["bndry"][0:2 * hp:2, 0:2 * hp:2].astype(np.float64) / seen["conf"][0:2 * hp:2, 0:2 * hp:2]
+    code = np.rint(val).astype(np.int32)
+    assert np.abs(val - code).max() < 0.1 and code.min() >= 1 and code.max() <= 36 * 4096
+    save("g8_big_tiler", code=code, big_img_size=np.array([H, W]), n_margin_patch=np.array(a.n_margin_patch))
+
+
 def G9():
     """GlobalStage eval on one [1,4096,38] feature tensor: strided subsample + checksums + state-dict key order."""
     m = ref_models.GlobalStage(in_parameter_size=38, out_parameter_size=12, device=torch.device("cpu"))
@@ -313,7 +370,7 @@ def G10():
     save("g10_metrics", metrics=np.array(r, dtype=np.float64))
 
 
-GROUPS = dict(G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G9=G9, G10=G10, G11=G11)
+GROUPS = dict(G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G8=G8, G9=G9, G10=G10, G11=G11)
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)
