@@ -66,6 +66,16 @@ _SIGNATURES = {
     "be_conv_pack_fused2_f32": (C.c_int, [_P] * 12 + [C.c_float] + [C.c_int] * 4 + [_P, _P, _P]),
     "be_conv_nhwc_fused2_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, C.c_int, _P, _P, _P, C.c_int, _P]),
     "be_maxpool_nhwc_f32": (C.c_int, [_P, _P] + [C.c_int] * 7 + [_P]),
+    "be_attention_train_workspace_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "be_attention_train_fwd_f32": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint32, _P]),
+    "be_attention_bwd_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint32, _P]),
+    "be_attention_dropout_mask_f32": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint32, _P]),
+    "be_dropout_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_float, C.c_uint32, C.c_uint32, _P]),
+    "be_add_layernorm_train_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_uint32,
+                                             C.c_uint32, _P]),
+    "be_layernorm_bwd_partial_floats": (C.c_size_t, [C.c_int64, C.c_int]),
+    "be_layernorm_bwd_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_uint32,
+                                       C.c_uint32, _P]),
     "be_nchw3_to_nhwc4_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
     "be_render_full_f32": (C.c_int, [C.POINTER(RenderOpts), C.POINTER(DepthConsts), C.c_float, C.c_int, _P,
                                      C.POINTER(PatchView), _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P]),

@@ -1,0 +1,216 @@
+"""GlobalStage training step on the GPU: train-mode forward (dropout at the four sites of every encoder layer) and
+the full backward, orchestrated over the kernels of libblurry_edges_hip (be_attn.hip, be_conv.hip, be_train.hip).
+
+Counterpart of `est = model(pm); loss.backward()` in global_training.py:207-213.  `GlobalStageTrainFn.apply(src, pe,
+seed, p, nhead, eps, *params)` is a torch.autograd.Function whose backward returns the gradient of every parameter in
+the reference's layout (nn.TransformerEncoderLayer, post-norm, ReLU; models/global_stage.py:28-32), so AdamW /
+clip_grad_norm_ / a gradient all-reduce work on it unchanged.  torch allocates buffers and supplies the stream.
+
+Dropout masks are counter-based (hash of element index, seed and site number), re-derived in the backward; the
+[L,L] attention probabilities are never stored (recomputed from the saved log-sum-exp).  Dropout sites per layer i:
+  16 i + 0  attention probabilities (one sub-site per batch*head inside the kernel)
+  16 i + 1  dropout1 (self-attention branch before norm1)
+  16 i + 2  dropout  (after the FFN ReLU)
+  16 i + 3  dropout2 (FFN branch before norm2)
+"""
+from __future__ import annotations
+
+import torch
+
+from . import native
+from .native import check, dptr, lib, stream_ptr
+from .train import _col_sum, _new, _wgrad
+
+PER_LAYER = 12       # in_proj w,b | out_proj w,b | linear1 w,b | linear2 w,b | norm1 w,b | norm2 w,b
+
+
+def parameter_list(model):
+    """The 102 tensors in the order GlobalStageTrainFn expects (= state-dict order of models/global_stage.py)."""
+    out = [model.in_src_projection.weight, model.in_src_projection.bias]
+    for lyr in model.encoder.layers:
+        a = lyr.self_attn
+        out += [a.in_proj_weight, a.in_proj_bias, a.out_proj.weight, a.out_proj.bias, lyr.linear1.weight, lyr.linear1.bias,
+                lyr.linear2.weight, lyr.linear2.bias, lyr.norm1.weight, lyr.norm1.bias, lyr.norm2.weight, lyr.norm2.bias]
+    out += [model.encoder.norm.weight, model.encoder.norm.bias, model.generator.weight, model.generator.bias]
+    return out
+
+
+def _linear(x, w, b, act=0):
+    pw, pb = native.conv_pack(w.contiguous(), b.contiguous())
+    return native.linear(x, pw, pb, w.shape[0], act=act)
+
+
+def _dgrad_lin(dy, w, residual=None):
+    """dy [T,cout] -> dx [T,cin] (+ residual) for y = x W^T."""
+    cout, cin = w.shape
+    dev = dy.device
+    pw = _new(lib().be_conv_dgrad_packed_floats(cout, cin, 1), dev)
+    pb = _new((cin + 31) // 32 * 32, dev)
+    check(lib().be_conv_pack_dgrad_f32(dptr(w.contiguous()), cout, cin, 1, 0, dptr(pw), dptr(pb), stream_ptr(dev)),
+          "be_conv_pack_dgrad_f32")
+    return native.linear(dy, pw, pb, cin, residual=residual)
+
+
+def _wgrad_lin(x, dy, w_shape):
+    t = x.shape[0]
+    return _wgrad(x.view(t, 1, 1, x.shape[1]), dy.view(t, 1, 1, dy.shape[1]), tuple(w_shape), 1)
+
+
+def attention_train_fwd(qkv, B, L, H, p, seed, ws=None):
+    dev = qkv.device
+    need = lib().be_attention_train_workspace_floats(B, L, H)
+    if ws is None or ws.numel() < need:
+        ws = _new(need, dev)
+    out = _new((B * L, H * 16), dev)
+    lse = _new((B * H, L), dev)
+    check(lib().be_attention_train_fwd_f32(dptr(qkv, "qkv"), dptr(out), dptr(lse), dptr(ws), B, L, H, float(p),
+                                           int(seed) & 0xffffffff, stream_ptr(dev)), "be_attention_train_fwd_f32")
+    return out, lse, ws
+
+
+def attention_bwd(qkv, out, lse, dout, B, L, H, p, seed, ws=None):
+    dev = qkv.device
+    need = lib().be_attention_train_workspace_floats(B, L, H)
+    if ws is None or ws.numel() < need:
+        ws = _new(need, dev)
+    dqkv = torch.empty_like(qkv)
+    check(lib().be_attention_bwd_f32(dptr(qkv, "qkv"), dptr(out), dptr(lse), dptr(dout.contiguous(), "dout"), dptr(dqkv),
+                                     dptr(ws), B, L, H, float(p), int(seed) & 0xffffffff, stream_ptr(dev)),
+          "be_attention_bwd_f32")
+    return dqkv, ws
+
+
+def attention_dropout_mask(B, L, H, p, seed, dev):
+    m = _new((B * H, L, L), dev)
+    check(lib().be_attention_dropout_mask_f32(dptr(m), B, L, H, float(p), int(seed) & 0xffffffff, stream_ptr(dev)),
+          "be_attention_dropout_mask_f32")
+    return m
+
+
+def dropout(x, p, seed, site, gate=None):
+    y = torch.empty_like(x)
+    check(lib().be_dropout_f32(dptr(x, "x"), dptr(gate), dptr(y), x.numel(), float(p), int(seed) & 0xffffffff, int(site),
+                               stream_ptr(x.device)), "be_dropout_f32")
+    return y
+
+
+def add_layernorm_train(x, res, gamma, beta, eps, p, seed, site):
+    rows, d = x.shape
+    v, y = torch.empty_like(x), torch.empty_like(x)
+    check(lib().be_add_layernorm_train_f32(dptr(x, "x"), dptr(res), dptr(gamma), dptr(beta), dptr(v), dptr(y), rows, d,
+                                           float(eps), float(p), int(seed) & 0xffffffff, int(site), stream_ptr(x.device)),
+          "be_add_layernorm_train_f32")
+    return v, y
+
+
+def layernorm_bwd(dy, v, gamma, eps, p, seed, site, want_dv=True, want_dx=True):
+    """-> (dv, dx, dgamma, dbeta)"""
+    rows, d = v.shape
+    dev = v.device
+    dv = torch.empty_like(v) if want_dv else None
+    dx = torch.empty_like(v) if want_dx else None
+    part = _new(lib().be_layernorm_bwd_partial_floats(rows, d), dev)
+    check(lib().be_layernorm_bwd_f32(dptr(dy.contiguous(), "dy"), dptr(v), dptr(gamma), dptr(dv), dptr(dx), dptr(part), rows, d,
+                                     float(eps), float(p), int(seed) & 0xffffffff, int(site), stream_ptr(dev)),
+          "be_layernorm_bwd_f32")
+    gb = _col_sum(part.view(-1, 2 * d))
+    return dv, dx, gb[:d].clone(), gb[d:].clone()
+
+
+def forward_train(src, pe, seed, p, H, eps, t):
+    """src [B,L,cin]; t = parameter_list order (detached).  -> (out [B,L,cout], saved)."""
+    B, L, cin = src.shape
+    T = B * L
+    dev = src.device
+    nl = (len(t) - 6) // PER_LAYER
+    pad = (-cin) % 32
+    x0 = src.reshape(T, cin).to(torch.float32)
+    if pad:
+        x0 = torch.cat([x0, x0.new_zeros(T, pad)], dim=1)
+    x0 = x0.contiguous()
+    w_in = torch.cat([t[0], t[0].new_zeros(t[0].shape[0], pad)], dim=1) if pad else t[0]
+    h = _linear(x0, w_in, t[1])
+    native.add_pe_(h, pe[:L].contiguous(), B)
+    S = dict(x0=x0, layers=[], shape=(B, L, cin), ws=None)
+    ws = None
+    for i in range(nl):
+        wqkv, bqkv, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2 = t[2 + PER_LAYER * i:2 + PER_LAYER * (i + 1)]
+        qkv = _linear(h, wqkv, bqkv)
+        a, lse, ws = attention_train_fwd(qkv, B, L, H, p, seed + 16 * i, ws)
+        sa = _linear(a, wo, bo)
+        v1, h1 = add_layernorm_train(sa, h, g1, be1, eps, p, seed, 16 * i + 1)
+        f = _linear(h1, w1, b1, act=2)
+        fd = dropout(f, p, seed, 16 * i + 2) if p > 0 else f
+        y2 = _linear(fd, w2, b2)
+        v2, h2 = add_layernorm_train(y2, h1, g2, be2, eps, p, seed, 16 * i + 3)
+        S["layers"].append((h, qkv, a, lse, v1, h1, f, v2))
+        h = h2
+    gN, bN, wg, bg = t[-4:]
+    vN, hN = add_layernorm_train(h, None, gN, bN, eps, 0.0, seed, 0)
+    out = _linear(hN, wg, bg)
+    S.update(vN=vN, hN=hN, ws=ws)
+    return out.view(B, L, -1), S
+
+
+def backward_train(dout, seed, p, H, eps, t, S):
+    """dout [B,L,cout] -> list of gradients in the order of t."""
+    B, L, cin = S["shape"]
+    T = B * L
+    dev = dout.device
+    nl = (len(t) - 6) // PER_LAYER
+    grads = [None] * len(t)
+    gN, bN, wg, bg = t[-4:]
+    cout = wg.shape[0]
+    # generator: pad the 12 output columns to 32 so that the MFMA dgrad / wgrad paths take it
+    cp = (cout + 31) // 32 * 32
+    dy = dout.reshape(T, cout).to(torch.float32)
+    dyp = torch.zeros(T, cp, dtype=torch.float32, device=dev)
+    dyp[:, :cout] = dy
+    wgp = torch.zeros(cp, wg.shape[1], dtype=torch.float32, device=dev)
+    wgp[:cout] = wg
+    grads[-2] = _wgrad_lin(S["hN"], dyp, wgp.shape)[:cout].contiguous()
+    grads[-1] = _col_sum(dyp)[:cout].contiguous()
+    d_hN = _dgrad_lin(dyp, wgp)
+    dh, _, grads[-4], grads[-3] = layernorm_bwd(d_hN, S["vN"], gN, eps, 0.0, seed, 0, want_dx=False)
+    ws = S["ws"]
+    for i in reversed(range(nl)):
+        base = 2 + PER_LAYER * i
+        wqkv, bqkv, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2 = t[base:base + PER_LAYER]
+        h_in, qkv, a, lse, v1, h1, f, v2 = S["layers"][i]
+        dv2, dy2, grads[base + 10], grads[base + 11] = layernorm_bwd(dh, v2, g2, eps, p, seed, 16 * i + 3)
+        fd = dropout(f, p, seed, 16 * i + 2) if p > 0 else f
+        grads[base + 6] = _wgrad_lin(fd, dy2, w2.shape)
+        grads[base + 7] = _col_sum(dy2)
+        dfd = _dgrad_lin(dy2, w2)
+        df = dropout(dfd, p, seed, 16 * i + 2, gate=f)                    # dropout' and relu' in one pass
+        grads[base + 4] = _wgrad_lin(h1, df, w1.shape)
+        grads[base + 5] = _col_sum(df)
+        dh1 = _dgrad_lin(df, w1, residual=dv2)
+        dv1, dsa, grads[base + 8], grads[base + 9] = layernorm_bwd(dh1, v1, g1, eps, p, seed, 16 * i + 1)
+        grads[base + 2] = _wgrad_lin(a, dsa, wo.shape)
+        grads[base + 3] = _col_sum(dsa)
+        da = _dgrad_lin(dsa, wo)
+        dqkv, ws = attention_bwd(qkv, a, lse, da, B, L, H, p, seed + 16 * i, ws)
+        grads[base] = _wgrad_lin(h_in, dqkv, wqkv.shape)
+        grads[base + 1] = _col_sum(dqkv)
+        dh = _dgrad_lin(dqkv, wqkv, residual=dv1)
+    x0 = S["x0"]
+    grads[0] = _wgrad_lin(x0, dh, (t[0].shape[0], x0.shape[1]))[:, :cin].contiguous()
+    grads[1] = _col_sum(dh)
+    return grads
+
+
+class GlobalStageTrainFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src, pe, seed, p, nhead, eps, *params):
+        t = [v.detach() for v in params]
+        out, S = forward_train(src.detach(), pe, int(seed), float(p), int(nhead), float(eps), t)
+        ctx.S, ctx.t, ctx.cfg = S, t, (int(seed), float(p), int(nhead), float(eps))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        seed, p, nhead, eps = ctx.cfg
+        grads = backward_train(dout.contiguous(), seed, p, nhead, eps, ctx.t, ctx.S)
+        ctx.S = None
+        return (None,) * 6 + tuple(grads)

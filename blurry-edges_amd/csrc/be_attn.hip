@@ -24,6 +24,17 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int DH = 16;       // head dim
 constexpr int KB = 32;       // keys per block
 
+// Counter-based dropout: element `idx` of dropout site `site` is kept iff mix32(idx ^ site_key) >= p * 2^32.
+// The same function is evaluated again in the backward kernels, so no mask is ever stored.
+__host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+    return x;
+}
+__host__ __device__ __forceinline__ uint32_t site_key(uint32_t seed, uint32_t site) {
+    return mix32(seed + 0x9e3779b9U * (site + 1U));
+}
+inline uint32_t drop_threshold(float p) { return p <= 0.f ? 0U : (uint32_t)((double)p * 4294967296.0); }
+
 // qkv [T, 3*D] (token-major rows from the in-projection) -> Q [BH][L][16] (pre-scaled by scale*log2 e),
 // K [BH][L][16], Vt [BH][16][L];  T = B*L, D = H*16
 __global__ void k_qkv_split(const float* __restrict__ qkv, float* __restrict__ Q, float* __restrict__ K,
@@ -44,9 +55,60 @@ __global__ void k_qkv_split(const float* __restrict__ qkv, float* __restrict__ Q
     }
 }
 
+// training: every operand the forward and the two backward kernels read, row-major [BH][L][16] and transposed
+// [BH][16][L] (Q pre-scaled in both)
+__global__ void k_qkv_split_train(const float* __restrict__ qkv, float* __restrict__ Q, float* __restrict__ K,
+                                  float* __restrict__ V, float* __restrict__ Qt, float* __restrict__ Kt,
+                                  float* __restrict__ Vt, int B, int L, int H, float qscale) {
+    const int64_t total = (int64_t)B * L * H * DH;
+    const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+    const int D = H * DH;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gs) {
+        const int d = (int)(idx % DH);
+        const int h = (int)((idx / DH) % H);
+        const int64_t t = idx / (DH * H);
+        const int64_t b = t / L, l = t % L;
+        const float* row = qkv + t * 3 * D + h * DH + d;
+        const int64_t bh = b * H + h;
+        const float q = row[0] * qscale, k = row[D], v = row[2 * D];
+        const int64_t rm = (bh * L + l) * DH + d, tr = (bh * DH + d) * L + l;
+        Q[rm] = q; K[rm] = k; V[rm] = v;
+        Qt[tr] = q; Kt[tr] = k; Vt[tr] = v;
+    }
+}
+
+// dout, out [T, D] token-major -> dOh [BH][L][16], dOt [BH][16][L], Drow [BH][L] = sum_d dO * O
+__global__ void k_dout_prep(const float* __restrict__ dout, const float* __restrict__ out, float* __restrict__ dOh,
+                            float* __restrict__ dOt, float* __restrict__ Drow, int B, int L, int H) {
+    const int64_t total = (int64_t)B * L * H;
+    const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+    const int D = H * DH;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gs) {
+        const int h = (int)(idx % H);
+        const int64_t t = idx / H;
+        const int64_t b = t / L, l = t % L;
+        const int64_t bh = b * H + h;
+        const float* g = dout + t * D + h * DH;
+        const float* o = out + t * D + h * DH;
+        float acc = 0.f;
+#pragma unroll
+        for (int d = 0; d < DH; ++d) {
+            const float gv = g[d];
+            acc = fmaf(gv, o[d], acc);
+            dOh[(bh * L + l) * DH + d] = gv;
+            dOt[(bh * DH + d) * L + l] = gv;
+        }
+        Drow[bh * L + l] = acc;
+    }
+}
+
+// TRAIN: dropout on the probabilities (nn.MultiheadAttention's dropout, models/global_stage.py:28) and the log2-sum-exp
+// of every query row saved for the backward
+template <bool TRAIN>
 __global__ __launch_bounds__(256)
 void k_attention(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
-                 float* __restrict__ out, int L, int H) {
+                 float* __restrict__ out, float* __restrict__ lse, int L, int H, uint32_t seed, uint32_t thresh,
+                 float inv_keep) {
     // grid.x = L/128 query blocks (4 waves x 32 queries), grid.y = B*H
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int j = lane & 31, h = lane >> 5;
@@ -107,6 +169,13 @@ void k_attention(const float* __restrict__ Q, const float* __restrict__ K, const
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = exp2f(s[r] - mnew); psum += s[r]; }
         lsum = lsum * alpha + psum;
+        if (TRAIN && thresh) {
+            const uint32_t hkey = site_key(seed, (uint32_t)bh);
+            const uint32_t base = (uint32_t)(q0 + j) * (uint32_t)L + (uint32_t)(kblk * KB + 4 * h);
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (mix32((base + (r & 3) + 8 * (r >> 2)) ^ hkey) < thresh) s[r] = 0.f;
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[r] *= alpha;
         // O^T[d][query] += V^T[d][key] P[key][query]; k-step r uses key (r&3)+8(r>>2)+4h: register r of s as it stands
@@ -114,7 +183,8 @@ void k_attention(const float* __restrict__ Q, const float* __restrict__ K, const
         for (int r = 0; r < 16; ++r) o = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[r >> 2][r & 3], s[r], o, 0, 0, 0);
     }
     const float ltot = lsum + __shfl_xor(lsum, 32, 64);
-    const float inv = 1.0f / ltot;
+    const float inv = TRAIN ? inv_keep / ltot : 1.0f / ltot;
+    if (TRAIN && h == 0) lse[(size_t)bh * L + q0 + j] = m + log2f(ltot);
     // accumulator row d = (r&3) + 8*(r>>2) + 4h; rows >= 16 (r >= 8) are the zero padding
     const int Dm = H * DH;
     const int b = bh / H, hd = bh % H;
@@ -124,6 +194,294 @@ void k_attention(const float* __restrict__ Q, const float* __restrict__ K, const
         f32x4 v = {o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv};
         *reinterpret_cast<f32x4*>(dst + 8 * g + 4 * h) = v;
     }
+}
+
+
+// ---- attention backward -------------------------------------------------------------------------------------
+// With P = softmax(S), Pd = dropout(P), O = Pd V:   dV = Pd^T dO,  dPd = dO V^T,  dS = P o (dropout'(dPd) - Drow),
+// Drow_i = sum_d dO_id O_id,  dQ = scale dS K,  dK = scale dS^T Q.   P is recomputed from the saved log2-sum-exp.
+// Two kernels, no atomics: k_attn_bwd_dq owns 32 queries per wave and streams the keys; k_attn_bwd_dkv owns 32 keys
+// per wave and streams the queries.  Same register trick as the forward: the [32x32] tile of dS (or Pd) sits in the
+// accumulator layout and is fed back as the B operand of the next product in the key (query) order
+// (r&3)+8(r>>2)+4h, with the transposed operand ([16][L]) read as 16-byte loads.
+__global__ __launch_bounds__(256)
+void k_attn_bwd_dq(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+                   const float* __restrict__ Kt, const float* __restrict__ dOh, const float* __restrict__ lse,
+                   const float* __restrict__ Drow, float* __restrict__ dqkv, int L, int H, uint32_t seed,
+                   uint32_t thresh, float inv_keep) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.y;
+    const int q0 = (blockIdx.x * 4 + wave) * 32;
+    const size_t hb = (size_t)bh * L * DH;
+    const float* Kh = K + hb;
+    const float* Vh = V + hb;
+    const float* Kth = Kt + hb;
+    const uint32_t hkey = site_key(seed, (uint32_t)bh);
+
+    const f32x4 qa = *reinterpret_cast<const f32x4*>(Q + hb + (size_t)(q0 + j) * DH + 8 * h);
+    const f32x4 qb = *reinterpret_cast<const f32x4*>(Q + hb + (size_t)(q0 + j) * DH + 8 * h + 4);
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(dOh + hb + (size_t)(q0 + j) * DH + 8 * h);
+    const f32x4 gb = *reinterpret_cast<const f32x4*>(dOh + hb + (size_t)(q0 + j) * DH + 8 * h + 4);
+    const float qf[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+    const float gf[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+    const float lse_q = lse[(size_t)bh * L + q0 + j];
+    const float d_q = Drow[(size_t)bh * L + q0 + j];
+
+    f32x16 dq;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) dq[r] = 0.f;
+    const bool drow = j < DH;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    f32x4 ka = *reinterpret_cast<const f32x4*>(Kh + (size_t)j * DH + 8 * h);
+    f32x4 kb = *reinterpret_cast<const f32x4*>(Kh + (size_t)j * DH + 8 * h + 4);
+    f32x4 va = *reinterpret_cast<const f32x4*>(Vh + (size_t)j * DH + 8 * h);
+    f32x4 vb = *reinterpret_cast<const f32x4*>(Vh + (size_t)j * DH + 8 * h + 4);
+    f32x4 kt[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) kt[g] = drow ? *reinterpret_cast<const f32x4*>(Kth + (size_t)j * L + 8 * g + 4 * h) : zero4;
+
+    const int nkb = L / KB;
+    for (int kblk = 0; kblk < nkb; ++kblk) {
+        const float kf[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
+        const float vf[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+        const f32x4 kc[4] = {kt[0], kt[1], kt[2], kt[3]};
+        const int kn = kblk + 1 < nkb ? kblk + 1 : kblk;
+        ka = *reinterpret_cast<const f32x4*>(Kh + (size_t)(kn * KB + j) * DH + 8 * h);
+        kb = *reinterpret_cast<const f32x4*>(Kh + (size_t)(kn * KB + j) * DH + 8 * h + 4);
+        va = *reinterpret_cast<const f32x4*>(Vh + (size_t)(kn * KB + j) * DH + 8 * h);
+        vb = *reinterpret_cast<const f32x4*>(Vh + (size_t)(kn * KB + j) * DH + 8 * h + 4);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            kt[g] = drow ? *reinterpret_cast<const f32x4*>(Kth + (size_t)j * L + kn * KB + 8 * g + 4 * h) : zero4;
+
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[t], qf[t], s, 0, 0, 0);      // S^T[key][query]
+#pragma unroll
+        for (int t = 0; t < 8; ++t) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[t], gf[t], dp, 0, 0, 0);    // dPd^T[key][query]
+        const uint32_t base = (uint32_t)(q0 + j) * (uint32_t)L + (uint32_t)(kblk * KB + 4 * h);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float p = exp2f(s[r] - lse_q);
+            float g = dp[r] * inv_keep;
+            if (thresh && mix32((base + (r & 3) + 8 * (r >> 2)) ^ hkey) < thresh) g = 0.f;
+            s[r] = p * (g - d_q);
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dq = __builtin_amdgcn_mfma_f32_32x32x2f32(kc[r >> 2][r & 3], s[r], dq, 0, 0, 0);
+    }
+    const int Dm = H * DH;
+    const int b = bh / H, hd = bh % H;
+    float* dst = dqkv + ((size_t)b * L + q0 + j) * 3 * Dm + hd * DH;
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        f32x4 v = {dq[4 * g] * 0.25f, dq[4 * g + 1] * 0.25f, dq[4 * g + 2] * 0.25f, dq[4 * g + 3] * 0.25f};
+        *reinterpret_cast<f32x4*>(dst + 8 * g + 4 * h) = v;
+    }
+}
+
+__global__ __launch_bounds__(256)
+void k_attn_bwd_dkv(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+                    const float* __restrict__ Qt, const float* __restrict__ dOh, const float* __restrict__ dOt,
+                    const float* __restrict__ lse, const float* __restrict__ Drow, float* __restrict__ dqkv, int L, int H,
+                    uint32_t seed, uint32_t thresh, float inv_keep) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = lane & 31, h = lane >> 5;
+    const int bh = blockIdx.y;
+    const int k0 = (blockIdx.x * 4 + wave) * 32;
+    const size_t hb = (size_t)bh * L * DH;
+    const float* Qh = Q + hb;
+    const float* Gh = dOh + hb;
+    const float* Qth = Qt + hb;
+    const float* Gth = dOt + hb;
+    const float* lse_h = lse + (size_t)bh * L;
+    const float* d_h = Drow + (size_t)bh * L;
+    const uint32_t hkey = site_key(seed, (uint32_t)bh);
+
+    const f32x4 ka = *reinterpret_cast<const f32x4*>(K + hb + (size_t)(k0 + j) * DH + 8 * h);
+    const f32x4 kb = *reinterpret_cast<const f32x4*>(K + hb + (size_t)(k0 + j) * DH + 8 * h + 4);
+    const f32x4 va = *reinterpret_cast<const f32x4*>(V + hb + (size_t)(k0 + j) * DH + 8 * h);
+    const f32x4 vb = *reinterpret_cast<const f32x4*>(V + hb + (size_t)(k0 + j) * DH + 8 * h + 4);
+    const float kf[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
+    const float vf[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+
+    f32x16 dv, dk;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { dv[r] = 0.f; dk[r] = 0.f; }
+    const bool drow = j < DH;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    f32x4 qa = *reinterpret_cast<const f32x4*>(Qh + (size_t)j * DH + 8 * h);
+    f32x4 qb = *reinterpret_cast<const f32x4*>(Qh + (size_t)j * DH + 8 * h + 4);
+    f32x4 ga = *reinterpret_cast<const f32x4*>(Gh + (size_t)j * DH + 8 * h);
+    f32x4 gb = *reinterpret_cast<const f32x4*>(Gh + (size_t)j * DH + 8 * h + 4);
+    f32x4 qt[4], gt[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        qt[g] = drow ? *reinterpret_cast<const f32x4*>(Qth + (size_t)j * L + 8 * g + 4 * h) : zero4;
+        gt[g] = drow ? *reinterpret_cast<const f32x4*>(Gth + (size_t)j * L + 8 * g + 4 * h) : zero4;
+    }
+
+    const int nqb = L / KB;
+    for (int qblk = 0; qblk < nqb; ++qblk) {
+        const float qf[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
+        const float gf[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
+        const f32x4 qc[4] = {qt[0], qt[1], qt[2], qt[3]};
+        const f32x4 gc[4] = {gt[0], gt[1], gt[2], gt[3]};
+        f32x4 ls[4], dr[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            ls[g] = *reinterpret_cast<const f32x4*>(lse_h + qblk * KB + 8 * g + 4 * h);
+            dr[g] = *reinterpret_cast<const f32x4*>(d_h + qblk * KB + 8 * g + 4 * h);
+        }
+        const int qn = qblk + 1 < nqb ? qblk + 1 : qblk;
+        qa = *reinterpret_cast<const f32x4*>(Qh + (size_t)(qn * KB + j) * DH + 8 * h);
+        qb = *reinterpret_cast<const f32x4*>(Qh + (size_t)(qn * KB + j) * DH + 8 * h + 4);
+        ga = *reinterpret_cast<const f32x4*>(Gh + (size_t)(qn * KB + j) * DH + 8 * h);
+        gb = *reinterpret_cast<const f32x4*>(Gh + (size_t)(qn * KB + j) * DH + 8 * h + 4);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            qt[g] = drow ? *reinterpret_cast<const f32x4*>(Qth + (size_t)j * L + qn * KB + 8 * g + 4 * h) : zero4;
+            gt[g] = drow ? *reinterpret_cast<const f32x4*>(Gth + (size_t)j * L + qn * KB + 8 * g + 4 * h) : zero4;
+        }
+
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) s = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[t], kf[t], s, 0, 0, 0);      // S[query][key]
+#pragma unroll
+        for (int t = 0; t < 8; ++t) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(gf[t], vf[t], dp, 0, 0, 0);    // dPd[query][key]
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int g = r >> 2, c = r & 3;
+            const float p = exp2f(s[r] - ls[g][c]);
+            float pd = p, gd = dp[r] * inv_keep;
+            if (thresh) {
+                const uint32_t idx = (uint32_t)(qblk * KB + 8 * g + 4 * h + c) * (uint32_t)L + (uint32_t)(k0 + j);
+                if (mix32(idx ^ hkey) < thresh) { pd = 0.f; gd = 0.f; }
+            }
+            s[r] = p * (gd - dr[g][c]);       // dS
+            dp[r] = pd;                        // Pd (without the 1/keep factor, applied once at the end)
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            dv = __builtin_amdgcn_mfma_f32_32x32x2f32(gc[r >> 2][r & 3], dp[r], dv, 0, 0, 0);   // dV^T[d][key]
+            dk = __builtin_amdgcn_mfma_f32_32x32x2f32(qc[r >> 2][r & 3], s[r], dk, 0, 0, 0);    // dK^T[d][key]
+        }
+    }
+    const int Dm = H * DH;
+    const int b = bh / H, hd = bh % H;
+    float* dst = dqkv + ((size_t)b * L + k0 + j) * 3 * Dm + hd * DH;
+    const float ln2 = 0.69314718055994530942f;            // Q carries scale * log2 e
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+        f32x4 vk = {dk[4 * g] * ln2, dk[4 * g + 1] * ln2, dk[4 * g + 2] * ln2, dk[4 * g + 3] * ln2};
+        f32x4 vv = {dv[4 * g] * inv_keep, dv[4 * g + 1] * inv_keep, dv[4 * g + 2] * inv_keep, dv[4 * g + 3] * inv_keep};
+        *reinterpret_cast<f32x4*>(dst + Dm + 8 * g + 4 * h) = vk;
+        *reinterpret_cast<f32x4*>(dst + 2 * Dm + 8 * g + 4 * h) = vv;
+    }
+}
+
+// keep mask of the attention dropout, for the parity tests: mask [BH][L][L] (query-major) in {0,1}
+__global__ void k_attn_dropout_mask(float* __restrict__ mask, int64_t BH, int L, uint32_t seed, uint32_t thresh) {
+    const int64_t total = BH * L * L;
+    const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gs) {
+        const int64_t bh = i / ((int64_t)L * L);
+        const uint32_t idx = (uint32_t)(i - bh * (int64_t)L * L);
+        mask[i] = mix32(idx ^ site_key(seed, (uint32_t)bh)) < thresh ? 0.f : 1.f;
+    }
+}
+
+// y = x * keep / (1-p) (* [gate > 0]); gate = the ReLU output makes this the backward of dropout(relu(.))
+__global__ void k_dropout(const float* __restrict__ x, const float* __restrict__ gate, float* __restrict__ y, int64_t n,
+                          uint32_t key, uint32_t thresh, float inv_keep) {
+    const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gs) {
+        float v = x[i] * inv_keep;
+        if (thresh && mix32((uint32_t)i ^ key) < thresh) v = 0.f;
+        if (gate && !(gate[i] > 0.f)) v = 0.f;
+        y[i] = v;
+    }
+}
+
+// training LayerNorm: v = res + dropout(x) is stored (the backward re-derives mean / rstd from it), y = LN(v)
+__global__ __launch_bounds__(256)
+void k_add_layernorm_train(const float* __restrict__ x, const float* __restrict__ res, const float* __restrict__ gamma,
+                           const float* __restrict__ beta, float* __restrict__ v_out, float* __restrict__ y, int64_t rows,
+                           float eps, uint32_t key, uint32_t thresh, float inv_keep) {
+    constexpr int D = 128;
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float v[2];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int64_t e = row * D + lane + 64 * i;
+        float a = x[e] * inv_keep;
+        if (thresh && mix32((uint32_t)e ^ key) < thresh) a = 0.f;
+        v[i] = a + (res ? res[e] : 0.f);
+        v_out[e] = v[i];
+        s += v[i];
+    }
+    const float mean = be::wave_sum(s) / D;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const float d = v[i] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(be::wave_sum(q) / D + eps);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) y[row * D + lane + 64 * i] = (v[i] - mean) * rstd * gamma[lane + 64 * i] + beta[lane + 64 * i];
+}
+
+// LayerNorm backward over D = 128: dv = rstd (g - mean(g) - xhat mean(g xhat)), g = dy gamma; the same dv is the gradient
+// of the residual input, and dx = dropout'(dv) of the dropped branch.  Each block reduces its 32 rows' dgamma / dbeta
+// contributions into partial[block][2][128]; be_col_sum finishes them.
+constexpr int LN_ROWS = 32;
+__global__ __launch_bounds__(256)
+void k_layernorm_bwd(const float* __restrict__ dy, const float* __restrict__ v, const float* __restrict__ gamma,
+                     float* __restrict__ dv, float* __restrict__ dx, float* __restrict__ partial, int64_t rows, float eps,
+                     uint32_t key, uint32_t thresh, float inv_keep) {
+    constexpr int D = 128;
+    __shared__ float red[4][2][D];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float dgam[2] = {0.f, 0.f}, dbet[2] = {0.f, 0.f};
+    const float g0 = gamma[lane], g1 = gamma[lane + 64];
+    for (int it = 0; it < LN_ROWS / 4; ++it) {
+        const int64_t row = (int64_t)blockIdx.x * LN_ROWS + it * 4 + wave;
+        if (row >= rows) break;
+        const int64_t e0 = row * D + lane, e1 = e0 + 64;
+        const float v0 = v[e0], v1 = v[e1];
+        const float mean = be::wave_sum(v0 + v1) / D;
+        const float c0 = v0 - mean, c1 = v1 - mean;
+        const float rstd = 1.0f / sqrtf(be::wave_sum(c0 * c0 + c1 * c1) / D + eps);
+        const float x0 = c0 * rstd, x1 = c1 * rstd;
+        const float y0 = dy[e0], y1 = dy[e1];
+        dgam[0] += y0 * x0; dgam[1] += y1 * x1;
+        dbet[0] += y0; dbet[1] += y1;
+        const float a0 = y0 * g0, a1 = y1 * g1;
+        const float ma = be::wave_sum(a0 + a1) / D;
+        const float mb = be::wave_sum(a0 * x0 + a1 * x1) / D;
+        const float r0 = rstd * (a0 - ma - x0 * mb), r1 = rstd * (a1 - ma - x1 * mb);
+        if (dv) { dv[e0] = r0; dv[e1] = r1; }
+        if (dx) {
+            float d0 = r0 * inv_keep, d1 = r1 * inv_keep;
+            if (thresh && mix32((uint32_t)e0 ^ key) < thresh) d0 = 0.f;
+            if (thresh && mix32((uint32_t)e1 ^ key) < thresh) d1 = 0.f;
+            dx[e0] = d0; dx[e1] = d1;
+        }
+    }
+    red[wave][0][lane] = dgam[0]; red[wave][0][lane + 64] = dgam[1];
+    red[wave][1][lane] = dbet[0]; red[wave][1][lane + 64] = dbet[1];
+    __syncthreads();
+    const int t = threadIdx.x;                                   // 256 threads = 2 x 128 outputs
+    partial[(size_t)blockIdx.x * 2 * D + t] = red[0][t >> 7][t & 127] + red[1][t >> 7][t & 127] + red[2][t >> 7][t & 127] +
+                                              red[3][t >> 7][t & 127];
 }
 
 // y = LayerNorm(x (+ res)) over the last dim D (= 128): one wave per row, two elements per lane
@@ -172,8 +530,112 @@ extern "C" int be_attention_f32(const float* qkv, float* out, float* workspace, 
     const float qscale = 0.25f * 1.44269504088896340736f;            // 1/sqrt(16) * log2(e)
     int64_t g = ((int64_t)n + 255) / 256; if (g > 4096) g = 4096;
     hipLaunchKernelGGL(k_qkv_split, dim3((unsigned)g), dim3(256), 0, s, qkv, Q, K, Vt, B, L, H, qscale);
-    hipLaunchKernelGGL(k_attention, dim3(L / 128, B * H), dim3(256), 0, s, Q, K, Vt, out, L, H);
+    hipLaunchKernelGGL(k_attention<false>, dim3(L / 128, B * H), dim3(256), 0, s, Q, K, Vt, out, (float*)nullptr, L, H, 0u,
+                       0u, 1.0f);
     return be::check_launch("be_attention_f32");
+}
+
+namespace {
+struct TrainWs { float *Q, *K, *V, *Qt, *Kt, *Vt, *dOh, *dOt, *Drow; };
+TrainWs train_ws(float* w, int B, int L, int H) {
+    const size_t n = (size_t)B * H * L * DH;
+    return {w, w + n, w + 2 * n, w + 3 * n, w + 4 * n, w + 5 * n, w + 6 * n, w + 7 * n, w + 8 * n};
+}
+int attn_args_ok(const char* who, int B, int L, int H, float p) {
+    BE_REQUIRE(B > 0 && H > 0 && L > 0 && L % 128 == 0 && L <= 65536, "%s: L must be a multiple of 128, <= 65536 (got %d)", who, L);
+    BE_REQUIRE(p >= 0.f && p < 1.f, "%s: dropout probability %g outside [0,1)", who, (double)p);
+    return BE_OK;
+}
+}  // namespace
+
+extern "C" size_t be_attention_train_workspace_floats(int B, int L, int H) {
+    return (size_t)8 * B * H * L * DH + (size_t)B * H * L;
+}
+
+extern "C" int be_attention_train_fwd_f32(const float* qkv, float* out, float* lse, float* workspace, int B, int L, int H,
+                                          float dropout_p, uint32_t seed, void* stream) {
+    BE_REQUIRE(qkv && out && lse && workspace, "be_attention_train_fwd_f32: null pointer");
+    if (int rc = attn_args_ok("be_attention_train_fwd_f32", B, L, H, dropout_p)) return rc;
+    BE_REQUIRE(be::aligned16(qkv) && be::aligned16(out) && be::aligned16(workspace), "be_attention_train_fwd_f32: 16-byte alignment");
+    hipStream_t s = be::as_stream(stream);
+    const TrainWs w = train_ws(workspace, B, L, H);
+    const size_t n = (size_t)B * H * L * DH;
+    int64_t g = ((int64_t)n + 255) / 256; if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_qkv_split_train, dim3((unsigned)g), dim3(256), 0, s, qkv, w.Q, w.K, w.V, w.Qt, w.Kt, w.Vt, B, L, H,
+                       0.25f * 1.44269504088896340736f);
+    hipLaunchKernelGGL(k_attention<true>, dim3(L / 128, B * H), dim3(256), 0, s, w.Q, w.K, w.Vt, out, lse, L, H, seed,
+                       drop_threshold(dropout_p), 1.0f / (1.0f - dropout_p));
+    return be::check_launch("be_attention_train_fwd_f32");
+}
+
+extern "C" int be_attention_bwd_f32(const float* qkv, const float* out, const float* lse, const float* dout, float* dqkv,
+                                    float* workspace, int B, int L, int H, float dropout_p, uint32_t seed, void* stream) {
+    BE_REQUIRE(qkv && out && lse && dout && dqkv && workspace, "be_attention_bwd_f32: null pointer");
+    if (int rc = attn_args_ok("be_attention_bwd_f32", B, L, H, dropout_p)) return rc;
+    BE_REQUIRE(be::aligned16(qkv) && be::aligned16(dqkv) && be::aligned16(workspace) && be::aligned16(lse),
+               "be_attention_bwd_f32: 16-byte alignment");
+    hipStream_t s = be::as_stream(stream);
+    const TrainWs w = train_ws(workspace, B, L, H);
+    const size_t n = (size_t)B * H * L * DH;
+    int64_t g = ((int64_t)n + 255) / 256; if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_qkv_split_train, dim3((unsigned)g), dim3(256), 0, s, qkv, w.Q, w.K, w.V, w.Qt, w.Kt, w.Vt, B, L, H,
+                       0.25f * 1.44269504088896340736f);
+    int64_t g2 = ((int64_t)B * L * H + 255) / 256; if (g2 > 4096) g2 = 4096;
+    hipLaunchKernelGGL(k_dout_prep, dim3((unsigned)g2), dim3(256), 0, s, dout, out, w.dOh, w.dOt, w.Drow, B, L, H);
+    const uint32_t th = drop_threshold(dropout_p);
+    const float ik = 1.0f / (1.0f - dropout_p);
+    hipLaunchKernelGGL(k_attn_bwd_dq, dim3(L / 128, B * H), dim3(256), 0, s, w.Q, w.K, w.V, w.Kt, w.dOh, lse, w.Drow, dqkv, L,
+                       H, seed, th, ik);
+    hipLaunchKernelGGL(k_attn_bwd_dkv, dim3(L / 128, B * H), dim3(256), 0, s, w.Q, w.K, w.V, w.Qt, w.dOh, w.dOt, lse, w.Drow,
+                       dqkv, L, H, seed, th, ik);
+    return be::check_launch("be_attention_bwd_f32");
+}
+
+extern "C" int be_attention_dropout_mask_f32(float* mask, int B, int L, int H, float dropout_p, uint32_t seed, void* stream) {
+    BE_REQUIRE(mask, "be_attention_dropout_mask_f32: null pointer");
+    if (int rc = attn_args_ok("be_attention_dropout_mask_f32", B, L, H, dropout_p)) return rc;
+    const int64_t total = (int64_t)B * H * L * L;
+    int64_t g = (total + 255) / 256; if (g > 8192) g = 8192;
+    hipLaunchKernelGGL(k_attn_dropout_mask, dim3((unsigned)g), dim3(256), 0, be::as_stream(stream), mask, (int64_t)B * H, L,
+                       seed, drop_threshold(dropout_p));
+    return be::check_launch("be_attention_dropout_mask_f32");
+}
+
+extern "C" int be_dropout_f32(const float* x, const float* gate, float* y, int64_t n, float dropout_p, uint32_t seed,
+                              uint32_t site, void* stream) {
+    BE_REQUIRE(x && y && n > 0 && n < ((int64_t)1 << 32), "be_dropout_f32: bad arguments");
+    BE_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "be_dropout_f32: dropout probability outside [0,1)");
+    int64_t g = (n + 255) / 256; if (g > 4096) g = 4096;
+    hipLaunchKernelGGL(k_dropout, dim3((unsigned)g), dim3(256), 0, be::as_stream(stream), x, gate, y, n, site_key(seed, site),
+                       drop_threshold(dropout_p), 1.0f / (1.0f - dropout_p));
+    return be::check_launch("be_dropout_f32");
+}
+
+extern "C" int be_add_layernorm_train_f32(const float* x, const float* res, const float* gamma, const float* beta, float* v,
+                                          float* y, int64_t rows, int D, float eps, float dropout_p, uint32_t seed,
+                                          uint32_t site, void* stream) {
+    BE_REQUIRE(x && gamma && beta && v && y && rows > 0, "be_add_layernorm_train_f32: bad arguments");
+    BE_REQUIRE(D == 128, "be_add_layernorm_train_f32: D must be 128 (got %d)", D);
+    BE_REQUIRE(rows * D < ((int64_t)1 << 32) && dropout_p >= 0.f && dropout_p < 1.f, "be_add_layernorm_train_f32: bad size / p");
+    hipLaunchKernelGGL(k_add_layernorm_train, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, be::as_stream(stream), x, res,
+                       gamma, beta, v, y, rows, eps, site_key(seed, site), drop_threshold(dropout_p), 1.0f / (1.0f - dropout_p));
+    return be::check_launch("be_add_layernorm_train_f32");
+}
+
+extern "C" size_t be_layernorm_bwd_partial_floats(int64_t rows, int D) {
+    return (size_t)((rows + LN_ROWS - 1) / LN_ROWS) * 2 * D;
+}
+
+extern "C" int be_layernorm_bwd_f32(const float* dy, const float* v, const float* gamma, float* dv, float* dx, float* partial,
+                                    int64_t rows, int D, float eps, float dropout_p, uint32_t seed, uint32_t site,
+                                    void* stream) {
+    BE_REQUIRE(dy && v && gamma && partial && rows > 0, "be_layernorm_bwd_f32: bad arguments");
+    BE_REQUIRE(D == 128, "be_layernorm_bwd_f32: D must be 128 (got %d)", D);
+    BE_REQUIRE(rows * D < ((int64_t)1 << 32) && dropout_p >= 0.f && dropout_p < 1.f, "be_layernorm_bwd_f32: bad size / p");
+    hipLaunchKernelGGL(k_layernorm_bwd, dim3((unsigned)((rows + LN_ROWS - 1) / LN_ROWS)), dim3(256), 0, be::as_stream(stream),
+                       dy, v, gamma, dv, dx, partial, rows, eps, site_key(seed, site), drop_threshold(dropout_p),
+                       1.0f / (1.0f - dropout_p));
+    return be::check_launch("be_layernorm_bwd_f32");
 }
 
 extern "C" size_t be_attention_workspace_floats(int B, int L, int H) { return (size_t)3 * B * H * L * DH; }

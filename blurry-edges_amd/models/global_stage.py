@@ -4,8 +4,9 @@ Boundary kept exactly (constructor signature, forward(src [B,L,38]) -> [B,L,12],
 sinusoidal position table held as a plain tensor that is NOT part of the state-dict): models/global_stage.py:6-38
 of the reference.  Inference on the GPU runs on libblurry_edges_hip: the linears on the implicit-GEMM kernel, a
 flash-style fp32-MFMA attention kernel whose scores never leave registers, fused residual + LayerNorm.
-Training and CPU use stock PyTorch ops (math SDPA backend: the flash / mem-efficient backends on ROCm are
-Triton-built).  The stage is ~2.4 % of the FLOPs of the path (18.9 of 794 MFLOP per pair).
+Training on the GPU (model.train(), grad enabled) runs the HIP training kernels as well: counter-based dropout at the
+four sites of every layer, flash-style attention backward, LayerNorm / linear backward (be_hip/train_global_stage.py).
+CPU tensors use stock PyTorch ops (math SDPA backend: the flash / mem-efficient backends on ROCm are Triton-built).  The stage is ~2.4 % of the FLOPs of the path (18.9 of 794 MFLOP per pair).
 """
 import math
 
@@ -51,13 +52,27 @@ class GlobalStage(nn.Module):
         self.generator = nn.Linear(d_model, out_parameter_size)
 
     def forward(self, src):
-        if src.is_cuda and not (self.training and torch.is_grad_enabled()) and src.shape[1] % 128 == 0:
-            return self._forward_hip(src)
-        # training / CPU: stock PyTorch ops (boundary kept; no Triton-built attention kernels)
+        if src.is_cuda and src.shape[1] % 128 == 0 and self._hip_shapes_ok():
+            if not (self.training and torch.is_grad_enabled()):
+                return self._forward_hip(src)
+            # model.train(): dropout + autograd on the HIP training kernels (be_hip/train_global_stage.py); the dropout
+            # seed is drawn from torch's CPU generator, so torch.manual_seed makes a run repeatable
+            from be_hip.train_global_stage import GlobalStageTrainFn, parameter_list
+            lyr = self.encoder.layers[0]
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+            return GlobalStageTrainFn.apply(src, self.positional_encoding.pe[0], seed, lyr.dropout.p, lyr.self_attn.num_heads,
+                                            lyr.norm1.eps, *parameter_list(self))
+        # CPU / other shapes: stock PyTorch ops (boundary kept; no Triton-built attention kernels)
         from torch.nn.attention import sdpa_kernel, SDPBackend
         with sdpa_kernel(SDPBackend.MATH):
             h = self.positional_encoding(self.in_src_projection(src))
             return self.generator(self.encoder(h))
+
+    def _hip_shapes_ok(self):
+        lyr = self.encoder.layers[0]
+        d = self.in_src_projection.out_features
+        return (d == 128 and d // lyr.self_attn.num_heads == 16 and lyr.linear1.out_features % 32 == 0
+                and lyr.self_attn.dropout == lyr.dropout.p == lyr.dropout1.p == lyr.dropout2.p)
 
     # ------------------------------------------------------------------ inference on the HIP library
     def _packed(self):

@@ -324,6 +324,36 @@ int be_add_layernorm_f32(const float* x, const float* res, const float* gamma, c
 int be_add_pe_f32(float* x, const float* pe, int64_t batches, int64_t per_batch, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * GlobalStage encoder, training (model.train() of global_training.py:207-213: dropout 0.1 at the four sites of
+ * nn.TransformerEncoderLayer, autograd through every layer).  Dropout is counter-based: element i of site `site` is
+ * kept iff hash(i, seed, site) >= p * 2^32, so the backward kernels re-derive the masks and nothing is stored.
+ * ------------------------------------------------------------------------------------------------- */
+/* Attention forward for training: out as be_attention_f32 with dropout on the probabilities (site = batch*H + head,
+ * element = query*L + key), lse [B*H, L] = log2-sum-exp of each score row (saved for the backward). */
+size_t be_attention_train_workspace_floats(int B, int L, int H);
+int be_attention_train_fwd_f32(const float* qkv, float* out, float* lse, float* workspace, int B, int L, int H,
+                               float dropout_p, uint32_t seed, void* stream);
+/* Attention backward: dout [B*L, H*16] -> dqkv [B*L, 3*H*16]; probabilities are recomputed from qkv and lse
+ * (no [L,L] tensor is ever stored); deterministic (no atomics).  Same workspace size as the forward. */
+int be_attention_bwd_f32(const float* qkv, const float* out, const float* lse, const float* dout, float* dqkv,
+                         float* workspace, int B, int L, int H, float dropout_p, uint32_t seed, void* stream);
+/* The keep mask the two functions above apply, [B*H, L, L] in {0,1} (test hook; small L only). */
+int be_attention_dropout_mask_f32(float* mask, int B, int L, int H, float dropout_p, uint32_t seed, void* stream);
+/* y = dropout(x) = x * keep / (1-p); with gate != NULL additionally zero where gate <= 0, which makes it the
+ * backward of dropout(relu(.)) given the ReLU output.  y may alias x.  n < 2^32. */
+int be_dropout_f32(const float* x, const float* gate, float* y, int64_t n, float dropout_p, uint32_t seed, uint32_t site,
+                   void* stream);
+/* v = res + dropout(x) (stored), y = LayerNorm(v); D = 128; res may be NULL. */
+int be_add_layernorm_train_f32(const float* x, const float* res, const float* gamma, const float* beta, float* v, float* y,
+                               int64_t rows, int D, float eps, float dropout_p, uint32_t seed, uint32_t site, void* stream);
+/* LayerNorm backward from the stored v: dv (gradient of v, hence of the residual input; NULL to skip),
+ * dx = dropout'(dv) (gradient of the dropped branch; NULL to skip), partial [be_layernorm_bwd_partial_floats]:
+ * per-block sums of (dy*xhat | dy) as rows of 2*D floats - be_col_sum_f32 over them gives dgamma | dbeta. */
+size_t be_layernorm_bwd_partial_floats(int64_t rows, int D);
+int be_layernorm_bwd_f32(const float* dy, const float* v, const float* gamma, float* dv, float* dx, float* partial,
+                         int64_t rows, int D, float eps, float dropout_p, uint32_t seed, uint32_t site, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py's roofline leg): opt-in hipEvent pair around every conv launch, recorded on
  * the launch stream.  be_profile_enable(0) turns it off and frees the events.  Not thread-safe.
  * ------------------------------------------------------------------------------------------------- */

@@ -216,3 +216,29 @@ def test_g11_global_loss_value_and_gradient():
         assert abs(float(loss.detach()) - ref) <= ltol * abs(ref), (tag, float(loss.detach()), ref)
         if gtol is not None:
             assert relmax(est.grad[0].numpy(), g[tag + "_grad"]) <= gtol
+
+
+def _g12_inputs(dt):
+    sd = {k: T(v, dt).requires_grad_(True) for k, v in synth.global_stage_state_dict().items()}
+    src = T(synth.global_features(512, name="g12_src").reshape(2, 256, 38), dt)
+    R = T(synth.hash_normal(12, "g12_R", (2, 256, 12)), dt)
+    return sd, src, R
+
+
+def test_g12_global_stage_oracle_matches_reference_train_mode_graph():
+    """oracle.global_stage.forward (explicit-mask restatement, masks = None) against the reference's GlobalStage in
+    train mode with p = 0: output, and every parameter gradient (norm + strided sample), float64."""
+    from oracle import global_stage as ogs
+    g = load_golden("g12_global_stage_train")
+    sd, src, R = _g12_inputs(torch.float64)
+    pe = ogs.position_table().double()
+    out = ogs.forward(sd, src, pe)
+    assert relmax(out.detach(), g["f64_out"]) <= 1e-12
+    (out * R).sum().backward()
+    for k, v in sd.items():
+        gr = v.grad.reshape(-1)
+        assert abs(float(gr.norm()) - float(g[f"f64_gnorm.{k}"])) <= 1e-10 * max(1.0, float(g[f"f64_gnorm.{k}"])), k
+        assert relmax(gr[::max(1, gr.numel() // 512)], g[f"f64_gsample.{k}"]) <= 1e-9, k
+    # all-ones masks with p = 0 are the same function
+    ones = [dict(attn=torch.ones(16, 256, 256), d1=torch.ones(512, 128), ff=torch.ones(512, 256), d2=torch.ones(512, 128))] * 8
+    assert relmax(ogs.forward(sd, src, pe, 0.0, ones).detach(), g["f64_out"]) <= 1e-12

@@ -125,3 +125,148 @@ def test_global_training_loop_runs_and_descends():
     sched = train_global.GammaSchedule(args)
     g0 = sched.step()
     assert abs(g0["color"] - 1.0) < 1e-12 and abs(sched.final()["depth"] - 0.5) < 1e-12
+
+
+# ---- GlobalStage training kernels: attention / LayerNorm / dropout forward + backward --------------------
+
+def _attn_ref(qkv, B, L, H, p, mask):
+    """float64 autograd reference of be_attention_train_fwd_f32 with the kernel's own keep mask."""
+    D = H * 16
+    q, k, v = [t.view(B, L, H, 16).permute(0, 2, 1, 3) for t in qkv.split(D, dim=-1)]
+    pr = torch.softmax(q @ k.transpose(-1, -2) / 4.0, dim=-1)
+    if mask is not None:
+        pr = pr * mask.view(B, H, L, L) / (1.0 - p)
+    return (pr @ v).permute(0, 2, 1, 3).reshape(B * L, D)
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_attention_train_forward_backward_vs_fp64_autograd(p):
+    from be_hip import train_global_stage as tg
+    from conftest import relmax
+    B, L, H, seed = 2, 256, 8, 4242
+    qkv = torch.from_numpy(synth.hash_normal(3, "attn_qkv", (B * L, 3 * H * 16)).astype(np.float32) * 1.5).to(DEV)
+    dout = torch.from_numpy(synth.hash_normal(4, "attn_dout", (B * L, H * 16)).astype(np.float32)).to(DEV)
+    out, lse, ws = tg.attention_train_fwd(qkv, B, L, H, p, seed)
+    dqkv, _ = tg.attention_bwd(qkv, out, lse, dout, B, L, H, p, seed, ws)
+    mask = tg.attention_dropout_mask(B, L, H, p, seed, DEV).double() if p > 0 else None
+    if p > 0:
+        frac = float(mask.mean())
+        assert abs(frac - (1 - p)) < 3e-3, frac                       # 1M draws: sigma = 3e-4
+        per_head = mask.view(B * H, -1).mean(dim=1)
+        assert float((per_head - (1 - p)).abs().max()) < 6e-3          # every (batch, head) has its own stream
+        assert not torch.equal(mask[0], mask[1])
+    q64 = qkv.double().requires_grad_(True)
+    ref = _attn_ref(q64, B, L, H, p, mask)
+    (ref * dout.double()).sum().backward()
+    assert relmax(out.cpu(), ref.detach().cpu()) <= 2e-6
+    assert relmax(dqkv.cpu(), q64.grad.cpu()) <= 5e-6
+    # log2-sum-exp of the scaled scores
+    s = (q64.detach()[:, :128].view(B, L, H, 16).permute(0, 2, 1, 3) @
+         q64.detach()[:, 128:256].view(B, L, H, 16).permute(0, 2, 3, 1)) / 4.0
+    assert relmax(lse.cpu(), (torch.logsumexp(s, dim=-1) / np.log(2.0)).view(B * H, L).cpu()) <= 2e-6
+    # no dropout: the training forward is the inference kernel
+    if p == 0:
+        from be_hip import native
+        inf, _ = native.attention(qkv, B, L, H)
+        assert torch.equal(inf, out)
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_layernorm_dropout_train_forward_backward_vs_fp64_autograd(p):
+    from be_hip import train_global_stage as tg
+    from conftest import relmax
+    rows, D, seed, site = 1000, 128, 77, 5
+    x = torch.from_numpy(synth.hash_normal(5, "ln_x", (rows, D)).astype(np.float32)).to(DEV)
+    res = torch.from_numpy(synth.hash_normal(6, "ln_r", (rows, D)).astype(np.float32)).to(DEV)
+    gam = torch.from_numpy((1 + 0.3 * synth.hash_normal(7, "ln_g", (D,))).astype(np.float32)).to(DEV)
+    bet = torch.from_numpy((0.1 * synth.hash_normal(8, "ln_b", (D,))).astype(np.float32)).to(DEV)
+    dy = torch.from_numpy(synth.hash_normal(9, "ln_dy", (rows, D)).astype(np.float32)).to(DEV)
+    v, y = tg.add_layernorm_train(x, res, gam, bet, 1e-5, p, seed, site)
+    dv, dx, dg, db = tg.layernorm_bwd(dy, v, gam, 1e-5, p, seed, site)
+    mask = tg.dropout(torch.ones_like(x), p, seed, site).double() * (1 - p)                  # the kernel's keep mask
+    assert set(mask.unique().round().tolist()) <= {0.0, 1.0}
+    if p > 0:
+        assert abs(float(mask.mean()) - (1 - p)) < 5e-3
+        other = tg.dropout(torch.ones_like(x), p, seed, site + 1)
+        assert not torch.equal(other, mask.float() / (1 - p))                                  # sites are independent
+    x64, r64 = x.double().requires_grad_(True), res.double().requires_grad_(True)
+    g64, b64 = gam.double().requires_grad_(True), bet.double().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(r64 + x64 * mask / (1 - p), (D,), g64, b64, 1e-5)
+    (ref * dy.double()).sum().backward()
+    assert relmax(y.cpu(), ref.detach().cpu()) <= 2e-6
+    assert relmax(dx.cpu(), x64.grad.cpu()) <= 5e-6 and relmax(dv.cpu(), r64.grad.cpu()) <= 5e-6
+    assert relmax(dg.cpu(), g64.grad.cpu()) <= 5e-6 and relmax(db.cpu(), b64.grad.cpu()) <= 5e-6
+    # dropout(relu) backward gate
+    f = torch.relu(x)
+    back = tg.dropout(dy, p, seed, site, gate=f)
+    assert relmax(back.cpu(), (dy.double() * mask / (1 - p) * (f > 0)).cpu()) <= 1e-6
+
+
+def _global_stage(dev, dt=torch.float32):
+    import models
+    m = models.GlobalStage(device=dev)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.global_stage_state_dict().items()})
+    return m.to(dev).to(dt)
+
+
+def test_global_stage_train_mode_without_dropout_matches_reference_golden():
+    """g12 = the REFERENCE GlobalStage in train mode with p = 0 (fp64): output and every parameter gradient."""
+    from conftest import load_golden, relmax
+    g = load_golden("g12_global_stage_train")
+    m = _global_stage(DEV)
+    for mod in m.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+        if isinstance(mod, torch.nn.MultiheadAttention):
+            mod.dropout = 0.0
+    m.train()
+    src = torch.from_numpy(synth.global_features(512, name="g12_src").reshape(2, 256, 38)).to(DEV)
+    R = torch.from_numpy(synth.hash_normal(12, "g12_R", (2, 256, 12)).astype(np.float32)).to(DEV)
+    out = m(src)
+    assert out.grad_fn is not None and "GlobalStageTrainFn" in type(out.grad_fn).__name__
+    (out * R).sum().backward()
+    assert relmax(out.detach().cpu(), g["f64_out"]) <= 2e-5
+    worst = 0.0
+    for k, prm in m.named_parameters():
+        gr = prm.grad.reshape(-1).double().cpu()
+        ref_norm = float(g[f"f64_gnorm.{k}"])
+        smp = g[f"f64_gsample.{k}"]
+        err = float(np.abs(gr[::max(1, gr.numel() // 512)].numpy() - smp).max()) / max(ref_norm / np.sqrt(gr.numel()), 1e-12)
+        worst = max(worst, err)
+        assert abs(float(gr.norm()) - ref_norm) <= 1e-4 * ref_norm, k
+        assert err <= 1e-4, (k, err)            # error relative to the RMS entry of that gradient
+    print("worst sampled gradient error / rms entry: %.2e" % worst)
+
+
+def test_global_stage_train_mode_with_dropout_vs_oracle_with_the_kernels_masks():
+    """p = 0.1: the masks the kernels derive from (seed, site, index) are read back and handed to the float64 oracle."""
+    from be_hip import train_global_stage as tg
+    from conftest import relmax
+    from oracle import global_stage as ogs
+    B, L, H, p, seed = 1, 256, 8, 0.1, 991
+    m = _global_stage(DEV)
+    t = [v.detach() for v in tg.parameter_list(m)]
+    src = torch.from_numpy(synth.global_features(B * L, name="g13_src").reshape(B, L, 38)).to(DEV)
+    R = torch.from_numpy(synth.hash_normal(13, "g13_R", (B, L, 12)).astype(np.float32)).to(DEV)
+    pe = m.positional_encoding.pe[0]
+    out, S = tg.forward_train(src, pe, seed, p, H, 1e-5, t)
+    grads = tg.backward_train(R, seed, p, H, 1e-5, t, S)
+    out2, _ = tg.forward_train(src, pe, seed, p, H, 1e-5, t)
+    out3, _ = tg.forward_train(src, pe, seed + 1, p, H, 1e-5, t)
+    assert torch.equal(out, out2) and not torch.equal(out, out3)            # repeatable per seed
+    ones128, ones256 = torch.ones(B * L, 128, device=DEV), torch.ones(B * L, 256, device=DEV)
+    masks = [dict(attn=tg.attention_dropout_mask(B, L, H, p, seed + 16 * i, DEV).cpu().double(),
+                  d1=(tg.dropout(ones128, p, seed, 16 * i + 1) * (1 - p)).round().cpu().double(),
+                  ff=(tg.dropout(ones256, p, seed, 16 * i + 2) * (1 - p)).round().cpu().double(),
+                  d2=(tg.dropout(ones128, p, seed, 16 * i + 3) * (1 - p)).round().cpu().double()) for i in range(8)]
+    sd = {k: v.detach().cpu().double().requires_grad_(True) for k, v in m.state_dict().items()}
+    ref = ogs.forward(sd, src.cpu().double(), pe.cpu().double(), p, masks)
+    (ref * R.cpu().double()).sum().backward()
+    assert relmax(out.cpu(), ref.detach()) <= 2e-5
+    names = [k for k, _ in m.named_parameters()]
+    order = {id(prm): k for k, prm in m.named_parameters()}
+    for prm, gr in zip(tg.parameter_list(m), grads):
+        k = order[id(prm)]
+        rg = sd[k].grad
+        assert relmax(gr.cpu(), rg) <= 1e-4, (k, relmax(gr.cpu(), rg))
+    assert len(names) == len(grads) == 102

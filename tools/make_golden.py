@@ -370,7 +370,38 @@ def G10():
     save("g10_metrics", metrics=np.array(r, dtype=np.float64))
 
 
-GROUPS = dict(G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G8=G8, G9=G9, G10=G10, G11=G11)
+def G12():
+    """GlobalStage in TRAIN mode with every dropout probability set to 0: output and parameter gradients.
+    (The reference's train-mode graph - nn.TransformerEncoder slow path + autograd - without the Philox masks no other
+    generator can reproduce.)  B=2, L=256, loss = sum(out * R) with a fixed R; float64 and float32."""
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.global_stage_state_dict().items()}
+    B, L = 2, 256
+    src = torch.from_numpy(synth.global_features(B * L, name="g12_src").reshape(B, L, 38))
+    R = torch.from_numpy(synth.hash_normal(12, "g12_R", (B, L, 12)))
+    out = {}
+    for tag, dt in (("f64", torch.float64), ("f32", torch.float32)):
+        m = ref_models.GlobalStage(in_parameter_size=38, out_parameter_size=12, device=torch.device("cpu"))
+        m.load_state_dict(sd, strict=True)
+        m = m.to(dt)
+        m.positional_encoding.pe = m.positional_encoding.pe.to(dt)
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+            if isinstance(mod, torch.nn.MultiheadAttention):
+                mod.dropout = 0.0
+        m.train()
+        y = m(src.to(dt))
+        (y * R.to(dt)).sum().backward()
+        out[tag + "_out"] = n(y)
+        for k, prm in m.named_parameters():             # per parameter: L2 norm + a strided sample of <= 512 entries
+            g = prm.grad.reshape(-1)
+            out[f"{tag}_gnorm.{k}"] = n(g.double().norm())
+            if tag == "f64":
+                out[f"{tag}_gsample.{k}"] = n(g[::max(1, g.numel() // 512)])
+    save("g12_global_stage_train", **out)
+
+
+GROUPS = dict(G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G8=G8, G9=G9, G10=G10, G11=G11, G12=G12)
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)
