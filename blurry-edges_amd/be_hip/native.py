@@ -66,6 +66,9 @@ _SIGNATURES = {
     "be_conv_pack_fused2_f32": (C.c_int, [_P] * 12 + [C.c_float] + [C.c_int] * 4 + [_P, _P, _P]),
     "be_conv_nhwc_fused2_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, C.c_int, _P, _P, _P, C.c_int, _P]),
     "be_maxpool_nhwc_f32": (C.c_int, [_P, _P] + [C.c_int] * 7 + [_P]),
+    "be_maxpool_nhwc_ld_f32": (C.c_int, [_P, C.c_int, _P] + [C.c_int] * 7 + [_P]),
+    "be_nchw_to_nhwc_pad_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int64, C.c_int, _P]),
+    "be_upconv2x2_scatter_f32": (C.c_int, [_P, _P, C.c_int64] + [C.c_int] * 9 + [_P]),
     "be_attention_train_workspace_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "be_attention_train_fwd_f32": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint32, _P]),
     "be_attention_bwd_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint32, _P]),
@@ -248,23 +251,42 @@ def conv_pack(weight, bias, bn=None, eps=1e-5, chw_hw=0):
     return pw, pb
 
 
-def conv_nhwc(x, pw, pb, cout, ksize, act, residual=None):
-    """x [N,H,W,Cin] NHWC -> [N,H,W,cout]."""
+def conv_nhwc(x, pw, pb, cout, ksize, act, residual=None, out=None):
+    """x [N,H,W,Cin] NHWC -> [N,H,W,cout]; out = a [N,H,W,ld] tensor whose first cout channels receive the result."""
     n, h, w, cin = x.shape
-    y = torch.empty(n, h, w, cout, dtype=torch.float32, device=x.device)
+    y = torch.empty(n, h, w, cout, dtype=torch.float32, device=x.device) if out is None else out
     d = ConvDesc(n, h, w, cin, cout, ksize, int(act))
-    check(lib().be_conv_nhwc_f32(C.byref(d), dptr(x, "x"), dptr(pw), dptr(pb), dptr(residual), dptr(y), cout,
+    check(lib().be_conv_nhwc_f32(C.byref(d), dptr(x, "x"), dptr(pw), dptr(pb), dptr(residual), dptr(y), y.shape[-1],
                                  stream_ptr(x.device)), "be_conv_nhwc_f32")
     return y
 
 
-def maxpool_nhwc(x, k, stride, pad):
-    n, h, w, c = x.shape
+def maxpool_nhwc(x, k, stride, pad, channels=None):
+    """x [N,H,W,ld]; pools its first `channels` channels (default: all)."""
+    n, h, w, ld = x.shape
+    c = ld if channels is None else channels
     oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
     y = torch.empty(n, oh, ow, c, dtype=torch.float32, device=x.device)
-    check(lib().be_maxpool_nhwc_f32(dptr(x, "x"), dptr(y), n, h, w, c, k, stride, pad, stream_ptr(x.device)),
+    check(lib().be_maxpool_nhwc_ld_f32(dptr(x, "x"), ld, dptr(y), n, h, w, c, k, stride, pad, stream_ptr(x.device)),
           "be_maxpool_nhwc_f32")
     return y
+
+
+def nchw_to_nhwc_pad(x, cpad):
+    """x [N,C,H,W] -> [N,H,W,cpad] with zero channels C..cpad-1."""
+    n, c, h, w = x.shape
+    y = torch.empty(n, h, w, cpad, dtype=torch.float32, device=x.device)
+    check(lib().be_nchw_to_nhwc_pad_f32(dptr(x, "x"), dptr(y), n, c, h * w, cpad, stream_ptr(x.device)), "be_nchw_to_nhwc_pad_f32")
+    return y
+
+
+def upconv2x2_scatter(t, out, cout, ch_off):
+    """t [N,h,w,4*cout] -> channels [ch_off, ch_off+cout) of out [N,oh,ow,ld], centred as F.pad(diff//2) does."""
+    n, h, w, _ = t.shape
+    _, oh, ow, ld = out.shape
+    check(lib().be_upconv2x2_scatter_f32(dptr(t, "t"), dptr(out, "out"), n, h, w, cout, oh, ow, (oh - 2 * h) // 2,
+                                         (ow - 2 * w) // 2, ld, ch_off, stream_ptr(t.device)), "be_upconv2x2_scatter_f32")
+    return out
 
 
 def nchw3_to_nhwc4(x):

@@ -2,8 +2,9 @@
 harness (depth_estimator in blurry_edges_test.py:102-145 and blurry_edges_test_big.py:113-192).
 
 image pair [2,3,H,W]  ->  unfold  ->  LocalStage (HIP)  ->  pass-A colours (HIP)  ->  feature normalisation (HIP)
-  ->  GlobalStage (PyTorch-ROCm, boundary kept)  ->  de-normalisation (HIP)  ->  pass-B records (HIP)
-  ->  owner-computes fold (HIP)  ->  six maps + thresholded depth.
+  ->  GlobalStage (HIP)  ->  de-normalisation (HIP)  ->  pass-B records (HIP)
+  ->  owner-computes fold (HIP)  ->  six maps + thresholded depth (or, with densify='pp', the DepthCompletion U-Net
+  on the folded depth map, blurry_edges_test.py:141-142).
 Nothing here computes on the CPU; tensors stay on the GPU until the caller asks for them.
 """
 from __future__ import annotations
@@ -16,11 +17,15 @@ from . import native
 
 
 class DepthPipeline:
-    def __init__(self, local_module, global_module, helper, depth_cal, rho_prime=10.39, densify=None, stride=2):
-        """helper: a utils.PostProcessGlobalBase (render options); depth_cal: utils.DepthEtas."""
-        if densify not in (None, "w"):  # noqa: E129
-            raise NotImplementedError("densify='pp' needs the DepthCompletion U-Net (out of scope, SURVEY §8f-4)")
-        self.local, self.globl = local_module, global_module
+    def __init__(self, local_module, global_module, helper, depth_cal, rho_prime=10.39, densify=None, stride=2,
+                 densify_pp_module=None):
+        """helper: a utils.PostProcessGlobalBase (render options); depth_cal: utils.DepthEtas;
+        densify_pp_module: a models.DepthCompletion in eval mode, required for densify='pp'."""
+        if densify not in (None, "w", "pp"):
+            raise ValueError(f"densify must be None, 'w' or 'pp' (utils/args.py:40), got {densify!r}")
+        if densify == "pp" and densify_pp_module is None:
+            raise ValueError("densify='pp' needs densify_pp_module (models.DepthCompletion, blurry_edges_test.py:193-196)")
+        self.local, self.globl, self.pp = local_module, global_module, densify_pp_module
         self.helper, self.dcal = helper, depth_cal
         self.rho_prime, self.densify, self.stride = rho_prime, densify, stride
         self.depth_thres = 0.0 if densify == "w" else 0.05          # blurry_edges_test.py:109-112
@@ -57,7 +62,10 @@ class DepthPipeline:
         est12 = self.global_pass(pm)
         rec, _ = self.records(est12, img)
         maps = native.fold_records(self.helper.render_opts(False), rec, hp, wp, H, W, self.stride, self.densify == "w")
-        maps["depth_map"] = torch.where(maps["conf"] > self.depth_thres, maps["depth"], torch.zeros_like(maps["depth"]))
+        if self.densify == "pp":
+            maps["depth_map"] = self.pp(maps["depth"][None, None])[0, 0]
+        else:
+            maps["depth_map"] = torch.where(maps["conf"] > self.depth_thres, maps["depth"], torch.zeros_like(maps["depth"]))
         maps.update(est10=est10, colors_a=colors, est12=est12, records=rec)
         return maps
 

@@ -271,6 +271,45 @@ def global_stage_state_dict(seed: int = SEED_DEFAULT, d_model=128, nlayers=8, d_
     return sd
 
 
+def unet_state_dict(seed: int = SEED_DEFAULT, n_channels=1, n_classes=1):
+    """DepthCompletion U-Net (bilinear=False) in the reference's state-dict layout
+    (models/depth_completion_unet.py:79-97): He-scaled conv weights, non-trivial BatchNorm statistics."""
+    sd: "OrderedDict[str, np.ndarray]" = OrderedDict()
+
+    def double(prefix, cin, cout):
+        for ci, bi, a, b in ((0, 1, cin, cout), (3, 4, cout, cout)):
+            sd[f"{prefix}.{ci}.weight"] = f32(math.sqrt(2.0 / (9 * a)) * hash_normal(seed, f"u.{prefix}.{ci}", (b, a, 3, 3)))
+            sd[f"{prefix}.{bi}.weight"] = f32(0.8 + 0.4 * hash_uniform(seed, f"u.{prefix}.{bi}.g", (b,)))
+            sd[f"{prefix}.{bi}.bias"] = f32(-0.1 + 0.2 * hash_uniform(seed, f"u.{prefix}.{bi}.b", (b,)))
+            sd[f"{prefix}.{bi}.running_mean"] = f32(0.1 * hash_normal(seed, f"u.{prefix}.{bi}.m", (b,)))
+            sd[f"{prefix}.{bi}.running_var"] = f32(0.5 + hash_uniform(seed, f"u.{prefix}.{bi}.v", (b,)))
+            sd[f"{prefix}.{bi}.num_batches_tracked"] = np.array(0, dtype=np.int64)
+
+    double("inc.double_conv", n_channels, 64)
+    for k, (a, b) in enumerate(((64, 128), (128, 256), (256, 512), (512, 1024)), start=1):
+        double(f"down{k}.maxpool_conv.1.double_conv", a, b)
+    for k, (a, b) in enumerate(((1024, 512), (512, 256), (256, 128), (128, 64)), start=1):
+        sd[f"up{k}.up.weight"] = f32(math.sqrt(1.0 / a) * hash_normal(seed, f"u.up{k}.w", (a, a // 2, 2, 2)))
+        sd[f"up{k}.up.bias"] = f32(-0.05 + 0.1 * hash_uniform(seed, f"u.up{k}.b", (a // 2,)))
+        double(f"up{k}.conv.double_conv", a, b)
+    sd["outc.conv.weight"] = f32(math.sqrt(1.0 / 64) * hash_normal(seed, "u.outc.w", (n_classes, 64, 1, 1)))
+    sd["outc.conv.bias"] = f32(-0.05 + 0.1 * hash_uniform(seed, "u.outc.b", (n_classes,)))
+    return sd
+
+
+def sparse_depth_map(h: int = 147, w: int = 147, seed: int = SEED_DEFAULT, name: str = "sparse_depth") -> np.ndarray:
+    """[1,1,h,w]: a piecewise-constant depth scene in Z_RANGE with ~60 % of the pixels zeroed, the kind of map
+    local2global_depth + the confidence threshold hand to DepthCompletion (blurry_edges_test.py:140-142)."""
+    yy, xx = np.meshgrid(np.arange(h), np.arange(w), indexing="ij")
+    u = hash_uniform(seed, name + ".p", (6, 4))
+    z = np.full((h, w), Z_RANGE[1], dtype=np.float64)
+    for k in range(6):
+        cy, cx, r = u[k, 0] * h, u[k, 1] * w, (0.1 + 0.25 * u[k, 2]) * min(h, w)
+        z[(yy - cy) ** 2 + (xx - cx) ** 2 < r * r] = Z_RANGE[0] + (Z_RANGE[1] - Z_RANGE[0]) * u[k, 3]
+    keep = hash_uniform(seed, name + ".keep", (h, w)) < 0.4
+    return f32(z * keep)[None, None]
+
+
 def global_features(p: int = 4096, seed: int = SEED_DEFAULT, name: str = "pm") -> np.ndarray:
     """[1,P,38] normalised features in the range blurry_edges_test.py:129-132 produces ([-1,1]-ish)."""
     return f32(-1.0 + 2.0 * hash_uniform(seed, name, (1, p, 38)))

@@ -404,7 +404,7 @@ __global__ void k_pack(PackArgs p) {
 
 // ------------------------------------------------------------------------------------------- pooling / layout
 __global__ void k_maxpool_nhwc(const float* __restrict__ x, float* __restrict__ y, int n, int h, int w, int c4,
-                               int oh, int ow, int k, int stride, int pad) {
+                               int oh, int ow, int k, int stride, int pad, int ldx4) {
     const int64_t total = (int64_t)n * oh * ow * c4;
     const int64_t gs = (int64_t)gridDim.x * blockDim.x;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gs) {
@@ -420,7 +420,7 @@ __global__ void k_maxpool_nhwc(const float* __restrict__ x, float* __restrict__ 
             for (int dx = 0; dx < k; ++dx) {
                 const int xx = ox * stride - pad + dx;
                 if ((unsigned)xx >= (unsigned)w) continue;
-                const float4 v = reinterpret_cast<const float4*>(x)[((img * h + yy) * w + xx) * c4 + cq];
+                const float4 v = reinterpret_cast<const float4*>(x)[((img * h + yy) * w + xx) * ldx4 + cq];
                 m.x = fmaxf(m.x, v.x); m.y = fmaxf(m.y, v.y); m.z = fmaxf(m.z, v.z); m.w = fmaxf(m.w, v.w);
             }
         }
@@ -613,14 +613,20 @@ static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2,
 
 extern "C" int be_maxpool_nhwc_f32(const float* x, float* y, int n, int h, int w, int c, int k, int stride, int pad,
                                    void* stream) {
+    return be_maxpool_nhwc_ld_f32(x, c, y, n, h, w, c, k, stride, pad, stream);
+}
+
+extern "C" int be_maxpool_nhwc_ld_f32(const float* x, int ldx, float* y, int n, int h, int w, int c, int k, int stride,
+                                      int pad, void* stream) {
     BE_REQUIRE(x && y, "be_maxpool_nhwc_f32: null pointer");
     BE_REQUIRE(n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "be_maxpool_nhwc_f32: bad shape (c %% 4 == 0)");
+    BE_REQUIRE(ldx >= c && ldx % 4 == 0 && be::aligned16(x), "be_maxpool_nhwc_f32: ldx must be >= c and a multiple of 4");
     BE_REQUIRE(k > 0 && stride > 0 && pad >= 0 && 2 * pad <= k, "be_maxpool_nhwc_f32: bad window");
     const int oh = (h + 2 * pad - k) / stride + 1, ow = (w + 2 * pad - k) / stride + 1;
     BE_REQUIRE(oh > 0 && ow > 0, "be_maxpool_nhwc_f32: empty output");
     const int64_t total = (int64_t)n * oh * ow * (c / 4);
     hipLaunchKernelGGL(k_maxpool_nhwc, dim3(grid_cap(total, 256)), dim3(256), 0, be::as_stream(stream), x, y, n, h, w,
-                       c / 4, oh, ow, k, stride, pad);
+                       c / 4, oh, ow, k, stride, pad, ldx / 4);
     return be::check_launch("be_maxpool_nhwc_f32");
 }
 

@@ -266,6 +266,9 @@ int be_conv_nhwc_fused2_f32(const be_conv_desc* desc_host, const float* x, const
 /* nn.MaxPool2d(k, stride, pad) on NHWC (models/local_stage.py:42-43). */
 int be_maxpool_nhwc_f32(const float* x, float* y, int n, int h, int w, int c, int k, int stride, int pad,
                         void* stream);
+/* The same pooling reading an input whose rows are ldx floats apart (a channel slice of a wider NHWC tensor). */
+int be_maxpool_nhwc_ld_f32(const float* x, int ldx, float* y, int n, int h, int w, int c, int k, int stride, int pad,
+                           void* stream);
 /* [N,3,21,21] NCHW -> [N,21,21,4] NHWC with a zero 4th channel (input staging of conv1). */
 int be_nchw3_to_nhwc4_f32(const float* x, float* y, int64_t n, int hw, void* stream);
 /* Patches [first, first+n) of a view -> [n,21,21,4] (the staging be_local_stage_forward_view_f32 uses). */
@@ -307,6 +310,19 @@ int be_conv_pack_dgrad_f32(const float* weight_oihw, int cout, int cin, int ksiz
 /* Last Linear (K -> J, J small): dx [M,K], dw [J,K], db [J] from x [M,K], w [J,K], dy [M,J]. */
 int be_linear_small_bwd_f32(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int M,
                             int K, int J, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Depth-completion U-Net glue ('--densify pp', models/depth_completion_unet.py:79-113; blurry_edges_test.py:141-142).
+ * Its convolutions are be_conv_nhwc_f32 launches (3x3 + folded BatchNorm + ReLU; ConvTranspose2d(k=2,s=2) as a 1x1
+ * convolution with 4*cout outputs ordered (dy,dx,co)); these two do the layout work around them.
+ * ------------------------------------------------------------------------------------------------- */
+/* x [N,C,HW] NCHW -> y [N,HW,cpad] NHWC, channels C..cpad-1 zero. */
+int be_nchw_to_nhwc_pad_f32(const float* x, float* y, int64_t n, int c, int64_t hw, int cpad, void* stream);
+/* Pixel shuffle of the transposed convolution into the decoder's concatenated input: t [N,h,w,4*cout] ->
+ * y[n, 2i+dy+top, 2j+dx+left, ch_off+co] of an [N,oh,ow,ldy] tensor (top/left = F.pad offsets diff//2, :63-65;
+ * positions outside are dropped; the caller zero-fills the padding border once). */
+int be_upconv2x2_scatter_f32(const float* t, float* y, int64_t n, int h, int w, int cout, int oh, int ow, int top, int left,
+                             int ldy, int ch_off, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
  * GlobalStage encoder pieces, inference (nn.TransformerEncoderLayer of models/global_stage.py:28-32; the linears

@@ -302,3 +302,31 @@ def test_attention_and_layernorm_kernels_vs_torch(env):
     y = n.add_layernorm(x.to(DEV), r.to(DEV), ga.to(DEV), be_.to(DEV))
     yr = torch.nn.functional.layer_norm((x + r).double(), (128,), ga.double(), be_.double(), 1e-5)
     assert relmax(y.cpu(), yr) <= 2e-6
+
+
+def test_depth_completion_unet_on_gpu_vs_golden_and_oracle(env):
+    """the '--densify pp' U-Net on the HIP conv kernels against the reference module (g13, float64) on the
+    147x147 case, and against the oracle on a batch of two odd-sized maps (F.pad offsets on both axes)."""
+    import models
+    from oracle import unet as ou
+    g = load_golden("g13_unet")
+    m = models.DepthCompletion()
+    m.load_state_dict({k: T(v) if v.dtype != np.int64 else torch.from_numpy(np.asarray(v)) for k, v in synth.unet_state_dict().items()})
+    m = m.to(DEV).eval()
+    y = m(T(synth.sparse_depth_map()).to(DEV))
+    assert tuple(y.shape) == (1, 1, 147, 147)
+    assert relmax(y.cpu(), g["f64_out"]) <= 2e-5
+    x = torch.cat([T(synth.sparse_depth_map(75, 54, name="sd_a")), T(synth.sparse_depth_map(75, 54, name="sd_b"))])
+    sd = {k: T(v, torch.float64) for k, v in synth.unet_state_dict().items() if not k.endswith("num_batches_tracked")}
+    assert relmax(m(x.to(DEV)).cpu(), ou.forward(sd, x.double())) <= 2e-5
+    with pytest.raises(NotImplementedError):
+        models.DepthCompletion(bilinear=True).to(DEV).eval()(x.to(DEV))
+    # --densify pp in the pipeline (blurry_edges_test.py:141-142): the U-Net sees the un-thresholded folded depth map
+    from be_hip.pipeline import DepthPipeline
+    base = _pipeline(env)
+    pp = DepthPipeline(base.local, base.globl, env["helper"], env["dcal"], densify="pp", densify_pp_module=m)
+    img = T(synth.synthetic_image_pair(147, 147)[0]).to(DEV)
+    out = pp(img)
+    assert torch.equal(out["depth_map"], m(out["depth"][None, None])[0, 0]) and torch.equal(out["depth"], base(img)["depth"])
+    with pytest.raises(ValueError):
+        DepthPipeline(base.local, base.globl, env["helper"], env["dcal"], densify="pp")

@@ -135,12 +135,6 @@ def test_training_schedules_match_the_reference_formulas():
     assert g.final() == {k: v[-1] for k, v in g.rng.items()}
 
 
-def test_depth_completion_name_is_importable_but_not_built():
-    import models
-    with pytest.raises(NotImplementedError):
-        models.DepthCompletion()
-
-
 def test_pipeline_big_windows_match_the_reference_block_loop():
     """DepthPipeline.big_windows (host logic of run_big) against golden g8, i.e. the reference's own block loop."""
     from conftest import load_golden
@@ -155,3 +149,17 @@ def test_pipeline_big_windows_match_the_reference_block_loop():
         assert top + 2 * vs == 2 * Vs and left + 2 * hs == 2 * Hs        # same pixels in block and big-image coordinates
         mine[Vs:Vs + ve - vs, Hs:Hs + he - hs] = k * 4096 + local[vs:ve, hs:he]
     assert np.array_equal(mine, code)
+
+
+def test_depth_completion_boundary_state_dict_and_cpu_forward_match_golden():
+    """models.DepthCompletion keeps the reference's constructor, state-dict keys and (on CPU tensors) its arithmetic."""
+    import models
+    from conftest import load_golden, relmax
+    g = load_golden("g13_unet")
+    m = models.DepthCompletion()
+    assert list(m.state_dict().keys()) == [k for k in g["keys"]]
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.unet_state_dict().items()}, strict=True)
+    m.eval()
+    with torch.no_grad():
+        y = m(torch.from_numpy(synth.sparse_depth_map()))
+    assert tuple(y.shape) == (1, 1, 147, 147) and relmax(y, g["f32_out"]) <= 1e-5

@@ -242,3 +242,16 @@ def test_g12_global_stage_oracle_matches_reference_train_mode_graph():
     # all-ones masks with p = 0 are the same function
     ones = [dict(attn=torch.ones(16, 256, 256), d1=torch.ones(512, 128), ff=torch.ones(512, 256), d2=torch.ones(512, 128))] * 8
     assert relmax(ogs.forward(sd, src, pe, 0.0, ones).detach(), g["f64_out"]) <= 1e-12
+
+
+def test_g13_unet_oracle_matches_reference_module():
+    """oracle.unet (index-arithmetic restatement) against the reference's DepthCompletion in eval mode, float64."""
+    from oracle import unet as ou
+    g = load_golden("g13_unet")
+    sd = {k: T(v, torch.float64) for k, v in synth.unet_state_dict().items() if not k.endswith("num_batches_tracked")}
+    assert [k for k in g["keys"]] == list(synth.unet_state_dict().keys())
+    out, xs = ou.forward(sd, T(synth.sparse_depth_map(), torch.float64), want_levels=True)
+    assert relmax(xs[0][0, ::8, ::6, ::6], g["f64_x1_sample"]) <= 1e-12
+    assert relmax(xs[4][0, ::16], g["f64_x5"]) <= 1e-6                       # stored as float32
+    assert relmax(ou.up_block(xs[4], xs[3], sd, "up1")[0, ::16], g["f64_up1_sample"]) <= 1e-12
+    assert relmax(out, g["f64_out"]) <= 1e-11

@@ -401,7 +401,30 @@ def G12():
     save("g12_global_stage_train", **out)
 
 
-GROUPS = dict(G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G8=G8, G9=G9, G10=G10, G11=G11, G12=G12)
+def G13():
+    """DepthCompletion U-Net (eval) on a sparse synthetic depth map: output, bottleneck and first-level activations."""
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.unet_state_dict().items()}
+    x = torch.from_numpy(synth.sparse_depth_map())
+    out = {}
+    for tag, dt in (("f64", torch.float64), ("f32", torch.float32)):
+        m = ref_models.DepthCompletion()
+        m.load_state_dict(sd, strict=True)
+        m = m.to(dt).eval()
+        with torch.no_grad():
+            xin = x.to(dt)
+            x1 = m.inc(xin); x2 = m.down1(x1); x3 = m.down2(x2); x4 = m.down3(x3); x5 = m.down4(x4)
+            u1 = m.up1(x5, x4)
+            y = m(xin)
+        out[tag + "_out"] = n(y).astype(np.float32) if tag == "f32" else n(y)
+        if tag == "f64":
+            out["f64_x1_sample"] = n(x1[0, ::8, ::6, ::6])
+            out["f64_x5"] = n(x5[0, ::16]).astype(np.float32)
+            out["f64_up1_sample"] = n(u1[0, ::16])
+    out["keys"] = np.array(list(m.state_dict().keys()))
+    save("g13_unet", **out)
+
+
+GROUPS = dict(G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G8=G8, G9=G9, G10=G10, G11=G11, G12=G12, G13=G13)
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)

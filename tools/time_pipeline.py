@@ -32,3 +32,13 @@ big = torch.from_numpy(synth.synthetic_image_pair(587, 587, nshape=14)[0]).to(de
 with torch.no_grad():
     t_big, _ = timed(lambda: pipe.run_big(big), n=2)
 print(f"587x587 pair (36 blocks): {t_big:.1f} ms -> {36 * 4096 / t_big * 1e3:.0f} pairs/s")
+
+import models
+unet = models.DepthCompletion()
+unet.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.unet_state_dict().items()})
+unet = unet.to(dev).eval()
+dm = torch.from_numpy(synth.sparse_depth_map()).to(dev)
+t_u, _ = timed(lambda: unet(dm))
+dm8 = dm.expand(8, 1, 147, 147).contiguous()
+t_u8, _ = timed(lambda: unet(dm8))
+print(f"DepthCompletion U-Net 147x147: {t_u:.2f} ms (batch 1), {t_u8:.2f} ms (batch 8)  [30.3 GFLOP per map]")
