@@ -69,6 +69,13 @@ _SIGNATURES = {
     "be_maxpool_nhwc_ld_f32": (C.c_int, [_P, C.c_int, _P] + [C.c_int] * 7 + [_P]),
     "be_nchw_to_nhwc_pad_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int64, C.c_int, _P]),
     "be_upconv2x2_scatter_f32": (C.c_int, [_P, _P, C.c_int64] + [C.c_int] * 9 + [_P]),
+    "be_datagen_scene_f64": (C.c_int, [_P, _P, _P, _P] + [C.c_int] * 4 + [C.c_double] + [_P] * 5),
+    "be_datagen_blur_scratch_bytes": (C.c_size_t, [C.c_int] * 3),
+    "be_datagen_blur_composite_f64": (C.c_int, [_P] * 5 + [C.c_int] * 5 + [_P, _P, C.c_size_t, _P]),
+    "be_datagen_finish_f64": (C.c_int, [_P] * 4 + [C.c_int] * 3 + [_P, C.c_size_t, _P]),
+    "be_datagen_noise_f64": (C.c_int, [_P, _P, C.c_double, C.c_uint32, C.c_int64, C.c_int64, _P, _P, _P]),
+    "be_datagen_candidates_f64": (C.c_int, [_P, _P] + [C.c_int] * 5 + [_P]),
+    "be_datagen_crop_f64": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64] + [C.c_int] * 4 + [_P, _P]),
     "be_attention_train_workspace_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "be_attention_train_fwd_f32": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint32, _P]),
     "be_attention_bwd_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint32, _P]),
@@ -140,15 +147,15 @@ def check(rc: int, what: str = ""):
         raise RuntimeError(f"{what or 'libblurry_edges_hip'} failed ({rc}): {lib().be_last_error().decode()}")
 
 
-def dptr(t: torch.Tensor | None, name: str = "tensor"):
-    """Device pointer of a contiguous fp32 HIP tensor (None -> NULL)."""
+def dptr(t: torch.Tensor | None, name: str = "tensor", dtypes=(torch.float32, torch.int32)):
+    """Device pointer of a contiguous HIP tensor of one of `dtypes` (fp32 unless told otherwise; None -> NULL)."""
     if t is None:
         return None
     if not isinstance(t, torch.Tensor) or not t.is_cuda:
         raise RuntimeError(f"{name}: expected a tensor on the GPU; the HIP path has no CPU fallback "
                            f"(got {type(t).__name__} on {getattr(t, 'device', '?')})")
-    if t.dtype != torch.float32 and t.dtype != torch.int32:
-        raise RuntimeError(f"{name}: expected float32, got {t.dtype}")
+    if t.dtype not in dtypes:
+        raise RuntimeError(f"{name}: expected {' / '.join(str(d) for d in dtypes)}, got {t.dtype}")
     if not t.is_contiguous():
         raise RuntimeError(f"{name}: expected a contiguous tensor")
     return C.c_void_p(t.data_ptr())

@@ -370,6 +370,38 @@ int be_layernorm_bwd_f32(const float* dy, const float* v, const float* gamma, fl
                          int64_t rows, int D, float eps, float dropout_p, uint32_t seed, uint32_t site, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
+ * Synthetic-shape training data (train_val_data_generator.py:31-275).  float64 throughout, the
+ * reference's array layouts.  shape [N,maxo,10] int32 = (kind 0 circle | 1 rectangle | 2 triangle, vertex count,
+ * x0,y0..x3,y3; circle: x0,y0 centre, x1 radius), prop [N,maxo,4] = (depth, c0,c1,c2), objects far -> near,
+ * nobj [N], bg [N,3], sig [N,maxo,2] PSF radius in pixels per aperture (utils/data_generator.py:16-17).
+ * N < 65536, maxo <= 32.
+ * ------------------------------------------------------------------------------------------------- */
+/* aif [N,H,W,3] (colour / 255, as images_aif is stored, :137), bloc [N,H,W] (0/255), idep, bdep [N,H,W]  (:36-41,77-85,100-103). */
+int be_datagen_scene_f64(const int* shape, const double* prop, const int* nobj, const double* bg, int n, int H, int W,
+                         int maxo, double z_far, double* aif, double* bloc, double* idep, double* bdep, void* stream);
+/* imgs [N,2,H,W,3]: background, then every object blurred with its PSF per aperture and alpha-composited (:87-94). */
+size_t be_datagen_blur_scratch_bytes(int n, int H, int W);
+int be_datagen_blur_composite_f64(const int* shape, const double* prop, const int* nobj, const double* bg, const double* sig,
+                                  int n, int H, int W, int maxo, int max_nobj, double* imgs, void* scratch,
+                                  size_t scratch_bytes, void* stream);
+/* imgs <- round(imgs); bdist [N,H,W] city-block distance to the nearest bloc > 0 pixel (ones when there is none);
+ * deri [N,2,H,W,3] Sobel magnitude / 255 with reflected borders (:105-123).  scratch >= N*H*W*4 bytes. */
+int be_datagen_finish_f64(double* imgs, const double* bloc, double* bdist, double* deri, int n, int H, int W, void* scratch,
+                          size_t scratch_bytes, void* stream);
+/* gt = imgs/255*alpha, ny = round(clip(Poisson(gt) + sigma*N(0,1), 0, alpha)) (:165-182); alpha [n], per_sample =
+ * elements per alpha; counter-based streams keyed by (seed, element). */
+int be_datagen_noise_f64(const double* imgs, const double* alpha, double sigma, uint32_t seed, int64_t n, int64_t per_sample,
+                         double* gt, double* ny, void* stream);
+/* cand [N,H,W] uint8: 1 where a boundary pixel lies within `reach` (Chebyshev) and the pixel is >= margin from every
+ * image border (:214-218). */
+int be_datagen_candidates_f64(const double* bloc, unsigned char* cand, int n, int H, int W, int reach, int margin, void* stream);
+/* R x R crops centred on flat pixel indices pick[i] (into [N,H,W]; must respect the margin R/2) of aperture aper[i]:
+ * in6 = aif [N,H,W,3], gt, ny, deri [N,2,H,W,3], idep, bdep [N,H,W]; out9 = aif, gt, ny, deri [P,R,R,3], idep, bdep,
+ * bloc, bdist (in-patch city-block distance) [P,R,R], alpha [P]  (:226-252). */
+int be_datagen_crop_f64(const double* const* in6, const double* bloc, const double* alpha, const int64_t* pick, const int* aper,
+                        int64_t n_patch, int n, int H, int W, int R, double* const* out9, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------
  * Measurement hooks (bench.py's roofline leg): opt-in hipEvent pair around every conv launch, recorded on
  * the launch stream.  be_profile_enable(0) turns it off and frees the events.  Not thread-safe.
  * ------------------------------------------------------------------------------------------------- */

@@ -330,3 +330,83 @@ def test_depth_completion_unet_on_gpu_vs_golden_and_oracle(env):
     assert torch.equal(out["depth_map"], m(out["depth"][None, None])[0, 0]) and torch.equal(out["depth"], base(img)["depth"])
     with pytest.raises(ValueError):
         DepthPipeline(base.local, base.globl, env["helper"], env["dcal"], densify="pp")
+
+
+def test_datagen_on_gpu_vs_oracle_and_reference_golden(env):
+    """the GPU generator against golden g14 (the reference's generate_synthetic_image on the same three
+    scenes) and, on six more scenes, against the oracle restatement; noise statistics; patch crops."""
+    from be_hip import datagen as dg
+    from oracle import datagen as odg
+    g = load_golden("g14_datagen")
+    sc = dg.draw_scenes(3, seed=1869)
+    d = dg.generate(sc, DEV, seed=11)
+    H = W = 147
+    for i in range(3):
+        assert np.array_equal(d["images_aif"][i].cpu().numpy(), g[f"aif{i}"].astype(np.float64) / 255)
+        assert np.array_equal(d["boundary_locations"][i].cpu().numpy().astype(np.uint8), g[f"bloc{i}"])
+        assert np.array_equal(d["boundary_distances"][i].cpu().numpy().astype(np.int16), g[f"bdist{i}"])
+        assert np.array_equal(d["image_depths"][i].cpu().numpy().astype(np.float32), g[f"idep{i}"])
+        assert np.array_equal(d["boundary_depths"][i].cpu().numpy().astype(np.float32), g[f"bdep{i}"])
+        diff = np.abs(d["images"][i].cpu().numpy() - g[f"imgs{i}"].astype(np.float64))
+        assert diff.max() <= 1 and (diff > 0).mean() <= 1e-4, (diff.max(), (diff > 0).mean())     # x.5 rounding ties only
+        same = (diff == 0).all(axis=-1)
+        same = same & np.roll(same, 1, 1) & np.roll(same, -1, 1) & np.roll(same, 1, 2) & np.roll(same, -1, 2)
+        dd = np.abs(d["derivative_maps"][i].cpu().numpy() - g[f"deri{i}"])[same]
+        assert dd.max() <= 1e-6
+    sc2 = dg.draw_scenes(6, seed=77, name="other")
+    d2 = dg.generate(sc2, DEV, seed=12)
+    sig = dg.kernel_sigmas(sc2["prop"], sc2["nobj"])
+    for i in range(6):
+        r = odg.generate_image(sc2["shape"][i], sc2["prop"][i], sc2["nobj"][i], sc2["bg"][i], sig[i], H, W, 1.18)
+        assert np.array_equal(d2["boundary_locations"][i].cpu().numpy(), r["boundary_loc"])
+        assert np.array_equal(d2["boundary_distances"][i].cpu().numpy(), r["boundary_dist"])
+        assert np.array_equal(d2["boundary_depths"][i].cpu().numpy(), r["boundary_depth"])
+        diff = np.abs(d2["images"][i].cpu().numpy() - r["imgs"])
+        assert diff.max() <= 1 and (diff > 0).mean() <= 1e-4
+        assert odg.candidates(r["boundary_loc"]).sum() > 0
+    # noise model: gt exact; ny integer-valued in [0, alpha]; mean / variance of (ny - gt) as Poisson + read noise predict
+    al = d2["alphas"].view(-1, 1, 1, 1, 1)
+    assert np.array_equal(d2["images_gt"].cpu().numpy(), d2["images"].cpu().numpy() / 255 * al.cpu().numpy())   # numpy divides
+    ny, gt = d2["images_ny"], d2["images_gt"]
+    assert torch.equal(ny, ny.round()) and float(ny.min()) >= 0 and bool((ny <= torch.ceil(al)).all())     # clip, THEN round
+    mid = (gt > 20) & (gt < al - 40)                      # away from the clipping at 0 and alpha
+    e = (ny - gt)[mid]
+    assert abs(float(e.mean())) < 0.05 and abs(float((e ** 2).mean()) / float((gt[mid] + 4.0 + 1 / 12).mean()) - 1) < 0.02
+    low = gt < 5                                          # the small-lambda branch of the Poisson sampler
+    if int(low.sum()) > 1000:
+        k = torch.clamp(ny[low], min=0)
+        assert abs(float(k.mean()) - float(torch.clamp(gt[low], min=0).mean())) < 0.6      # clipping at 0 biases upward a little
+    # patches: candidates as the oracle's, windows copied verbatim, in-patch distance transform as the oracle's
+    pt = dg.crop_patches(d2, 12, seed=5)
+    cand = np.stack([odg.candidates(d2["boundary_locations"][i].cpu().numpy()) for i in range(6)])
+    flat = pt["index"].cpu().numpy()
+    assert cand.reshape(-1)[flat].all() and len(set(flat.tolist())) == 12
+    for p_ in range(12):
+        im, cy, cx = flat[p_] // (H * W), (flat[p_] // W) % H, flat[p_] % W
+        ap = int(pt["aperture"][p_])
+        win = (slice(cy - 10, cy + 11), slice(cx - 10, cx + 11))
+        assert torch.equal(pt["patches_ny"][p_], d2["images_ny"][im, ap][win])
+        assert torch.equal(pt["patches_aif"][p_], d2["images_aif"][im][win])
+        bl = d2["boundary_locations"][im][win].cpu().numpy()
+        assert np.array_equal(pt["boundary_locations"][p_].cpu().numpy(), bl)
+        assert np.array_equal(pt["boundary_distances"][p_].cpu().numpy(), odg.l1_distance(bl > 0))
+        assert float(pt["alphas"][p_]) == float(d2["alphas"][im])
+
+
+def test_datagen_files_feed_the_local_training_dataset(env, tmp_path):
+    """generate -> crop -> save -> data.ShapeDataset: the .npy wire format either side of training."""
+    import data
+    from be_hip import datagen as dg
+    sc = dg.draw_scenes(8, seed=3, name="files")
+    d = dg.generate(sc, DEV, seed=3)
+    p = dg.crop_patches(d, 16, seed=3)
+    dg.save(d, p, str(tmp_path), "train")
+    ds = data.ShapeDataset(DEV, data_path=str(tmp_path / "patches"), train=True, mode="local")
+    assert len(ds) == 16
+    ny, gt, bd, de = ds[5]
+    assert tuple(ny.shape) == (21, 21, 3) and tuple(de.shape) == (19, 19, 3) and ny.is_cuda
+    assert torch.allclose(gt, (p["patches_gt"][5] / p["alphas"][5]).float()) and float(gt.max()) <= 1.0 + 1e-6
+    assert torch.equal(bd, p["boundary_distances"][5].float())
+    g = data.ShapeDataset(DEV, data_path=str(tmp_path), train=True, mode="global_pre")
+    assert len(g) == 8 and tuple(g[0].shape) == (2, 147, 147, 3)
+    assert np.load(tmp_path / "images_ny_train.npy").dtype == np.float64

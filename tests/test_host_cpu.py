@@ -163,3 +163,38 @@ def test_depth_completion_boundary_state_dict_and_cpu_forward_match_golden():
     with torch.no_grad():
         y = m(torch.from_numpy(synth.sparse_depth_map()))
     assert tuple(y.shape) == (1, 1, 147, 147) and relmax(y, g["f32_out"]) <= 1e-5
+
+
+def test_shape_dataset_and_test_dataset_read_the_generator_file_layout(tmp_path):
+    """data.ShapeDataset / TestDataset over hand-made .npy files with the generator's names (data/dataset.py:6-73)."""
+    import data
+    rng = np.random.default_rng(0)
+    n, R = 5, 21
+    al = rng.uniform(180, 200, n)
+    files = dict(patches_ny=rng.integers(0, 200, (n, R, R, 3)).astype(np.float64), patches_gt=rng.uniform(0, 200, (n, R, R, 3)),
+                 alphas=al, boundary_distances=rng.integers(0, 9, (n, R, R)).astype(np.float64),
+                 derivative_maps=rng.uniform(0, 1, (n, R, R, 3)))
+    for k, v in files.items():
+        np.save(tmp_path / f"{k}_val.npy", v)
+    ds = data.ShapeDataset("cpu", data_path=str(tmp_path), train=False, mode="local")
+    assert len(ds) == n
+    ny, gt, bd, de = ds[3]
+    assert ny.dtype == torch.float32 and tuple(de.shape) == (19, 19, 3) and tuple(bd.shape) == (R, R)
+    assert torch.allclose(ny, torch.from_numpy(files["patches_ny"][3]).float() / float(np.float32(al[3])))
+    assert torch.equal(de, torch.from_numpy(files["derivative_maps"][3, 1:-1, 1:-1]).float())
+    H = 31
+    g = dict(params_src=rng.normal(size=(n, 36, 38)), images_ny=rng.uniform(0, 200, (n, 2, H, H, 3)),
+             images_gt=rng.uniform(0, 200, (n, 2, H, H, 3)), derivative_maps=rng.uniform(0, 1, (n, 2, H, H, 3)),
+             boundary_distances=rng.uniform(0, 9, (n, H, H)), boundary_depths=rng.uniform(0, 1, (n, H, H)), alphas=al)
+    for k, v in g.items():
+        np.save(tmp_path / f"{k}_train.npy", v)
+    dg_ = data.ShapeDataset("cpu", data_path=str(tmp_path), train=True, mode="global")
+    pm, ny, gt, bd, de, bdep = dg_[1]
+    assert tuple(pm.shape) == (36, 38) and tuple(de.shape) == (2, H - 2, H - 2, 3) and tuple(bdep.shape) == (H, H)
+    assert tuple(data.ShapeDataset("cpu", data_path=str(tmp_path), train=True, mode="global_pre")[0].shape) == (2, H, H, 3)
+    for k, v in dict(images_ny=g["images_ny"], depth_maps=rng.uniform(0.7, 1.2, (n, H, H)), alphas=al).items():
+        np.save(tmp_path / f"{k}.npy", v)
+    img, dep = data.TestDataset("cpu", data_path=str(tmp_path))[2]
+    assert tuple(img.shape) == (2, H, H, 3) and tuple(dep.shape) == (H, H)
+    with pytest.raises(ValueError):
+        data.ShapeDataset("cpu", data_path=str(tmp_path), mode="nope")

@@ -255,3 +255,31 @@ def test_g13_unet_oracle_matches_reference_module():
     assert relmax(xs[4][0, ::16], g["f64_x5"]) <= 1e-6                       # stored as float32
     assert relmax(ou.up_block(xs[4], xs[3], sd, "up1")[0, ::16], g["f64_up1_sample"]) <= 1e-12
     assert relmax(out, g["f64_out"]) <= 1e-11
+
+
+def test_g14_datagen_oracle_matches_reference_generator():
+    """oracle.datagen.generate_image against the reference's generate_synthetic_image on three replayed scenes (same
+    scene parameters, same rasterisation rule), and DataGenerator's PSF helpers."""
+    from be_hip import datagen as dg
+    from oracle import datagen as odg
+    import utils
+    g = load_golden("g14_datagen")
+    a = utils.get_args("data_gen_train_val", argv=[])
+    scenes = dg.draw_scenes(3, seed=1869, img_size=tuple(a.img_size), num_shape=tuple(a.num_shape), z_range=tuple(a.Z_range))
+    sig = dg.kernel_sigmas(scenes["prop"], scenes["nobj"])
+    H, W = a.img_size
+    for i in range(3):
+        r = odg.generate_image(scenes["shape"][i], scenes["prop"][i], scenes["nobj"][i], scenes["bg"][i], sig[i], H, W, a.Z_range[1])
+        assert np.array_equal(r["imgs"].astype(np.uint8), g[f"imgs{i}"]) and np.array_equal(r["aif"].astype(np.uint8), g[f"aif{i}"])
+        assert np.array_equal(r["boundary_loc"].astype(np.uint8), g[f"bloc{i}"])
+        assert np.array_equal(r["boundary_dist"].astype(np.int16), g[f"bdist{i}"])
+        assert np.array_equal(r["image_depth"].astype(np.float32), g[f"idep{i}"])
+        assert np.array_equal(r["boundary_depth"].astype(np.float32), g[f"bdep{i}"])
+        assert np.array_equal(r["deri"].astype(np.float32), g[f"deri{i}"])
+        assert 0.02 < (r["boundary_loc"] > 0).mean() < 0.3                   # the scenes are not degenerate
+    gen = utils.DataGenerator(a)
+    zs = np.array([0.75, 0.9, 1.0, 1.18])
+    assert np.allclose(np.stack([gen.get_kernel_sigma(z) for z in zs]), g["sigmas"], rtol=1e-15, atol=0)
+    assert np.allclose(gen.get_blur_kernel(2.0), g["kernel_s2"], rtol=1e-14, atol=1e-300)
+    assert np.array_equal(gen.get_blur_kernel(0.0), g["kernel_tiny"])
+    assert np.allclose(odg.blur_kernel(2.0), g["kernel_s2"], rtol=1e-15, atol=0)

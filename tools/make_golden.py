@@ -424,7 +424,70 @@ def G13():
     save("g13_unet", **out)
 
 
-GROUPS = dict(G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G8=G8, G9=G9, G10=G10, G11=G11, G12=G12, G13=G13)
+def G14():
+    """Synthetic-shape generator: the reference's generate_synthetic_image run on 3 replayed scenes.
+    np.random is replayed from be_hip.datagen.draw_scenes' `raw` record (same draws, same order) and the three cv2 drawing
+    calls are served by oracle.datagen.Cv2Stub (the build's rasterisation rule); dilation, PSF blur, compositing,
+    distance transform and Sobel maps are the reference's own code.  Also DataGenerator's kernel helpers."""
+    import importlib
+    from be_hip import datagen as dg
+    od = importlib.machinery.SourceFileLoader("oracle_datagen", os.path.join(ROOT, "oracle", "datagen.py")).load_module()
+    stub = sys.modules["cv2"]
+    for k in ("circle", "boxPoints", "drawContours", "imwrite"):
+        setattr(stub, k, getattr(od.Cv2Stub, k))
+    sys.modules.setdefault("tqdm", types.ModuleType("tqdm"))
+    if not hasattr(sys.modules["tqdm"], "tqdm"):
+        sys.modules["tqdm"].tqdm = lambda it, **k: it
+    ref_gen = importlib.import_module("train_val_data_generator")
+    argv, sys.argv = sys.argv, ["x"]
+    try:
+        a = ref_utils.get_args("data_gen_train_val")
+    finally:
+        sys.argv = argv
+    gen = ref_gen.SyntheticShapeDataGenerator(a)
+    scenes = dg.draw_scenes(3, seed=1869, img_size=tuple(a.img_size), num_shape=tuple(a.num_shape), z_range=tuple(a.Z_range))
+
+    class Replay:
+        def __init__(self, raw):
+            self.q = [("randint", raw["bg"]), ("randint", raw["kind_col"]), ("uniform", raw["z"]), ("uniform", raw["ctr"])]
+            # the reference sorts only the depths (far first); kind / colour / centre / per-object draws keep their
+            # row, which is how draw_scenes pairs them
+            self.per = list(raw["per_obj"])
+
+        def randint(self, low, high=None, size=None):
+            if self.q and self.q[0][0] == "randint":
+                return self.q.pop(0)[1]
+            return self.per.pop(0)
+
+        def uniform(self, low, high=None, size=None):
+            if self.q and self.q[0][0] == "uniform":
+                return self.q.pop(0)[1]
+            return self.per.pop(0)
+
+    out = {}
+    real_randint, real_uniform = np.random.randint, np.random.uniform
+    for i in range(3):
+        rp = Replay(scenes["raw"][i])
+        np.random.randint, np.random.uniform = rp.randint, rp.uniform
+        try:
+            imgs, aif, bloc, idep, bdep, bdist, deri = gen.generate_synthetic_image(int(scenes["nobj"][i]))
+        finally:
+            np.random.randint, np.random.uniform = real_randint, real_uniform
+        assert not rp.q and not rp.per
+        out[f"imgs{i}"] = imgs.astype(np.uint8)
+        out[f"aif{i}"] = aif.astype(np.uint8)
+        out[f"bloc{i}"] = bloc.astype(np.uint8)
+        out[f"idep{i}"], out[f"bdep{i}"] = idep.astype(np.float32), bdep.astype(np.float32)
+        out[f"bdist{i}"] = bdist.astype(np.int16)
+        out[f"deri{i}"] = deri.astype(np.float32)
+    zs = np.array([0.75, 0.9, 1.0, 1.18])
+    out["sigmas"] = np.stack([gen.get_kernel_sigma(z) for z in zs])
+    out["kernel_s2"] = gen.get_blur_kernel(2.0)
+    out["kernel_tiny"] = gen.get_blur_kernel(0.0)
+    save("g14_datagen", **out)
+
+
+GROUPS = dict(G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G8=G8, G9=G9, G10=G10, G11=G11, G12=G12, G13=G13, G14=G14)
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)
