@@ -91,7 +91,10 @@ class DepthPipeline:
         return out
 
     @torch.no_grad()
-    def run_big(self, img, block=147, n_margin=10):
+    def run_big(self, img, block=147, n_margin=10, rank=0, world=1, group=None):
+        """rank / world: this process handles the blocks shard.my_blocks gives it; the record grid is completed with one
+        all-reduce (shard.assemble_records) and every rank folds the full image.  world = 1: no communication."""
+        from . import shard
         img = img.contiguous()
         _, _, H, W = img.shape
         s, R = self.stride, native.BE_R
@@ -99,11 +102,15 @@ class DepthPipeline:
         HP, WP = (H - R) // s + 1, (W - R) // s + 1                                 # 284
         # blocks are windows of the big image: no cropped copies, no unfolded copies
         big = torch.zeros(HP * WP, native.RECORD_FLOATS, dtype=torch.float32, device=img.device).view(HP, WP, -1)
-        for win, (vs, ve, hs, he), (Vs, Hs) in self.big_windows(H, W, block, n_margin, s, R):
+        wins = self.big_windows(H, W, block, n_margin, s, R)
+        for k in shard.my_blocks(len(wins), rank, world):
+            win, (vs, ve, hs, he), (Vs, Hs) = wins[k]
             _, _, _, pm = self.local_pass(img, win)
             est12 = self.global_pass(pm)
             rec, _ = self.records(est12, img, window=win)
             big[Vs:Vs + ve - vs, Hs:Hs + he - hs] = rec.view(hp, hp, -1)[vs:ve, hs:he]
+        if world > 1:
+            big = shard.assemble_records(big, group)
         maps = native.fold_records(self.helper.render_opts(False), big.view(HP * WP, -1), HP, WP, H, W, s, self.densify == "w")
         maps["depth_map"] = torch.where(maps["conf"] > 0.05, maps["depth"], torch.zeros_like(maps["depth"]))
         return maps

@@ -38,3 +38,28 @@ def gather_pairs(local: torch.Tensor, n_pairs: int, group=None) -> torch.Tensor:
     out = [torch.empty_like(buf) for _ in range(world)]
     dist.all_gather(out, buf, group=group)
     return torch.cat([o[:s] for o, s in zip(out, sizes)], dim=0)
+
+
+# ---- big-image tiler ("tiled image"): shard by 147x147 block --------------------------------------------
+
+def block_owner(block_index: int, world: int) -> int:
+    """Blocks are dealt round-robin: neighbouring blocks (which share margin patches and cost the same) land on
+    different ranks, so every rank gets ceil/floor(36/world) blocks of a 587x587 image."""
+    return block_index % world
+
+
+def my_blocks(n_blocks: int, rank: int, world: int):
+    if not (0 <= rank < world):
+        raise ValueError(f"rank {rank} outside world {world}")
+    return [k for k in range(n_blocks) if block_owner(k, world) == rank]
+
+
+def assemble_records(big_local: torch.Tensor, group=None) -> torch.Tensor:
+    """big_local [HP,WP,32]: the record grid with this rank's kept block windows filled and zeros elsewhere.
+    The kept windows of the 36 blocks tile the grid exactly once (golden g8), so ONE sum all-reduce (10.3 MB for
+    284x284 records of 128 B; x + 0 is exact) gives every rank the full grid, and each rank then folds it.
+    GlobalStage's attention couples the 4096 tokens of a block, so a block is never split across ranks."""
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(big_local, op=dist.ReduceOp.SUM, group=group)
+    return big_local

@@ -57,3 +57,51 @@ def test_two_rank_shard_and_gather_matches_single_process(n_pairs):
     params = torch.from_numpy(synth.plausible_params10(2 * n_pairs, name="shard"))
     ref = orr.local_depth(od.depth_consts(), params[:n_pairs], params[n_pairs:]).numpy()
     assert np.array_equal(got, ref)
+
+
+def _tiler_worker(rank, world, port, q):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from be_hip import shard
+    from be_hip.pipeline import DepthPipeline
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    wins = DepthPipeline.big_windows(587, 587)
+    big = torch.zeros(284, 284, 32)
+    for k in shard.my_blocks(len(wins), rank, world):
+        _, (vs, ve, hs, he), (Vs, Hs) = wins[k]
+        rec = _fake_block_records(k)                       # stands in for CNN + GlobalStage + pass B of block k
+        big[Vs:Vs + ve - vs, Hs:Hs + he - hs] = rec[vs:ve, hs:he]
+    big = shard.assemble_records(big)
+    if rank == 0:
+        q.put(big.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _fake_block_records(k):
+    g = torch.Generator().manual_seed(1000 + k)
+    return torch.randn(64, 64, 32, generator=g)
+
+
+def test_two_rank_big_image_block_sharding_assembles_the_full_record_grid():
+    """SURVEY 8e (tiled image): 36 blocks dealt over 2 gloo ranks, one sum all-reduce, result = single-process grid."""
+    from be_hip import shard
+    from be_hip.pipeline import DepthPipeline
+    assert shard.my_blocks(36, 1, 8) == [1, 9, 17, 25, 33] and sorted(sum((shard.my_blocks(36, r, 8) for r in range(8)), [])) == list(range(36))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_tiler_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=120)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = torch.zeros(284, 284, 32)
+    for k, (_, (vs, ve, hs, he), (Vs, Hs)) in enumerate(DepthPipeline.big_windows(587, 587)):
+        ref[Vs:Vs + ve - vs, Hs:Hs + he - hs] = _fake_block_records(k)[vs:ve, hs:he]
+    assert np.array_equal(got, ref.numpy())
