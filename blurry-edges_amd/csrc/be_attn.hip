@@ -33,6 +33,9 @@ __host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
 __host__ __device__ __forceinline__ uint32_t site_key(uint32_t seed, uint32_t site) {
     return mix32(seed + 0x9e3779b9U * (site + 1U));
 }
+// raw v_exp_f32: exp2f() wraps it in denormal-range scaling (5 instructions); results below 2^-126 flush to zero here,
+// which a softmax weight may
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 inline uint32_t drop_threshold(float p) { return p <= 0.f ? 0U : (uint32_t)((double)p * 4294967296.0); }
 
 // qkv [T, 3*D] (token-major rows from the in-projection) -> Q [BH][L][16] (pre-scaled by scale*log2 e),
@@ -127,7 +130,8 @@ void k_attention(const float* __restrict__ Q, const float* __restrict__ K, const
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[r] = 0.f;
     float m = -INFINITY, lsum = 0.f;
-    const bool vrow = j < DH;                              // lanes 16..31 of each half feed zero rows of V^T
+    const int jd = j & (DH - 1);        // lanes 16..31 of each half feed accumulator rows >= 16, which are never stored:
+                                        // they re-read rows 0..15 instead of being masked
 
     // prefetch block 0
     f32x4 ka = *reinterpret_cast<const f32x4*>(Kh + (size_t)j * DH + 8 * h);
@@ -135,7 +139,7 @@ void k_attention(const float* __restrict__ Q, const float* __restrict__ K, const
     f32x4 vt[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g)
-        vt[g] = vrow ? *reinterpret_cast<const f32x4*>(Vh + (size_t)j * L + 8 * g + 4 * h) : f32x4{0.f, 0.f, 0.f, 0.f};
+        vt[g] = *reinterpret_cast<const f32x4*>(Vh + (size_t)jd * L + 8 * g + 4 * h);
 
     const int nkb = L / KB;
     for (int kblk = 0; kblk < nkb; ++kblk) {
@@ -147,8 +151,7 @@ void k_attention(const float* __restrict__ Q, const float* __restrict__ K, const
         kb = *reinterpret_cast<const f32x4*>(Kh + (size_t)(kn * KB + j) * DH + 8 * h + 4);
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-            vt[g] = vrow ? *reinterpret_cast<const f32x4*>(Vh + (size_t)j * L + kn * KB + 8 * g + 4 * h)
-                         : f32x4{0.f, 0.f, 0.f, 0.f};
+            vt[g] = *reinterpret_cast<const f32x4*>(Vh + (size_t)jd * L + kn * KB + 8 * g + 4 * h);
 
         // S^T[key][query] (log2 units: Q carries scale*log2 e)
         f32x16 s;
@@ -163,11 +166,11 @@ void k_attention(const float* __restrict__ Q, const float* __restrict__ K, const
         for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
         mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
         const float mnew = fmaxf(m, mloc);
-        const float alpha = exp2f(m - mnew);
+        const float alpha = fast_exp2(m - mnew);
         m = mnew;
         float psum = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = exp2f(s[r] - mnew); psum += s[r]; }
+        for (int r = 0; r < 16; ++r) { s[r] = fast_exp2(s[r] - mnew); psum += s[r]; }
         lsum = lsum * alpha + psum;
         if (TRAIN && thresh) {
             const uint32_t hkey = site_key(seed, (uint32_t)bh);
@@ -231,8 +234,7 @@ void k_attn_bwd_dq(const float* __restrict__ Q, const float* __restrict__ K, con
     f32x16 dq;
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq[r] = 0.f;
-    const bool drow = j < DH;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const int jd = j & (DH - 1);        // rows >= 16 of dQ^T are never stored: those lanes re-read rows 0..15
 
     f32x4 ka = *reinterpret_cast<const f32x4*>(Kh + (size_t)j * DH + 8 * h);
     f32x4 kb = *reinterpret_cast<const f32x4*>(Kh + (size_t)j * DH + 8 * h + 4);
@@ -240,7 +242,7 @@ void k_attn_bwd_dq(const float* __restrict__ Q, const float* __restrict__ K, con
     f32x4 vb = *reinterpret_cast<const f32x4*>(Vh + (size_t)j * DH + 8 * h + 4);
     f32x4 kt[4];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) kt[g] = drow ? *reinterpret_cast<const f32x4*>(Kth + (size_t)j * L + 8 * g + 4 * h) : zero4;
+    for (int g = 0; g < 4; ++g) kt[g] = *reinterpret_cast<const f32x4*>(Kth + (size_t)jd * L + 8 * g + 4 * h);
 
     const int nkb = L / KB;
     for (int kblk = 0; kblk < nkb; ++kblk) {
@@ -254,7 +256,7 @@ void k_attn_bwd_dq(const float* __restrict__ Q, const float* __restrict__ K, con
         vb = *reinterpret_cast<const f32x4*>(Vh + (size_t)(kn * KB + j) * DH + 8 * h + 4);
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-            kt[g] = drow ? *reinterpret_cast<const f32x4*>(Kth + (size_t)j * L + kn * KB + 8 * g + 4 * h) : zero4;
+            kt[g] = *reinterpret_cast<const f32x4*>(Kth + (size_t)jd * L + kn * KB + 8 * g + 4 * h);
 
         f32x16 s, dp;
 #pragma unroll
@@ -266,7 +268,7 @@ void k_attn_bwd_dq(const float* __restrict__ Q, const float* __restrict__ K, con
         const uint32_t base = (uint32_t)(q0 + j) * (uint32_t)L + (uint32_t)(kblk * KB + 4 * h);
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float p = exp2f(s[r] - lse_q);
+            const float p = fast_exp2(s[r] - lse_q);
             float g = dp[r] * inv_keep;
             if (thresh && mix32((base + (r & 3) + 8 * (r >> 2)) ^ hkey) < thresh) g = 0.f;
             s[r] = p * (g - d_q);
@@ -312,8 +314,7 @@ void k_attn_bwd_dkv(const float* __restrict__ Q, const float* __restrict__ K, co
     f32x16 dv, dk;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dv[r] = 0.f; dk[r] = 0.f; }
-    const bool drow = j < DH;
-    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const int jd = j & (DH - 1);        // rows >= 16 of dV^T / dK^T are never stored: those lanes re-read rows 0..15
 
     f32x4 qa = *reinterpret_cast<const f32x4*>(Qh + (size_t)j * DH + 8 * h);
     f32x4 qb = *reinterpret_cast<const f32x4*>(Qh + (size_t)j * DH + 8 * h + 4);
@@ -322,8 +323,8 @@ void k_attn_bwd_dkv(const float* __restrict__ Q, const float* __restrict__ K, co
     f32x4 qt[4], gt[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        qt[g] = drow ? *reinterpret_cast<const f32x4*>(Qth + (size_t)j * L + 8 * g + 4 * h) : zero4;
-        gt[g] = drow ? *reinterpret_cast<const f32x4*>(Gth + (size_t)j * L + 8 * g + 4 * h) : zero4;
+        qt[g] = *reinterpret_cast<const f32x4*>(Qth + (size_t)jd * L + 8 * g + 4 * h);
+        gt[g] = *reinterpret_cast<const f32x4*>(Gth + (size_t)jd * L + 8 * g + 4 * h);
     }
 
     const int nqb = L / KB;
@@ -345,8 +346,8 @@ void k_attn_bwd_dkv(const float* __restrict__ Q, const float* __restrict__ K, co
         gb = *reinterpret_cast<const f32x4*>(Gh + (size_t)(qn * KB + j) * DH + 8 * h + 4);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            qt[g] = drow ? *reinterpret_cast<const f32x4*>(Qth + (size_t)j * L + qn * KB + 8 * g + 4 * h) : zero4;
-            gt[g] = drow ? *reinterpret_cast<const f32x4*>(Gth + (size_t)j * L + qn * KB + 8 * g + 4 * h) : zero4;
+            qt[g] = *reinterpret_cast<const f32x4*>(Qth + (size_t)jd * L + qn * KB + 8 * g + 4 * h);
+            gt[g] = *reinterpret_cast<const f32x4*>(Gth + (size_t)jd * L + qn * KB + 8 * g + 4 * h);
         }
 
         f32x16 s, dp;
@@ -359,7 +360,7 @@ void k_attn_bwd_dkv(const float* __restrict__ Q, const float* __restrict__ K, co
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int g = r >> 2, c = r & 3;
-            const float p = exp2f(s[r] - ls[g][c]);
+            const float p = fast_exp2(s[r] - ls[g][c]);
             float pd = p, gd = dp[r] * inv_keep;
             if (thresh) {
                 const uint32_t idx = (uint32_t)(qblk * KB + 8 * g + 4 * h + c) * (uint32_t)L + (uint32_t)(k0 + j);
