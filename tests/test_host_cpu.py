@@ -198,3 +198,27 @@ def test_shape_dataset_and_test_dataset_read_the_generator_file_layout(tmp_path)
     assert tuple(img.shape) == (2, H, H, 3) and tuple(dep.shape) == (H, H)
     with pytest.raises(ValueError):
         data.ShapeDataset("cpu", data_path=str(tmp_path), mode="nope")
+
+
+def test_drawing_helpers_keep_the_reference_names(tmp_path, monkeypatch):
+    """utils.showCurve / utils.Visualizer: what local_training.py:120 and blurry_edges_test.py:157-168,202 import.
+    cv2 is not installed here: a four-function stand-in checks the sheet geometry (10 panels of img_size*scale)."""
+    import sys
+    import types
+    import utils
+    a = types.SimpleNamespace(log_path=str(tmp_path))
+    utils.showCurve(a, np.array([1.0, 0.5, 0.25, 0.2]), "curve")
+    assert (tmp_path / "curve.png").stat().st_size > 1000
+    calls = []
+    cv2 = types.ModuleType("cv2")
+    cv2.COLORMAP_RAINBOW, cv2.INTER_NEAREST, cv2.FONT_HERSHEY_SIMPLEX = 4, 0, 0
+    cv2.applyColorMap = lambda img, cmap: np.repeat(np.asarray(img)[..., None] if np.asarray(img).ndim == 2 else np.asarray(img), 3, axis=-1)[..., :3]
+    cv2.resize = lambda img, size, interpolation=0: np.asarray(img)[(np.arange(size[1]) * np.asarray(img).shape[0] // size[1])][:, (np.arange(size[0]) * np.asarray(img).shape[1] // size[0])]
+    cv2.putText = lambda canvas, txt, org, *rest: calls.append(txt)
+    monkeypatch.setitem(sys.modules, "cv2", cv2)
+    v = utils.Visualizer(10.39, img_size=8, scale=2)
+    assert v.canvas_blank.shape == ((2 * 8 + 60) * 2, (5 * 8 + 25 + 40) * 2, 3) and "Estimated depth map" in calls
+    rgb = np.full((8, 8, 3), 0.5)
+    sheet = v.visualize(rgb, rgb, rgb, rgb, rgb, rgb, np.ones((8, 8)), np.zeros((8, 8)), np.full((8, 8), 0.9), np.full((8, 8), 0.9))
+    assert sheet.dtype == np.uint8 and sheet.shape == v.canvas_blank.shape
+    assert (sheet[40:56, 0:16] == 127).all() and (sheet[40:56, (3 * 13) * 2:(3 * 13) * 2 + 16] == 255).all()   # input panel, confidence panel
