@@ -82,6 +82,8 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+    if local_rank >= torch.cuda.device_count() >= 1:
+        local_rank = 0                             # the launcher masked the devices: each rank sees only its own GPU
     dist = None
     if world > 1:
         import torch.distributed as dist
