@@ -62,6 +62,7 @@ _SIGNATURES = {
     "be_conv_packed_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "be_conv_pack_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "be_conv_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, C.c_int, _P]),
+    "be_conv_nhwc_splitk_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, C.c_int, _P, C.c_size_t, _P]),
     "be_conv_fused2_packed_floats": (C.c_size_t, [C.c_int] * 4),
     "be_conv_pack_fused2_f32": (C.c_int, [_P] * 12 + [C.c_float] + [C.c_int] * 4 + [_P, _P, _P]),
     "be_conv_nhwc_fused2_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, C.c_int, _P, _P, _P, C.c_int, _P]),
@@ -258,11 +259,16 @@ def conv_pack(weight, bias, bn=None, eps=1e-5, chw_hw=0):
     return pw, pb
 
 
-def conv_nhwc(x, pw, pb, cout, ksize, act, residual=None, out=None):
-    """x [N,H,W,Cin] NHWC -> [N,H,W,cout]; out = a [N,H,W,ld] tensor whose first cout channels receive the result."""
+def conv_nhwc(x, pw, pb, cout, ksize, act, residual=None, out=None, scratch=None):
+    """x [N,H,W,Cin] NHWC -> [N,H,W,cout]; out = a [N,H,W,ld] tensor whose first cout channels receive the result;
+    scratch = a float32 buffer the library may use to split the K loop of small launches (training)."""
     n, h, w, cin = x.shape
     y = torch.empty(n, h, w, cout, dtype=torch.float32, device=x.device) if out is None else out
     d = ConvDesc(n, h, w, cin, cout, ksize, int(act))
+    if scratch is not None:
+        check(lib().be_conv_nhwc_splitk_f32(C.byref(d), dptr(x, "x"), dptr(pw), dptr(pb), dptr(residual), dptr(y), y.shape[-1],
+                                            dptr(scratch), scratch.numel() * 4, stream_ptr(x.device)), "be_conv_nhwc_splitk_f32")
+        return y
     check(lib().be_conv_nhwc_f32(C.byref(d), dptr(x, "x"), dptr(pw), dptr(pb), dptr(residual), dptr(y), y.shape[-1],
                                  stream_ptr(x.device)), "be_conv_nhwc_f32")
     return y

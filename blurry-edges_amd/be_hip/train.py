@@ -42,7 +42,7 @@ def _new(shape, dev):
 def _conv_fwd(x, w, b, cout, ks, chw_hw=0):
     """plain conv / linear + bias (no BatchNorm fold): x NHWC -> y NHWC."""
     pw, pb = native.conv_pack(w, b, bn=None, chw_hw=chw_hw)
-    return native.conv_nhwc(x, pw, pb, cout, ks, act=0)
+    return native.conv_nhwc(x, pw, pb, cout, ks, act=0, scratch=_Scratch.get(x.device))
 
 
 def _bn_fwd(y, gamma, beta, rm, rv, res, act):
@@ -97,7 +97,7 @@ def _dgrad(dy, w, cin, ks, chw_hw=0):
     pb = _new((cin + 31) // 32 * 32, dev)
     check(lib().be_conv_pack_dgrad_f32(dptr(w.contiguous()), cout, cin, ks, chw_hw, dptr(pw), dptr(pb), stream_ptr(dev)),
           "be_conv_pack_dgrad_f32")
-    return native.conv_nhwc(dy, pw, pb, cin, ks, act=0)
+    return native.conv_nhwc(dy, pw, pb, cin, ks, act=0, scratch=_Scratch.get(dev))
 
 
 def _pool_bwd(x, dout, k, stride, pad):

@@ -43,6 +43,9 @@ struct ConvArgs {
     int pixmaj, Nimg;     // pixel-major M tiles: a tile = ONE pixel position of BM consecutive images (see kernel)
     const float* x2;      // optional second input [N,H,W,Cin2]: its 1x1 conv is appended to the K loop (the residual
     int Cin2;             //   block's downsample branch fused into conv2: out = act(conv3x3(x) + conv1x1(x2) + bias))
+    int ksplit;           // > 1: blockIdx.y = K slice; raw partial sums go to `partial` [ksplit][M][ldp], no epilogue math
+    int ldp;
+    float* partial;
 };
 
 // __launch_bounds__(256, w): w = workgroups per CU the LDS admits (= waves per SIMD), so the register allocator may
@@ -220,12 +223,15 @@ void k_conv_igemm(ConvArgs a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
     const int n1 = (MODE == MODE_TAPS ? (a.nchunk / ntap_all) * ntap : ntap) * SUB;       // only the taps this tile visits
-    const int nchunk = n1 + (a.x2 ? (a.Cin2 / 32) * SUB : 0);                              // + the fused 1x1 branch
-    BE_LOAD_CHUNK(0);
-    BE_STORE_CHUNK(0);
+    const int nchunk_all = n1 + (a.x2 ? (a.Cin2 / 32) * SUB : 0);                          // + the fused 1x1 branch
+    // split-K (small-M launches): this block walks the chunks [kc0, nchunk) of its K slice
+    const int kc0 = a.ksplit > 1 ? (int)((int64_t)nchunk_all * blockIdx.y / a.ksplit) : 0;
+    const int nchunk = a.ksplit > 1 ? (int)((int64_t)nchunk_all * (blockIdx.y + 1) / a.ksplit) : nchunk_all;
+    BE_LOAD_CHUNK(kc0);
+    BE_STORE_CHUNK(kc0 & 1);
     __syncthreads();
 
-    for (int kc = 0; kc < nchunk; ++kc) {
+    for (int kc = kc0; kc < nchunk; ++kc) {
         const int buf = kc & 1;
         // always prefetch (the last iteration re-reads its own chunk into the idle buffer: keeps the body branch-free)
         const int kn = kc + 1 < nchunk ? kc + 1 : kc;
@@ -260,6 +266,22 @@ void k_conv_igemm(ConvArgs a) {
 #undef BE_STORE_CHUNK
 
     // ---- epilogue: D[row][col], col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if (a.ksplit > 1) {                                // raw partial sums; k_splitk_reduce does bias / residual / activation
+        float* P = a.partial + (size_t)blockIdx.y * a.M * a.ldp;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int c = n0 + (wn * NT + j) * 32 + li;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int rr = row_base + (wm * MT + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    const int m = a.pixmaj ? rr * a.HW + pix_u : rr;
+                    if (c < a.ldp && (a.pixmaj ? rr < a.Nimg : rr < a.M)) P[(size_t)m * a.ldp + c] = acc[i][j][r];
+                }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < NT; ++j) {
         const int c = n0 + (wn * NT + j) * 32 + li;
@@ -325,7 +347,8 @@ int launch_conv(const ConvArgs& a, hipStream_t s, int kernel_id) {
         be::ProfileScope prof(s, kernel_id, 2.0 * a.M * (k_real + k2_real) * a.Cout,
                               4.0 * (a.M * (cin_real + k2_real) + (k_real + k2_real) * a.Cout + (double)a.M * a.Cout * (a.res ? 2 : 1)),
                               chunks * 2.0 * BM * BN * BKT);
-        hipLaunchKernelGGL((k_conv_igemm<WM, WN, MT, NT, MODE, BKT, PRIO>), dim3(grid), dim3(256), lds, s, a);
+        hipLaunchKernelGGL((k_conv_igemm<WM, WN, MT, NT, MODE, BKT, PRIO>), dim3(grid, a.ksplit > 1 ? a.ksplit : 1), dim3(256),
+                           lds, s, a);
     }
     return be::check_launch("be_conv_nhwc_f32");
 }
@@ -528,8 +551,27 @@ extern "C" int be_conv_pack_dgrad_f32(const float* w, int cout, int cin, int ksi
     return be::check_launch("be_conv_pack_dgrad_f32");
 }
 
+// y = act(sum_s partial[s] + bias (+ res)): the epilogue of a split-K launch, fixed summation order
+__global__ void k_splitk_reduce(const float* __restrict__ partial, int S, int64_t M, int Cout, int ldp,
+                                const float* __restrict__ bias, const float* __restrict__ res, int act,
+                                float* __restrict__ y, int ldy) {
+    const int64_t total = M * Cout;
+    const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gs) {
+        const int64_t m = idx / Cout;
+        const int c = (int)(idx - m * Cout);
+        float v = partial[m * ldp + c];
+        for (int s = 1; s < S; ++s) v += partial[((int64_t)s * M + m) * ldp + c];
+        v += bias[c];
+        if (res) v += res[m * ldy + c];
+        if (act == 1) v = be::smish(v);
+        else if (act == 2) v = fmaxf(v, 0.0f);
+        y[m * ldy + c] = v;
+    }
+}
+
 static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2, int cin2, const float* pw, const float* pb,
-                         const float* res, float* y, int ldy, void* stream);
+                         const float* res, float* y, int ldy, void* stream, void* scratch = nullptr, size_t scratch_bytes = 0);
 
 extern "C" int be_conv_nhwc_f32(const be_conv_desc* d, const float* x, const float* pw, const float* pb,
                                 const float* res, float* y, int ldy, void* stream) {
@@ -544,8 +586,14 @@ extern "C" int be_conv_nhwc_fused2_f32(const be_conv_desc* d, const float* x, co
     return conv_dispatch(d, x, x2, cin2, pw, pb, nullptr, y, ldy, stream);
 }
 
+extern "C" int be_conv_nhwc_splitk_f32(const be_conv_desc* d, const float* x, const float* pw, const float* pb,
+                                       const float* res, float* y, int ldy, void* scratch, size_t scratch_bytes, void* stream) {
+    BE_REQUIRE(scratch && be::aligned16(scratch), "be_conv_nhwc_splitk_f32: scratch required (16-byte aligned)");
+    return conv_dispatch(d, x, nullptr, 0, pw, pb, res, y, ldy, stream, scratch, scratch_bytes);
+}
+
 static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2, int cin2, const float* pw, const float* pb,
-                         const float* res, float* y, int ldy, void* stream) {
+                         const float* res, float* y, int ldy, void* stream, void* scratch, size_t scratch_bytes) {
     BE_REQUIRE(d && x && pw && pb && y, "be_conv_nhwc_f32: null pointer");
     BE_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cout > 0, "be_conv_nhwc_f32: empty shape");
     BE_REQUIRE(d->h < 32768 && d->w < 32768, "be_conv_nhwc_f32: image too large");
@@ -564,13 +612,15 @@ static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2,
     a.x2 = x2; a.Cin2 = cin2;
     a.m_tiles = (int)((M + 127) / 128);
     a.pixmaj = 0; a.Nimg = d->n;
+    a.ksplit = 1; a.ldp = 0; a.partial = nullptr;
     const int cp = round_up(d->cout, 32);
     hipStream_t s = be::as_stream(stream);
     // Small-M regime (training at batch 64: M = 2304 rows at 6x6): the 128-row tiles give a few dozen workgroups on
     // 256 CUs and one launch lasts as long as ONE workgroup's serial K loop.  Below ~1.5 workgroups per CU switch to
     // 64x64 (or 128x32) tiles: 4x the workgroups, each with a quarter of the work.
     if (!row8 && (int64_t)a.m_tiles * ((cp + 127) / 128) < 384) {
-        if (cp % 64 == 0) {
+        const bool t64 = cp % 64 == 0;
+        if (t64) {
             a.m_tiles = (int)((M + 63) / 64); a.n_tiles = cp / 64;
             if (d->ksize > 1 && d->n >= 64 && d->n % 64 == 0 && conv_variant() != 99) {
                 // full 64-image tiles (the training batch): pixel-major here too, tiles dealt round-robin over the
@@ -578,10 +628,32 @@ static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2,
                 a.pixmaj = 2;
                 a.m_tiles = a.HW * (d->n / 64);
             }
-            return launch_conv<2, 2, 1, 1, MODE_TAPS, 16, 0>(a, s, BE_KERNEL_CONV_SMALL);
+        } else {
+            a.n_tiles = cp / 32;
         }
-        a.n_tiles = cp / 32;
-        return launch_conv<4, 1, 1, 1, MODE_TAPS, 16, 0>(a, s, BE_KERNEL_CONV_SMALL);
+        // split-K when the caller lent scratch: a few hundred workgroups each walking the whole K loop leave most of
+        // the chip idle (batch-64 training: 144-216 tiles, up to 216 chunks each); S slices make S times the
+        // workgroups, each 1/S as long, and a small reduce kernel applies bias / residual / activation
+        if (scratch) {
+            const int64_t tiles = (int64_t)a.m_tiles * a.n_tiles;
+            const int kchunks = a.nchunk * 2;                               // 16-float chunks of the longest tile
+            int S = (int)((768 + tiles - 1) / tiles);
+            if (S > 8) S = 8;
+            while (S > 1 && kchunks / S < 12) --S;
+            while (S > 1 && (size_t)S * M * cp * sizeof(float) > scratch_bytes) --S;
+            if (S > 1) {
+                a.ksplit = S; a.ldp = cp; a.partial = static_cast<float*>(scratch);
+                const int rc = t64 ? launch_conv<2, 2, 1, 1, MODE_TAPS, 16, 0>(a, s, BE_KERNEL_CONV_SMALL)
+                                   : launch_conv<4, 1, 1, 1, MODE_TAPS, 16, 0>(a, s, BE_KERNEL_CONV_SMALL);
+                if (rc) return rc;
+                const int64_t total = M * d->cout;
+                hipLaunchKernelGGL(k_splitk_reduce, dim3(grid_cap(total, 256)), dim3(256), 0, s, a.partial, S, M, d->cout, cp,
+                                   pb, res, d->act, y, ldy);
+                return be::check_launch("be_conv_nhwc_splitk_f32");
+            }
+        }
+        return t64 ? launch_conv<2, 2, 1, 1, MODE_TAPS, 16, 0>(a, s, BE_KERNEL_CONV_SMALL)
+                   : launch_conv<4, 1, 1, 1, MODE_TAPS, 16, 0>(a, s, BE_KERNEL_CONV_SMALL);
     }
     // large batches of small images: pixel-major tiles skip the taps that fall into the zero padding
     if (d->ksize > 1 && d->n >= 512 && conv_variant() != 99) {

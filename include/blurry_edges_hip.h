@@ -252,6 +252,12 @@ int be_conv_pack_f32(const float* weight_oihw, const float* bias, const float* b
 /* y[n,h,w,cout] = act(conv(x) + bias (+ residual)); residual may be NULL; ldy = row stride of y in floats. */
 int be_conv_nhwc_f32(const be_conv_desc* desc_host, const float* x, const float* packed_w,
                      const float* packed_bias, const float* residual, float* y, int ldy, void* stream);
+/* The same convolution with scratch lent by the caller: launches with few output tiles (batch-64 training: M = 2304
+ * rows) split their K loop over up to 8 slices (partial sums in scratch, summed in a fixed order with the bias /
+ * residual / activation applied by a second small kernel); large launches behave exactly as be_conv_nhwc_f32.
+ * scratch: 8 * M * cout_pad32 * 4 bytes is always enough (fewer slices are used when it is smaller). */
+int be_conv_nhwc_splitk_f32(const be_conv_desc* d, const float* x, const float* packed_w, const float* packed_bias,
+                            const float* residual, float* y, int ldy, void* scratch, size_t scratch_bytes, void* stream);
 /* ResidualBlock tail in ONE launch (models/local_stage.py:22-27): y = act(conv_kxk(x) + conv_1x1(x2) + bias) where the
  * second branch is the block's downsample; its 1x1 conv is appended to the K loop of the first (no residual tensor
  * in HBM).  Weights: both branches (each with its own folded BatchNorm) packed side by side, biases summed. */

@@ -374,3 +374,24 @@ def test_render_edge_case_parameters_vs_oracle(native, args):
     assert int(stable.sum()) >= 56
     assert relmax(col.cpu()[stable], r64["colors"][stable]) <= 1e-4
     assert relmax(ex["recon"].cpu()[stable], r64["recon"][stable]) <= 1e-4
+
+
+@pytest.mark.parametrize("n,hw,cin,cout,ks", [(64, 6, 256, 384, 3), (64, 6, 96, 256, 3), (64, 1, 2304, 1024, 1), (48, 6, 384, 96, 3)])
+def test_split_k_conv_matches_the_single_pass_kernel(n, hw, cin, cout, ks):
+    """be_conv_nhwc_splitk_f32 (K loop of a small-M launch cut into slices + fixed-order reduce with the epilogue) against
+    be_conv_nhwc_f32 on training-sized problems, with residual and Smish; a large launch must take the unsplit path."""
+    from be_hip import native
+    x = T(synth.hash_normal(21, "sk_x", (n, hw, hw, cin)).astype(np.float32)).to(DEV)
+    w = T((synth.hash_normal(22, "sk_w", (cout, cin, ks, ks)) / np.sqrt(cin * ks * ks)).astype(np.float32)).to(DEV)
+    b = T(synth.hash_normal(23, "sk_b", (cout,)).astype(np.float32)).to(DEV)
+    res = T(synth.hash_normal(24, "sk_r", (n, hw, hw, cout)).astype(np.float32)).to(DEV)
+    pw, pb = native.conv_pack(w if ks > 1 else w.reshape(cout, cin), b)
+    scratch = torch.empty(8 * n * hw * hw * ((cout + 31) // 32 * 32), dtype=torch.float32, device=DEV)
+    for act, r in ((0, None), (1, res)):
+        ref = native.conv_nhwc(x, pw, pb, cout, ks, act, residual=r)
+        got = native.conv_nhwc(x, pw, pb, cout, ks, act, residual=r, scratch=scratch)
+        assert relmax(got.cpu(), ref.cpu()) <= 2e-6
+        small = native.conv_nhwc(x, pw, pb, cout, ks, act, residual=r, scratch=scratch[:n * hw * hw * ((cout + 31) // 32 * 32)])
+        assert torch.equal(small, ref)                              # scratch for one slice only: no split, same kernel
+    big = T(synth.hash_normal(25, "sk_big", (2048, hw, hw, cin)).astype(np.float32)).to(DEV)
+    assert torch.equal(native.conv_nhwc(big, pw, pb, cout, ks, 1), native.conv_nhwc(big, pw, pb, cout, ks, 1, scratch=scratch))
