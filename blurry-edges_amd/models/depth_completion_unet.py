@@ -138,12 +138,16 @@ class UNet(nn.Module):
         B, _, H, W = x.shape
         dev = x.device
         relu = 2
+        # the deep levels are tiny GEMM-M (81 .. 5329 rows) with long K (up to 9216): lend scratch so their K loops split
+        if getattr(self, "_scratch", None) is None or self._scratch.device != dev:
+            self._scratch = torch.empty(16 << 20, dtype=torch.float32, device=dev)
+        sk = self._scratch
         x0 = native.nchw_to_nhwc_pad(x.to(torch.float32).contiguous(), (self.n_channels + 31) // 32 * 32)
 
         def double(xin, packs, out=None):
             (w1, b1, c1), (w2, b2, c2) = packs
-            t = native.conv_nhwc(xin, w1, b1, c1, 3, relu)
-            return native.conv_nhwc(t, w2, b2, c2, 3, relu, out=out)
+            t = native.conv_nhwc(xin, w1, b1, c1, 3, relu, scratch=sk)
+            return native.conv_nhwc(t, w2, b2, c2, 3, relu, out=out, scratch=sk)
 
         # encoder: each level's output lands in channels [0, C) of the [B,h,w,2C] buffer its decoder level will read
         cats, cur, chans = [], x0, [64, 128, 256, 512]
