@@ -115,12 +115,18 @@ def main(argv=None):
     gamma = sched.final()
     model.train()
     losses = []
+
+    def batch_of(it):
+        idx = [(it * a.batch + j) % a.images for j in range(a.batch)]
+        return {k: torch.stack([data[i][k] for i in idx]) for k in ("pm", "img_gt", "bndry_dist", "deri", "bndry_depth")}
+
+    for it in range(2):                                   # warm-up (kernel loading, allocator), not timed, weights untouched
+        with torch.no_grad():
+            model(batch_of(it)["pm"])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for it in range(a.steps):
-        idx = [(it * a.batch + j) % a.images for j in range(a.batch)]
-        batch = {k: torch.stack([data[i][k] for i in idx]) for k in ("pm", "img_gt", "bndry_dist", "deri", "bndry_depth")}
-        losses.append(float(train_step(model, helper, dcal, opt, batch, gamma, flat, world)))
+        losses.append(float(train_step(model, helper, dcal, opt, batch_of(it), gamma, flat, world)))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     if rank == 0:

@@ -68,15 +68,16 @@ def attention_train_fwd(qkv, B, L, H, p, seed, ws=None):
     return out, lse, ws
 
 
-def attention_bwd(qkv, out, lse, dout, B, L, H, p, seed, ws=None):
+def attention_bwd(qkv, out, lse, dout, B, L, H, p, seed, ws=None, operands_ready=False):
+    """operands_ready: ws is the workspace attention_train_fwd returned for THIS qkv and is untouched since."""
     dev = qkv.device
     need = lib().be_attention_train_workspace_floats(B, L, H)
     if ws is None or ws.numel() < need:
-        ws = _new(need, dev)
+        ws, operands_ready = _new(need, dev), False
     dqkv = torch.empty_like(qkv)
     check(lib().be_attention_bwd_f32(dptr(qkv, "qkv"), dptr(out), dptr(lse), dptr(dout.contiguous(), "dout"), dptr(dqkv),
-                                     dptr(ws), B, L, H, float(p), int(seed) & 0xffffffff, stream_ptr(dev)),
-          "be_attention_bwd_f32")
+                                     dptr(ws), int(bool(operands_ready)), B, L, H, float(p), int(seed) & 0xffffffff,
+                                     stream_ptr(dev)), "be_attention_bwd_f32")
     return dqkv, ws
 
 
@@ -131,24 +132,24 @@ def forward_train(src, pe, seed, p, H, eps, t):
     w_in = torch.cat([t[0], t[0].new_zeros(t[0].shape[0], pad)], dim=1) if pad else t[0]
     h = _linear(x0, w_in, t[1])
     native.add_pe_(h, pe[:L].contiguous(), B)
-    S = dict(x0=x0, layers=[], shape=(B, L, cin), ws=None)
-    ws = None
+    S = dict(x0=x0, layers=[], shape=(B, L, cin))
     for i in range(nl):
         wqkv, bqkv, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2 = t[2 + PER_LAYER * i:2 + PER_LAYER * (i + 1)]
         qkv = _linear(h, wqkv, bqkv)
-        a, lse, ws = attention_train_fwd(qkv, B, L, H, p, seed + 16 * i, ws)
+        a, lse, ws = attention_train_fwd(qkv, B, L, H, p, seed + 16 * i)      # one workspace per layer: the split q/k/v
+                                                                              # (6 x 16 B per token and head) are reused by the backward
         sa = _linear(a, wo, bo)
         v1, h1 = add_layernorm_train(sa, h, g1, be1, eps, p, seed, 16 * i + 1)
         f = _linear(h1, w1, b1, act=2)
         fd = dropout(f, p, seed, 16 * i + 2) if p > 0 else f
         y2 = _linear(fd, w2, b2)
         v2, h2 = add_layernorm_train(y2, h1, g2, be2, eps, p, seed, 16 * i + 3)
-        S["layers"].append((h, qkv, a, lse, v1, h1, f, v2))
+        S["layers"].append((h, qkv, a, lse, v1, h1, f, v2, ws))
         h = h2
     gN, bN, wg, bg = t[-4:]
     vN, hN = add_layernorm_train(h, None, gN, bN, eps, 0.0, seed, 0)
     out = _linear(hN, wg, bg)
-    S.update(vN=vN, hN=hN, ws=ws)
+    S.update(vN=vN, hN=hN)
     return out.view(B, L, -1), S
 
 
@@ -172,11 +173,10 @@ def backward_train(dout, seed, p, H, eps, t, S):
     grads[-1] = _col_sum(dyp)[:cout].contiguous()
     d_hN = _dgrad_lin(dyp, wgp)
     dh, _, grads[-4], grads[-3] = layernorm_bwd(d_hN, S["vN"], gN, eps, 0.0, seed, 0, want_dx=False)
-    ws = S["ws"]
     for i in reversed(range(nl)):
         base = 2 + PER_LAYER * i
         wqkv, bqkv, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2 = t[base:base + PER_LAYER]
-        h_in, qkv, a, lse, v1, h1, f, v2 = S["layers"][i]
+        h_in, qkv, a, lse, v1, h1, f, v2, ws = S["layers"][i]
         dv2, dy2, grads[base + 10], grads[base + 11] = layernorm_bwd(dh, v2, g2, eps, p, seed, 16 * i + 3)
         fd = dropout(f, p, seed, 16 * i + 2) if p > 0 else f
         grads[base + 6] = _wgrad_lin(fd, dy2, w2.shape)
@@ -190,7 +190,7 @@ def backward_train(dout, seed, p, H, eps, t, S):
         grads[base + 2] = _wgrad_lin(a, dsa, wo.shape)
         grads[base + 3] = _col_sum(dsa)
         da = _dgrad_lin(dsa, wo)
-        dqkv, ws = attention_bwd(qkv, a, lse, da, B, L, H, p, seed + 16 * i, ws)
+        dqkv, _ = attention_bwd(qkv, a, lse, da, B, L, H, p, seed + 16 * i, ws, operands_ready=True)
         grads[base] = _wgrad_lin(h_in, dqkv, wqkv.shape)
         grads[base + 1] = _col_sum(dqkv)
         dh = _dgrad_lin(dqkv, wqkv, residual=dv1)

@@ -6,13 +6,9 @@
 // L = 4096 tokens, d_model 128, 8 heads of 16.  The reference's eager attention materialises a [8,4096,4096]
 // score tensor per layer (537 MB); here scores never leave registers.
 //
-// k_attention: one wavefront = 32 queries of one (batch, head), streaming all keys in blocks of 32.
-//   S^T = K Q^T on v_mfma_f32_32x32x2_f32 with the KEY on the accumulator rows and the QUERY on the lane, so the
-//   softmax statistics of a query are lane-local (16 scores in registers + one exchange with lane^32);
-//   the probabilities stay in the accumulator registers and are fed straight back as the B operand of
-//   O^T = V^T P^T: accumulator register r of lane-half h IS key (r&3)+8(r>>2)+4h, so using that key order for the
-//   k-steps needs no data movement at all; V is read pre-transposed ([head][d][L]) so the A operand is 4 x 16-B loads.
-//   d_head = 16 fills only half of the 32 accumulator rows of the PV product (the other half multiplies zeros).
+// k_attention: one wavefront = 32 queries of one (batch, head), streaming all keys in blocks of 32, on the 16x16x4 f32
+//   MFMA (see the comment above the kernel): scores and probabilities live in accumulator registers and are fed straight
+//   back as the B operand of the next product; K / Q rows and the transposed V are read as 16-byte loads.
 #include "be_common.h"
 #include "be_device_math.h"
 
@@ -59,50 +55,89 @@ __global__ void k_qkv_split(const float* __restrict__ qkv, float* __restrict__ Q
 }
 
 // training: every operand the forward and the two backward kernels read, row-major [BH][L][16] and transposed
-// [BH][16][L] (Q pre-scaled in both)
+// [BH][16][L] (Q pre-scaled in both).  One thread = one (batch, head, token), token fastest: 64-byte row reads and
+// writes, and for each d the transposed stores of consecutive threads are consecutive floats.
 __global__ void k_qkv_split_train(const float* __restrict__ qkv, float* __restrict__ Q, float* __restrict__ K,
                                   float* __restrict__ V, float* __restrict__ Qt, float* __restrict__ Kt,
                                   float* __restrict__ Vt, int B, int L, int H, float qscale) {
-    const int64_t total = (int64_t)B * L * H * DH;
+    const int64_t total = (int64_t)B * H * L;
     const int64_t gs = (int64_t)gridDim.x * blockDim.x;
     const int D = H * DH;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gs) {
-        const int d = (int)(idx % DH);
-        const int h = (int)((idx / DH) % H);
-        const int64_t t = idx / (DH * H);
-        const int64_t b = t / L, l = t % L;
-        const float* row = qkv + t * 3 * D + h * DH + d;
-        const int64_t bh = b * H + h;
-        const float q = row[0] * qscale, k = row[D], v = row[2 * D];
-        const int64_t rm = (bh * L + l) * DH + d, tr = (bh * DH + d) * L + l;
-        Q[rm] = q; K[rm] = k; V[rm] = v;
-        Qt[tr] = q; Kt[tr] = k; Vt[tr] = v;
+        const int64_t l = idx % L, bh = idx / L;
+        const int64_t b = bh / H, h = bh % H;
+        const float* row = qkv + (b * L + l) * 3 * D + h * DH;
+        f32x4 q[4], k[4], v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            q[i] = *reinterpret_cast<const f32x4*>(row + 4 * i) * qscale;
+            k[i] = *reinterpret_cast<const f32x4*>(row + D + 4 * i);
+            v[i] = *reinterpret_cast<const f32x4*>(row + 2 * D + 4 * i);
+        }
+        const int64_t rm = (bh * L + l) * DH;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            *reinterpret_cast<f32x4*>(Q + rm + 4 * i) = q[i];
+            *reinterpret_cast<f32x4*>(K + rm + 4 * i) = k[i];
+            *reinterpret_cast<f32x4*>(V + rm + 4 * i) = v[i];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t tr = (bh * DH + 4 * i + e) * L + l;
+                Qt[tr] = q[i][e]; Kt[tr] = k[i][e]; Vt[tr] = v[i][e];
+            }
+        }
     }
 }
 
-// dout, out [T, D] token-major -> dOh [BH][L][16], dOt [BH][16][L], Drow [BH][L] = sum_d dO * O
+// dout, out [T, D] token-major -> dOh [BH][L][16], dOt [BH][16][L], Drow [BH][L] = sum_d dO * O  (token fastest)
 __global__ void k_dout_prep(const float* __restrict__ dout, const float* __restrict__ out, float* __restrict__ dOh,
                             float* __restrict__ dOt, float* __restrict__ Drow, int B, int L, int H) {
     const int64_t total = (int64_t)B * L * H;
     const int64_t gs = (int64_t)gridDim.x * blockDim.x;
     const int D = H * DH;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gs) {
-        const int h = (int)(idx % H);
-        const int64_t t = idx / H;
-        const int64_t b = t / L, l = t % L;
-        const int64_t bh = b * H + h;
-        const float* g = dout + t * D + h * DH;
-        const float* o = out + t * D + h * DH;
+        const int64_t l = idx % L, bh = idx / L;
+        const int64_t b = bh / H, h = bh % H;
+        const float* g = dout + (b * L + l) * D + h * DH;
+        const float* o = out + (b * L + l) * D + h * DH;
         float acc = 0.f;
 #pragma unroll
-        for (int d = 0; d < DH; ++d) {
-            const float gv = g[d];
-            acc = fmaf(gv, o[d], acc);
-            dOh[(bh * L + l) * DH + d] = gv;
-            dOt[(bh * DH + d) * L + l] = gv;
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(g + 4 * i);
+            const f32x4 ov = *reinterpret_cast<const f32x4*>(o + 4 * i);
+            *reinterpret_cast<f32x4*>(dOh + (bh * L + l) * DH + 4 * i) = gv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc = fmaf(gv[e], ov[e], acc);
+                dOt[(bh * DH + 4 * i + e) * L + l] = gv[e];
+            }
         }
         Drow[bh * L + l] = acc;
     }
+}
+
+// ---- attention on v_mfma_f32_16x16x4_f32 -----------------------------------------------------------------------
+// With d_head = 16 every product here has a 16-wide side, so the 16x16x4 shape wastes nothing (the 32x32x2 shape
+// multiplied zeros in half of its rows for O^T = V^T P^T and the three backward products: 24 -> 16 MFMA-cycles per
+// unit in the forward, 80 -> 56 in the backward).  Operand maps of the instruction: lane l (c = l & 15, g = l >> 4)
+// supplies A[row c][k = g] and B[k = g][col c]; it receives D[row 4g + r][col c] in register r = 0..3.
+// One wave = 32 queries (two column tiles qc) against key blocks of 32 (two row tiles kt):
+//   S^T tile [16 keys x 16 queries] = K Q^T, contraction over d in the order d = 4g + t (t = MFMA step), so both
+//   operands are ONE 16-byte load of a row-major [L][16] row;
+//   a lane then holds, for its query 16 qc + c, the scores of keys 16 kt + 4g + r: the softmax statistics need the
+//   four lanes c, c+16, c+32, c+48 (two xor-shuffles); the probabilities stay in those registers and are the B operand
+//   of O^T[d][query] += V^T[d][key] P[key][query] with the k-step (kt, r) <-> key 16 kt + 4g + r, whose A operand is one
+//   16-byte load of the transposed V ([16][L]).  The accumulator O^T[d = 4g + r][query] is stored as 16-byte rows.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+__device__ __forceinline__ float quad_max(float v) {          // over the lanes c, c+16, c+32, c+48
+    v = fmaxf(v, __shfl_xor(v, 16, 64));
+    return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    return v + __shfl_xor(v, 32, 64);
 }
 
 // TRAIN: dropout on the probabilities (nn.MultiheadAttention's dropout, models/global_stage.py:28) and the log2-sum-exp
@@ -114,106 +149,104 @@ void k_attention(const float* __restrict__ Q, const float* __restrict__ K, const
                  float inv_keep) {
     // grid.x = L/128 query blocks (4 waves x 32 queries), grid.y = B*H
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int j = lane & 31, h = lane >> 5;
+    const int c = lane & 15, g = lane >> 4;
     const int bh = blockIdx.y;
     const int q0 = (blockIdx.x * 4 + wave) * 32;
     const float* Qh = Q + (size_t)bh * L * DH;
     const float* Kh = K + (size_t)bh * L * DH;
     const float* Vh = Vt + (size_t)bh * DH * L;
+    const uint32_t hkey = site_key(seed, (uint32_t)bh);
 
-    // B operand of S^T = K Q^T: this lane's query, d = 8h .. 8h+7
-    const f32x4 qa = *reinterpret_cast<const f32x4*>(Qh + (size_t)(q0 + j) * DH + 8 * h);
-    const f32x4 qb = *reinterpret_cast<const f32x4*>(Qh + (size_t)(q0 + j) * DH + 8 * h + 4);
-    const float qf[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
-
-    f32x16 o;
+    f32x4v qf[2], o[2];
+    float m[2], lsum[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) o[r] = 0.f;
-    float m = -INFINITY, lsum = 0.f;
-    const int jd = j & (DH - 1);        // lanes 16..31 of each half feed accumulator rows >= 16, which are never stored:
-                                        // they re-read rows 0..15 instead of being masked
-
-    // prefetch block 0
-    f32x4 ka = *reinterpret_cast<const f32x4*>(Kh + (size_t)j * DH + 8 * h);
-    f32x4 kb = *reinterpret_cast<const f32x4*>(Kh + (size_t)j * DH + 8 * h + 4);
-    f32x4 vt[4];
+    for (int qc = 0; qc < 2; ++qc) {
+        qf[qc] = *reinterpret_cast<const f32x4v*>(Qh + (size_t)(q0 + 16 * qc + c) * DH + 4 * g);
+        o[qc] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        m[qc] = -INFINITY; lsum[qc] = 0.f;
+    }
+    f32x4v kn[2], vn[2];
 #pragma unroll
-    for (int g = 0; g < 4; ++g)
-        vt[g] = *reinterpret_cast<const f32x4*>(Vh + (size_t)jd * L + 8 * g + 4 * h);
-
+    for (int kt = 0; kt < 2; ++kt) {
+        kn[kt] = *reinterpret_cast<const f32x4v*>(Kh + (size_t)(16 * kt + c) * DH + 4 * g);
+        vn[kt] = *reinterpret_cast<const f32x4v*>(Vh + (size_t)c * L + 16 * kt + 4 * g);
+    }
     const int nkb = L / KB;
     for (int kblk = 0; kblk < nkb; ++kblk) {
-        const float kf[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
-        f32x4 vc[4] = {vt[0], vt[1], vt[2], vt[3]};
-        // prefetch the next key/value block (clamped on the last iteration)
-        const int kn = kblk + 1 < nkb ? kblk + 1 : kblk;
-        ka = *reinterpret_cast<const f32x4*>(Kh + (size_t)(kn * KB + j) * DH + 8 * h);
-        kb = *reinterpret_cast<const f32x4*>(Kh + (size_t)(kn * KB + j) * DH + 8 * h + 4);
+        const f32x4v kf[2] = {kn[0], kn[1]}, vf[2] = {vn[0], vn[1]};
+        const int nx = kblk + 1 < nkb ? kblk + 1 : kblk;                 // prefetch (clamped on the last block)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            vt[g] = *reinterpret_cast<const f32x4*>(Vh + (size_t)jd * L + kn * KB + 8 * g + 4 * h);
-
-        // S^T[key][query] (log2 units: Q carries scale*log2 e)
-        f32x16 s;
+        for (int kt = 0; kt < 2; ++kt) {
+            kn[kt] = *reinterpret_cast<const f32x4v*>(Kh + (size_t)(nx * KB + 16 * kt + c) * DH + 4 * g);
+            vn[kt] = *reinterpret_cast<const f32x4v*>(Vh + (size_t)c * L + nx * KB + 16 * kt + 4 * g);
+        }
+        f32x4v s[2][2];                                                  // [kt][qc], log2 units (Q carries scale*log2 e)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) s[r] = 0.f;
+        for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int t = 0; t < 8; ++t) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[t], qf[t], s, 0, 0, 0);
-
-        // online softmax for this lane's query: 16 keys here, 16 on lane^32
-        float mloc = s[0];
+            for (int qc = 0; qc < 2; ++qc) s[kt][qc] = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int r = 1; r < 16; ++r) mloc = fmaxf(mloc, s[r]);
-        mloc = fmaxf(mloc, __shfl_xor(mloc, 32, 64));
-        const float mnew = fmaxf(m, mloc);
-        const float alpha = fast_exp2(m - mnew);
-        m = mnew;
-        float psum = 0.f;
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = fast_exp2(s[r] - mnew); psum += s[r]; }
-        lsum = lsum * alpha + psum;
-        if (TRAIN && thresh) {
-            const uint32_t hkey = site_key(seed, (uint32_t)bh);
-            const uint32_t base = (uint32_t)(q0 + j) * (uint32_t)L + (uint32_t)(kblk * KB + 4 * h);
+            for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (mix32((base + (r & 3) + 8 * (r >> 2)) ^ hkey) < thresh) s[r] = 0.f;
+                for (int qc = 0; qc < 2; ++qc) s[kt][qc] = MFMA16(kf[kt][t], qf[qc][t], s[kt][qc]);
+#pragma unroll
+        for (int qc = 0; qc < 2; ++qc) {
+            float mloc = fmaxf(fmaxf(fmaxf(s[0][qc][0], s[0][qc][1]), fmaxf(s[0][qc][2], s[0][qc][3])),
+                               fmaxf(fmaxf(s[1][qc][0], s[1][qc][1]), fmaxf(s[1][qc][2], s[1][qc][3])));
+            mloc = quad_max(mloc);
+            const float mnew = fmaxf(m[qc], mloc);
+            const float alpha = fast_exp2(m[qc] - mnew);
+            m[qc] = mnew;
+            float psum = 0.f;
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s[kt][qc][r] = fast_exp2(s[kt][qc][r] - mnew); psum += s[kt][qc][r]; }
+            lsum[qc] = lsum[qc] * alpha + psum;                           // this lane's 8 keys; the quad is summed at the end
+            if (TRAIN && thresh) {
+                const uint32_t base = (uint32_t)(q0 + 16 * qc + c) * (uint32_t)L + (uint32_t)(kblk * KB + 4 * g);
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        if (mix32((base + 16 * kt + r) ^ hkey) < thresh) s[kt][qc][r] = 0.f;
+            }
+            o[qc] *= alpha;
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[r] *= alpha;
-        // O^T[d][query] += V^T[d][key] P[key][query]; k-step r uses key (r&3)+8(r>>2)+4h: register r of s as it stands
+        for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o = __builtin_amdgcn_mfma_f32_32x32x2f32(vc[r >> 2][r & 3], s[r], o, 0, 0, 0);
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int qc = 0; qc < 2; ++qc) o[qc] = MFMA16(vf[kt][r], s[kt][qc][r], o[qc]);
     }
-    const float ltot = lsum + __shfl_xor(lsum, 32, 64);
-    const float inv = TRAIN ? inv_keep / ltot : 1.0f / ltot;
-    if (TRAIN && h == 0) lse[(size_t)bh * L + q0 + j] = m + log2f(ltot);
-    // accumulator row d = (r&3) + 8*(r>>2) + 4h; rows >= 16 (r >= 8) are the zero padding
     const int Dm = H * DH;
     const int b = bh / H, hd = bh % H;
-    float* dst = out + ((size_t)b * L + q0 + j) * Dm + hd * DH;
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        f32x4 v = {o[4 * g] * inv, o[4 * g + 1] * inv, o[4 * g + 2] * inv, o[4 * g + 3] * inv};
-        *reinterpret_cast<f32x4*>(dst + 8 * g + 4 * h) = v;
+    for (int qc = 0; qc < 2; ++qc) {
+        const float ltot = quad_sum(lsum[qc]);
+        const float inv = TRAIN ? inv_keep / ltot : 1.0f / ltot;
+        if (TRAIN && g == 0) lse[(size_t)bh * L + q0 + 16 * qc + c] = m[qc] + log2f(ltot);
+        *reinterpret_cast<f32x4v*>(out + ((size_t)b * L + q0 + 16 * qc + c) * Dm + hd * DH + 4 * g) = o[qc] * inv;
     }
 }
-
 
 // ---- attention backward -------------------------------------------------------------------------------------
 // With P = softmax(S), Pd = dropout(P), O = Pd V:   dV = Pd^T dO,  dPd = dO V^T,  dS = P o (dropout'(dPd) - Drow),
 // Drow_i = sum_d dO_id O_id,  dQ = scale dS K,  dK = scale dS^T Q.   P is recomputed from the saved log2-sum-exp.
 // Two kernels, no atomics: k_attn_bwd_dq owns 32 queries per wave and streams the keys; k_attn_bwd_dkv owns 32 keys
-// per wave and streams the queries.  Same register trick as the forward: the [32x32] tile of dS (or Pd) sits in the
-// accumulator layout and is fed back as the B operand of the next product in the key (query) order
-// (r&3)+8(r>>2)+4h, with the transposed operand ([16][L]) read as 16-byte loads.
+// per wave and streams the queries.  Same register trick as the forward: a [16x16] tile of dS (or Pd) sits in the
+// accumulator layout and is fed back as the B operand of the next product, whose A operand is a 16-byte load of the
+// transposed tensor ([16][L]).
 __global__ __launch_bounds__(256)
 void k_attn_bwd_dq(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
                    const float* __restrict__ Kt, const float* __restrict__ dOh, const float* __restrict__ lse,
                    const float* __restrict__ Drow, float* __restrict__ dqkv, int L, int H, uint32_t seed,
                    uint32_t thresh, float inv_keep) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int j = lane & 31, h = lane >> 5;
+    const int c = lane & 15, g = lane >> 4;
     const int bh = blockIdx.y;
     const int q0 = (blockIdx.x * 4 + wave) * 32;
     const size_t hb = (size_t)bh * L * DH;
@@ -222,68 +255,73 @@ void k_attn_bwd_dq(const float* __restrict__ Q, const float* __restrict__ K, con
     const float* Kth = Kt + hb;
     const uint32_t hkey = site_key(seed, (uint32_t)bh);
 
-    const f32x4 qa = *reinterpret_cast<const f32x4*>(Q + hb + (size_t)(q0 + j) * DH + 8 * h);
-    const f32x4 qb = *reinterpret_cast<const f32x4*>(Q + hb + (size_t)(q0 + j) * DH + 8 * h + 4);
-    const f32x4 ga = *reinterpret_cast<const f32x4*>(dOh + hb + (size_t)(q0 + j) * DH + 8 * h);
-    const f32x4 gb = *reinterpret_cast<const f32x4*>(dOh + hb + (size_t)(q0 + j) * DH + 8 * h + 4);
-    const float qf[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
-    const float gf[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
-    const float lse_q = lse[(size_t)bh * L + q0 + j];
-    const float d_q = Drow[(size_t)bh * L + q0 + j];
-
-    f32x16 dq;
+    f32x4v qf[2], gf[2], dq[2];
+    float lse_q[2], d_q[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) dq[r] = 0.f;
-    const int jd = j & (DH - 1);        // rows >= 16 of dQ^T are never stored: those lanes re-read rows 0..15
-
-    f32x4 ka = *reinterpret_cast<const f32x4*>(Kh + (size_t)j * DH + 8 * h);
-    f32x4 kb = *reinterpret_cast<const f32x4*>(Kh + (size_t)j * DH + 8 * h + 4);
-    f32x4 va = *reinterpret_cast<const f32x4*>(Vh + (size_t)j * DH + 8 * h);
-    f32x4 vb = *reinterpret_cast<const f32x4*>(Vh + (size_t)j * DH + 8 * h + 4);
-    f32x4 kt[4];
+    for (int qc = 0; qc < 2; ++qc) {
+        const size_t row = (size_t)(q0 + 16 * qc + c);
+        qf[qc] = *reinterpret_cast<const f32x4v*>(Q + hb + row * DH + 4 * g);
+        gf[qc] = *reinterpret_cast<const f32x4v*>(dOh + hb + row * DH + 4 * g);
+        lse_q[qc] = lse[(size_t)bh * L + row];
+        d_q[qc] = Drow[(size_t)bh * L + row];
+        dq[qc] = f32x4v{0.f, 0.f, 0.f, 0.f};
+    }
+    f32x4v kn[2], vn[2], tn[2];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) kt[g] = *reinterpret_cast<const f32x4*>(Kth + (size_t)jd * L + 8 * g + 4 * h);
-
+    for (int kt = 0; kt < 2; ++kt) {
+        kn[kt] = *reinterpret_cast<const f32x4v*>(Kh + (size_t)(16 * kt + c) * DH + 4 * g);
+        vn[kt] = *reinterpret_cast<const f32x4v*>(Vh + (size_t)(16 * kt + c) * DH + 4 * g);
+        tn[kt] = *reinterpret_cast<const f32x4v*>(Kth + (size_t)c * L + 16 * kt + 4 * g);
+    }
     const int nkb = L / KB;
     for (int kblk = 0; kblk < nkb; ++kblk) {
-        const float kf[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
-        const float vf[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
-        const f32x4 kc[4] = {kt[0], kt[1], kt[2], kt[3]};
-        const int kn = kblk + 1 < nkb ? kblk + 1 : kblk;
-        ka = *reinterpret_cast<const f32x4*>(Kh + (size_t)(kn * KB + j) * DH + 8 * h);
-        kb = *reinterpret_cast<const f32x4*>(Kh + (size_t)(kn * KB + j) * DH + 8 * h + 4);
-        va = *reinterpret_cast<const f32x4*>(Vh + (size_t)(kn * KB + j) * DH + 8 * h);
-        vb = *reinterpret_cast<const f32x4*>(Vh + (size_t)(kn * KB + j) * DH + 8 * h + 4);
+        const f32x4v kf[2] = {kn[0], kn[1]}, vf[2] = {vn[0], vn[1]}, tf[2] = {tn[0], tn[1]};
+        const int nx = kblk + 1 < nkb ? kblk + 1 : kblk;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-            kt[g] = *reinterpret_cast<const f32x4*>(Kth + (size_t)jd * L + kn * KB + 8 * g + 4 * h);
-
-        f32x16 s, dp;
+        for (int kt = 0; kt < 2; ++kt) {
+            kn[kt] = *reinterpret_cast<const f32x4v*>(Kh + (size_t)(nx * KB + 16 * kt + c) * DH + 4 * g);
+            vn[kt] = *reinterpret_cast<const f32x4v*>(Vh + (size_t)(nx * KB + 16 * kt + c) * DH + 4 * g);
+            tn[kt] = *reinterpret_cast<const f32x4v*>(Kth + (size_t)c * L + nx * KB + 16 * kt + 4 * g);
+        }
+        f32x4v s[2][2], dp[2][2];
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int t = 0; t < 8; ++t) s = __builtin_amdgcn_mfma_f32_32x32x2f32(kf[t], qf[t], s, 0, 0, 0);      // S^T[key][query]
+            for (int qc = 0; qc < 2; ++qc) { s[kt][qc] = f32x4v{0.f, 0.f, 0.f, 0.f}; dp[kt][qc] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-        for (int t = 0; t < 8; ++t) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(vf[t], gf[t], dp, 0, 0, 0);    // dPd^T[key][query]
-        const uint32_t base = (uint32_t)(q0 + j) * (uint32_t)L + (uint32_t)(kblk * KB + 4 * h);
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const float p = fast_exp2(s[r] - lse_q);
-            float g = dp[r] * inv_keep;
-            if (thresh && mix32((base + (r & 3) + 8 * (r >> 2)) ^ hkey) < thresh) g = 0.f;
-            s[r] = p * (g - d_q);
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int qc = 0; qc < 2; ++qc) {
+                    s[kt][qc] = MFMA16(kf[kt][t], qf[qc][t], s[kt][qc]);        // S^T[key][query]
+                    dp[kt][qc] = MFMA16(vf[kt][t], gf[qc][t], dp[kt][qc]);      // dPd^T[key][query]
+                }
+#pragma unroll
+        for (int qc = 0; qc < 2; ++qc) {
+            const uint32_t base = (uint32_t)(q0 + 16 * qc + c) * (uint32_t)L + (uint32_t)(kblk * KB + 4 * g);
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = fast_exp2(s[kt][qc][r] - lse_q[qc]);
+                    float gd = dp[kt][qc][r] * inv_keep;
+                    if (thresh && mix32((base + 16 * kt + r) ^ hkey) < thresh) gd = 0.f;
+                    s[kt][qc][r] = p * (gd - d_q[qc]);                           // dS
+                }
         }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) dq = __builtin_amdgcn_mfma_f32_32x32x2f32(kc[r >> 2][r & 3], s[r], dq, 0, 0, 0);
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int qc = 0; qc < 2; ++qc) dq[qc] = MFMA16(tf[kt][r], s[kt][qc][r], dq[qc]);   // dQ^T[d][query]
     }
     const int Dm = H * DH;
     const int b = bh / H, hd = bh % H;
-    float* dst = dqkv + ((size_t)b * L + q0 + j) * 3 * Dm + hd * DH;
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        f32x4 v = {dq[4 * g] * 0.25f, dq[4 * g + 1] * 0.25f, dq[4 * g + 2] * 0.25f, dq[4 * g + 3] * 0.25f};
-        *reinterpret_cast<f32x4*>(dst + 8 * g + 4 * h) = v;
-    }
+    for (int qc = 0; qc < 2; ++qc)
+        *reinterpret_cast<f32x4v*>(dqkv + ((size_t)b * L + q0 + 16 * qc + c) * 3 * Dm + hd * DH + 4 * g) = dq[qc] * 0.25f;
 }
 
 __global__ __launch_bounds__(256)
@@ -292,7 +330,7 @@ void k_attn_bwd_dkv(const float* __restrict__ Q, const float* __restrict__ K, co
                     const float* __restrict__ lse, const float* __restrict__ Drow, float* __restrict__ dqkv, int L, int H,
                     uint32_t seed, uint32_t thresh, float inv_keep) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int j = lane & 31, h = lane >> 5;
+    const int c = lane & 15, g = lane >> 4;
     const int bh = blockIdx.y;
     const int k0 = (blockIdx.x * 4 + wave) * 32;
     const size_t hb = (size_t)bh * L * DH;
@@ -304,87 +342,86 @@ void k_attn_bwd_dkv(const float* __restrict__ Q, const float* __restrict__ K, co
     const float* d_h = Drow + (size_t)bh * L;
     const uint32_t hkey = site_key(seed, (uint32_t)bh);
 
-    const f32x4 ka = *reinterpret_cast<const f32x4*>(K + hb + (size_t)(k0 + j) * DH + 8 * h);
-    const f32x4 kb = *reinterpret_cast<const f32x4*>(K + hb + (size_t)(k0 + j) * DH + 8 * h + 4);
-    const f32x4 va = *reinterpret_cast<const f32x4*>(V + hb + (size_t)(k0 + j) * DH + 8 * h);
-    const f32x4 vb = *reinterpret_cast<const f32x4*>(V + hb + (size_t)(k0 + j) * DH + 8 * h + 4);
-    const float kf[8] = {ka.x, ka.y, ka.z, ka.w, kb.x, kb.y, kb.z, kb.w};
-    const float vf[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
-
-    f32x16 dv, dk;
+    f32x4v kf[2], vf[2], dv[2], dk[2];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { dv[r] = 0.f; dk[r] = 0.f; }
-    const int jd = j & (DH - 1);        // rows >= 16 of dV^T / dK^T are never stored: those lanes re-read rows 0..15
-
-    f32x4 qa = *reinterpret_cast<const f32x4*>(Qh + (size_t)j * DH + 8 * h);
-    f32x4 qb = *reinterpret_cast<const f32x4*>(Qh + (size_t)j * DH + 8 * h + 4);
-    f32x4 ga = *reinterpret_cast<const f32x4*>(Gh + (size_t)j * DH + 8 * h);
-    f32x4 gb = *reinterpret_cast<const f32x4*>(Gh + (size_t)j * DH + 8 * h + 4);
-    f32x4 qt[4], gt[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-        qt[g] = *reinterpret_cast<const f32x4*>(Qth + (size_t)jd * L + 8 * g + 4 * h);
-        gt[g] = *reinterpret_cast<const f32x4*>(Gth + (size_t)jd * L + 8 * g + 4 * h);
+    for (int kc = 0; kc < 2; ++kc) {
+        kf[kc] = *reinterpret_cast<const f32x4v*>(K + hb + (size_t)(k0 + 16 * kc + c) * DH + 4 * g);
+        vf[kc] = *reinterpret_cast<const f32x4v*>(V + hb + (size_t)(k0 + 16 * kc + c) * DH + 4 * g);
+        dv[kc] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        dk[kc] = f32x4v{0.f, 0.f, 0.f, 0.f};
     }
-
+    f32x4v qn[2], gn[2], qtn[2], gtn[2];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        qn[qt] = *reinterpret_cast<const f32x4v*>(Qh + (size_t)(16 * qt + c) * DH + 4 * g);
+        gn[qt] = *reinterpret_cast<const f32x4v*>(Gh + (size_t)(16 * qt + c) * DH + 4 * g);
+        qtn[qt] = *reinterpret_cast<const f32x4v*>(Qth + (size_t)c * L + 16 * qt + 4 * g);
+        gtn[qt] = *reinterpret_cast<const f32x4v*>(Gth + (size_t)c * L + 16 * qt + 4 * g);
+    }
     const int nqb = L / KB;
     for (int qblk = 0; qblk < nqb; ++qblk) {
-        const float qf[8] = {qa.x, qa.y, qa.z, qa.w, qb.x, qb.y, qb.z, qb.w};
-        const float gf[8] = {ga.x, ga.y, ga.z, ga.w, gb.x, gb.y, gb.z, gb.w};
-        const f32x4 qc[4] = {qt[0], qt[1], qt[2], qt[3]};
-        const f32x4 gc[4] = {gt[0], gt[1], gt[2], gt[3]};
-        f32x4 ls[4], dr[4];
+        const f32x4v qf[2] = {qn[0], qn[1]}, gf[2] = {gn[0], gn[1]}, qtf[2] = {qtn[0], qtn[1]}, gtf[2] = {gtn[0], gtn[1]};
+        f32x4v ls[2], dr[2];                                             // per query row 16 qt + 4g + r
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            ls[g] = *reinterpret_cast<const f32x4*>(lse_h + qblk * KB + 8 * g + 4 * h);
-            dr[g] = *reinterpret_cast<const f32x4*>(d_h + qblk * KB + 8 * g + 4 * h);
+        for (int qt = 0; qt < 2; ++qt) {
+            ls[qt] = *reinterpret_cast<const f32x4v*>(lse_h + qblk * KB + 16 * qt + 4 * g);
+            dr[qt] = *reinterpret_cast<const f32x4v*>(d_h + qblk * KB + 16 * qt + 4 * g);
         }
-        const int qn = qblk + 1 < nqb ? qblk + 1 : qblk;
-        qa = *reinterpret_cast<const f32x4*>(Qh + (size_t)(qn * KB + j) * DH + 8 * h);
-        qb = *reinterpret_cast<const f32x4*>(Qh + (size_t)(qn * KB + j) * DH + 8 * h + 4);
-        ga = *reinterpret_cast<const f32x4*>(Gh + (size_t)(qn * KB + j) * DH + 8 * h);
-        gb = *reinterpret_cast<const f32x4*>(Gh + (size_t)(qn * KB + j) * DH + 8 * h + 4);
+        const int nx = qblk + 1 < nqb ? qblk + 1 : qblk;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            qt[g] = *reinterpret_cast<const f32x4*>(Qth + (size_t)jd * L + qn * KB + 8 * g + 4 * h);
-            gt[g] = *reinterpret_cast<const f32x4*>(Gth + (size_t)jd * L + qn * KB + 8 * g + 4 * h);
+        for (int qt = 0; qt < 2; ++qt) {
+            qn[qt] = *reinterpret_cast<const f32x4v*>(Qh + (size_t)(nx * KB + 16 * qt + c) * DH + 4 * g);
+            gn[qt] = *reinterpret_cast<const f32x4v*>(Gh + (size_t)(nx * KB + 16 * qt + c) * DH + 4 * g);
+            qtn[qt] = *reinterpret_cast<const f32x4v*>(Qth + (size_t)c * L + nx * KB + 16 * qt + 4 * g);
+            gtn[qt] = *reinterpret_cast<const f32x4v*>(Gth + (size_t)c * L + nx * KB + 16 * qt + 4 * g);
         }
-
-        f32x16 s, dp;
+        f32x4v s[2][2], dp[2][2];                                        // [qt][kc]: rows = queries, columns = keys
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-        for (int t = 0; t < 8; ++t) s = __builtin_amdgcn_mfma_f32_32x32x2f32(qf[t], kf[t], s, 0, 0, 0);      // S[query][key]
+            for (int kc = 0; kc < 2; ++kc) { s[qt][kc] = f32x4v{0.f, 0.f, 0.f, 0.f}; dp[qt][kc] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-        for (int t = 0; t < 8; ++t) dp = __builtin_amdgcn_mfma_f32_32x32x2f32(gf[t], vf[t], dp, 0, 0, 0);    // dPd[query][key]
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int g = r >> 2, c = r & 3;
-            const float p = fast_exp2(s[r] - ls[g][c]);
-            float pd = p, gd = dp[r] * inv_keep;
-            if (thresh) {
-                const uint32_t idx = (uint32_t)(qblk * KB + 8 * g + 4 * h + c) * (uint32_t)L + (uint32_t)(k0 + j);
-                if (mix32(idx ^ hkey) < thresh) { pd = 0.f; gd = 0.f; }
-            }
-            s[r] = p * (gd - dr[g][c]);       // dS
-            dp[r] = pd;                        // Pd (without the 1/keep factor, applied once at the end)
-        }
+            for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            dv = __builtin_amdgcn_mfma_f32_32x32x2f32(gc[r >> 2][r & 3], dp[r], dv, 0, 0, 0);   // dV^T[d][key]
-            dk = __builtin_amdgcn_mfma_f32_32x32x2f32(qc[r >> 2][r & 3], s[r], dk, 0, 0, 0);    // dK^T[d][key]
-        }
+                for (int kc = 0; kc < 2; ++kc) {
+                    s[qt][kc] = MFMA16(qf[qt][t], kf[kc][t], s[qt][kc]);        // S[query][key]
+                    dp[qt][kc] = MFMA16(gf[qt][t], vf[kc][t], dp[qt][kc]);      // dPd[query][key]
+                }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float p = fast_exp2(s[qt][kc][r] - ls[qt][r]);
+                    float pd = p, gd = dp[qt][kc][r] * inv_keep;
+                    if (thresh) {
+                        const uint32_t idx = (uint32_t)(qblk * KB + 16 * qt + 4 * g + r) * (uint32_t)L + (uint32_t)(k0 + 16 * kc + c);
+                        if (mix32(idx ^ hkey) < thresh) { pd = 0.f; gd = 0.f; }
+                    }
+                    s[qt][kc][r] = p * (gd - dr[qt][r]);       // dS
+                    dp[qt][kc][r] = pd;                         // Pd (the 1/keep factor is applied once at the end)
+                }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int kc = 0; kc < 2; ++kc) {
+                    dv[kc] = MFMA16(gtf[qt][r], dp[qt][kc][r], dv[kc]);          // dV^T[d][key]
+                    dk[kc] = MFMA16(qtf[qt][r], s[qt][kc][r], dk[kc]);           // dK^T[d][key]
+                }
     }
     const int Dm = H * DH;
     const int b = bh / H, hd = bh % H;
-    float* dst = dqkv + ((size_t)b * L + k0 + j) * 3 * Dm + hd * DH;
     const float ln2 = 0.69314718055994530942f;            // Q carries scale * log2 e
 #pragma unroll
-    for (int g = 0; g < 2; ++g) {
-        f32x4 vk = {dk[4 * g] * ln2, dk[4 * g + 1] * ln2, dk[4 * g + 2] * ln2, dk[4 * g + 3] * ln2};
-        f32x4 vv = {dv[4 * g] * inv_keep, dv[4 * g + 1] * inv_keep, dv[4 * g + 2] * inv_keep, dv[4 * g + 3] * inv_keep};
-        *reinterpret_cast<f32x4*>(dst + Dm + 8 * g + 4 * h) = vk;
-        *reinterpret_cast<f32x4*>(dst + 2 * Dm + 8 * g + 4 * h) = vv;
+    for (int kc = 0; kc < 2; ++kc) {
+        float* dst = dqkv + ((size_t)b * L + k0 + 16 * kc + c) * 3 * Dm + hd * DH + 4 * g;
+        *reinterpret_cast<f32x4v*>(dst + Dm) = dk[kc] * ln2;
+        *reinterpret_cast<f32x4v*>(dst + 2 * Dm) = dv[kc] * inv_keep;
     }
 }
 
@@ -560,8 +597,7 @@ extern "C" int be_attention_train_fwd_f32(const float* qkv, float* out, float* l
     BE_REQUIRE(be::aligned16(qkv) && be::aligned16(out) && be::aligned16(workspace), "be_attention_train_fwd_f32: 16-byte alignment");
     hipStream_t s = be::as_stream(stream);
     const TrainWs w = train_ws(workspace, B, L, H);
-    const size_t n = (size_t)B * H * L * DH;
-    int64_t g = ((int64_t)n + 255) / 256; if (g > 4096) g = 4096;
+    int64_t g = ((int64_t)B * H * L + 255) / 256; if (g > 8192) g = 8192;
     hipLaunchKernelGGL(k_qkv_split_train, dim3((unsigned)g), dim3(256), 0, s, qkv, w.Q, w.K, w.V, w.Qt, w.Kt, w.Vt, B, L, H,
                        0.25f * 1.44269504088896340736f);
     hipLaunchKernelGGL(k_attention<true>, dim3(L / 128, B * H), dim3(256), 0, s, w.Q, w.K, w.Vt, out, lse, L, H, seed,
@@ -570,18 +606,19 @@ extern "C" int be_attention_train_fwd_f32(const float* qkv, float* out, float* l
 }
 
 extern "C" int be_attention_bwd_f32(const float* qkv, const float* out, const float* lse, const float* dout, float* dqkv,
-                                    float* workspace, int B, int L, int H, float dropout_p, uint32_t seed, void* stream) {
+                                    float* workspace, int operands_ready, int B, int L, int H, float dropout_p,
+                                    uint32_t seed, void* stream) {
     BE_REQUIRE(qkv && out && lse && dout && dqkv && workspace, "be_attention_bwd_f32: null pointer");
     if (int rc = attn_args_ok("be_attention_bwd_f32", B, L, H, dropout_p)) return rc;
     BE_REQUIRE(be::aligned16(qkv) && be::aligned16(dqkv) && be::aligned16(workspace) && be::aligned16(lse),
                "be_attention_bwd_f32: 16-byte alignment");
     hipStream_t s = be::as_stream(stream);
     const TrainWs w = train_ws(workspace, B, L, H);
-    const size_t n = (size_t)B * H * L * DH;
-    int64_t g = ((int64_t)n + 255) / 256; if (g > 4096) g = 4096;
-    hipLaunchKernelGGL(k_qkv_split_train, dim3((unsigned)g), dim3(256), 0, s, qkv, w.Q, w.K, w.V, w.Qt, w.Kt, w.Vt, B, L, H,
-                       0.25f * 1.44269504088896340736f);
-    int64_t g2 = ((int64_t)B * L * H + 255) / 256; if (g2 > 4096) g2 = 4096;
+    int64_t g = ((int64_t)B * H * L + 255) / 256; if (g > 8192) g = 8192;
+    if (!operands_ready)          // the workspace of this layer's forward call was reused in between: split q/k/v again
+        hipLaunchKernelGGL(k_qkv_split_train, dim3((unsigned)g), dim3(256), 0, s, qkv, w.Q, w.K, w.V, w.Qt, w.Kt, w.Vt, B, L,
+                           H, 0.25f * 1.44269504088896340736f);
+    int64_t g2 = g;
     hipLaunchKernelGGL(k_dout_prep, dim3((unsigned)g2), dim3(256), 0, s, dout, out, w.dOh, w.dOt, w.Drow, B, L, H);
     const uint32_t th = drop_threshold(dropout_p);
     const float ik = 1.0f / (1.0f - dropout_p);

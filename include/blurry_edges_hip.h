@@ -356,9 +356,12 @@ size_t be_attention_train_workspace_floats(int B, int L, int H);
 int be_attention_train_fwd_f32(const float* qkv, float* out, float* lse, float* workspace, int B, int L, int H,
                                float dropout_p, uint32_t seed, void* stream);
 /* Attention backward: dout [B*L, H*16] -> dqkv [B*L, 3*H*16]; probabilities are recomputed from qkv and lse
- * (no [L,L] tensor is ever stored); deterministic (no atomics).  Same workspace size as the forward. */
+ * (no [L,L] tensor is ever stored); deterministic (no atomics).  Same workspace size as the forward.
+ * operands_ready != 0: `workspace` is the buffer the forward call of this layer used and nothing wrote to it since
+ * (its split q/k/v are reused); 0: they are split again from qkv. */
 int be_attention_bwd_f32(const float* qkv, const float* out, const float* lse, const float* dout, float* dqkv,
-                         float* workspace, int B, int L, int H, float dropout_p, uint32_t seed, void* stream);
+                         float* workspace, int operands_ready, int B, int L, int H, float dropout_p, uint32_t seed,
+                         void* stream);
 /* The keep mask the two functions above apply, [B*H, L, L] in {0,1} (test hook; small L only). */
 int be_attention_dropout_mask_f32(float* mask, int B, int L, int H, float dropout_p, uint32_t seed, void* stream);
 /* y = dropout(x) = x * keep / (1-p); with gate != NULL additionally zero where gate <= 0, which makes it the

@@ -148,6 +148,8 @@ def test_attention_train_forward_backward_vs_fp64_autograd(p):
     dout = torch.from_numpy(synth.hash_normal(4, "attn_dout", (B * L, H * 16)).astype(np.float32)).to(DEV)
     out, lse, ws = tg.attention_train_fwd(qkv, B, L, H, p, seed)
     dqkv, _ = tg.attention_bwd(qkv, out, lse, dout, B, L, H, p, seed, ws)
+    again, _ = tg.attention_bwd(qkv, out, lse, dout, B, L, H, p, seed, ws, operands_ready=True)    # forward's split reused
+    assert torch.equal(dqkv, again)
     mask = tg.attention_dropout_mask(B, L, H, p, seed, DEV).double() if p > 0 else None
     if p > 0:
         frac = float(mask.mean())
