@@ -103,10 +103,16 @@ class DepthPipeline:
         # blocks are windows of the big image: no cropped copies, no unfolded copies
         big = torch.zeros(HP * WP, native.RECORD_FLOATS, dtype=torch.float32, device=img.device).view(HP, WP, -1)
         wins = self.big_windows(H, W, block, n_margin, s, R)
-        for k in shard.my_blocks(len(wins), rank, world):
+        mine = shard.my_blocks(len(wins), rank, world)
+        # local stage block by block (8192 patches each = one CNN sub-batch), then GlobalStage on groups of blocks in one
+        # batch (attention at batch 1 leaves three quarters of the SIMD slots empty), then pass B per block
+        feats = [self.local_pass(img, wins[k][0])[3] for k in mine]
+        est = []
+        for g0 in range(0, len(mine), 12):
+            y = self.globl(torch.stack(feats[g0:g0 + 12]))                          # [g,4096,12]
+            est.extend(native.global_denorm(y[i]) for i in range(y.shape[0]))
+        for k, est12 in zip(mine, est):
             win, (vs, ve, hs, he), (Vs, Hs) = wins[k]
-            _, _, _, pm = self.local_pass(img, win)
-            est12 = self.global_pass(pm)
             rec, _ = self.records(est12, img, window=win)
             big[Vs:Vs + ve - vs, Hs:Hs + he - hs] = rec.view(hp, hp, -1)[vs:ve, hs:he]
         if world > 1:
