@@ -30,6 +30,9 @@ PAIRS = 4096                          # configs[1]
 FLOP_PER_PATCH = 387.716e6            # SURVEY.md A.2 (2*MAC, convs + linears)
 FLOP_PER_PAIR = 2 * FLOP_PER_PATCH    # 775.43 MFLOP, SURVEY.md 8d
 PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: dense fp32 matrix peak
+# opt-in experiment (BE_CONV_PRECISION=bf16x3, never the default): six bf16 MFMAs per fp32 product -> the price is a
+# sixth of the dense bf16 peak (~2.5 PFLOP/s)
+PEAK_BF16X3_TFLOPS = 2500.0 / 6
 CPU_SAMPLE_PAIRS = 4096                 # the whole batch: ~10 s on 16 threads
 
 
@@ -167,20 +170,21 @@ def main():
         dom = [r for r in recs if r[0] == 0]
         conv_ms = sum(r[3] for r in recs) / args.steps
         if dom:
+            peak = PEAK_FP32_MFMA_TFLOPS if model.conv_precision == "f32" else PEAK_BF16X3_TFLOPS
             avg_ms = sum(r[3] for r in dom) / len(dom)
             avg_flop = sum(r[1] for r in dom) / len(dom)
             ach = avg_flop / (avg_ms * 1e-3) / 1e12
             roof = dict(bound="mfma", kernel=native.KERNEL_NAMES[0], achieved=round(ach, 2),
-                        peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s", frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4),
+                        peak=round(peak, 1), unit="TFLOP/s", frac=round(ach / peak, 4),
                         traffic=None, launches_per_step=len(dom) // args.steps,
                         avg_launch_ms=round(avg_ms, 4), flop_per_launch=avg_flop,
                         algo_bytes_per_launch=sum(r[2] for r in dom) / len(dom),
                         # MFMA work actually issued (pixel-major tiles skip the zero-padding taps the algorithmic
                         # count includes; tile padding counted): the busy fraction of the matrix pipe at nominal clock
                         mfma_executed_tflops=round(sum(r[4] for r in dom) / sum(r[3] for r in dom) / 1e9, 2),
-                        mfma_executed_frac=round(sum(r[4] for r in dom) / sum(r[3] for r in dom) / 1e9 / PEAK_FP32_MFMA_TFLOPS, 4),
+                        mfma_executed_frac=round(sum(r[4] for r in dom) / sum(r[3] for r in dom) / 1e9 / peak, 4),
                         all_conv_ms_per_step=round(conv_ms, 3),
-                        end_to_end_frac=round(PAIRS * args.steps / elapsed * FLOP_PER_PAIR / (PEAK_FP32_MFMA_TFLOPS * 1e12), 4))
+                        end_to_end_frac=round(PAIRS * args.steps / elapsed * FLOP_PER_PAIR / (peak * 1e12), 4))
             pmc = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
             if os.path.exists(pmc):                 # HBM bytes per launch from the separate --pmc passes
                 try:
@@ -208,7 +212,7 @@ def main():
             "metric": "patch-pairs/s (local CNN + render + depth) on 21x21 synth",
             "value": round(world * PAIRS * args.steps / elapsed, 1), "unit": "patch-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if model.conv_precision == "f32" else "f32 operands split exactly into 3 bf16 pieces, 6 bf16 MFMAs per product, f32 accumulate (opt-in experiment)", "data": "synthetic",
             "config": {"workload": "configs[1]: batch of 4096 synthetic 21x21 two-aperture patch pairs per GPU "
                                    "(8192 CNN patches): LocalStage inference + pass-A colour solve + depth solve",
                        "pairs_per_gpu": PAIRS, "weights": "portable-generator random init (no checkpoint offline)",

@@ -63,6 +63,8 @@ _SIGNATURES = {
     "be_conv_pack_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "be_conv_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, C.c_int, _P]),
     "be_conv_nhwc_splitk_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, C.c_int, _P, C.c_size_t, _P]),
+    "be_conv_split_b3_f32": (C.c_int, [_P, C.c_size_t, _P, _P]),
+    "be_conv_use_b3": (C.c_int, [_P, _P, C.c_size_t]),
     "be_conv_fused2_packed_floats": (C.c_size_t, [C.c_int] * 4),
     "be_conv_pack_fused2_f32": (C.c_int, [_P] * 12 + [C.c_float] + [C.c_int] * 4 + [_P, _P, _P]),
     "be_conv_nhwc_fused2_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, C.c_int, _P, _P, _P, C.c_int, _P]),
@@ -336,6 +338,22 @@ def local_stage_forward(packed, x, out=None, workspace=None):
     check(lib().be_local_stage_forward_f32(dptr(packed, "packed"), dptr(x, "x"), dptr(out), n, dptr(workspace),
                                            workspace.numel() * 4, stream_ptr(dev)), "be_local_stage_forward_f32")
     return out, workspace
+
+
+def conv_use_b3(packed=None):
+    """Opt-in split-bf16 mode for the convolutions reading `packed` (a float32 GPU buffer of packed weights); None switches
+    it off.  Returns the bf16 planes tensor, which the caller must keep alive while the mode is on."""
+    if packed is None:
+        check(lib().be_conv_use_b3(None, None, 0), "be_conv_use_b3")
+        return None
+    n = packed.numel()
+    if n % 16:
+        raise RuntimeError("conv_use_b3: packed buffer length must be a multiple of 16 floats")
+    planes = torch.empty(3 * n, dtype=torch.int16, device=packed.device)
+    check(lib().be_conv_split_b3_f32(dptr(packed, "packed"), n, C.c_void_p(planes.data_ptr()), stream_ptr(packed.device)),
+          "be_conv_split_b3_f32")
+    check(lib().be_conv_use_b3(dptr(packed), C.c_void_p(planes.data_ptr()), n), "be_conv_use_b3")
+    return planes
 
 
 def local_stage_forward_view(packed, view, patches_per_image: int, n: int, device, out=None, workspace=None):

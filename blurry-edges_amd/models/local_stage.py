@@ -8,6 +8,8 @@ through the C ABI in include/blurry_edges_hip.h.  There is no eager / CPU path.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -93,11 +95,19 @@ class LocalStage(nn.Module):
                     fc4.weight, fc4.bias])
         return out
 
+    # "f32" (default): exact fp32 MFMA.  "bf16x3" (EXPERIMENTAL, opt-in; also BE_CONV_PRECISION=bf16x3): the 128x128-tile
+    # convolutions of layers 1-3 and fc.1 split every fp32 operand exactly into three bf16 pieces and take six bf16 MFMAs
+    # per product with fp32 accumulation (include/blurry_edges_hip.h, be_conv_use_b3).
+    conv_precision = os.environ.get("BE_CONV_PRECISION", "f32")
+
     def _packed_weights(self):
         tensors = [t.detach() for t in self._tensor_list()]
-        key = tuple((t.data_ptr(), t._version) for t in tensors)
+        key = tuple((t.data_ptr(), t._version) for t in tensors) + (self.conv_precision,)
         if self._packed is None or key != self._packed_key:
+            if self.conv_precision not in ("f32", "bf16x3"):
+                raise ValueError(f"LocalStage.conv_precision must be 'f32' or 'bf16x3', got {self.conv_precision!r}")
             self._packed = native.local_stage_pack(tensors, eps=self.conv1[1].eps)
+            self._b3_planes = native.conv_use_b3(self._packed if self.conv_precision == "bf16x3" else None)
             self._packed_key = key
         return self._packed
 

@@ -269,6 +269,14 @@ int be_conv_pack_fused2_f32(const float* weight_oihw, const float* bias, const f
                             void* stream);
 int be_conv_nhwc_fused2_f32(const be_conv_desc* desc_host, const float* x, const float* x2, int cin2,
                             const float* packed_w, const float* packed_bias, float* y, int ldy, void* stream);
+/* EXPERIMENTAL, opt-in: split-bf16 arithmetic for the 128x128-tile convolutions.  Every fp32 operand is split exactly
+ * into three bf16 pieces (x = hi + mid + lo) and a product is six bf16 MFMAs accumulated in fp32 (the three dropped
+ * cross terms are <= 2^-24 relative, the size of one fp32 rounding).  be_conv_split_b3_f32 turns a packed weight
+ * buffer of n floats into planes [3][n] bf16; be_conv_use_b3(packed, planes, n) makes every later convolution whose
+ * packed weights lie inside that buffer use them (NULL, NULL, 0 switches back).  Default is off: exact fp32 MFMA. */
+int be_conv_split_b3_f32(const float* packed, size_t n, void* planes, void* stream);
+int be_conv_use_b3(const float* packed, const void* planes, size_t n);
+
 /* nn.MaxPool2d(k, stride, pad) on NHWC (models/local_stage.py:42-43). */
 int be_maxpool_nhwc_f32(const float* x, float* y, int n, int h, int w, int c, int k, int stride, int pad,
                         void* stream);

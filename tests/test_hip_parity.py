@@ -1,6 +1,8 @@
 """GPU parity tests: the HIP path (through the C ABI via be_hip.native / the reference-shaped classes)
 against the CPU oracle on identical seeded inputs, and against the committed golden vectors.
 Tolerances are the ones SURVEY.md 8c derives from measurements on the reference (L-inf / L-inf)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -395,3 +397,27 @@ def test_split_k_conv_matches_the_single_pass_kernel(n, hw, cin, cout, ks):
         assert torch.equal(small, ref)                              # scratch for one slice only: no split, same kernel
     big = T(synth.hash_normal(25, "sk_big", (2048, hw, hw, cin)).astype(np.float32)).to(DEV)
     assert torch.equal(native.conv_nhwc(big, pw, pb, cout, ks, 1), native.conv_nhwc(big, pw, pb, cout, ks, 1, scratch=scratch))
+
+
+def test_split_bf16_conv_mode_is_opt_in_and_stays_within_the_fp32_tolerance(native):
+    """EXPERIMENTAL bf16x3 mode (six bf16 MFMAs per product, operands split exactly into three bf16 pieces): off by
+    default; when switched on the logits stay within the 1e-5 tolerance of the fp32 path against the oracle."""
+    import models
+    from oracle import local_stage as ols
+    m = models.LocalStage()
+    m.load_state_dict({k: T(v) for k, v in synth.local_stage_state_dict().items()})
+    m = m.to(DEV).eval()
+    assert m.conv_precision == os.environ.get("BE_CONV_PRECISION", "f32")
+    x = T(synth.uniform_patches(1024, name="b3")).to(DEV)
+    m.conv_precision = "f32"
+    with torch.no_grad():
+        y32 = m(x).clone()
+        m.conv_precision = "bf16x3"
+        y3 = m(x).clone()
+        m.conv_precision = "f32"
+        y32b = m(x)
+    assert torch.equal(y32, y32b) and not torch.equal(y32, y3)          # the mode really switches, and switches back
+    ref = ols.local_stage_forward(ols.to_torch_sd(synth.local_stage_state_dict(), torch.float64), x[:256].cpu().double())
+    e32, e3 = relmax(y32[:256].cpu(), ref), relmax(y3[:256].cpu(), ref)
+    print("logits vs fp64 oracle: fp32 MFMA %.2e, bf16x3 %.2e" % (e32, e3))
+    assert e32 <= 1e-5 and e3 <= 1e-5
