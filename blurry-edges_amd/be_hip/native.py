@@ -69,6 +69,7 @@ _SIGNATURES = {
     "be_conv_pack_fused2_f32": (C.c_int, [_P] * 12 + [C.c_float] + [C.c_int] * 4 + [_P, _P, _P]),
     "be_conv_nhwc_fused2_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, C.c_int, _P, _P, _P, C.c_int, _P]),
     "be_maxpool_nhwc_f32": (C.c_int, [_P, _P] + [C.c_int] * 7 + [_P]),
+    "be_eval_depth_f32": (C.c_int, [_P, _P, _P] + [C.c_int] * 4 + [C.c_float] * 3 + [_P, _P]),
     "be_maxpool_nhwc_ld_f32": (C.c_int, [_P, C.c_int, _P] + [C.c_int] * 7 + [_P]),
     "be_nchw_to_nhwc_pad_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int64, C.c_int, _P]),
     "be_upconv2x2_scatter_f32": (C.c_int, [_P, _P, C.c_int64] + [C.c_int] * 9 + [_P]),
@@ -285,6 +286,16 @@ def maxpool_nhwc(x, k, stride, pad, channels=None):
     check(lib().be_maxpool_nhwc_ld_f32(dptr(x, "x"), ld, dptr(y), n, h, w, c, k, stride, pad, stream_ptr(x.device)),
           "be_maxpool_nhwc_f32")
     return y
+
+
+def eval_depth(pred, gt, mask_src, crop=0, tau_n=1.25, z_min=0.75, z_max=1.18):
+    """pred, gt, mask_src [B,H,W] float32 on the GPU -> float64 tensor [5] (delta1-3, RMSE cm, AbsRel cm) on the GPU."""
+    b, h, w = pred.shape
+    out = torch.empty(5, dtype=torch.float64, device=pred.device)
+    check(lib().be_eval_depth_f32(dptr(pred, "pred"), dptr(gt, "gt"), dptr(mask_src, "mask"), b, h, w, int(crop), float(tau_n),
+                                  float(z_min), float(z_max), C.c_void_p(out.data_ptr()), stream_ptr(pred.device)),
+          "be_eval_depth_f32")
+    return out
 
 
 def nchw_to_nhwc_pad(x, cpad):

@@ -93,3 +93,55 @@ extern "C" int be_local_depth_f32(const be_depth_consts* c, const float* params1
                        params10, depth, n_pairs);
     return be::check_launch("be_local_depth_f32");
 }
+
+// ---- eval_depth (utils/metrics.py:3-20) on the device: delta1-3, RMSE (cm), AbsRel (cm) over the masked, cropped pixels
+// of a [B,H,W] batch, summed jointly as the reference does.  One workgroup, fp64 accumulation, fixed order.
+namespace {
+__global__ __launch_bounds__(1024)
+void k_eval_depth(const float* __restrict__ pred, const float* __restrict__ gt, const float* __restrict__ thr_src,
+                  int B, int H, int W, int crop, float tau, float zmin, float zmax, double* __restrict__ out) {
+    __shared__ double red[6][16];
+    double acc[6] = {0, 0, 0, 0, 0, 0};               // n(d1), n(d2), n(d3), sum err^2, sum err/gt, count
+    const int h = H - 2 * crop, w = W - 2 * crop;
+    const int64_t total = (int64_t)B * h * w;
+    const float span = zmax - zmin;
+    const float t1 = tau, t2 = tau * tau, t3 = tau * tau * tau;
+    for (int64_t i = threadIdx.x; i < total; i += blockDim.x) {
+        const int x = (int)(i % w) + crop, y = (int)((i / w) % h) + crop;
+        const int64_t e = ((i / ((int64_t)w * h)) * H + y) * W + x;
+        if (!(thr_src[e] > 0.0f)) continue;            // mask = depth_map > 0 (blurry_edges_test.py:148)
+        const float g = gt[e];
+        const float p = fminf(fmaxf(pred[e], zmin), zmax);
+        const float pn = fminf(fmaxf((p - zmin) / span, 0.f), 1.f), gn = fminf(fmaxf((g - zmin) / span, 0.f), 1.f);
+        const float ratio = fmaxf(gn / (pn + 1e-8f), pn / (gn + 1e-8f));
+        const float err = fabsf(g - p);
+        acc[0] += ratio < t1; acc[1] += ratio < t2; acc[2] += ratio < t3;
+        acc[3] += (double)err * err; acc[4] += (double)(err / g); acc[5] += 1.0;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+        double v = acc[k];
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+        if (lane == 0) red[k][wave] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s[6];
+        for (int k = 0; k < 6; ++k) { s[k] = 0; for (int wv = 0; wv < (int)(blockDim.x >> 6); ++wv) s[k] += red[k][wv]; }
+        const double n = s[5];
+        out[0] = s[0] / n; out[1] = s[1] / n; out[2] = s[2] / n;
+        out[3] = sqrt(s[3] / n) * 100.0; out[4] = s[4] / n * 100.0;
+    }
+}
+}  // namespace
+
+extern "C" int be_eval_depth_f32(const float* pred, const float* gt, const float* mask_src, int B, int H, int W, int crop,
+                                 float tau_n, float z_min, float z_max, double* out5, void* stream) {
+    BE_REQUIRE(pred && gt && mask_src && out5, "be_eval_depth_f32: null pointer");
+    BE_REQUIRE(B > 0 && H > 0 && W > 0 && crop >= 0 && 2 * crop < H && 2 * crop < W, "be_eval_depth_f32: bad shape / crop");
+    BE_REQUIRE(z_max > z_min && tau_n > 0.f, "be_eval_depth_f32: bad range");
+    hipLaunchKernelGGL(k_eval_depth, dim3(1), dim3(1024), 0, be::as_stream(stream), pred, gt, mask_src, B, H, W, crop, tau_n,
+                       z_min, z_max, out5);
+    return be::check_launch("be_eval_depth_f32");
+}

@@ -325,6 +325,12 @@ int be_conv_pack_dgrad_f32(const float* weight_oihw, int cout, int cin, int ksiz
 int be_linear_small_bwd_f32(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int M,
                             int K, int J, void* stream);
 
+/* eval_depth (utils/metrics.py:3-20) on the device: pred, gt [B,H,W]; a pixel counts when mask_src > 0 (the scripts pass
+ * the estimated depth map itself, blurry_edges_test.py:148); crop pixels dropped on every side; out5 (device, float64) =
+ * delta1, delta2, delta3, RMSE in cm, AbsRel in cm, summed jointly over the batch as the reference does. */
+int be_eval_depth_f32(const float* pred, const float* gt, const float* mask_src, int B, int H, int W, int crop, float tau_n,
+                      float z_min, float z_max, double* out5, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * Depth-completion U-Net glue ('--densify pp', models/depth_completion_unet.py:79-113; blurry_edges_test.py:141-142).
  * Its convolutions are be_conv_nhwc_f32 launches (3x3 + folded BatchNorm + ReLU; ConvTranspose2d(k=2,s=2) as a 1x1

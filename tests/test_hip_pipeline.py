@@ -410,3 +410,18 @@ def test_datagen_files_feed_the_local_training_dataset(env, tmp_path):
     g = data.ShapeDataset(DEV, data_path=str(tmp_path), train=True, mode="global_pre")
     assert len(g) == 8 and tuple(g[0].shape) == (2, 147, 147, 3)
     assert np.load(tmp_path / "images_ny_train.npy").dtype == np.float64
+
+
+def test_eval_depth_on_device_matches_reference_golden(env):
+    """utils.eval_depth on GPU tensors (be_eval_depth_f32) against g10 = the reference's numpy function."""
+    import utils
+    S = synth.SEED_DEFAULT
+    pred = 0.7 + 0.6 * synth.hash_uniform(S, "m_pred", (1, 147, 147))
+    gt = 0.75 + 0.43 * synth.hash_uniform(S, "m_gt", (1, 147, 147))
+    msk = synth.hash_uniform(S, "m_msk", (1, 147, 147)) > 0.3
+    pred = np.where(msk, pred, 0.0).astype(np.float32)
+    p, g = T(pred).to(DEV), T(gt.astype(np.float32)).to(DEV)
+    r = utils.eval_depth(p, g, (p > 0), crop=10)
+    assert np.allclose(np.array(r), load_golden("g10_metrics")["metrics"], rtol=2e-6)
+    two = utils.eval_depth(torch.cat([p, p]), torch.cat([g, g]), torch.cat([p, p]) > 0, crop=10)
+    assert np.allclose(np.array(two), np.array(r), rtol=1e-9)                  # batch is pooled, as in the reference
