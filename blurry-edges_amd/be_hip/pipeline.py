@@ -118,5 +118,8 @@ class DepthPipeline:
         if world > 1:
             big = shard.assemble_records(big, group)
         maps = native.fold_records(self.helper.render_opts(False), big.view(HP * WP, -1), HP, WP, H, W, s, self.densify == "w")
-        maps["depth_map"] = torch.where(maps["conf"] > 0.05, maps["depth"], torch.zeros_like(maps["depth"]))
+        if self.densify == "pp":
+            maps["depth_map"] = self.pp(maps["depth"][None, None])[0, 0]
+        else:                                                                       # blurry_edges_test_big.py:189
+            maps["depth_map"] = torch.where(maps["conf"] > 0.05, maps["depth"], torch.zeros_like(maps["depth"]))
         return maps

@@ -1,0 +1,233 @@
+"""The reference's driver scripts as functions + a small CLI, running on this package's HIP path and the reference's file
+formats (argument names and defaults = utils/args.py of the reference):
+
+    python -m be_hip.datagen      [...]        train_val_data_generator.py  (data set -> .npy files)
+    python -m be_hip.workflow local_train      local_training.py:68-121     (ShapeDataset 'local' -> best_run_exp_local_stage.pth)
+    python -m be_hip.workflow global_pre       global_data_pre_cal.py:52-69 (local stage over images -> params_src_*.npy)
+    python -m be_hip.workflow global_train     global_training.py:168-224   (ShapeDataset 'global' -> best_run_exp_global_stage.pth)
+    python -m be_hip.workflow eval [--big]     blurry_edges_test.py:102-176 / blurry_edges_test_big.py (TestDataset -> metrics)
+
+Checkpoints are `torch.save(model.state_dict())` files in the reference's key layout, so they are interchangeable with
+the reference's.  Epoch loops, schedules (beta / gamma ramps, ReduceLROnPlateau with the growing patience), xavier
+initialisation, clipping and AdamW settings follow the scripts cited above; the compute inside a step is the HIP path.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+
+def _device(args):
+    return torch.device(args.cuda if torch.cuda.is_available() else "cpu")
+
+
+def _xavier_(model):
+    for p in model.parameters():
+        if p.dim() > 1:
+            torch.nn.init.xavier_normal_(p)
+
+
+def _log_header(f, args):
+    print('Arguments:', file=f, flush=True)
+    for k in vars(args):
+        print(f'{k:<20}: {getattr(args, k)}', file=f, flush=True)
+    print('\nTraining:', file=f, flush=True)
+    print(f'{"Epoch":<10} {"Loss":<20} {"Scheduler patience":<20} {"Learning rate"}', file=f, flush=True)
+
+
+# ---------------------------------------------------------------------------------------------- local_training.py
+def local_train(args, quiet=False):
+    import data, models, utils
+    from .train_local import BetaSchedule, train_step
+    utils.set_seed(1869)
+    utils.create_directory(args.log_path, overwrite=False)
+    os.makedirs(args.model_path, exist_ok=True)
+    dev = _device(args)
+    tr = data.ShapeDataset(dev, data_path=args.data_path, train=True)
+    va = data.ShapeDataset(dev, data_path=args.data_path, train=False)
+    tr_loader = DataLoader(tr, batch_size=args.batch_size, shuffle=True, drop_last=True)
+    va_loader = DataLoader(va, batch_size=args.batch_size, shuffle=False, drop_last=True)
+    model = models.LocalStage().to(dev)
+    _xavier_(model)
+    opt = torch.optim.AdamW(model.parameters(), lr=args.learning_rate)
+    helper = utils.PostProcessLocalBase(args, dev)
+    beta = BetaSchedule(args.beta_bndry_loc, args.beta_smthns, args.dynamic_epoch)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, 'min', factor=0.9, patience=2, min_lr=args.learning_rate * 0.1)
+    curve = np.zeros((args.epoch_num,), dtype=float)
+    best, best_epoch = np.inf, 0
+    with open(f'{args.log_path}/exp_local_stage_training.txt', 'wt') as f:
+        _log_header(f, args)
+        for epoch in range(args.epoch_num):
+            beta.step()
+            model.train()
+            for img_ny, img_gt, bndry_dist, deri in tr_loader:
+                train_step(model, helper, opt, dict(img_ny=img_ny, img_gt=img_gt, bndry_dist=bndry_dist, deri=deri),
+                           beta.beta_b, beta.beta_s)
+            # validation with the final betas (local_training.py:54-66)
+            model.eval()
+            total = 0.0
+            with torch.no_grad():
+                for img_ny, img_gt, bndry_dist, deri in va_loader:
+                    est = model(img_ny.permute(0, 3, 1, 2).contiguous())
+                    total += float(utils.local_loss(helper, est, img_ny, img_gt, bndry_dist, deri, args.beta_bndry_loc,
+                                                    args.beta_smthns))
+            curve[epoch] = total / max(len(va) // args.batch_size, 1)
+            sched.step(curve[epoch])
+            sched.patience = 2 + int(np.log2(epoch + 1)) * 3
+            print(f'{epoch + 1:<10} {curve[epoch]:<20.10f} {sched.patience:<20} {opt.param_groups[0]["lr"]:.4e}', file=f, flush=True)
+            if curve[epoch] < best:
+                best, best_epoch = curve[epoch], epoch
+                torch.save(model.state_dict(), f'{args.model_path}/best_run_exp_local_stage.pth')
+            if not quiet:
+                print(f'epoch {epoch + 1}: validation loss {curve[epoch]:.6f}')
+        print(f'\n-- Best epoch is the {best_epoch + 1:d}th, with average loss of {best:.10f}', file=f, flush=True)
+    np.save(f'{args.log_path}/loss_curve_exp_local_stage.npy', curve)
+    utils.showCurve(args, curve, 'loss_curve_exp_local_stage')
+    return curve
+
+
+# ------------------------------------------------------------------------------------------- global_data_pre_cal.py
+@torch.no_grad()
+def global_pre(args, local_weights=None, quiet=False):
+    """params_src_{train,val}.npy [n, 2, P, 19] float64: the normalised local-stage output + colours of every image."""
+    import data, models, utils
+    from . import native
+    from .pipeline import DepthPipeline
+    dev = _device(args)
+    model = models.LocalStage().to(dev)
+    model.load_state_dict(torch.load(local_weights or f'{args.model_path}/pretrained_local_stage.pth', map_location=dev))
+    model.eval()
+    pipe = DepthPipeline(model, None, utils.PostProcessGlobalBase(args, dev), None, stride=args.stride)
+    for part, train in (("train", True), ("val", False)):
+        ds = data.ShapeDataset(dev, data_path=args.data_path, train=train, mode='global_pre')
+        out = None
+        for j in range(len(ds)):
+            img = ds[j].permute(0, 3, 1, 2).contiguous()                     # [2,3,H,W]
+            pm = pipe.local_pass(img)[3]                                      # [P,38] = [P, (aperture, 19)]
+            if out is None:
+                out = np.zeros((len(ds), 2, pm.shape[0], 19), dtype=np.float64)
+            out[j] = pm.view(-1, 2, 19).permute(1, 0, 2).cpu().numpy()
+        np.save(f'{args.data_path}/params_src_{part}.npy', out)
+        if not quiet:
+            print(f'{part}: {len(ds)} images -> params_src_{part}.npy')
+
+
+# ------------------------------------------------------------------------------------------------ global_training.py
+def global_train(args, quiet=False):
+    import data, models, utils
+    from .train_global import GammaSchedule, train_step
+    utils.set_seed(1898)
+    utils.create_directory(args.log_path, overwrite=False)
+    os.makedirs(args.model_path, exist_ok=True)
+    dev = _device(args)
+    tr = data.ShapeDataset(dev, data_path=args.data_path, train=True, mode='global')
+    va = data.ShapeDataset(dev, data_path=args.data_path, train=False, mode='global')
+    tr_loader = DataLoader(tr, batch_size=args.batch_size, shuffle=True, drop_last=True)
+    va_loader = DataLoader(va, batch_size=args.batch_size, shuffle=False, drop_last=True)
+    model = models.GlobalStage(in_parameter_size=args.input_size, out_parameter_size=args.output_size, device=dev).to(dev)
+    _xavier_(model)
+    opt = torch.optim.AdamW(model.parameters(), lr=args.learning_rate)
+    helper = utils.PostProcessGlobalBase(args, dev)
+    dcal = utils.DepthEtas(args, dev)
+    gamma = GammaSchedule(args)
+    sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, 'min', factor=0.975, patience=5, min_lr=args.learning_rate * 0.5)
+    curve = np.zeros((args.epoch_num,), dtype=float)
+    best, best_epoch = np.inf, 0
+    feats = lambda p: p.permute(0, 2, 1, 3).flatten(2, 3).contiguous()          # [B,2,P,19] -> [B,P,38]
+    with open(f'{args.log_path}/exp_global_stage_training.txt', 'wt') as f:
+        _log_header(f, args)
+        for epoch in range(args.epoch_num):
+            g = gamma.step()
+            model.train()
+            for param, _, img_gt, bndry_dist, deri, bndry_depth in tr_loader:
+                train_step(model, helper, dcal, opt, dict(pm=feats(param), img_gt=img_gt, bndry_dist=bndry_dist, deri=deri,
+                                                          bndry_depth=bndry_depth), g)
+            model.eval()
+            total, gf = 0.0, gamma.final()
+            with torch.no_grad():
+                for param, img_ny, img_gt, bndry_dist, deri, bndry_depth in va_loader:
+                    est = model(feats(param))
+                    total += float(utils.global_loss(helper, dcal, est, img_ny, img_gt, bndry_dist, deri, bndry_depth, gf))
+            gamma.step(idx_update=False)
+            curve[epoch] = total / max(len(va) // args.batch_size, 1)
+            print(f'{epoch + 1:<10} {curve[epoch]:<20.10f} {sched.patience:<20} {opt.param_groups[0]["lr"]:.4e}', file=f, flush=True)
+            if curve[epoch] < best:
+                best, best_epoch = curve[epoch], epoch
+                torch.save(model.state_dict(), f'{args.model_path}/best_run_exp_global_stage.pth')
+            if epoch >= args.dynamic_epoch[1]:
+                sched.step(curve[epoch])
+            if not quiet:
+                print(f'epoch {epoch + 1}: validation loss {curve[epoch]:.6f}')
+        print(f'\n-- Best epoch is the {best_epoch + 1:d}th, with average loss of {best:.10f}.', file=f, flush=True)
+    np.save(f'{args.log_path}/loss_curve_exp_global_stage.npy', curve)
+    utils.showCurve(args, curve, 'loss_curve_exp_global_stage')
+    return curve
+
+
+# ------------------------------------------------------------------------- blurry_edges_test.py / blurry_edges_test_big.py
+@torch.no_grad()
+def evaluate(args, big=False, local_weights=None, global_weights=None, pp_weights=None, quiet=False):
+    """-> dict(delta1, delta2, delta3, RMSE, AbsRel, seconds_per_pair), averaged over the test set as the scripts do."""
+    import data, models, utils
+    from .pipeline import DepthPipeline
+    dev = _device(args)
+    load = lambda m, path: (m.load_state_dict(torch.load(path, map_location=dev)), m.eval())[1]
+    local = load(models.LocalStage().to(dev), local_weights or f'{args.model_path}/pretrained_local_stage.pth')
+    globl = load(models.GlobalStage(in_parameter_size=38, out_parameter_size=12, device=dev).to(dev),
+                 global_weights or f'{args.model_path}/pretrained_global_stage.pth')
+    pp = None
+    if args.densify == 'pp':
+        pp = load(models.DepthCompletion().to(dev), pp_weights or f'{args.model_path}/pretrained_depth_completion_pp.pth')
+    pipe = DepthPipeline(local, globl, utils.PostProcessGlobalBase(args, dev), utils.DepthEtas(args, dev),
+                         rho_prime=args.rho_prime, densify=args.densify, stride=args.stride, densify_pp_module=pp)
+    ds = data.TestDataset(dev, data_path=args.data_path)
+    tot = np.zeros(5)
+    secs = 0.0
+    for j in range(len(ds)):
+        img_ny, gt = ds[j]
+        img = img_ny.permute(0, 3, 1, 2).contiguous()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        maps = pipe.run_big(img, n_margin=args.n_margin_patch) if big else pipe(img)
+        torch.cuda.synchronize()
+        secs += time.perf_counter() - t0
+        depth = maps["depth_map"][None]
+        m = np.array(utils.eval_depth(depth, gt[None].to(depth.dtype), depth, crop=args.crop))
+        tot += m
+        if not quiet:
+            print(f'Image pair #{j}: delta1 ={m[0]: .3f}, delta2 ={m[1]: .3f}, delta3 ={m[2]: .3f}, RMSE ={m[3]: .3f} cm, '
+                  f'AbsRel ={m[4]: .3f} cm')
+    n = max(len(ds), 1)
+    res = dict(zip(("delta1", "delta2", "delta3", "RMSE", "AbsRel"), (tot / n).tolist()), seconds_per_pair=secs / n)
+    if not quiet:
+        print(f'\nAverage running time:{secs / n: .3f} s')
+        print('Average metrics for whole dataset: ' + ', '.join(f'{k} ={v: .3f}' for k, v in res.items() if k != "seconds_per_pair"))
+    return res
+
+
+def main(argv=None):
+    import utils
+    argv = list(sys.argv[1:] if argv is None else argv)
+    if not argv or argv[0] not in ("local_train", "global_pre", "global_train", "eval"):
+        raise SystemExit("usage: python -m be_hip.workflow {local_train|global_pre|global_train|eval} [--big] [reference arguments]")
+    cmd, rest = argv[0], argv[1:]
+    big = "--big" in rest
+    rest = [a for a in rest if a != "--big"]
+    if cmd == "eval":
+        evaluate(utils.get_args('eval', big=big, argv=rest), big=big)
+    elif cmd == "local_train":
+        local_train(utils.get_args('local_train', argv=rest))
+    elif cmd == "global_pre":
+        global_pre(utils.get_args('global_pre', argv=rest))
+    else:
+        global_train(utils.get_args('global_train', argv=rest))
+
+
+if __name__ == "__main__":
+    main()

@@ -425,3 +425,41 @@ def test_eval_depth_on_device_matches_reference_golden(env):
     assert np.allclose(np.array(r), load_golden("g10_metrics")["metrics"], rtol=2e-6)
     two = utils.eval_depth(torch.cat([p, p]), torch.cat([g, g]), torch.cat([p, p]) > 0, crop=10)
     assert np.allclose(np.array(two), np.array(r), rtol=1e-9)                  # batch is pooled, as in the reference
+
+
+def test_workflow_datagen_train_precalc_train_eval_end_to_end(env, tmp_path):
+    """The five driver scripts of the reference, end to end on this package, through the reference's FILE formats:
+    data generator -> ShapeDataset 'local' -> local training (2 epochs) -> checkpoint -> global_pre -> params_src files ->
+    ShapeDataset 'global' -> global training (1 epoch) -> checkpoint -> TestDataset -> evaluation metrics."""
+    import utils
+    from be_hip import datagen as dg, workflow as wf
+    root = tmp_path / "data"
+    for part, n, seed in (("train", 12, 21), ("val", 6, 22)):
+        d = dg.generate(dg.draw_scenes(n, seed=seed, name="wf"), DEV, seed=seed)
+        dg.save(d, dg.crop_patches(d, 8 * n, seed=seed), str(root), part)
+    models_dir, logs = tmp_path / "weights", tmp_path / "logs"
+    common = ["--model_path", str(models_dir), "--cuda", DEV]
+    a = utils.get_args("local_train", argv=common + ["--data_path", str(root / "patches"), "--log_path", str(logs), "--epoch_num", "2",
+                                                     "--batch_size", "32"])
+    curve = wf.local_train(a, quiet=True)
+    assert curve.shape == (2,) and np.isfinite(curve).all() and (models_dir / "best_run_exp_local_stage.pth").exists()
+    assert (logs / "loss_curve_exp_local_stage.png").exists() and "Best epoch" in (logs / "exp_local_stage_training.txt").read_text()
+    a = utils.get_args("global_pre", argv=common + ["--data_path", str(root)])
+    wf.global_pre(a, local_weights=str(models_dir / "best_run_exp_local_stage.pth"), quiet=True)
+    ps = np.load(root / "params_src_train.npy")
+    assert ps.shape == (12, 2, 4096, 19) and ps.dtype == np.float64 and np.isfinite(ps).all()
+    a = utils.get_args("global_train", argv=common + ["--data_path", str(root), "--log_path", str(logs), "--epoch_num", "1",
+                                                      "--batch_size", "2"])
+    gcurve = wf.global_train(a, quiet=True)
+    assert np.isfinite(gcurve).all() and (models_dir / "best_run_exp_global_stage.pth").exists()
+    # a test set in TestDataset's format made of the validation images (depth_maps = the generator's image depths)
+    test_dir = tmp_path / "test"
+    test_dir.mkdir()
+    np.save(test_dir / "images_ny.npy", np.load(root / "images_ny_val.npy"))
+    np.save(test_dir / "depth_maps.npy", np.load(root / "image_depths_val.npy"))
+    np.save(test_dir / "alphas.npy", np.load(root / "alphas_val.npy"))
+    a = utils.get_args("eval", argv=common + ["--data_path", str(test_dir), "--densify", "w"])
+    res = wf.evaluate(a, local_weights=str(models_dir / "best_run_exp_local_stage.pth"),
+                      global_weights=str(models_dir / "best_run_exp_global_stage.pth"), quiet=True)
+    assert set(res) == {"delta1", "delta2", "delta3", "RMSE", "AbsRel", "seconds_per_pair"}
+    assert all(np.isfinite(v) for v in res.values()) and 0 <= res["delta1"] <= res["delta2"] <= res["delta3"] <= 1
