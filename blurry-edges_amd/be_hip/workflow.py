@@ -20,7 +20,6 @@ import time
 
 import numpy as np
 import torch
-from torch.utils.data import DataLoader
 
 
 def _device(args):
@@ -42,21 +41,23 @@ def _log_header(f, args):
 
 
 # ---------------------------------------------------------------------------------------------- local_training.py
-def local_train(args, quiet=False):
+def local_train(args, quiet=False, graph=True):
+    """graph: replay the training step as a hipGraph (train_local.GraphedStep); batches are gathered on the device
+    (data.ShapeDataset.batches) instead of sample by sample."""
     import data, models, utils
-    from .train_local import BetaSchedule, train_step
+    from .train_local import BetaSchedule, GraphedStep, train_step
     utils.set_seed(1869)
     utils.create_directory(args.log_path, overwrite=False)
     os.makedirs(args.model_path, exist_ok=True)
     dev = _device(args)
     tr = data.ShapeDataset(dev, data_path=args.data_path, train=True)
     va = data.ShapeDataset(dev, data_path=args.data_path, train=False)
-    tr_loader = DataLoader(tr, batch_size=args.batch_size, shuffle=True, drop_last=True)
-    va_loader = DataLoader(va, batch_size=args.batch_size, shuffle=False, drop_last=True)
     model = models.LocalStage().to(dev)
     _xavier_(model)
-    opt = torch.optim.AdamW(model.parameters(), lr=args.learning_rate)
+    opt = torch.optim.AdamW(model.parameters(), lr=args.learning_rate, capturable=graph)
     helper = utils.PostProcessLocalBase(args, dev)
+    gstep = GraphedStep(model, helper, opt) if graph else None
+    sampler = torch.Generator().manual_seed(1869)
     beta = BetaSchedule(args.beta_bndry_loc, args.beta_smthns, args.dynamic_epoch)
     sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, 'min', factor=0.9, patience=2, min_lr=args.learning_rate * 0.1)
     curve = np.zeros((args.epoch_num,), dtype=float)
@@ -66,14 +67,17 @@ def local_train(args, quiet=False):
         for epoch in range(args.epoch_num):
             beta.step()
             model.train()
-            for img_ny, img_gt, bndry_dist, deri in tr_loader:
-                train_step(model, helper, opt, dict(img_ny=img_ny, img_gt=img_gt, bndry_dist=bndry_dist, deri=deri),
-                           beta.beta_b, beta.beta_s)
+            for img_ny, img_gt, bndry_dist, deri in tr.batches(args.batch_size, shuffle=True, drop_last=True, generator=sampler):
+                b = dict(img_ny=img_ny, img_gt=img_gt, bndry_dist=bndry_dist, deri=deri)
+                if gstep is not None:
+                    gstep(b, beta.beta_b, beta.beta_s)
+                else:
+                    train_step(model, helper, opt, b, beta.beta_b, beta.beta_s)
             # validation with the final betas (local_training.py:54-66)
             model.eval()
             total = 0.0
             with torch.no_grad():
-                for img_ny, img_gt, bndry_dist, deri in va_loader:
+                for img_ny, img_gt, bndry_dist, deri in va.batches(args.batch_size, shuffle=False, drop_last=True):
                     est = model(img_ny.permute(0, 3, 1, 2).contiguous())
                     total += float(utils.local_loss(helper, est, img_ny, img_gt, bndry_dist, deri, args.beta_bndry_loc,
                                                     args.beta_smthns))
@@ -128,8 +132,7 @@ def global_train(args, quiet=False):
     dev = _device(args)
     tr = data.ShapeDataset(dev, data_path=args.data_path, train=True, mode='global')
     va = data.ShapeDataset(dev, data_path=args.data_path, train=False, mode='global')
-    tr_loader = DataLoader(tr, batch_size=args.batch_size, shuffle=True, drop_last=True)
-    va_loader = DataLoader(va, batch_size=args.batch_size, shuffle=False, drop_last=True)
+    sampler = torch.Generator().manual_seed(1898)
     model = models.GlobalStage(in_parameter_size=args.input_size, out_parameter_size=args.output_size, device=dev).to(dev)
     _xavier_(model)
     opt = torch.optim.AdamW(model.parameters(), lr=args.learning_rate)
@@ -145,13 +148,14 @@ def global_train(args, quiet=False):
         for epoch in range(args.epoch_num):
             g = gamma.step()
             model.train()
-            for param, _, img_gt, bndry_dist, deri, bndry_depth in tr_loader:
+            for param, _, img_gt, bndry_dist, deri, bndry_depth in tr.batches(args.batch_size, shuffle=True, drop_last=True,
+                                                                              generator=sampler):
                 train_step(model, helper, dcal, opt, dict(pm=feats(param), img_gt=img_gt, bndry_dist=bndry_dist, deri=deri,
                                                           bndry_depth=bndry_depth), g)
             model.eval()
             total, gf = 0.0, gamma.final()
             with torch.no_grad():
-                for param, img_ny, img_gt, bndry_dist, deri, bndry_depth in va_loader:
+                for param, img_ny, img_gt, bndry_dist, deri, bndry_depth in va.batches(args.batch_size, shuffle=False, drop_last=True):
                     est = model(feats(param))
                     total += float(utils.global_loss(helper, dcal, est, img_ny, img_gt, bndry_dist, deri, bndry_depth, gf))
             gamma.step(idx_update=False)

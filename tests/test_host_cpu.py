@@ -198,6 +198,14 @@ def test_shape_dataset_and_test_dataset_read_the_generator_file_layout(tmp_path)
     assert tuple(img.shape) == (2, H, H, 3) and tuple(dep.shape) == (H, H)
     with pytest.raises(ValueError):
         data.ShapeDataset("cpu", data_path=str(tmp_path), mode="nope")
+    # device-resident batches = what DataLoader would collate from __getitem__
+    from torch.utils.data import DataLoader
+    ref = list(DataLoader(ds, batch_size=2, shuffle=False, drop_last=True))
+    got = list(ds.batches(2, shuffle=False, drop_last=True))
+    assert len(ref) == len(got) == 2 and all(torch.equal(a, b) for r, g_ in zip(ref, got) for a, b in zip(r, g_))
+    seen = torch.cat([b[2].reshape(len(b[2]), -1)[:, 0] for b in ds.batches(2, shuffle=True, drop_last=False,
+                                                                             generator=torch.Generator().manual_seed(0))])
+    assert sorted(seen.tolist()) == sorted(ds.bndry_dist.reshape(n, -1)[:, 0].tolist())        # a permutation of the set
 
 
 def test_drawing_helpers_keep_the_reference_names(tmp_path, monkeypatch):
