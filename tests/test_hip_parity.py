@@ -421,3 +421,32 @@ def test_split_bf16_conv_mode_is_opt_in_and_stays_within_the_fp32_tolerance(nati
     e32, e3 = relmax(y32[:256].cpu(), ref), relmax(y3[:256].cpu(), ref)
     print("logits vs fp64 oracle: fp32 MFMA %.2e, bf16x3 %.2e" % (e32, e3))
     assert e32 <= 1e-5 and e3 <= 1e-5
+
+
+def test_entry_points_reject_bad_arguments_before_launching(native):
+    """Every C entry point validates on the host and returns an error code + message (BE_EINVAL / BE_EWORKSPACE) instead
+    of launching with shapes its kernels do not support; the Python layer raises RuntimeError(be_last_error())."""
+    from be_hip import train_global_stage as tg, datagen as dg
+    n = native
+    z = torch.zeros(256, 384, device=DEV)
+    with pytest.raises(RuntimeError, match="multiple of 128"):
+        n.attention(z[:200], 1, 200, 8)                                   # L not a multiple of 128
+    with pytest.raises(RuntimeError, match="dropout probability"):
+        tg.attention_train_fwd(z, 1, 256, 8, 1.5, 0)
+    with pytest.raises(RuntimeError, match="D must be 128"):
+        tg.add_layernorm_train(torch.zeros(4, 64, device=DEV), None, torch.ones(64, device=DEV), torch.zeros(64, device=DEV), 1e-5, 0.0, 0, 0)
+    with pytest.raises(RuntimeError, match="unsupported"):
+        n.conv_pack(torch.zeros(8, 12, 3, 3, device=DEV), None)           # cin not a multiple of 32
+    with pytest.raises(RuntimeError, match="workspace"):
+        n.check(n.lib().be_local_stage_forward_f32(n.dptr(torch.zeros(int(n.lib().be_local_stage_packed_floats()), device=DEV)),
+                                                   n.dptr(torch.zeros(64, 3, 21, 21, device=DEV)), n.dptr(torch.zeros(64, 10, device=DEV)),
+                                                   64, n.dptr(torch.zeros(16, device=DEV)), 64, None), "be_local_stage_forward_f32")
+    with pytest.raises(RuntimeError, match="ldx"):
+        n.check(n.lib().be_maxpool_nhwc_ld_f32(n.dptr(z), 6, n.dptr(torch.zeros(64, device=DEV)), 1, 4, 4, 8, 2, 2, 0, None), "pool")
+    with pytest.raises(RuntimeError, match="channels must be multiples of 4"):
+        n.upconv2x2_scatter(torch.zeros(1, 2, 2, 24, device=DEV), torch.zeros(1, 4, 4, 14, device=DEV), 6, 6)
+    with pytest.raises(ValueError, match="at most"):
+        dg.draw_scenes(2, num_shape=(40, 41))
+    with pytest.raises(RuntimeError, match="float64|expected"):
+        dg.dptr(torch.zeros(4, device=DEV))                               # the generator's buffers are float64
+    assert n.lib().be_last_error()                                        # the last message is kept for the caller
