@@ -238,5 +238,6 @@ class _GlobalLossFn(torch.autograd.Function):
 
 def global_loss(helper, depth_cal, est, img_ny, img_gt, bndry_dist, deri, bndry_depth, gamma):
     """GlobalLoss.forward (global_training.py:147-157) as fused HIP launches; differentiable w.r.t. est [B,P,12].
-    helper: a PostProcessGlobalBase; gamma: dict with the seven keys of oracle/global_loss.GAMMA_FINAL."""
+    helper: a PostProcessGlobalBase; gamma: dict with the seven weights color, color_cons, bndry_cons,
+    smthns, smthns_cons, bndry_loc, depth (the --gamma_* arguments of utils/args.py:53-59)."""
     return _GlobalLossFn.apply(est, helper, depth_cal, img_ny, img_gt, bndry_dist, deri, bndry_depth, dict(gamma))
