@@ -2,19 +2,23 @@
 Host-side constants only; the image synthesis itself runs on the GPU (be_hip/datagen.py)."""
 import numpy as np
 
+_CAMERA_FIELDS = (("s", "s"), ("Sigma_cam", "sigma_cam"), ("pixel_pitch", "pixel_pitch"))
+
 
 class DataGenerator:
     def __init__(self, args):
-        cam = args.cam_params
-        self.data_path, self.Z_range = args.data_path, args.Z_range
-        self.s, self.rhos = cam['s'], np.array([cam['rho_1'], cam['rho_2']])
-        self.Sigma_cam, self.pixel_pitch, self.mag = cam['sigma_cam'], cam['pixel_pitch'], args.mag
-        self.alpha, self.sigma = args.alpha, args.sigma
-        self.n_img = len(self.rhos)
+        camera = args.cam_params
+        for attr, key in _CAMERA_FIELDS:
+            setattr(self, attr, camera[key])
+        self.rhos = np.array([camera['rho_1'], camera['rho_2']])       # optical power of the two apertures
+        self.n_img = self.rhos.size
+        self.mag = args.mag
+        self.data_path, self.Z_range, self.alpha, self.sigma = args.data_path, args.Z_range, args.alpha, args.sigma
 
     def get_kernel_sigma(self, z):
-        """Blur radius in pixels of each aperture for an object at distance z (m): |(1/z - rho) s + 1| Sigma / pitch / mag."""
-        return np.abs((1 / z - self.rhos) * self.s + 1) * self.Sigma_cam / self.pixel_pitch / self.mag
+        """Blur radius in pixels, one per aperture, of an object z metres away: |(1/z - rho) s + 1| Sigma / pitch / mag."""
+        defocus = np.abs((1.0 / z - self.rhos) * self.s + 1.0)
+        return defocus * self.Sigma_cam / self.pixel_pitch / self.mag
 
     def get_blur_kernel(self, sigma, order=2):
         """(2k+1)^2 generalised-Gaussian PSF, k = ceil(3 sigma), normalised to unit sum (order 2 = Gaussian)."""

@@ -1,4 +1,4 @@
-"""Small helpers with the reference's names (utils/util_func.py:8-38)."""
+"""Run-time helpers under the reference's names (utils/util_func.py:8-38): seeding, log directories, the loss-curve plot."""
 import os
 import random
 import shutil
@@ -8,30 +8,35 @@ import torch
 
 
 def set_seed(seed, deterministic=False):
-    random.seed(seed)
-    np.random.seed(seed)
-    torch.manual_seed(seed)
+    """Seed Python, numpy and torch (CPU + every GPU).  The HIP kernels of this package are deterministic by construction
+    (no float atomics, fixed reduction orders), so `deterministic` only has to switch torch's own ops."""
+    os.environ['PYTHONHASHSEED'] = str(seed)
+    for seeder in (random.seed, np.random.seed, torch.manual_seed):
+        seeder(seed)
     if torch.cuda.is_available():
         torch.cuda.manual_seed_all(seed)
-    os.environ['PYTHONHASHSEED'] = str(seed)
     if deterministic:
         torch.use_deterministic_algorithms(True, warn_only=False)
 
 
 def create_directory(path, overwrite=True):
-    if os.path.exists(path) and overwrite:
+    """Make `path`; an existing one is emptied first when overwrite is set, kept otherwise."""
+    if overwrite and os.path.isdir(path):
         shutil.rmtree(path)
     os.makedirs(path, exist_ok=True)
 
 
 def showCurve(args, points, figname):
-    """Loss curve (log scale) saved as <log_path>/<figname>.png (utils/util_func.py:29-38); matplotlib is imported here,
-    with the Agg backend, so the training loops run headless."""
+    """Loss curve on a log axis, written to <args.log_path>/<figname>.png.  matplotlib is imported here with the Agg
+    backend so that the training loops run headless."""
     import matplotlib
     matplotlib.use("Agg", force=False)
-    import matplotlib.pyplot as plt
-    fig, ax = plt.subplots(figsize=(8, 6))
-    ax.set(xlabel='Epochs', ylabel='Average loss', yscale='log')
-    ax.plot(np.arange(np.shape(points)[0]), points, linestyle='-', color='b', linewidth=2)
-    fig.savefig(f'{args.log_path}/{figname}.png', format='png', bbox_inches='tight', dpi=600)
-    plt.close(fig)
+    from matplotlib import pyplot
+
+    values = np.asarray(points, dtype=float)
+    fig, axis = pyplot.subplots(figsize=(8, 6))
+    axis.semilogy(np.arange(values.shape[0]), values, 'b-', linewidth=2)
+    axis.set_xlabel('Epochs')
+    axis.set_ylabel('Average loss')
+    fig.savefig(os.path.join(args.log_path, figname + '.png'), bbox_inches='tight', dpi=600)
+    pyplot.close(fig)
