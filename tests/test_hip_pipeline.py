@@ -463,3 +463,59 @@ def test_workflow_datagen_train_precalc_train_eval_end_to_end(env, tmp_path):
                       global_weights=str(models_dir / "best_run_exp_global_stage.pth"), quiet=True)
     assert set(res) == {"delta1", "delta2", "delta3", "RMSE", "AbsRel", "seconds_per_pair"}
     assert all(np.isfinite(v) for v in res.values()) and 0 <= res["delta1"] <= res["delta2"] <= res["delta3"] <= 1
+
+
+def test_reference_style_postprocess_subclass_agrees_with_the_fused_pipeline(env):
+    """A caller-written PostProcess(PostProcessGlobalBase) in the style of blurry_edges_test.py:12-100 - composed ONLY
+    of the inherited methods, tensors in the reference's [B,.,21,21,Hp,Wp] layout - must give the maps of the fused
+    records + fold path (DepthPipeline), i.e. the reference's own evaluation script can keep its subclass."""
+    import utils
+    n = env["native"]
+
+    class PostProcess(utils.PostProcessGlobalBase):
+        def __init__(self, args, depth_cal, device):
+            super().__init__(args, device)
+            self.depthCal, self.rho_prime = depth_cal, 10.39
+
+        def solve_colors(self, wedges_pair, patches_pair):          # both apertures stacked: one colour set (882 rows)
+            B, Hp, Wp = self.batch_size, self.H_patches, self.W_patches
+            A = wedges_pair.permute(0, 5, 6, 1, 3, 4, 2).reshape(B, Hp, Wp, -1, 3)
+            y = patches_pair.permute(0, 5, 6, 1, 3, 4, 2).reshape(B, Hp, Wp, -1, 3)
+            At = A.transpose(-1, -2)
+            return torch.matmul(self.inverse_3by3(torch.matmul(At, A) + self.ridge), torch.matmul(At, y)).permute(0, 4, 3, 1, 2)
+
+        def composite(self, wedges, colors):
+            return (wedges.unsqueeze(1) * colors.unsqueeze(-3).unsqueeze(-3)).sum(dim=2)
+
+        def forward(self, est12, img_patches):
+            est = est12.permute(0, 2, 1).reshape(self.batch_size, 12, self.H_patches, self.W_patches)
+            dists = self.params2dists(est[:, :8].contiguous())
+            etas = self.params2etas(est[:, 8:].contiguous())
+            w1, w2 = self.dists2indicators(dists, etas[:, :2].contiguous()), self.dists2indicators(dists, etas[:, 2:].contiguous())
+            colors = self.solve_colors(torch.stack([w1, w2], dim=1), img_patches.unsqueeze(0))
+            patches = torch.stack([self.composite(w1, colors), self.composite(w2, colors)], dim=1)
+            z1 = self.depthCal.etas2depth(etas[:, 0].contiguous(), etas[:, 2].contiguous())
+            z2 = self.depthCal.etas2depth(etas[:, 1].contiguous(), etas[:, 3].contiguous())
+            m1 = (self.normalized_gaussian(dists[:, 0]) > 0.5).to(torch.int32)
+            m2 = (self.normalized_gaussian(dists[:, 1]) > 0.5).to(torch.int32) * 2
+            mask = torch.where((m2 == 2) | (dists[:, 1] >= 0), m2, m1)
+            zmap = torch.where(mask == 1, z1[:, None, None], torch.where(mask == 2, z2[:, None, None], torch.zeros_like(dists[:, 0])))
+            d1, d2 = dists[:, 0].abs(), dists[:, 1].abs()
+            bnd = self.normalized_gaussian(torch.where(dists[:, 1] >= 0, dists[:, 1], torch.minimum(d1, d2)))
+            sharp = self.composite(self.dists2indicators(dists, torch.full_like(etas[:, :2], 1e-4)), colors)
+            depth, conf = self.local2global_depth(zmap.contiguous(), mask.contiguous())
+            return dict(image=self.local2global_color(patches.contiguous())[0], shpd=self.local2global_color(sharp.contiguous(), pair=False)[0],
+                        bndry=self.local2global_bndry(bnd[:, None].contiguous())[0, 0], depth=depth[0], conf=conf[0])
+
+    pipe = _pipeline(env)
+    img = T(synth.synthetic_image_pair(147, 147)[0]).to(DEV)
+    fused = pipe(img)
+    helper = PostProcess(env["args"], env["dcal"], DEV)
+    unfolded = n.unfold_patches(img).view(2, 64, 64, 3, 21, 21).permute(0, 3, 4, 5, 1, 2).contiguous()      # nn.Unfold layout
+    mine = helper(fused["est12"][None], unfolded)
+    assert relmax(mine["image"].cpu(), fused["image"].cpu()) <= 2e-3          # the subclass solves colours with the fp32 closed-form inverse
+    assert relmax(mine["shpd"].cpu(), fused["shpd"].cpu()) <= 2e-3
+    assert relmax(mine["bndry"].cpu(), fused["bndry"].cpu()) <= 1e-5
+    assert relmax(mine["conf"].cpu(), fused["conf"].cpu()) <= 1e-6
+    ok = (fused["conf"] > 0.05).cpu()
+    assert relmax(mine["depth"].cpu()[ok], fused["depth"].cpu()[ok]) <= 1e-5
