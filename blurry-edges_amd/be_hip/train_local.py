@@ -12,7 +12,9 @@ import os
 import time
 
 import numpy as np
-import torch
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC for RCCL, before any HIP call
+import torch  # noqa: E402
 
 from . import dp, synth
 
