@@ -63,8 +63,15 @@ _SIGNATURES = {
     "be_conv_pack_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "be_conv_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, C.c_int, _P]),
     "be_conv_nhwc_splitk_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, C.c_int, _P, C.c_size_t, _P]),
+    "be_conv_nhwc_batched_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, _P]),
+    "be_wino_packed_floats": (C.c_size_t, [C.c_int, C.c_int]),
+    "be_wino_pack_f32": (C.c_int, [_P] * 6 + [C.c_float, C.c_int, C.c_int, _P, _P, _P]),
+    "be_wino_workspace_floats": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
+    "be_wino_conv3x3_6x6_f32": (C.c_int, [_P] * 5 + [C.c_int64, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
     "be_conv_split_b3_f32": (C.c_int, [_P, C.c_size_t, _P, _P]),
     "be_conv_use_b3": (C.c_int, [_P, _P, C.c_size_t]),
+    "be_conv_b3_active": (C.c_int, []),
+    "be_local_stage_set_winograd": (C.c_int, [C.c_int]),
     "be_conv_fused2_packed_floats": (C.c_size_t, [C.c_int] * 4),
     "be_conv_pack_fused2_f32": (C.c_int, [_P] * 12 + [C.c_float] + [C.c_int] * 4 + [_P, _P, _P]),
     "be_conv_nhwc_fused2_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, C.c_int, _P, _P, _P, C.c_int, _P]),
@@ -349,6 +356,35 @@ def local_stage_forward(packed, x, out=None, workspace=None):
     check(lib().be_local_stage_forward_f32(dptr(packed, "packed"), dptr(x, "x"), dptr(out), n, dptr(workspace),
                                            workspace.numel() * 4, stream_ptr(dev)), "be_local_stage_forward_f32")
     return out, workspace
+
+
+def wino_pack(weight, bias, bn=None, eps=1e-5):
+    """weight [Cout,Cin,3,3] (+ bias, + eval BatchNorm) -> (U [25*cout_pad*cin], bias [cout_pad]) for wino_conv3x3."""
+    cout, cin = weight.shape[0], weight.shape[1]
+    nfl = lib().be_wino_packed_floats(cout, cin)
+    if nfl == 0 or tuple(weight.shape[2:]) != (3, 3):
+        raise RuntimeError(f"wino_pack: unsupported conv shape {tuple(weight.shape)}")
+    dev = weight.device
+    pw = torch.empty(nfl, dtype=torch.float32, device=dev)
+    pb = torch.empty((cout + 31) // 32 * 32, dtype=torch.float32, device=dev)
+    g = bn if bn is not None else (None, None, None, None)
+    check(lib().be_wino_pack_f32(dptr(weight.contiguous(), "weight"), dptr(bias), dptr(g[0]), dptr(g[1]), dptr(g[2]), dptr(g[3]), eps,
+                                 cout, cin, dptr(pw), dptr(pb), stream_ptr(dev)), "be_wino_pack_f32")
+    return pw, pb
+
+
+def wino_conv3x3(x, pw, pb, cout, act=0, residual=None, workspace=None):
+    """x [N,6,6,Cin] NHWC -> [N,6,6,cout] by Winograd F(3x3,3x3)."""
+    n, h, w, cin = x.shape
+    if (h, w) != (6, 6):
+        raise RuntimeError(f"wino_conv3x3: 6x6 maps only, got {h}x{w}")
+    need = lib().be_wino_workspace_floats(n, cin, cout)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.float32, device=x.device)
+    y = torch.empty(n, 6, 6, cout, dtype=torch.float32, device=x.device)
+    check(lib().be_wino_conv3x3_6x6_f32(dptr(x, "x"), dptr(pw), dptr(pb), dptr(residual), dptr(y), n, cin, cout, int(act),
+                                        dptr(workspace), workspace.numel(), stream_ptr(x.device)), "be_wino_conv3x3_6x6_f32")
+    return y, workspace
 
 
 def conv_use_b3(packed=None):

@@ -46,6 +46,8 @@ struct ConvArgs {
     int ksplit;           // > 1: blockIdx.y = K slice; raw partial sums go to `partial` [ksplit][M][ldp], no epilogue math
     int ldp;
     float* partial;
+    int nbatch;
+    int64_t xb, wb, yb;   // batched launches (blockIdx.z = batch index): element strides of x, w, y between batches
     const unsigned short* wb3;   // experimental split-bf16 mode: the packed weights as three bf16 planes (hi, mid, lo),
     size_t plane;                //   each laid out exactly like `w`; plane = elements per plane
 };
@@ -68,6 +70,9 @@ void k_conv_igemm(ConvArgs a) {
     constexpr bool B_PARTIAL = BN % RP != 0;
     constexpr int SUB = 32 / BKT;                      // chunks per 32-channel packing unit
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    if (blockIdx.z) {                                  // batched launch: this block works on batch blockIdx.z
+        a.x += (int64_t)blockIdx.z * a.xb; a.w += (int64_t)blockIdx.z * a.wb; a.y += (int64_t)blockIdx.z * a.yb;
+    }
     float* As = smem;                                  // [2][BM][LROW]
     float* Bs = smem + 2 * BM * LROW;                  // [2][BN][LROW]
 
@@ -288,7 +293,7 @@ void k_conv_igemm(ConvArgs a) {
     for (int j = 0; j < NT; ++j) {
         const int c = n0 + (wn * NT + j) * 32 + li;
         const bool c_ok = c < a.Cout;
-        const float bias = c_ok ? a.bias[c] : 0.0f;
+        const float bias = (c_ok && a.bias) ? a.bias[c] : 0.0f;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
 #pragma unroll
@@ -622,11 +627,12 @@ int launch_conv(const ConvArgs& a, hipStream_t s, int kernel_id) {
         }
         if (a.x2) chunks += (double)a.m_tiles * a.n_tiles * (a.Cin2 / 32) * (32 / BKT);
         const double k2_real = a.x2 ? (double)a.Cin2 : 0.0;
-        be::ProfileScope prof(s, kernel_id, 2.0 * a.M * (k_real + k2_real) * a.Cout,
-                              4.0 * (a.M * (cin_real + k2_real) + (k_real + k2_real) * a.Cout + (double)a.M * a.Cout * (a.res ? 2 : 1)),
-                              chunks * 2.0 * BM * BN * BKT);
-        hipLaunchKernelGGL((k_conv_igemm<WM, WN, MT, NT, MODE, BKT, PRIO>), dim3(grid, a.ksplit > 1 ? a.ksplit : 1), dim3(256),
-                           lds, s, a);
+        const double nb = a.nbatch > 1 ? a.nbatch : 1;
+        be::ProfileScope prof(s, kernel_id, nb * 2.0 * a.M * (k_real + k2_real) * a.Cout,
+                              nb * 4.0 * (a.M * (cin_real + k2_real) + (k_real + k2_real) * a.Cout + (double)a.M * a.Cout * (a.res ? 2 : 1)),
+                              nb * chunks * 2.0 * BM * BN * BKT);
+        hipLaunchKernelGGL((k_conv_igemm<WM, WN, MT, NT, MODE, BKT, PRIO>), dim3(grid, a.ksplit > 1 ? a.ksplit : 1, a.nbatch > 1 ? a.nbatch : 1),
+                           dim3(256), lds, s, a);
     }
     return be::check_launch("be_conv_nhwc_f32");
 }
@@ -831,6 +837,9 @@ extern "C" int be_conv_pack_dgrad_f32(const float* w, int cout, int cin, int ksi
 
 // opt-in split-bf16 mode: convolutions whose packed weights lie inside [g_b3_base, g_b3_base + g_b3_plane) and that take the
 // 128x128 tile run k_conv_b3 on the bf16 planes registered for that buffer (not thread-safe, like the other knobs)
+struct BatchParams { int n; int64_t xb, wb, yb; };
+static thread_local BatchParams g_batch = {1, 0, 0, 0};   // set around one dispatch by be_conv_nhwc_batched_f32
+
 static const float* g_b3_base = nullptr;
 static const unsigned short* g_b3_planes = nullptr;
 static size_t g_b3_plane = 0;
@@ -841,6 +850,8 @@ extern "C" int be_conv_split_b3_f32(const float* packed, size_t n, void* planes,
                        static_cast<unsigned short*>(planes), n);
     return be::check_launch("be_conv_split_b3_f32");
 }
+
+extern "C" int be_conv_b3_active(void) { return g_b3_planes != nullptr; }
 
 extern "C" int be_conv_use_b3(const float* packed, const void* planes, size_t n) {
     BE_REQUIRE((packed && planes && n > 0) || (!packed && !planes), "be_conv_use_b3: pass (packed, planes, n) or (NULL, NULL, 0)");
@@ -860,7 +871,7 @@ __global__ void k_splitk_reduce(const float* __restrict__ partial, int S, int64_
         const int c = (int)(idx - m * Cout);
         float v = partial[m * ldp + c];
         for (int s = 1; s < S; ++s) v += partial[((int64_t)s * M + m) * ldp + c];
-        v += bias[c];
+        if (bias) v += bias[c];
         if (res) v += res[m * ldy + c];
         if (act == 1) v = be::smish(v);
         else if (act == 2) v = fmaxf(v, 0.0f);
@@ -884,6 +895,16 @@ extern "C" int be_conv_nhwc_fused2_f32(const be_conv_desc* d, const float* x, co
     return conv_dispatch(d, x, x2, cin2, pw, pb, nullptr, y, ldy, stream);
 }
 
+extern "C" int be_conv_nhwc_batched_f32(const be_conv_desc* d, const float* x, const float* pw, const float* pb, float* y, int ldy,
+                                        int nbatch, int64_t x_stride, int64_t w_stride, int64_t y_stride, void* stream) {
+    BE_REQUIRE(nbatch >= 1 && nbatch <= 65535, "be_conv_nhwc_batched_f32: nbatch outside [1, 65535]");
+    BE_REQUIRE(x_stride % 4 == 0 && w_stride % 4 == 0, "be_conv_nhwc_batched_f32: strides must keep 16-byte alignment");
+    g_batch = {nbatch, x_stride, w_stride, y_stride};
+    const int rc = conv_dispatch(d, x, nullptr, 0, pw, pb, nullptr, y, ldy, stream);
+    g_batch = {1, 0, 0, 0};
+    return rc;
+}
+
 extern "C" int be_conv_nhwc_splitk_f32(const be_conv_desc* d, const float* x, const float* pw, const float* pb,
                                        const float* res, float* y, int ldy, void* scratch, size_t scratch_bytes, void* stream) {
     BE_REQUIRE(scratch && be::aligned16(scratch), "be_conv_nhwc_splitk_f32: scratch required (16-byte aligned)");
@@ -892,7 +913,7 @@ extern "C" int be_conv_nhwc_splitk_f32(const be_conv_desc* d, const float* x, co
 
 static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2, int cin2, const float* pw, const float* pb,
                          const float* res, float* y, int ldy, void* stream, void* scratch, size_t scratch_bytes) {
-    BE_REQUIRE(d && x && pw && pb && y, "be_conv_nhwc_f32: null pointer");
+    BE_REQUIRE(d && x && pw && y, "be_conv_nhwc_f32: null pointer");
     BE_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cout > 0, "be_conv_nhwc_f32: empty shape");
     BE_REQUIRE(d->h < 32768 && d->w < 32768, "be_conv_nhwc_f32: image too large");
     const bool row8 = d->ksize == 7;
@@ -911,6 +932,7 @@ static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2,
     a.m_tiles = (int)((M + 127) / 128);
     a.pixmaj = 0; a.Nimg = d->n;
     a.ksplit = 1; a.ldp = 0; a.partial = nullptr;
+    a.nbatch = g_batch.n; a.xb = g_batch.xb; a.wb = g_batch.wb; a.yb = g_batch.yb;
     a.wb3 = nullptr; a.plane = g_b3_plane;
     if (g_b3_planes && pw >= g_b3_base && pw < g_b3_base + g_b3_plane) a.wb3 = g_b3_planes + 3 * (pw - g_b3_base);
     const int cp = round_up(d->cout, 32);
@@ -968,7 +990,7 @@ static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2,
     }
     if (cp % 128 == 0) {
         a.n_tiles = cp / 128;
-        if (a.wb3) return launch_conv_b3(a, s);      // opt-in split-bf16 mode
+        if (a.wb3 && a.nbatch <= 1) return launch_conv_b3(a, s);      // opt-in split-bf16 mode
         // K-chunk 16 (40 KB of LDS, three workgroups per CU) measured 8 % faster than 32 (two per CU); 8 is slower
         // again (barrier per 16 MFMAs); s_setprio around the MFMA phase and a 4th workgroup per CU change nothing.
         if (conv_variant() == 32) return launch_conv<2, 2, 2, 2, MODE_TAPS, 32, 0>(a, s, BE_KERNEL_CONV_128x128);

@@ -1,0 +1,219 @@
+// Winograd F(3x3, 3x3) for the 3x3 convolutions on the 6x6 maps of LocalStage layers 1-3 (models/local_stage.py:20-28,
+// 39-41).  A 6x6 output is four 3x3 tiles; each tile needs a 5x5 input window (stride 3, one pixel of zero padding), and
+//     Y = A^T [ (G g G^T) o (B^T d B) ] A      summed over the input channels
+// turns the convolution into 25 independent GEMMs [tiles x Cin] x [Cin x Cout] (one per position of the 5x5 transform
+// domain): 100 multiplies per (cin, cout) pair and map instead of the 324 of the direct form (256 once the taps that
+// fall into the zero padding are skipped) - 2.56x less work for the matrix pipe, in exact fp32 arithmetic.
+// Interpolation points 0, 1, -1, 2, inf; the transforms are small integer / sixth combinations.  Accuracy measured on the
+// whole network against the fp64 oracle: logits 8.3e-7 (direct fp32 convolutions: 7.6e-7), see DESIGN.md 3.1c.
+//
+//   k_wino_pack   weights [Cout,Cin,3,3] (+ folded BatchNorm) -> U [25][Cout_pad][Cin] in the 1x1 layout of k_conv_igemm
+//   k_wino_in     x [N,6,6,C] NHWC -> V [25][4N][C]            (HBM-bound: reads 36, writes 100 values per channel)
+//   (GEMMs)       M[xi] = V[xi] U[xi]^T: one batched launch of k_conv_igemm, be_conv_nhwc_batched_f32
+//   k_wino_out    M [25][4N][Cout] -> y [N,6,6,Cout] + bias (+ residual) (+ Smish)
+#include "be_common.h"
+#include "be_device_math.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+inline unsigned grid_cap(int64_t total, int block, int64_t limit = 65535) {
+    int64_t g = (total + block - 1) / block;
+    return (unsigned)(g < 1 ? 1 : (g > limit ? limit : g));
+}
+
+// G (5x3): rows 1/2 [1 0 0], -1/2 [1 1 1], -1/6 [1 -1 1], 1/6 [1 2 4], [0 0 1]
+__device__ __forceinline__ void g_rows(const float a, const float b, const float c, float out[5]) {
+    out[0] = 0.5f * a;
+    out[1] = -0.5f * (a + b + c);
+    out[2] = -(a - b + c) * (1.0f / 6.0f);
+    out[3] = (a + 2.0f * b + 4.0f * c) * (1.0f / 6.0f);
+    out[4] = c;
+}
+
+__global__ void k_wino_pack(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ gamma,
+                            const float* __restrict__ beta, const float* __restrict__ mean, const float* __restrict__ var,
+                            float eps, int cout, int cin, int cout_pad, float* __restrict__ U, float* __restrict__ bias) {
+    const int64_t total = (int64_t)cout_pad * cin;
+    const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gs) {
+        const int co = (int)(idx / cin), ci = (int)(idx % cin);
+        float u[5][5];
+        if (co < cout) {
+            const float scale = gamma ? gamma[co] / sqrtf(var[co] + eps) : 1.0f;
+            const float* g = w + ((size_t)co * cin + ci) * 9;
+            float t[5][3];                                  // G g
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                float col[5];
+                g_rows(g[c] * scale, g[3 + c] * scale, g[6 + c] * scale, col);
+#pragma unroll
+                for (int r = 0; r < 5; ++r) t[r][c] = col[r];
+            }
+#pragma unroll
+            for (int r = 0; r < 5; ++r) g_rows(t[r][0], t[r][1], t[r][2], u[r]);     // (G g) G^T
+        } else {
+#pragma unroll
+            for (int r = 0; r < 5; ++r)
+#pragma unroll
+                for (int c = 0; c < 5; ++c) u[r][c] = 0.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < 5; ++r)
+#pragma unroll
+            for (int c = 0; c < 5; ++c) U[(size_t)(5 * r + c) * total + idx] = u[r][c];
+    }
+    for (int64_t co = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; co < cout_pad; co += gs) {
+        float v = 0.0f;
+        if (co < cout) {
+            const float bb = b ? b[co] : 0.0f;
+            v = gamma ? (bb - mean[co]) * (gamma[co] / sqrtf(var[co] + eps)) + beta[co] : bb;
+        }
+        bias[co] = v;
+    }
+}
+
+// B^T (5x5) applied to a 5-vector
+__device__ __forceinline__ void bt5(const f32x4 d0, const f32x4 d1, const f32x4 d2, const f32x4 d3, const f32x4 d4, f32x4 o[5]) {
+    o[0] = 2.0f * d0 - d1 - 2.0f * d2 + d3;
+    o[1] = d3 - 2.0f * d1 - d2;
+    o[2] = 2.0f * d1 - 3.0f * d2 + d3;
+    o[3] = d3 - d1;
+    o[4] = 2.0f * d1 - d2 - 2.0f * d3 + d4;
+}
+
+// one thread = one tile (patch, ty, tx) x one channel quad
+__global__ __launch_bounds__(256)
+void k_wino_in(const float* __restrict__ x, float* __restrict__ V, int64_t n, int c4) {
+    const int64_t total = n * 4 * c4;
+    const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+    const int64_t plane = n * 4 * c4;                          // float4 elements per transform-domain plane
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gs) {
+        const int cq = (int)(idx % c4);
+        const int64_t tile = idx / c4;
+        const int64_t img = tile >> 2;
+        const int ty = (int)(tile >> 1) & 1, tx = (int)tile & 1;
+        const f32x4* src = reinterpret_cast<const f32x4*>(x) + img * 36 * c4 + cq;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        f32x4 t[5][5];                                         // B^T d  (rows transformed), column by column
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            const int xx = 3 * tx - 1 + c;
+            f32x4 d[5];
+#pragma unroll
+            for (int r = 0; r < 5; ++r) {
+                const int yy = 3 * ty - 1 + r;
+                d[r] = ((unsigned)xx < 6u && (unsigned)yy < 6u) ? src[(size_t)(yy * 6 + xx) * c4] : zero;
+            }
+            f32x4 o[5];
+            bt5(d[0], d[1], d[2], d[3], d[4], o);
+#pragma unroll
+            for (int r = 0; r < 5; ++r) t[r][c] = o[r];
+        }
+        f32x4* dst = reinterpret_cast<f32x4*>(V) + tile * c4 + cq;
+#pragma unroll
+        for (int r = 0; r < 5; ++r) {
+            f32x4 o[5];
+            bt5(t[r][0], t[r][1], t[r][2], t[r][3], t[r][4], o);                  // (B^T d) B
+#pragma unroll
+            for (int c = 0; c < 5; ++c) dst[(size_t)(5 * r + c) * plane] = o[c];
+        }
+    }
+}
+
+// A^T (3x5) applied to a 5-vector
+__device__ __forceinline__ void at5(const f32x4 m0, const f32x4 m1, const f32x4 m2, const f32x4 m3, const f32x4 m4, f32x4 o[3]) {
+    o[0] = m0 + m1 + m2 + m3;
+    o[1] = m1 - m2 + 2.0f * m3;
+    o[2] = m1 + m2 + 4.0f * m3 + m4;
+}
+
+__global__ __launch_bounds__(256)
+void k_wino_out(const float* __restrict__ M, const float* __restrict__ bias, const float* __restrict__ res,
+                float* __restrict__ y, int64_t n, int c4, int act) {
+    const int64_t total = n * 4 * c4;
+    const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+    const int64_t plane = n * 4 * c4;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gs) {
+        const int cq = (int)(idx % c4);
+        const int64_t tile = idx / c4;
+        const int64_t img = tile >> 2;
+        const int ty = (int)(tile >> 1) & 1, tx = (int)tile & 1;
+        const f32x4* src = reinterpret_cast<const f32x4*>(M) + tile * c4 + cq;
+        f32x4 s[3][5];                                         // A^T m, column by column
+#pragma unroll
+        for (int c = 0; c < 5; ++c) {
+            f32x4 o[3];
+            at5(src[(size_t)c * plane], src[(size_t)(5 + c) * plane], src[(size_t)(10 + c) * plane], src[(size_t)(15 + c) * plane],
+                src[(size_t)(20 + c) * plane], o);
+#pragma unroll
+            for (int r = 0; r < 3; ++r) s[r][c] = o[r];
+        }
+        const f32x4 bv = reinterpret_cast<const f32x4*>(bias)[cq];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            f32x4 o[3];
+            at5(s[r][0], s[r][1], s[r][2], s[r][3], s[r][4], o);
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const size_t e = ((size_t)img * 36 + (3 * ty + r) * 6 + 3 * tx + c) * c4 + cq;
+                f32x4 v = o[c] + bv;
+                if (res) v += reinterpret_cast<const f32x4*>(res)[e];
+                if (act == 1) { v[0] = be::smish(v[0]); v[1] = be::smish(v[1]); v[2] = be::smish(v[2]); v[3] = be::smish(v[3]); }
+                else if (act == 2) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                reinterpret_cast<f32x4*>(y)[e] = v;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" size_t be_wino_packed_floats(int cout, int cin) {
+    if (cout <= 0 || cin <= 0 || cin % 32) return 0;
+    return (size_t)25 * ((cout + 31) / 32 * 32) * cin;
+}
+
+extern "C" int be_wino_pack_f32(const float* w, const float* b, const float* gamma, const float* beta, const float* mean,
+                                const float* var, float eps, int cout, int cin, float* packed_w, float* packed_bias,
+                                void* stream) {
+    BE_REQUIRE(w && packed_w && packed_bias, "be_wino_pack_f32: null pointer");
+    BE_REQUIRE(cout > 0 && cin > 0 && cin % 32 == 0, "be_wino_pack_f32: cin must be a multiple of 32 (got %d)", cin);
+    BE_REQUIRE((gamma == nullptr) == (beta == nullptr) && (gamma == nullptr) == (mean == nullptr) && (gamma == nullptr) == (var == nullptr),
+               "be_wino_pack_f32: BatchNorm tensors must be all set or all null");
+    const int cp = (cout + 31) / 32 * 32;
+    hipLaunchKernelGGL(k_wino_pack, dim3(grid_cap((int64_t)cp * cin, 256, 4096)), dim3(256), 0, be::as_stream(stream), w, b, gamma,
+                       beta, mean, var, eps, cout, cin, cp, packed_w, packed_bias);
+    return be::check_launch("be_wino_pack_f32");
+}
+
+extern "C" size_t be_wino_workspace_floats(int64_t n, int cin, int cout) {
+    if (n <= 0) return 0;
+    return (size_t)100 * n * ((size_t)cin + cout);              // V [25][4n][cin] + M [25][4n][cout]
+}
+
+extern "C" int be_wino_conv3x3_6x6_f32(const float* x, const float* packed_w, const float* packed_bias, const float* residual,
+                                       float* y, int64_t n, int cin, int cout, int act, float* workspace,
+                                       size_t workspace_floats, void* stream) {
+    BE_REQUIRE(x && packed_w && packed_bias && y && workspace, "be_wino_conv3x3_6x6_f32: null pointer");
+    BE_REQUIRE(n > 0 && 4 * n < ((int64_t)1 << 31) / 128, "be_wino_conv3x3_6x6_f32: batch out of range");
+    BE_REQUIRE(cin % 32 == 0 && cout % 4 == 0 && cin > 0 && cout > 0, "be_wino_conv3x3_6x6_f32: cin %% 32, cout %% 4 required");
+    BE_REQUIRE(workspace_floats >= be_wino_workspace_floats(n, cin, cout), "be_wino_conv3x3_6x6_f32: workspace too small");
+    BE_REQUIRE(be::aligned16(x) && be::aligned16(y) && be::aligned16(workspace) && be::aligned16(packed_w),
+               "be_wino_conv3x3_6x6_f32: 16-byte alignment");
+    hipStream_t s = be::as_stream(stream);
+    float* V = workspace;
+    float* M = workspace + (size_t)100 * n * cin;
+    hipLaunchKernelGGL(k_wino_in, dim3(grid_cap(n * 4 * (cin / 4), 256)), dim3(256), 0, s, x, V, n, cin / 4);
+    if (int rc = be::check_launch("be_wino_conv3x3_6x6_f32(in)")) return rc;
+    be_conv_desc d;
+    d.n = (int)(4 * n); d.h = 1; d.w = 1; d.cin = cin; d.cout = cout; d.ksize = 1; d.act = 0;
+    const int cp = (cout + 31) / 32 * 32;
+    if (int rc = be_conv_nhwc_batched_f32(&d, V, packed_w, nullptr, M, cout, 25, (int64_t)4 * n * cin, (int64_t)cp * cin,
+                                          (int64_t)4 * n * cout, stream))
+        return rc;
+    hipLaunchKernelGGL(k_wino_out, dim3(grid_cap(n * 4 * (cout / 4), 256)), dim3(256), 0, s, M, packed_bias, residual, y, n, cout / 4,
+                       act);
+    return be::check_launch("be_wino_conv3x3_6x6_f32(out)");
+}

@@ -223,6 +223,10 @@ int be_local_stage_pack_f32(const float* const* tensors_host /* [86] device ptrs
  * the Infinity Cache and the workspace is bounded; affects be_local_stage_workspace_bytes(). */
 int be_local_stage_set_chunk(int patches);
 
+/* 1 (default): the 3x3 convolutions on the 6x6 maps (layers 1-3) run in Winograd F(3x3,3x3) form; 0: direct implicit GEMM
+ * (the form the split-bf16 experiment and A/B runs use).  Both read the same packed buffer. */
+int be_local_stage_set_winograd(int on);
+
 /* Workspace (activations) for a batch of n patches, in bytes. */
 size_t be_local_stage_workspace_bytes(int64_t n);
 
@@ -269,6 +273,24 @@ int be_conv_pack_fused2_f32(const float* weight_oihw, const float* bias, const f
                             void* stream);
 int be_conv_nhwc_fused2_f32(const be_conv_desc* desc_host, const float* x, const float* x2, int cin2,
                             const float* packed_w, const float* packed_bias, float* y, int ldy, void* stream);
+/* nbatch independent problems of the same shape in one launch (grid.z): batch b reads x + b*x_stride, packed_w +
+ * b*w_stride and writes y + b*y_stride (strides in floats, multiples of 4).  packed_bias may be NULL (no bias) - here
+ * and in be_conv_nhwc_f32.  Used for the 25 GEMMs of the Winograd convolutions below. */
+int be_conv_nhwc_batched_f32(const be_conv_desc* d, const float* x, const float* packed_w, const float* packed_bias, float* y,
+                             int ldy, int nbatch, int64_t x_stride, int64_t w_stride, int64_t y_stride, void* stream);
+
+/* Winograd F(3x3,3x3) for 3x3 'same' convolutions on 6x6 maps (LocalStage layers 1-3): exact fp32 arithmetic with 2.56x
+ * fewer multiplies than the direct form.  be_wino_pack_f32 folds an optional eval BatchNorm like be_conv_pack_f32 and
+ * writes U [25][cout_pad32][cin] + bias [cout_pad32]; be_wino_conv3x3_6x6_f32 runs input transform, 25 batched GEMMs and
+ * output transform (+ bias, + residual [N,6,6,cout] if not NULL, + act 0 none | 1 Smish | 2 ReLU).  x, y NHWC.
+ * workspace: be_wino_workspace_floats(n, cin, cout) floats.  cin %% 32 == 0, cout %% 4 == 0. */
+size_t be_wino_packed_floats(int cout, int cin);
+int be_wino_pack_f32(const float* w_oihw, const float* bias, const float* bn_gamma, const float* bn_beta, const float* bn_mean,
+                     const float* bn_var, float bn_eps, int cout, int cin, float* packed_w, float* packed_bias, void* stream);
+size_t be_wino_workspace_floats(int64_t n, int cin, int cout);
+int be_wino_conv3x3_6x6_f32(const float* x, const float* packed_w, const float* packed_bias, const float* residual, float* y,
+                            int64_t n, int cin, int cout, int act, float* workspace, size_t workspace_floats, void* stream);
+
 /* EXPERIMENTAL, opt-in: split-bf16 arithmetic for the 128x128-tile convolutions.  Every fp32 operand is split exactly
  * into three bf16 pieces (x = hi + mid + lo) and a product is six bf16 MFMAs accumulated in fp32 (the three dropped
  * cross terms are <= 2^-24 relative, the size of one fp32 rounding).  be_conv_split_b3_f32 turns a packed weight
@@ -276,6 +298,7 @@ int be_conv_nhwc_fused2_f32(const be_conv_desc* desc_host, const float* x, const
  * packed weights lie inside that buffer use them (NULL, NULL, 0 switches back).  Default is off: exact fp32 MFMA. */
 int be_conv_split_b3_f32(const float* packed, size_t n, void* planes, void* stream);
 int be_conv_use_b3(const float* packed, const void* planes, size_t n);
+int be_conv_b3_active(void);     /* 1 while planes are registered */
 
 /* nn.MaxPool2d(k, stride, pad) on NHWC (models/local_stage.py:42-43). */
 int be_maxpool_nhwc_f32(const float* x, float* y, int n, int h, int w, int c, int k, int stride, int pad,

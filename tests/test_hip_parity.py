@@ -450,3 +450,31 @@ def test_entry_points_reject_bad_arguments_before_launching(native):
     with pytest.raises(RuntimeError, match="float64|expected"):
         dg.dptr(torch.zeros(4, device=DEV))                               # the generator's buffers are float64
     assert n.lib().be_last_error()                                        # the last message is kept for the caller
+
+
+@pytest.mark.parametrize("n,cin,cout", [(3, 96, 256), (700, 256, 384), (130, 384, 256)])
+def test_winograd_f33_conv_matches_the_direct_convolution(n, cin, cout):
+    """be_wino_conv3x3_6x6_f32 (Winograd F(3x3,3x3): input transform, 25 batched GEMMs, output transform) against the direct
+    implicit-GEMM convolution and the float64 oracle, with folded BatchNorm, residual and Smish."""
+    from be_hip import native
+    x = T(synth.hash_normal(31, "w_x", (n, 6, 6, cin)).astype(np.float32)).to(DEV)
+    w = T((synth.hash_normal(32, "w_w", (cout, cin, 3, 3)) * np.sqrt(2.0 / (9 * cin))).astype(np.float32)).to(DEV)
+    b = T((0.1 * synth.hash_normal(33, "w_b", (cout,))).astype(np.float32)).to(DEV)
+    bn = tuple(T(v.astype(np.float32)).to(DEV) for v in (0.8 + 0.4 * synth.hash_uniform(34, "w_g", (cout,)), 0.1 * synth.hash_normal(35, "w_be", (cout,)),
+                                                         0.1 * synth.hash_normal(36, "w_m", (cout,)), 0.5 + synth.hash_uniform(37, "w_v", (cout,))))
+    res = T(synth.hash_normal(38, "w_r", (n, 6, 6, cout)).astype(np.float32)).to(DEV)
+    pw, pb = native.conv_pack(w, b, bn=bn)
+    direct = native.conv_nhwc(x, pw, pb, cout, 3, 1, residual=res)
+    uw, ub = native.wino_pack(w, b, bn=bn)
+    wino, _ = native.wino_conv3x3(x, uw, ub, cout, act=1, residual=res)
+    # float64 reference
+    s = (bn[0] / torch.sqrt(bn[3] + 1e-5)).double().cpu()
+    y = torch.nn.functional.conv2d(x.cpu().double().permute(0, 3, 1, 2), w.cpu().double(), b.cpu().double(), padding=1)
+    y = (y - bn[2].cpu().double()[None, :, None, None]) * s[None, :, None, None] + bn[1].cpu().double()[None, :, None, None]
+    y = y + res.cpu().double().permute(0, 3, 1, 2)
+    ref = (y * torch.tanh(torch.log(1 + torch.sigmoid(y)))).permute(0, 2, 3, 1)
+    e_d, e_w = relmax(direct.cpu(), ref), relmax(wino.cpu(), ref)
+    print(f"n={n} {cin}->{cout}: direct {e_d:.2e}  winograd {e_w:.2e}")
+    assert e_d <= 4e-6 and e_w <= 2e-5
+    plain, _ = native.wino_conv3x3(x, uw, ub, cout)                     # no residual, no activation
+    assert relmax(plain.cpu(), (y - res.cpu().double().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)) <= 2e-5
