@@ -13,7 +13,8 @@ import sys
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
 tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
 NAMES = {"k_conv_igemm<2, 2, 2, 2, 0,": "conv128x128", "k_conv_igemm<4, 1, 1, 3, 0,": "conv128x96",
-         "k_conv_igemm<4, 1, 1, 2, 1,": "conv1_row8", "k_render_colors": "render_pass_a"}
+         "k_conv_igemm<4, 1, 1, 2, 1,": "conv1_row8", "k_render_colors": "render_pass_a",
+         "k_wino_in": "wino_in", "k_wino_out": "wino_out"}
 
 
 def short(name):
