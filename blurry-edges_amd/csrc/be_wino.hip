@@ -11,6 +11,7 @@
 //   k_wino_in     x [N,6,6,C] NHWC -> V [25][4N][C]            (HBM-bound: reads 36, writes 100 values per channel)
 //   (GEMMs)       M[xi] = V[xi] U[xi]^T: one batched launch of k_conv_igemm, be_conv_nhwc_batched_f32
 //   k_wino_out    M [25][4N][Cout] -> y [N,6,6,Cout] + bias (+ residual) (+ Smish)
+#include <cstdlib>
 #include "be_common.h"
 #include "be_device_math.h"
 
@@ -168,6 +169,132 @@ void k_wino_out(const float* __restrict__ M, const float* __restrict__ bias, con
     }
 }
 
+
+// ---- the 25 transform-domain GEMMs of one (M tile, N tile), walked by ONE workgroup --------------------------------
+// M[z] = V[z] U[z]^T for z = 0..24: each problem has a K loop of only Cin/16 = 6-24 chunks, so as separate tiles every
+// 12.6 MFLOP pay a prologue (first loads exposed), an epilogue and a workgroup turnover.  Here the software pipeline
+// (register-staged global loads one chunk ahead, double-buffered LDS, one barrier per chunk) runs straight through the
+// problem boundaries; at a boundary the accumulators are stored raw (no bias / residual / activation: the output
+// transform does those) and cleared.  Same 128x128 tile, fragment layout and MFMA inner loop as k_conv_igemm<2,2,2,2>.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct GemmArgs {
+    const float* x;       // [nb][M][K]
+    const float* w;       // [nb][Npad][K]
+    float* y;             // [nb][M][ldy]
+    int M, K, N, ldy, nb, m_tiles, n_tiles;
+    int64_t xb, wb, yb;
+};
+
+__global__ __launch_bounds__(256, 3)
+void k_wino_gemm(GemmArgs a) {
+    constexpr int BM = 128, BN = 128, BKT = 16, LROW = BKT + 4, RP = 64;
+    extern __shared__ __attribute__((aligned(16))) float smem_w[];
+    float* As = smem_w;                                // [2][BM][LROW]
+    float* Bs = smem_w + 2 * BM * LROW;                // [2][BN][LROW]
+    const int bid = blockIdx.x;
+    const int xcd = bid & 7, slot = bid >> 3;          // all N tiles of an M tile on one XCD
+    const int n_tile = slot % a.n_tiles;
+    const int m_tile = (slot / a.n_tiles) * 8 + xcd;
+    if (m_tile >= a.m_tiles) return;
+    const int n0 = n_tile * BN, row_base = m_tile * BM;
+    const int tid = threadIdx.x;
+    const int q = tid & 3, r0 = tid >> 2;
+    // staging: two rows of A and two rows of B per thread, 16 bytes each
+    const float* ap[2];
+    const float* bp[2];
+    bool a_live[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int ra = row_base + r0 + RP * i;
+        a_live[i] = ra < a.M;
+        ap[i] = a.x + (size_t)(a_live[i] ? ra : 0) * a.K + 4 * q;
+        bp[i] = a.w + (size_t)(n0 + r0 + RP * i) * a.K + 4 * q;       // rows up to Npad exist (zero rows past N)
+    }
+    const int kchunks = a.K / BKT, total = kchunks * a.nb;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int a_frag0 = (wm * 64 + li) * LROW + 4 * lh;
+    const int b_frag0 = (wn * 64 + li) * LROW + 4 * lh;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+    f32x4 a_st[2], b_st[2];
+    int lz = 0, lk = 0;                                // (problem, chunk) of the next load, advanced incrementally
+#define WG_LOAD()                                                                                               \
+    do {                                                                                                        \
+        const int64_t xo_ = (int64_t)lz * a.xb + lk * BKT, wo_ = (int64_t)lz * a.wb + lk * BKT;                  \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                      \
+            a_st[i_] = *reinterpret_cast<const f32x4*>(ap[i_] + xo_);                                           \
+            b_st[i_] = *reinterpret_cast<const f32x4*>(bp[i_] + wo_);                                           \
+        }                                                                                                       \
+        if (++lk == kchunks) { lk = 0; ++lz; }                                                                  \
+    } while (0)
+#define WG_STORE(BUF)                                                                                           \
+    do {                                                                                                        \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                      \
+            *reinterpret_cast<f32x4*>(As + (BUF) * BM * LROW + (r0 + RP * i_) * LROW + 4 * q) =                 \
+                a_live[i_] ? a_st[i_] : f32x4{0.f, 0.f, 0.f, 0.f};                                              \
+            *reinterpret_cast<f32x4*>(Bs + (BUF) * BN * LROW + (r0 + RP * i_) * LROW + 4 * q) = b_st[i_];       \
+        }                                                                                                       \
+    } while (0)
+    WG_LOAD();
+    WG_STORE(0);
+    __syncthreads();
+    int cz = 0, ck = 0;                                // (problem, chunk) being multiplied
+    for (int kc = 0; kc < total; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < total) WG_LOAD();
+        __builtin_amdgcn_sched_barrier(0);
+        const float* Ab = As + buf * BM * LROW + a_frag0;
+        const float* Bb = Bs + buf * BN * LROW + b_frag0;
+#pragma unroll
+        for (int g = 0; g < BKT / 8; ++g) {
+            f32x4 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LROW + 8 * g);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LROW + 8 * g);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (++ck == kchunks) {                          // problem cz is complete: raw store, clear
+            float* yz = a.y + (int64_t)cz * a.yb + (size_t)(row_base + wm * 64 + 4 * lh) * a.ldy + n0 + wn * 64 + li;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const bool c_ok = n0 + wn * 64 + j * 32 + li < a.N;
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ro = i * 32 + (r & 3) + 8 * (r >> 2);
+                        if (c_ok && row_base + wm * 64 + 4 * lh + ro < a.M) yz[(size_t)ro * a.ldy + j * 32] = acc[i][j][r];
+                        acc[i][j][r] = 0.0f;
+                    }
+            }
+            ck = 0; ++cz;
+        }
+        WG_STORE(buf ^ 1);
+        __syncthreads();
+    }
+#undef WG_LOAD
+#undef WG_STORE
+}
+
 }  // namespace
 
 extern "C" size_t be_wino_packed_floats(int cout, int cin) {
@@ -207,12 +334,34 @@ extern "C" int be_wino_conv3x3_6x6_f32(const float* x, const float* packed_w, co
     float* M = workspace + (size_t)100 * n * cin;
     hipLaunchKernelGGL(k_wino_in, dim3(grid_cap(n * 4 * (cin / 4), 256)), dim3(256), 0, s, x, V, n, cin / 4);
     if (int rc = be::check_launch("be_wino_conv3x3_6x6_f32(in)")) return rc;
-    be_conv_desc d;
-    d.n = (int)(4 * n); d.h = 1; d.w = 1; d.cin = cin; d.cout = cout; d.ksize = 1; d.act = 0;
     const int cp = (cout + 31) / 32 * 32;
-    if (int rc = be_conv_nhwc_batched_f32(&d, V, packed_w, nullptr, M, cout, 25, (int64_t)4 * n * cin, (int64_t)cp * cin,
-                                          (int64_t)4 * n * cout, stream))
-        return rc;
+    static const bool no_persist = getenv("BE_WINO_NO_PERSIST") != nullptr;        // A/B knob
+    if (cp % 128 == 0 && 4 * n >= 4096 && !no_persist) {
+        // large batches: one workgroup per (M tile, N tile) walks the 25 problems back to back
+        constexpr size_t lds = (size_t)2 * (128 + 128) * 20 * sizeof(float);
+        static bool attr_set = false;
+        if (!attr_set) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino_gemm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return be::fail(BE_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+            attr_set = true;
+        }
+        GemmArgs g{V, packed_w, M, (int)(4 * n), cin, cout, cout, 25, (int)((4 * n + 127) / 128), cp / 128,
+                   (int64_t)4 * n * cin, (int64_t)cp * cin, (int64_t)4 * n * cout};
+        const unsigned grid = (unsigned)(8 * ((g.m_tiles + 7) / 8) * g.n_tiles);
+        {
+            be::ProfileScope prof(s, BE_KERNEL_CONV_128x128, 25.0 * 2.0 * 4 * n * cin * cout,
+                                  25.0 * 4.0 * (4.0 * n * cin + (double)cin * cout + 4.0 * n * cout),
+                                  25.0 * 2.0 * g.m_tiles * g.n_tiles * 128.0 * 128.0 * cin);
+            hipLaunchKernelGGL(k_wino_gemm, dim3(grid), dim3(256), lds, s, g);
+        }
+        if (int rc = be::check_launch("be_wino_conv3x3_6x6_f32(gemm)")) return rc;
+    } else {
+        be_conv_desc d;
+        d.n = (int)(4 * n); d.h = 1; d.w = 1; d.cin = cin; d.cout = cout; d.ksize = 1; d.act = 0;
+        if (int rc = be_conv_nhwc_batched_f32(&d, V, packed_w, nullptr, M, cout, 25, (int64_t)4 * n * cin, (int64_t)cp * cin,
+                                              (int64_t)4 * n * cout, stream))
+            return rc;
+    }
     hipLaunchKernelGGL(k_wino_out, dim3(grid_cap(n * 4 * (cout / 4), 256)), dim3(256), 0, s, M, packed_bias, residual, y, n, cout / 4,
                        act);
     return be::check_launch("be_wino_conv3x3_6x6_f32(out)");
