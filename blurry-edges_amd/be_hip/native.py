@@ -68,6 +68,9 @@ _SIGNATURES = {
     "be_wino_pack_f32": (C.c_int, [_P] * 6 + [C.c_float, C.c_int, C.c_int, _P, _P, _P]),
     "be_wino_workspace_floats": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
     "be_wino_conv3x3_6x6_f32": (C.c_int, [_P] * 5 + [C.c_int64, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
+    "be_wino_pair_workspace_floats": (C.c_size_t, [C.c_int64, C.c_int, C.c_int, C.c_int]),
+    "be_wino_conv3x3_pair_6x6_f32": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P, C.c_int, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P,
+                                               C.c_size_t, _P]),
     "be_conv_split_b3_f32": (C.c_int, [_P, C.c_size_t, _P, _P]),
     "be_conv_use_b3": (C.c_int, [_P, _P, C.c_size_t]),
     "be_conv_b3_active": (C.c_int, []),
@@ -384,6 +387,19 @@ def wino_conv3x3(x, pw, pb, cout, act=0, residual=None, workspace=None):
     y = torch.empty(n, 6, 6, cout, dtype=torch.float32, device=x.device)
     check(lib().be_wino_conv3x3_6x6_f32(dptr(x, "x"), dptr(pw), dptr(pb), dptr(residual), dptr(y), n, cin, cout, int(act),
                                         dptr(workspace), workspace.numel(), stream_ptr(x.device)), "be_wino_conv3x3_6x6_f32")
+    return y, workspace
+
+
+def wino_conv3x3_pair(x, pw1, pb1, cmid, pw2, pb2, cout, act1=1, act2=1, residual=None, workspace=None):
+    """conv3x3 -> act1 -> conv3x3 (+ residual) -> act2 on 6x6 maps, intermediate map never written."""
+    n_, h, w, cin = x.shape
+    need = lib().be_wino_pair_workspace_floats(n_, cin, cmid, cout)
+    if workspace is None or workspace.numel() < need:
+        workspace = torch.empty(need, dtype=torch.float32, device=x.device)
+    y = torch.empty(n_, 6, 6, cout, dtype=torch.float32, device=x.device)
+    check(lib().be_wino_conv3x3_pair_6x6_f32(dptr(x, "x"), dptr(pw1), dptr(pb1), int(act1), dptr(pw2), dptr(pb2), dptr(residual),
+                                             int(act2), dptr(y), n_, cin, cmid, cout, dptr(workspace), workspace.numel(),
+                                             stream_ptr(x.device)), "be_wino_conv3x3_pair_6x6_f32")
     return y, workspace
 
 

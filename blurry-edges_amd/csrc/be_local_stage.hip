@@ -146,13 +146,12 @@ int block(const float* packed, int l0, const float* x, float* t, float* o, int n
 int block_wino(const float* packed, int l0, const float* x, float* t, float* o, float* r, float* w, int n, void* stream) {
     const PackedLayout& L = layout();
     const int c = kLayers[l0].cout;
-    int rc;
-    if ((rc = be_wino_conv3x3_6x6_f32(x, packed + L.uw_off[l0], packed + L.ub_off[l0], nullptr, t, n, kLayers[l0].cin, c, 1, w,
-                                      (size_t)n * RW, stream))) return rc;
+    (void)t;                                          // conv1's 6x6 result only ever exists in registers (k_wino_out_in)
     be_conv_desc d;
     d.n = n; d.h = 6; d.w = 6; d.cin = kLayers[l0 + 2].cin; d.cout = c; d.ksize = 1; d.act = 0;
-    if ((rc = be_conv_nhwc_f32(&d, x, packed + L.dw_off[l0 + 2], packed + L.db_off[l0 + 2], nullptr, r, c, stream))) return rc;
-    return be_wino_conv3x3_6x6_f32(t, packed + L.uw_off[l0 + 1], packed + L.ub_off[l0 + 1], r, o, n, c, c, 1, w, (size_t)n * RW, stream);
+    if (int rc = be_conv_nhwc_f32(&d, x, packed + L.dw_off[l0 + 2], packed + L.db_off[l0 + 2], nullptr, r, c, stream)) return rc;
+    return be_wino_conv3x3_pair_6x6_f32(x, packed + L.uw_off[l0], packed + L.ub_off[l0], 1, packed + L.uw_off[l0 + 1],
+                                        packed + L.ub_off[l0 + 1], r, 1, o, n, kLayers[l0].cin, c, c, w, (size_t)n * RW, stream);
 }
 
 }  // namespace

@@ -170,6 +170,79 @@ void k_wino_out(const float* __restrict__ M, const float* __restrict__ bias, con
 }
 
 
+
+// conv1 -> conv2 of a residual block without the intermediate map in HBM: one thread = one image x one channel quad reads the
+// 100 transform-domain values of conv1's result, forms the 6x6 map (+ bias, Smish) in registers and writes the 100
+// transform-domain values conv2's GEMMs read.  Saves the 36 values written and re-read (4x, tile overlap) per channel.
+__global__ __launch_bounds__(256, 1)
+void k_wino_out_in(const float* __restrict__ M, const float* __restrict__ bias, float* __restrict__ V, int64_t n, int c4, int act) {
+    const int64_t total = n * c4;
+    const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+    const int64_t plane = n * 4 * c4;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gs) {
+        const int cq = (int)(idx % c4);
+        const int64_t img = idx / c4;
+        const f32x4 bv = reinterpret_cast<const f32x4*>(bias)[cq];
+        f32x4 y[6][6];
+#pragma unroll
+        for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+            for (int tx = 0; tx < 2; ++tx) {
+                const f32x4* src = reinterpret_cast<const f32x4*>(M) + (img * 4 + ty * 2 + tx) * c4 + cq;
+                f32x4 s[3][5];
+#pragma unroll
+                for (int c = 0; c < 5; ++c) {
+                    f32x4 o[3];
+                    at5(src[(size_t)c * plane], src[(size_t)(5 + c) * plane], src[(size_t)(10 + c) * plane],
+                        src[(size_t)(15 + c) * plane], src[(size_t)(20 + c) * plane], o);
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) s[r][c] = o[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    f32x4 o[3];
+                    at5(s[r][0], s[r][1], s[r][2], s[r][3], s[r][4], o);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        f32x4 v = o[c] + bv;
+                        if (act == 1) { v[0] = be::smish(v[0]); v[1] = be::smish(v[1]); v[2] = be::smish(v[2]); v[3] = be::smish(v[3]); }
+                        else if (act == 2) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+                        y[3 * ty + r][3 * tx + c] = v;
+                    }
+                }
+            }
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+            for (int tx = 0; tx < 2; ++tx) {
+                f32x4 t[5][5];
+#pragma unroll
+                for (int c = 0; c < 5; ++c) {
+                    const int xx = 3 * tx - 1 + c;
+                    f32x4 d[5];
+#pragma unroll
+                    for (int r = 0; r < 5; ++r) {
+                        const int yy = 3 * ty - 1 + r;
+                        d[r] = (xx >= 0 && xx < 6 && yy >= 0 && yy < 6) ? y[yy < 0 ? 0 : (yy > 5 ? 5 : yy)][xx < 0 ? 0 : (xx > 5 ? 5 : xx)] : zero;
+                    }
+                    f32x4 o[5];
+                    bt5(d[0], d[1], d[2], d[3], d[4], o);
+#pragma unroll
+                    for (int r = 0; r < 5; ++r) t[r][c] = o[r];
+                }
+                f32x4* dst = reinterpret_cast<f32x4*>(V) + (img * 4 + ty * 2 + tx) * c4 + cq;
+#pragma unroll
+                for (int r = 0; r < 5; ++r) {
+                    f32x4 o[5];
+                    bt5(t[r][0], t[r][1], t[r][2], t[r][3], t[r][4], o);
+#pragma unroll
+                    for (int c = 0; c < 5; ++c) dst[(size_t)(5 * r + c) * plane] = o[c];
+                }
+            }
+    }
+}
+
 // ---- the 25 transform-domain GEMMs of one (M tile, N tile), walked by ONE workgroup --------------------------------
 // M[z] = V[z] U[z]^T for z = 0..24: each problem has a K loop of only Cin/16 = 6-24 chunks, so as separate tiles every
 // 12.6 MFLOP pay a prologue (first loads exposed), an epilogue and a workgroup turnover.  Here the software pipeline
@@ -320,20 +393,9 @@ extern "C" size_t be_wino_workspace_floats(int64_t n, int cin, int cout) {
     return (size_t)100 * n * ((size_t)cin + cout);              // V [25][4n][cin] + M [25][4n][cout]
 }
 
-extern "C" int be_wino_conv3x3_6x6_f32(const float* x, const float* packed_w, const float* packed_bias, const float* residual,
-                                       float* y, int64_t n, int cin, int cout, int act, float* workspace,
-                                       size_t workspace_floats, void* stream) {
-    BE_REQUIRE(x && packed_w && packed_bias && y && workspace, "be_wino_conv3x3_6x6_f32: null pointer");
-    BE_REQUIRE(n > 0 && 4 * n < ((int64_t)1 << 31) / 128, "be_wino_conv3x3_6x6_f32: batch out of range");
-    BE_REQUIRE(cin % 32 == 0 && cout % 4 == 0 && cin > 0 && cout > 0, "be_wino_conv3x3_6x6_f32: cin %% 32, cout %% 4 required");
-    BE_REQUIRE(workspace_floats >= be_wino_workspace_floats(n, cin, cout), "be_wino_conv3x3_6x6_f32: workspace too small");
-    BE_REQUIRE(be::aligned16(x) && be::aligned16(y) && be::aligned16(workspace) && be::aligned16(packed_w),
-               "be_wino_conv3x3_6x6_f32: 16-byte alignment");
-    hipStream_t s = be::as_stream(stream);
-    float* V = workspace;
-    float* M = workspace + (size_t)100 * n * cin;
-    hipLaunchKernelGGL(k_wino_in, dim3(grid_cap(n * 4 * (cin / 4), 256)), dim3(256), 0, s, x, V, n, cin / 4);
-    if (int rc = be::check_launch("be_wino_conv3x3_6x6_f32(in)")) return rc;
+namespace {
+
+int wino_gemms(const float* V, const float* packed_w, float* M, int64_t n, int cin, int cout, hipStream_t s, void* stream) {
     const int cp = (cout + 31) / 32 * 32;
     static const bool no_persist = getenv("BE_WINO_NO_PERSIST") != nullptr;        // A/B knob
     if (cp % 128 == 0 && 4 * n >= 4096 && !no_persist) {
@@ -354,15 +416,69 @@ extern "C" int be_wino_conv3x3_6x6_f32(const float* x, const float* packed_w, co
                                   25.0 * 2.0 * g.m_tiles * g.n_tiles * 128.0 * 128.0 * cin);
             hipLaunchKernelGGL(k_wino_gemm, dim3(grid), dim3(256), lds, s, g);
         }
-        if (int rc = be::check_launch("be_wino_conv3x3_6x6_f32(gemm)")) return rc;
-    } else {
-        be_conv_desc d;
-        d.n = (int)(4 * n); d.h = 1; d.w = 1; d.cin = cin; d.cout = cout; d.ksize = 1; d.act = 0;
-        if (int rc = be_conv_nhwc_batched_f32(&d, V, packed_w, nullptr, M, cout, 25, (int64_t)4 * n * cin, (int64_t)cp * cin,
-                                              (int64_t)4 * n * cout, stream))
-            return rc;
+        return be::check_launch("be_wino_conv3x3_6x6_f32(gemm)");
     }
+    be_conv_desc d;
+    d.n = (int)(4 * n); d.h = 1; d.w = 1; d.cin = cin; d.cout = cout; d.ksize = 1; d.act = 0;
+    return be_conv_nhwc_batched_f32(&d, V, packed_w, nullptr, M, cout, 25, (int64_t)4 * n * cin, (int64_t)cp * cin,
+                                    (int64_t)4 * n * cout, stream);
+}
+
+int wino_args_ok(const char* who, int64_t n, int cin, int cout) {
+    BE_REQUIRE(n > 0 && 4 * n < ((int64_t)1 << 31) / 128, "%s: batch out of range", who);
+    BE_REQUIRE(cin % 32 == 0 && cout % 4 == 0 && cin > 0 && cout > 0, "%s: cin %% 32, cout %% 4 required", who);
+    return BE_OK;
+}
+
+}  // namespace
+
+extern "C" int be_wino_conv3x3_6x6_f32(const float* x, const float* packed_w, const float* packed_bias, const float* residual,
+                                       float* y, int64_t n, int cin, int cout, int act, float* workspace,
+                                       size_t workspace_floats, void* stream) {
+    BE_REQUIRE(x && packed_w && packed_bias && y && workspace, "be_wino_conv3x3_6x6_f32: null pointer");
+    if (int rc = wino_args_ok("be_wino_conv3x3_6x6_f32", n, cin, cout)) return rc;
+    BE_REQUIRE(workspace_floats >= be_wino_workspace_floats(n, cin, cout), "be_wino_conv3x3_6x6_f32: workspace too small");
+    BE_REQUIRE(be::aligned16(x) && be::aligned16(y) && be::aligned16(workspace) && be::aligned16(packed_w),
+               "be_wino_conv3x3_6x6_f32: 16-byte alignment");
+    hipStream_t s = be::as_stream(stream);
+    float* V = workspace;
+    float* M = workspace + (size_t)100 * n * cin;
+    hipLaunchKernelGGL(k_wino_in, dim3(grid_cap(n * 4 * (cin / 4), 256)), dim3(256), 0, s, x, V, n, cin / 4);
+    if (int rc = be::check_launch("be_wino_conv3x3_6x6_f32(in)")) return rc;
+    if (int rc = wino_gemms(V, packed_w, M, n, cin, cout, s, stream)) return rc;
     hipLaunchKernelGGL(k_wino_out, dim3(grid_cap(n * 4 * (cout / 4), 256)), dim3(256), 0, s, M, packed_bias, residual, y, n, cout / 4,
                        act);
     return be::check_launch("be_wino_conv3x3_6x6_f32(out)");
+}
+
+extern "C" size_t be_wino_pair_workspace_floats(int64_t n, int cin, int cmid, int cout) {
+    if (n <= 0) return 0;
+    const size_t big = (size_t)(cin > cmid ? cin : cmid), out = (size_t)(cmid > cout ? cmid : cout);
+    return (size_t)100 * n * (big + out);                       // V (cin, then cmid) + M (cmid, then cout)
+}
+
+extern "C" int be_wino_conv3x3_pair_6x6_f32(const float* x, const float* packed_w1, const float* packed_bias1, int act1,
+                                            const float* packed_w2, const float* packed_bias2, const float* residual, int act2,
+                                            float* y, int64_t n, int cin, int cmid, int cout, float* workspace,
+                                            size_t workspace_floats, void* stream) {
+    BE_REQUIRE(x && packed_w1 && packed_bias1 && packed_w2 && packed_bias2 && y && workspace,
+               "be_wino_conv3x3_pair_6x6_f32: null pointer");
+    if (int rc = wino_args_ok("be_wino_conv3x3_pair_6x6_f32", n, cin, cmid)) return rc;
+    if (int rc = wino_args_ok("be_wino_conv3x3_pair_6x6_f32", n, cmid, cout)) return rc;
+    BE_REQUIRE(workspace_floats >= be_wino_pair_workspace_floats(n, cin, cmid, cout), "be_wino_conv3x3_pair_6x6_f32: workspace too small");
+    BE_REQUIRE(be::aligned16(x) && be::aligned16(y) && be::aligned16(workspace) && be::aligned16(packed_w1) && be::aligned16(packed_w2),
+               "be_wino_conv3x3_pair_6x6_f32: 16-byte alignment");
+    hipStream_t s = be::as_stream(stream);
+    const size_t big = (size_t)(cin > cmid ? cin : cmid);
+    float* V = workspace;
+    float* M = workspace + (size_t)100 * n * big;
+    hipLaunchKernelGGL(k_wino_in, dim3(grid_cap(n * 4 * (cin / 4), 256)), dim3(256), 0, s, x, V, n, cin / 4);
+    if (int rc = be::check_launch("be_wino_conv3x3_pair_6x6_f32(in)")) return rc;
+    if (int rc = wino_gemms(V, packed_w1, M, n, cin, cmid, s, stream)) return rc;
+    hipLaunchKernelGGL(k_wino_out_in, dim3(grid_cap(n * (cmid / 4), 256)), dim3(256), 0, s, M, packed_bias1, V, n, cmid / 4, act1);
+    if (int rc = be::check_launch("be_wino_conv3x3_pair_6x6_f32(out_in)")) return rc;
+    if (int rc = wino_gemms(V, packed_w2, M, n, cmid, cout, s, stream)) return rc;
+    hipLaunchKernelGGL(k_wino_out, dim3(grid_cap(n * 4 * (cout / 4), 256)), dim3(256), 0, s, M, packed_bias2, residual, y, n, cout / 4,
+                       act2);
+    return be::check_launch("be_wino_conv3x3_pair_6x6_f32(out)");
 }

@@ -291,6 +291,13 @@ size_t be_wino_workspace_floats(int64_t n, int cin, int cout);
 int be_wino_conv3x3_6x6_f32(const float* x, const float* packed_w, const float* packed_bias, const float* residual, float* y,
                             int64_t n, int cin, int cout, int act, float* workspace, size_t workspace_floats, void* stream);
 
+/* Two chained 3x3 convolutions (conv1 -> act1 -> conv2 -> + residual -> act2: a residual block of LocalStage) with the
+ * intermediate 6x6 map kept in registers between conv1's output transform and conv2's input transform. */
+size_t be_wino_pair_workspace_floats(int64_t n, int cin, int cmid, int cout);
+int be_wino_conv3x3_pair_6x6_f32(const float* x, const float* packed_w1, const float* packed_bias1, int act1,
+                                 const float* packed_w2, const float* packed_bias2, const float* residual, int act2, float* y,
+                                 int64_t n, int cin, int cmid, int cout, float* workspace, size_t workspace_floats, void* stream);
+
 /* EXPERIMENTAL, opt-in: split-bf16 arithmetic for the 128x128-tile convolutions.  Every fp32 operand is split exactly
  * into three bf16 pieces (x = hi + mid + lo) and a product is six bf16 MFMAs accumulated in fp32 (the three dropped
  * cross terms are <= 2^-24 relative, the size of one fp32 rounding).  be_conv_split_b3_f32 turns a packed weight

@@ -476,5 +476,12 @@ def test_winograd_f33_conv_matches_the_direct_convolution(n, cin, cout):
     e_d, e_w = relmax(direct.cpu(), ref), relmax(wino.cpu(), ref)
     print(f"n={n} {cin}->{cout}: direct {e_d:.2e}  winograd {e_w:.2e}")
     assert e_d <= 4e-6 and e_w <= 2e-5
+    # chained pair with the intermediate map in registers == two single convolutions
+    w2 = T((synth.hash_normal(39, "w_w2", (cout, cout, 3, 3)) * np.sqrt(2.0 / (9 * cout))).astype(np.float32)).to(DEV)
+    uw2, ub2 = native.wino_pack(w2, b)
+    mid, _ = native.wino_conv3x3(x, uw, ub, cout, act=1)
+    two, _ = native.wino_conv3x3(mid, uw2, ub2, cout, act=1, residual=res)
+    pair, _ = native.wino_conv3x3_pair(x, uw, ub, cout, uw2, ub2, cout, residual=res)
+    assert torch.equal(pair, two)
     plain, _ = native.wino_conv3x3(x, uw, ub, cout)                     # no residual, no activation
     assert relmax(plain.cpu(), (y - res.cpu().double().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)) <= 2e-5
