@@ -168,14 +168,18 @@ def main():
                 rr = recs[i::nl]
                 ms_i = sum(r[3] for r in rr) / len(rr)
                 print(f"{i:4d}  {rr[0][0]:5d}  {rr[0][1] / 1e9:8.2f}  {ms_i:7.4f}  {rr[0][1] / ms_i / 1e9:8.2f}", file=sys.stderr)
-        dom = [r for r in recs if r[0] == 0]
+        by_id = {}
+        for r in recs:
+            by_id[r[0]] = by_id.get(r[0], 0.0) + r[3]
+        dom_id = max(by_id, key=by_id.get) if by_id else 0           # dominant = the kernel with the most time in the step
+        dom = [r for r in recs if r[0] == dom_id]
         conv_ms = sum(r[3] for r in recs) / args.steps
         if dom:
             peak = PEAK_FP32_MFMA_TFLOPS if model.conv_precision == "f32" else PEAK_BF16X3_TFLOPS
             avg_ms = sum(r[3] for r in dom) / len(dom)
             avg_flop = sum(r[1] for r in dom) / len(dom)
             ach = avg_flop / (avg_ms * 1e-3) / 1e12
-            roof = dict(bound="mfma", kernel=native.KERNEL_NAMES[0], achieved=round(ach, 2),
+            roof = dict(bound="mfma", kernel=native.KERNEL_NAMES[dom_id], achieved=round(ach, 2),
                         peak=round(peak, 1), unit="TFLOP/s", frac=round(ach / peak, 4),
                         traffic=None, launches_per_step=len(dom) // args.steps,
                         avg_launch_ms=round(avg_ms, 4), flop_per_launch=avg_flop,

@@ -411,7 +411,7 @@ int wino_gemms(const float* V, const float* packed_w, float* M, int64_t n, int c
                    (int64_t)4 * n * cin, (int64_t)cp * cin, (int64_t)4 * n * cout};
         const unsigned grid = (unsigned)(8 * ((g.m_tiles + 7) / 8) * g.n_tiles);
         {
-            be::ProfileScope prof(s, BE_KERNEL_CONV_128x128, 25.0 * 2.0 * 4 * n * cin * cout,
+            be::ProfileScope prof(s, BE_KERNEL_WINO_GEMM, 25.0 * 2.0 * 4 * n * cin * cout,
                                   25.0 * 4.0 * (4.0 * n * cin + (double)cin * cout + 4.0 * n * cout),
                                   25.0 * 2.0 * g.m_tiles * g.n_tiles * 128.0 * 128.0 * cin);
             hipLaunchKernelGGL(k_wino_gemm, dim3(grid), dim3(256), lds, s, g);

@@ -14,7 +14,7 @@ src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/pmc"
 tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
 NAMES = {"k_conv_igemm<2, 2, 2, 2, 0,": "conv128x128", "k_conv_igemm<4, 1, 1, 3, 0,": "conv128x96",
          "k_conv_igemm<4, 1, 1, 2, 1,": "conv1_row8", "k_render_colors": "render_pass_a",
-         "k_wino_in": "wino_in", "k_wino_out": "wino_out"}
+         "k_wino_in": "wino_in", "k_wino_out_in": "wino_out_in", "k_wino_out(": "wino_out", "k_wino_gemm": "wino_gemm"}
 
 
 def short(name):
@@ -42,11 +42,11 @@ for k, cs in out.items():
         h, m = cs["TCC_HIT_sum"]["mean_per_launch"], cs["TCC_MISS_sum"]["mean_per_launch"]
         cs.setdefault("derived", {})["l2_hit_rate"] = h / (h + m)
 json.dump(out, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
-dom = out.get("conv128x128", {})
+dom = out.get("wino_gemm") or out.get("conv128x128", {})
 if "FETCH_SIZE" in dom and "WRITE_SIZE" in dom:
     rd = dom["FETCH_SIZE"]["mean_per_launch"] * 1024 * 2
     wr = dom["WRITE_SIZE"]["mean_per_launch"] * 1024
-    json.dump({"kernel": "k_conv_igemm<2,2,2,2,TAPS>", "bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr,
+    json.dump({"kernel": "k_wino_gemm" if "wino_gemm" in out else "k_conv_igemm<2,2,2,2,TAPS>", "bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr,
                "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 (gfx950), KiB -> B",
                "launches_averaged": dom["FETCH_SIZE"]["launches"]}, open("profiles/r01_pmc_traffic.json", "w"), indent=1)
 print(json.dumps({k: v.get("derived") for k, v in out.items()}, indent=1))
