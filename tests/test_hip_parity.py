@@ -171,6 +171,15 @@ def test_conv_layers_one_by_one_vs_oracle(native):
                                            bnp(name + ".downsample"))
         of = native.conv_nhwc_fused2(t, xin, pwf, pbf, cout, 3, act=1)
         assert relmax(of.cpu(), o.cpu()) <= 2e-6, name
+        if xin.shape[1] == 6:
+            # the form LocalStage.forward uses on the 6x6 maps since v10: both 3x3 convs as Winograd F(3x3,3x3), the
+            # downsample as its own 1x1 conv joining in conv2's output transform, conv1's map kept in registers
+            wpack = lambda pre: native.wino_pack(dev(pre + ".0.weight"), dev(pre + ".0.bias"), bn=bnp(pre))
+            (u1, b1), (u2, b2) = wpack(name + ".conv1"), wpack(name + ".conv2")
+            ow, _ = native.wino_conv3x3_pair(xin, u1, b1, cout, u2, b2, cout, residual=d)
+            assert relmax(ow.cpu(), _nhwc(taps[name.split(".")[0]])) <= 1e-5, name
+            tw, _ = native.wino_conv3x3(xin, u1, b1, cout, act=1)
+            assert relmax(tw.cpu(), t.cpu()) <= 1e-5, name
     p3 = native.maxpool_nhwc(_nhwc(taps["layer3"]).to(DEV), 2, 2, 0)
     assert relmax(p3.cpu(), _nhwc(taps["pool3"])) <= 1e-6
     # fc.1 + BN1d + Smish on the (H,W,C)-flattened features
