@@ -243,7 +243,7 @@ def test_local_stage_full_batch_8192_properties(native):
     assert relmax(ys.cpu(), yo) <= 1e-5
 
 
-@pytest.mark.parametrize("n", [1, 3, 513, 1000, 8492])
+@pytest.mark.parametrize("n", [1, 3, 513, 1000, 1500, 8492])
 def test_local_stage_ragged_batches_are_position_independent(native, n):
     """Edge sizes: a single patch, a ragged small batch, and ragged LARGE batches (pixel-major conv tiles with a
     partly empty last tile) give bit-identical logits to the same patches run in another batch."""
@@ -461,7 +461,7 @@ def test_entry_points_reject_bad_arguments_before_launching(native):
     assert n.lib().be_last_error()                                        # the last message is kept for the caller
 
 
-@pytest.mark.parametrize("n,cin,cout", [(3, 96, 256), (700, 256, 384), (130, 384, 256)])
+@pytest.mark.parametrize("n,cin,cout", [(3, 96, 256), (700, 256, 384), (130, 384, 256), (1501, 256, 256)])
 def test_winograd_f33_conv_matches_the_direct_convolution(n, cin, cout):
     """be_wino_conv3x3_6x6_f32 (Winograd F(3x3,3x3): input transform, 25 batched GEMMs, output transform) against the direct
     implicit-GEMM convolution and the float64 oracle, with folded BatchNorm, residual and Smish."""
