@@ -5,12 +5,14 @@
 // domain): 100 multiplies per (cin, cout) pair and map instead of the 324 of the direct form (256 once the taps that
 // fall into the zero padding are skipped) - 2.56x less work for the matrix pipe, in exact fp32 arithmetic.
 // Interpolation points 0, 1, -1, 2, inf; the transforms are small integer / sixth combinations.  Accuracy measured on the
-// whole network against the fp64 oracle: logits 8.3e-7 (direct fp32 convolutions: 7.6e-7), see DESIGN.md 3.1c.
+// whole network against the fp64 oracle: logits 2.0e-6 (direct fp32 convolutions: 2.3e-6), see DESIGN.md 3.1c.
 //
 //   k_wino_pack   weights [Cout,Cin,3,3] (+ folded BatchNorm) -> U [25][Cout_pad][Cin] in the 1x1 layout of k_conv_igemm
 //   k_wino_in     x [N,6,6,C] NHWC -> V [25][4N][C]            (HBM-bound: reads 36, writes 100 values per channel)
-//   (GEMMs)       M[xi] = V[xi] U[xi]^T: one batched launch of k_conv_igemm, be_conv_nhwc_batched_f32
+//   k_wino_gemm   M[xi] = V[xi] U[xi]^T for the 25 positions xi: one workgroup per 128x128 tile walks all 25 (large batches;
+//                 small ones go through be_conv_nhwc_batched_f32 on k_conv_igemm, same arithmetic per output element)
 //   k_wino_out    M [25][4N][Cout] -> y [N,6,6,Cout] + bias (+ residual) (+ Smish)
+//   k_wino_out_in conv1 -> conv2 of a residual block: output transform + Smish + input transform, the map stays in registers
 #include <cstdlib>
 #include "be_common.h"
 #include "be_device_math.h"
