@@ -99,6 +99,9 @@ class LocalStage(nn.Module):
     # convolutions of layers 1-3 and fc.1 split every fp32 operand exactly into three bf16 pieces and take six bf16 MFMAs
     # per product with fp32 accumulation (include/blurry_edges_hip.h, be_conv_use_b3).
     conv_precision = os.environ.get("BE_CONV_PRECISION", "f32")
+    # True (default): the 3x3 convolutions on the 6x6 maps run as Winograd F(3x3,3x3) (2.56x fewer multiplies, exact fp32
+    # products; be_wino.hip).  False: direct implicit-GEMM convolutions everywhere (be_local_stage_set_winograd).
+    winograd = os.environ.get("BE_WINOGRAD", "1") != "0"
 
     def _packed_weights(self):
         tensors = [t.detach() for t in self._tensor_list()]
@@ -125,6 +128,7 @@ class LocalStage(nn.Module):
                     m.num_batches_tracked += 1
             return out
         x = x.to(torch.float32).contiguous()
+        native.check(native.lib().be_local_stage_set_winograd(int(bool(self.winograd))), "be_local_stage_set_winograd")
         out, self._workspace = native.local_stage_forward(self._packed_weights(), x, workspace=self._workspace)
         return out
 
@@ -136,6 +140,7 @@ class LocalStage(nn.Module):
         if self.training:
             raise RuntimeError("LocalStage.forward_image_pair is an inference entry point; call .eval() first")
         img = img.to(torch.float32).contiguous()
+        native.check(native.lib().be_local_stage_set_winograd(int(bool(self.winograd))), "be_local_stage_set_winograd")
         view = native.view_image_pair(img, stride, window)
         P = (((window[2] if window is not None else img.shape[2]) - native.BE_R) // stride + 1) * view.wp
         out, self._workspace = native.local_stage_forward_view(self._packed_weights(), view, P, 2 * P, img.device,

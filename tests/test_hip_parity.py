@@ -430,6 +430,16 @@ def test_split_bf16_conv_mode_is_opt_in_and_stays_within_the_fp32_tolerance(nati
     e32, e3 = relmax(y32[:256].cpu(), ref), relmax(y3[:256].cpu(), ref)
     print("logits vs fp64 oracle: fp32 MFMA %.2e, bf16x3 %.2e" % (e32, e3))
     assert e32 <= 1e-5 and e3 <= 1e-5
+    # the Winograd switch: default on; off = direct convolutions on the 6x6 maps, both inside the tolerance
+    assert m.winograd
+    m.winograd = False
+    with torch.no_grad():
+        yd = m(x).clone()
+        m.winograd = True
+        yw = m(x)
+    ed = relmax(yd[:256].cpu(), ref)
+    print("logits vs fp64 oracle: direct %.2e, winograd %.2e" % (ed, e32))
+    assert torch.equal(yw, y32) and not torch.equal(yd, y32) and ed <= 1e-5
 
 
 def test_entry_points_reject_bad_arguments_before_launching(native):
