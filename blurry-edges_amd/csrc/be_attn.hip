@@ -145,8 +145,9 @@ template <bool TRAIN>
 __global__ __launch_bounds__(256)
 void k_attention(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
                  float* __restrict__ out, float* __restrict__ lse, int L, int H, uint32_t seed, uint32_t thresh,
-                 float inv_keep) {
-    // grid.x = L/128 query blocks (4 waves x 32 queries), grid.y = B*H
+                 float inv_keep, float* __restrict__ part) {
+    // grid.x = L/128 query blocks (4 waves x 32 queries), grid.y = B*H, grid.z = key slices (inference at small batch:
+    // 256 workgroups cannot fill 256 CUs x 4 SIMDs; each slice then leaves un-normalised partials for k_attn_combine)
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = lane & 15, g = lane >> 4;
     const int bh = blockIdx.y;
@@ -164,14 +165,15 @@ void k_attention(const float* __restrict__ Q, const float* __restrict__ K, const
         o[qc] = f32x4v{0.f, 0.f, 0.f, 0.f};
         m[qc] = -INFINITY; lsum[qc] = 0.f;
     }
+    const int kb0 = (L / KB) * blockIdx.z / gridDim.z;
     f32x4v kn[2], vn[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
-        kn[kt] = *reinterpret_cast<const f32x4v*>(Kh + (size_t)(16 * kt + c) * DH + 4 * g);
-        vn[kt] = *reinterpret_cast<const f32x4v*>(Vh + (size_t)c * L + 16 * kt + 4 * g);
+        kn[kt] = *reinterpret_cast<const f32x4v*>(Kh + (size_t)(kb0 * KB + 16 * kt + c) * DH + 4 * g);
+        vn[kt] = *reinterpret_cast<const f32x4v*>(Vh + (size_t)c * L + kb0 * KB + 16 * kt + 4 * g);
     }
-    const int nkb = L / KB;
-    for (int kblk = 0; kblk < nkb; ++kblk) {
+    const int nkb = (L / KB) * (blockIdx.z + 1) / gridDim.z;              // this slice: key blocks [kb0, nkb)
+    for (int kblk = kb0; kblk < nkb; ++kblk) {
         const f32x4v kf[2] = {kn[0], kn[1]}, vf[2] = {vn[0], vn[1]};
         const int nx = kblk + 1 < nkb ? kblk + 1 : kblk;                 // prefetch (clamped on the last block)
 #pragma unroll
@@ -221,6 +223,18 @@ void k_attention(const float* __restrict__ Q, const float* __restrict__ K, const
 #pragma unroll
                 for (int qc = 0; qc < 2; ++qc) o[qc] = MFMA16(vf[kt][r], s[kt][qc][r], o[qc]);
     }
+    if (gridDim.z > 1) {          // partials of this key slice: o (un-normalised) [z][bh][L][16], then m and l [z][bh][L]
+        const size_t rows = (size_t)gridDim.y * L;
+        float* po = part + (size_t)blockIdx.z * rows * (DH + 2);
+#pragma unroll
+        for (int qc = 0; qc < 2; ++qc) {
+            const size_t row = (size_t)bh * L + q0 + 16 * qc + c;
+            const float ltot = quad_sum(lsum[qc]);
+            *reinterpret_cast<f32x4v*>(po + row * DH + 4 * g) = o[qc];
+            if (g == 0) { po[rows * DH + row] = m[qc]; po[rows * (DH + 1) + row] = ltot; }
+        }
+        return;
+    }
     const int Dm = H * DH;
     const int b = bh / H, hd = bh % H;
 #pragma unroll
@@ -229,6 +243,29 @@ void k_attention(const float* __restrict__ Q, const float* __restrict__ K, const
         const float inv = TRAIN ? inv_keep / ltot : 1.0f / ltot;
         if (TRAIN && g == 0) lse[(size_t)bh * L + q0 + 16 * qc + c] = m[qc] + log2f(ltot);
         *reinterpret_cast<f32x4v*>(out + ((size_t)b * L + q0 + 16 * qc + c) * Dm + hd * DH + 4 * g) = o[qc] * inv;
+    }
+}
+
+// merges the key slices: out = sum_z o_z 2^(m_z - M) / sum_z l_z 2^(m_z - M), M = max_z m_z; one thread per (row, d quad)
+__global__ void k_attn_combine(const float* __restrict__ part, float* __restrict__ out, int nz, int64_t BH, int L, int H) {
+    const int64_t rows = BH * L, total = rows * 4;
+    const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gs) {
+        const int64_t row = idx >> 2;
+        const int dq = (int)(idx & 3);
+        float M = -INFINITY;
+        for (int z = 0; z < nz; ++z) M = fmaxf(M, part[(size_t)z * rows * (DH + 2) + rows * DH + row]);
+        f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+        float l = 0.f;
+        for (int z = 0; z < nz; ++z) {
+            const float* pz = part + (size_t)z * rows * (DH + 2);
+            const float wgt = fast_exp2(pz[rows * DH + row] - M);
+            acc += *reinterpret_cast<const f32x4v*>(pz + row * DH + 4 * dq) * wgt;
+            l += pz[rows * (DH + 1) + row] * wgt;
+        }
+        const int64_t bh = row / L, q = row % L;
+        const int64_t b = bh / H, hd = bh % H;
+        *reinterpret_cast<f32x4v*>(out + ((size_t)b * L + q) * H * DH + hd * DH + 4 * dq) = acc * (1.0f / l);
     }
 }
 
@@ -567,8 +604,17 @@ extern "C" int be_attention_f32(const float* qkv, float* out, float* workspace, 
     const float qscale = 0.25f * 1.44269504088896340736f;            // 1/sqrt(16) * log2(e)
     int64_t g = ((int64_t)n + 255) / 256; if (g > 4096) g = 4096;
     hipLaunchKernelGGL(k_qkv_split, dim3((unsigned)g), dim3(256), 0, s, qkv, Q, K, Vt, B, L, H, qscale);
-    hipLaunchKernelGGL(k_attention<false>, dim3(L / 128, B * H), dim3(256), 0, s, Q, K, Vt, out, (float*)nullptr, L, H, 0u,
-                       0u, 1.0f);
+    // key slices when the query tiles alone leave the chip mostly empty (one 147x147 pair: 256 workgroups on 256 CUs)
+    const int wgs = (L / 128) * B * H;
+    const int nz = (L >= 2048 && wgs < 512) ? (wgs <= 256 ? 4 : 2) : 1;
+    float* part = workspace + 3 * n;
+    hipLaunchKernelGGL(k_attention<false>, dim3(L / 128, B * H, nz), dim3(256), 0, s, Q, K, Vt, out, (float*)nullptr, L, H, 0u,
+                       0u, 1.0f, part);
+    if (nz > 1) {
+        const int64_t total = (int64_t)B * H * L * 4;
+        hipLaunchKernelGGL(k_attn_combine, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256), 0, s,
+                           part, out, nz, (int64_t)B * H, L, H);
+    }
     return be::check_launch("be_attention_f32");
 }
 
@@ -600,7 +646,7 @@ extern "C" int be_attention_train_fwd_f32(const float* qkv, float* out, float* l
     hipLaunchKernelGGL(k_qkv_split_train, dim3((unsigned)g), dim3(256), 0, s, qkv, w.Q, w.K, w.V, w.Qt, w.Kt, w.Vt, B, L, H,
                        0.25f * 1.44269504088896340736f);
     hipLaunchKernelGGL(k_attention<true>, dim3(L / 128, B * H), dim3(256), 0, s, w.Q, w.K, w.Vt, out, lse, L, H, seed,
-                       drop_threshold(dropout_p), 1.0f / (1.0f - dropout_p));
+                       drop_threshold(dropout_p), 1.0f / (1.0f - dropout_p), (float*)nullptr);
     return be::check_launch("be_attention_train_fwd_f32");
 }
 
@@ -675,7 +721,9 @@ extern "C" int be_layernorm_bwd_f32(const float* dy, const float* v, const float
     return be::check_launch("be_layernorm_bwd_f32");
 }
 
-extern "C" size_t be_attention_workspace_floats(int B, int L, int H) { return (size_t)3 * B * H * L * DH; }
+extern "C" size_t be_attention_workspace_floats(int B, int L, int H) {
+    return (size_t)3 * B * H * L * DH + (size_t)4 * B * H * L * (DH + 2);      // q / k / v^T + up to 4 key-slice partials
+}
 
 extern "C" int be_add_layernorm_f32(const float* x, const float* res, const float* gamma, const float* beta, float* y,
                                     int64_t rows, int D, float eps, void* stream) {
