@@ -247,11 +247,22 @@ void k_wino_out_in(const float* __restrict__ M, const float* __restrict__ bias, 
 
 // ---- the 25 transform-domain GEMMs of one (M tile, N tile), walked by ONE workgroup --------------------------------
 // M[z] = V[z] U[z]^T for z = 0..24: each problem has a K loop of only Cin/16 = 6-24 chunks, so as separate tiles every
-// 12.6 MFLOP pay a prologue (first loads exposed), an epilogue and a workgroup turnover.  Here the software pipeline
-// (register-staged global loads one chunk ahead, double-buffered LDS, one barrier per chunk) runs straight through the
-// problem boundaries; at a boundary the accumulators are stored raw (no bias / residual / activation: the output
-// transform does those) and cleared.  Same 128x128 tile, fragment layout and MFMA inner loop as k_conv_igemm<2,2,2,2>.
+// 12.6 MFLOP pay a prologue (first loads exposed), an epilogue and a workgroup turnover.  Here the software pipeline runs
+// straight through the problem boundaries; at a boundary the accumulators are stored raw (no bias / residual / activation:
+// the output transform does those) and cleared.  128x128 tile, 2x2 waves of 2x2 MFMA tiles (32x32x2 f32).
+//
+// Operand staging is global -> LDS directly (global_load_lds_dwordx4: no VGPR round trip, no ds_write, no per-chunk vector
+// address arithmetic).  Knock-out runs of the register-staged version (tools/wino_gemm_lab.hip) showed that
+// the MFMA pipe loses about as many cycles as the other instructions of the resident waves move registers: a loop of
+// nothing but MFMAs runs at 99 % of the matrix rate, + the fragment ds_reads 94 %, + ds_writes 91 %, + global loads into
+// registers 80 %; barriers and load latency cost nothing measurable.  So the loop carries as little else as it can.
+// One DMA instruction of a wave fills a 1-KB piece = 16 rows x 64 B, lane-linear (LDS destination = piece base + lane x
+// 16); without row padding the fragment reads would be 4-way bank conflicts, so the 16-byte quads of a row are
+// XOR-swizzled by (row >> 2) & 3 - on the SOURCE address of the DMA and on the ds_read_b128 of the fragments
+// (conflict-free for the four 16-lane groups of that instruction).  Rows past M load a valid row and are never stored.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 struct GemmArgs {
     const float* x;       // [nb][M][K]
@@ -263,10 +274,9 @@ struct GemmArgs {
 
 __global__ __launch_bounds__(256, 3)
 void k_wino_gemm(GemmArgs a) {
-    constexpr int BM = 128, BN = 128, BKT = 16, LROW = BKT + 4, RP = 64;
+    constexpr int BM = 128, BN = 128, BKT = 16;
+    constexpr int STAGE = (BM + BN) * BKT;             // floats per stage: A 128 x 16, then B 128 x 16 (16 KB)
     extern __shared__ __attribute__((aligned(16))) float smem_w[];
-    float* As = smem_w;                                // [2][BM][LROW]
-    float* Bs = smem_w + 2 * BM * LROW;                // [2][BN][LROW]
     const int bid = blockIdx.x;
     const int xcd = bid & 7, slot = bid >> 3;          // all N tiles of an M tile on one XCD
     const int n_tile = slot % a.n_tiles;
@@ -274,24 +284,28 @@ void k_wino_gemm(GemmArgs a) {
     if (m_tile >= a.m_tiles) return;
     const int n0 = n_tile * BN, row_base = m_tile * BM;
     const int tid = threadIdx.x;
-    const int q = tid & 3, r0 = tid >> 2;
-    // staging: two rows of A and two rows of B per thread, 16 bytes each
-    const float* ap[2];
-    const float* bp[2];
-    bool a_live[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int ra = row_base + r0 + RP * i;
-        a_live[i] = ra < a.M;
-        ap[i] = a.x + (size_t)(a_live[i] ? ra : 0) * a.K + 4 * q;
-        bp[i] = a.w + (size_t)(n0 + r0 + RP * i) * a.K + 4 * q;       // rows up to Npad exist (zero rows past N)
-    }
-    const int kchunks = a.K / BKT, total = kchunks * a.nb;
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, lh = lane >> 5;
-    const int a_frag0 = (wm * 64 + li) * LROW + 4 * lh;
-    const int b_frag0 = (wn * 64 + li) * LROW + 4 * lh;
+    // staging: wave w fills pieces 2w, 2w+1 of the A tile and of the B tile; lane -> (row = lane >> 2, slot = lane & 3),
+    // and fetches the quad that belongs into that slot after the swizzle
+    const int srow = lane >> 2, sq = (lane & 3) ^ ((lane >> 4) & 3);
+    unsigned a_off[2], b_off[2];                       // byte offsets from the tile's first row (tiles span < 2^31 bytes)
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const int r = (2 * wave + p) * 16 + srow;
+        a_off[p] = (unsigned)((row_base + r < a.M ? r : 0) * a.K + 4 * sq) * 4u;
+        b_off[p] = (unsigned)(r * a.K + 4 * sq) * 4u;  // rows up to Npad exist (zero rows past N)
+    }
+    const float* xt = a.x + (int64_t)row_base * a.K;   // uniform
+    const float* wt = a.w + (int64_t)n0 * a.K;
+    const int kchunks = a.K / BKT, total = kchunks * a.nb;
+    // fragment reads: row = 64 wm + 32 i + li, quad (lh + 2 g) ^ ((li >> 2) & 3)
+    const int fsw = (li >> 2) & 3;
+    const int a_fr0 = (wm * 64 + li) * BKT + 4 * (lh ^ fsw);
+    const int a_fr1 = (wm * 64 + li) * BKT + 4 * ((lh + 2) ^ fsw);
+    const int b_fr0 = BM * BKT + (wn * 64 + li) * BKT + 4 * (lh ^ fsw);
+    const int b_fr1 = BM * BKT + (wn * 64 + li) * BKT + 4 * ((lh + 2) ^ fsw);
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -299,75 +313,90 @@ void k_wino_gemm(GemmArgs a) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-    f32x4 a_st[2], b_st[2];
     int lz = 0, lk = 0;                                // (problem, chunk) of the next load, advanced incrementally
-#define WG_LOAD()                                                                                               \
+#define WG_LOAD(BUF)                                                                                            \
     do {                                                                                                        \
-        const int64_t xo_ = (int64_t)lz * a.xb + lk * BKT, wo_ = (int64_t)lz * a.wb + lk * BKT;                  \
-        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                      \
-            a_st[i_] = *reinterpret_cast<const f32x4*>(ap[i_] + xo_);                                           \
-            b_st[i_] = *reinterpret_cast<const f32x4*>(bp[i_] + wo_);                                           \
+        const char* xs_ = reinterpret_cast<const char*>(xt + (int64_t)lz * a.xb + lk * BKT);                     \
+        const char* ws_ = reinterpret_cast<const char*>(wt + (int64_t)lz * a.wb + lk * BKT);                     \
+        float* st_ = smem_w + (BUF) * STAGE + (2 * wave) * 256;                                                 \
+        _Pragma("unroll") for (int p_ = 0; p_ < 2; ++p_) {                                                      \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(xs_ + a_off[p_]), (lds_ptr_t)(st_ + p_ * 256), 16, 0, 0);            \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(ws_ + b_off[p_]), (lds_ptr_t)(st_ + BM * BKT + p_ * 256), 16, 0, 0); \
         }                                                                                                       \
-        if (++lk == kchunks) { lk = 0; ++lz; }                                                                  \
+        if (lk + 1 < kchunks) ++lk; else if (lz + 1 < a.nb) { lk = 0; ++lz; }   /* past the end: the last chunk again */ \
     } while (0)
-#define WG_STORE(BUF)                                                                                           \
-    do {                                                                                                        \
-        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                      \
-            *reinterpret_cast<f32x4*>(As + (BUF) * BM * LROW + (r0 + RP * i_) * LROW + 4 * q) =                 \
-                a_live[i_] ? a_st[i_] : f32x4{0.f, 0.f, 0.f, 0.f};                                              \
-            *reinterpret_cast<f32x4*>(Bs + (BUF) * BN * LROW + (r0 + RP * i_) * LROW + 4 * q) = b_st[i_];       \
-        }                                                                                                       \
-    } while (0)
-    WG_LOAD();
-    WG_STORE(0);
-    __syncthreads();
+    const bool interior = row_base + BM <= a.M && n0 + BN <= a.N;
+    const unsigned y_off = (unsigned)((wm * 64 + 4 * lh) * a.ldy + wn * 64 + li) * 4u;
+    WG_LOAD(0);
+    __syncthreads();                                   // (hipcc drains the DMA with vmcnt(0) before the barrier)
     int cz = 0, ck = 0;                                // (problem, chunk) being multiplied
     for (int kc = 0; kc < total; ++kc) {
         const int buf = kc & 1;
-        if (kc + 1 < total) WG_LOAD();
+        WG_LOAD(buf ^ 1);                              // everyone left that buffer at the barrier of the last iteration
         __builtin_amdgcn_sched_barrier(0);
-        const float* Ab = As + buf * BM * LROW + a_frag0;
-        const float* Bb = Bs + buf * BN * LROW + b_frag0;
+        {
+            const float* sb = smem_w + buf * STAGE;
+            f32x4 af[2][2], bf[2][2];
 #pragma unroll
-        for (int g = 0; g < BKT / 8; ++g) {
-            f32x4 af[2], bf[2];
+            for (int i = 0; i < 2; ++i) {
+                af[0][i] = *reinterpret_cast<const f32x4*>(sb + a_fr0 + i * 32 * BKT);
+                bf[0][i] = *reinterpret_cast<const f32x4*>(sb + b_fr0 + i * 32 * BKT);
+            }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LROW + 8 * g);
+            for (int i = 0; i < 2; ++i) {
+                af[1][i] = *reinterpret_cast<const f32x4*>(sb + a_fr1 + i * 32 * BKT);
+                bf[1][i] = *reinterpret_cast<const f32x4*>(sb + b_fr1 + i * 32 * BKT);
+            }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LROW + 8 * g);
+            for (int g = 0; g < 2; ++g)
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-                }
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][i].x, bf[g][j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][i].y, bf[g][j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][i].z, bf[g][j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][i].w, bf[g][j].w, acc[i][j], 0, 0, 0);
+                    }
         }
         __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
         if (++ck == kchunks) {                          // problem cz is complete: raw store, clear
-            float* yz = a.y + (int64_t)cz * a.yb + (size_t)(row_base + wm * 64 + 4 * lh) * a.ldy + n0 + wn * 64 + li;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const bool c_ok = n0 + wn * 64 + j * 32 + li < a.N;
+            char* yt = reinterpret_cast<char*>(a.y + (int64_t)cz * a.yb + (int64_t)row_base * a.ldy + n0);   // uniform
+            if (interior) {                             // no per-element bounds checks (they cost 10 instructions a store)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int ro = i * 32 + (r & 3) + 8 * (r >> 2);
-                        if (c_ok && row_base + wm * 64 + 4 * lh + ro < a.M) yz[(size_t)ro * a.ldy + j * 32] = acc[i][j][r];
-                        acc[i][j][r] = 0.0f;
+                        float* yr = reinterpret_cast<float*>(yt + (size_t)ro * a.ldy * 4 + y_off);
+                        yr[0] = acc[i][0][r];
+                        yr[32] = acc[i][1][r];
                     }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const bool c_ok = n0 + wn * 64 + j * 32 + li < a.N;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int ro = i * 32 + (r & 3) + 8 * (r >> 2);
+                            if (c_ok && row_base + wm * 64 + 4 * lh + ro < a.M)
+                                reinterpret_cast<float*>(yt + (size_t)ro * a.ldy * 4 + y_off)[j * 32] = acc[i][j][r];
+                        }
+                }
             }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
             ck = 0; ++cz;
         }
-        WG_STORE(buf ^ 1);
-        __syncthreads();
     }
 #undef WG_LOAD
-#undef WG_STORE
 }
 
 }  // namespace
@@ -402,7 +431,7 @@ int wino_gemms(const float* V, const float* packed_w, float* M, int64_t n, int c
     static const bool no_persist = getenv("BE_WINO_NO_PERSIST") != nullptr;        // A/B knob
     if (cp % 128 == 0 && 4 * n >= 4096 && !no_persist) {
         // large batches: one workgroup per (M tile, N tile) walks the 25 problems back to back
-        constexpr size_t lds = (size_t)2 * (128 + 128) * 20 * sizeof(float);
+        constexpr size_t lds = (size_t)2 * (128 + 128) * 16 * sizeof(float);
         static bool attr_set = false;
         if (!attr_set) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino_gemm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
