@@ -35,6 +35,10 @@ struct ProfileScope {
     hipStream_t s_; int slot_;
 };
 
+// be_wino.hip: row GEMM on the LDS-DMA kernel (1x1 convolutions / linears of large batches); preconditions at the definition
+int gemm_rows(const float* x, int64_t M, int K, const float* packed_w, int N, const float* bias, const float* res, int act,
+              float* y, int ldy, void* stream);
+
 #define BE_REQUIRE(cond, ...) do { if (!(cond)) return be::fail(BE_EINVAL, __VA_ARGS__); } while (0)
 
 }  // namespace be

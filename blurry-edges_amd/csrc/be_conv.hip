@@ -977,6 +977,10 @@ static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2,
         return t64 ? launch_conv<2, 2, 1, 1, MODE_TAPS, 16, 0>(a, s, BE_KERNEL_CONV_SMALL)
                    : launch_conv<4, 1, 1, 1, MODE_TAPS, 16, 0>(a, s, BE_KERNEL_CONV_SMALL);
     }
+    // 1x1 convolutions / linears of large batches are plain row GEMMs: the LDS-DMA kernel of be_wino.hip (bit-identical)
+    static const bool no_rows = getenv("BE_NO_GEMM_ROWS") != nullptr;             // A/B knob
+    if (d->ksize == 1 && !x2 && cp % 128 == 0 && M >= 4096 && a.nbatch <= 1 && !a.wb3 && !no_rows && d->cin % 16 == 0)
+        return be::gemm_rows(x, M, d->cin, pw, d->cout, pb, res, d->act, y, ldy, stream);
     // large batches of small images: pixel-major tiles skip the taps that fall into the zero padding
     if (d->ksize > 1 && d->n >= 512 && conv_variant() != 99) {
         a.pixmaj = 1;

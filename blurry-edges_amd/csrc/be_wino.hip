@@ -265,13 +265,21 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
 struct GemmArgs {
-    const float* x;       // [nb][M][K]
-    const float* w;       // [nb][Npad][K]
-    float* y;             // [nb][M][ldy]
+    const float* x;       // problem z: rows [M][K] at x + z * xb
+    const float* w;       //            [Npad][K] at w + z * wb
+    float* y;             //            [M][ldy] at y + z * yb
     int M, K, N, ldy, nb, m_tiles, n_tiles;
     int64_t xb, wb, yb;
+    // the same kernel as a plain row GEMM (1x1 convolutions, linears: EPI = 1): the "problems" a workgroup walks are nb
+    // consecutive 128-row tiles of ONE matrix (short K loops get the same continuous pipeline): mrows = 128 nb rows per
+    // workgroup, zrows = 128 rows per problem, xb = 128 K, yb = 128 ldy, wb = 0.  Winograd: mrows = 128, zrows = 0.
+    int mrows, zrows;
+    const float* bias;    // EPI = 1: y = act(acc + bias[col] (+ res[row][col]))
+    const float* res;     //          same row stride as y
+    int act;
 };
 
+template <int EPI>
 __global__ __launch_bounds__(256, 3)
 void k_wino_gemm(GemmArgs a) {
     constexpr int BM = 128, BN = 128, BKT = 16;
@@ -282,7 +290,7 @@ void k_wino_gemm(GemmArgs a) {
     const int n_tile = slot % a.n_tiles;
     const int m_tile = (slot / a.n_tiles) * 8 + xcd;
     if (m_tile >= a.m_tiles) return;
-    const int n0 = n_tile * BN, row_base = m_tile * BM;
+    const int n0 = n_tile * BN, row_base = m_tile * a.mrows;
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int wm = wave >> 1, wn = wave & 1;
@@ -294,6 +302,7 @@ void k_wino_gemm(GemmArgs a) {
 #pragma unroll
     for (int p = 0; p < 2; ++p) {
         const int r = (2 * wave + p) * 16 + srow;
+        // (walked tiles, zrows > 0, are launched only when every tile is full: M % (128 nb) == 0)
         a_off[p] = (unsigned)((row_base + r < a.M ? r : 0) * a.K + 4 * sq) * 4u;
         b_off[p] = (unsigned)(r * a.K + 4 * sq) * 4u;  // rows up to Npad exist (zero rows past N)
     }
@@ -325,8 +334,15 @@ void k_wino_gemm(GemmArgs a) {
         }                                                                                                       \
         if (lk + 1 < kchunks) ++lk; else if (lz + 1 < a.nb) { lk = 0; ++lz; }   /* past the end: the last chunk again */ \
     } while (0)
-    const bool interior = row_base + BM <= a.M && n0 + BN <= a.N;
     const unsigned y_off = (unsigned)((wm * 64 + 4 * lh) * a.ldy + wn * 64 + li) * 4u;
+    float bias_v[2] = {0.f, 0.f};
+    if (EPI) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = n0 + wn * 64 + j * 32 + li;
+            bias_v[j] = (a.bias && c < a.N) ? a.bias[c] : 0.0f;
+        }
+    }
     WG_LOAD(0);
     __syncthreads();                                   // (hipcc drains the DMA with vmcnt(0) before the barrier)
     int cz = 0, ck = 0;                                // (problem, chunk) being multiplied
@@ -361,8 +377,19 @@ void k_wino_gemm(GemmArgs a) {
         }
         __builtin_amdgcn_sched_barrier(0);
         __syncthreads();
-        if (++ck == kchunks) {                          // problem cz is complete: raw store, clear
-            char* yt = reinterpret_cast<char*>(a.y + (int64_t)cz * a.yb + (int64_t)row_base * a.ldy + n0);   // uniform
+        if (++ck == kchunks) {                          // problem cz is complete: store, clear
+            const int zrow = row_base + cz * a.zrows;
+            const int64_t yo = (int64_t)cz * a.yb + (int64_t)row_base * a.ldy + n0;                           // uniform
+            char* yt = reinterpret_cast<char*>(a.y + yo);
+            const char* rt = reinterpret_cast<const char*>(a.res + yo);
+            const bool interior = zrow + BM <= a.M && n0 + BN <= a.N;
+#define WG_VALUE(J)                                                                                             \
+            float v_ = acc[i][J][r];                                                                            \
+            if (EPI) {                                                                                          \
+                v_ += bias_v[J];                                                                                \
+                if (a.res) v_ += reinterpret_cast<const float*>(rt + (size_t)ro * a.ldy * 4 + y_off)[(J) * 32]; \
+                if (a.act == 1) v_ = be::smish(v_); else if (a.act == 2) v_ = fmaxf(v_, 0.0f);                  \
+            }
             if (interior) {                             // no per-element bounds checks (they cost 10 instructions a store)
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
@@ -370,8 +397,8 @@ void k_wino_gemm(GemmArgs a) {
                     for (int r = 0; r < 16; ++r) {
                         const int ro = i * 32 + (r & 3) + 8 * (r >> 2);
                         float* yr = reinterpret_cast<float*>(yt + (size_t)ro * a.ldy * 4 + y_off);
-                        yr[0] = acc[i][0][r];
-                        yr[32] = acc[i][1][r];
+                        { WG_VALUE(0) yr[0] = v_; }
+                        { WG_VALUE(1) yr[32] = v_; }
                     }
             } else {
 #pragma unroll
@@ -382,11 +409,14 @@ void k_wino_gemm(GemmArgs a) {
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const int ro = i * 32 + (r & 3) + 8 * (r >> 2);
-                            if (c_ok && row_base + wm * 64 + 4 * lh + ro < a.M)
-                                reinterpret_cast<float*>(yt + (size_t)ro * a.ldy * 4 + y_off)[j * 32] = acc[i][j][r];
+                            if (c_ok && zrow + wm * 64 + 4 * lh + ro < a.M) {
+                                WG_VALUE(j)
+                                reinterpret_cast<float*>(yt + (size_t)ro * a.ldy * 4 + y_off)[j * 32] = v_;
+                            }
                         }
                 }
             }
+#undef WG_VALUE
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -434,18 +464,18 @@ int wino_gemms(const float* V, const float* packed_w, float* M, int64_t n, int c
         constexpr size_t lds = (size_t)2 * (128 + 128) * 16 * sizeof(float);
         static bool attr_set = false;
         if (!attr_set) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino_gemm), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino_gemm<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return be::fail(BE_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
             attr_set = true;
         }
         GemmArgs g{V, packed_w, M, (int)(4 * n), cin, cout, cout, 25, (int)((4 * n + 127) / 128), cp / 128,
-                   (int64_t)4 * n * cin, (int64_t)cp * cin, (int64_t)4 * n * cout};
+                   (int64_t)4 * n * cin, (int64_t)cp * cin, (int64_t)4 * n * cout, 128, 0, nullptr, nullptr, 0};
         const unsigned grid = (unsigned)(8 * ((g.m_tiles + 7) / 8) * g.n_tiles);
         {
             be::ProfileScope prof(s, BE_KERNEL_WINO_GEMM, 25.0 * 2.0 * 4 * n * cin * cout,
                                   25.0 * 4.0 * (4.0 * n * cin + (double)cin * cout + 4.0 * n * cout),
                                   25.0 * 2.0 * g.m_tiles * g.n_tiles * 128.0 * 128.0 * cin);
-            hipLaunchKernelGGL(k_wino_gemm, dim3(grid), dim3(256), lds, s, g);
+            hipLaunchKernelGGL(k_wino_gemm<0>, dim3(grid), dim3(256), lds, s, g);
         }
         return be::check_launch("be_wino_conv3x3_6x6_f32(gemm)");
     }
@@ -462,6 +492,38 @@ int wino_args_ok(const char* who, int64_t n, int cin, int cout) {
 }
 
 }  // namespace
+
+// 1x1 convolutions and linears of large batches through the same kernel: y[M][ldy] = act(x[M][K] w[Npad][K]^T + bias (+ res)).
+// The caller (conv_dispatch in be_conv.hip) has checked: K % 16 == 0, Npad % 128 == 0, 16-byte aligned x / w, M >= 4096.
+// Same order of operations per output element as k_conv_igemm (K ascending in chunks of 16, fp32 MFMA): bit-identical.
+int be::gemm_rows(const float* x, int64_t M, int K, const float* packed_w, int N, const float* bias, const float* res, int act,
+                  float* y, int ldy, void* stream) {
+    hipStream_t s = be::as_stream(stream);
+    constexpr size_t lds = (size_t)2 * (128 + 128) * 16 * sizeof(float);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino_gemm<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return be::fail(BE_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
+    const int cp = (N + 127) / 128 * 128, n_tiles = cp / 128;
+    const int64_t tiles = (M + 127) / 128;
+    // short K loops: one workgroup walks nb consecutive row tiles (only when all of them are full), about one round of
+    // the 768 resident workgroups
+    int nb = 1;
+    if (M % 128 == 0)
+        for (int c = 2; c <= 16; ++c)
+            if (tiles % c == 0 && (tiles / c) * n_tiles >= 768) nb = c;
+    GemmArgs g{x, packed_w, y, (int)M, K, N, ldy, nb, (int)(tiles / nb), n_tiles, (int64_t)128 * K, 0, (int64_t)128 * ldy,
+               128 * nb, nb > 1 ? 128 : 0, bias, res, act};
+    const unsigned grid = (unsigned)(8 * ((g.m_tiles + 7) / 8) * g.n_tiles);
+    {
+        be::ProfileScope prof(s, BE_KERNEL_GEMM_ROWS, 2.0 * M * K * N, 4.0 * ((double)M * K + (double)K * N + (double)M * N),
+                              2.0 * tiles * n_tiles * 128.0 * 128.0 * K);
+        hipLaunchKernelGGL(k_wino_gemm<1>, dim3(grid), dim3(256), lds, s, g);
+    }
+    return be::check_launch("be_conv_nhwc_f32(gemm rows)");
+}
 
 extern "C" int be_wino_conv3x3_6x6_f32(const float* x, const float* packed_w, const float* packed_bias, const float* residual,
                                        float* y, int64_t n, int cin, int cout, int act, float* workspace,
