@@ -39,6 +39,11 @@ struct ProfileScope {
 int gemm_rows(const float* x, int64_t M, int K, const float* packed_w, int N, const float* bias, const float* res, int act,
               float* y, int ldy, void* stream);
 
+// be_conv_pm.hip: pixel-major LDS-DMA convolution for large batches (3x3 (+ fused 1x1 on x2), or the 7x7 conv1 on the padded
+// staging with `wrow` pixels per row); returns 1 when the shape is not one it is built for (the caller falls back)
+int conv_pm(const be_conv_desc* d, const float* x, int wrow, const float* x2, int cin2, const float* pw, const float* pb,
+            float* y, int ldy, int ktot, void* stream);
+
 #define BE_REQUIRE(cond, ...) do { if (!(cond)) return be::fail(BE_EINVAL, __VA_ARGS__); } while (0)
 
 }  // namespace be

@@ -761,6 +761,44 @@ __global__ void k_view_to_nhwc4(be_patch_view v, int64_t P, int64_t first, float
     }
 }
 
+// the padded form of the two stagings: [n,h,wrow,4], image column c at padded column c + 3, zeros elsewhere (the 8-pixel
+// kernel rows of conv1 then never leave a row: be_conv_pm.hip)
+__global__ void k_nchw3_to_nhwc4p(const float* __restrict__ x, float* __restrict__ y, int64_t n, int h, int w, int wrow) {
+    const int64_t total = n * h * wrow;
+    const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gs) {
+        const int64_t rowi = idx / wrow;
+        const int col = (int)(idx - rowi * wrow) - 3;
+        const int64_t img = rowi / h;
+        const int row = (int)(rowi - img * h);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)col < (unsigned)w) {
+            const float* s = x + img * 3 * h * w + row * w + col;
+            v = make_float4(s[0], s[h * w], s[2 * h * w], 0.0f);
+        }
+        reinterpret_cast<float4*>(y)[idx] = v;
+    }
+}
+
+__global__ void k_view_to_nhwc4p(be_patch_view v, int64_t P, int64_t first, float* __restrict__ y, int64_t n, int wrow) {
+    const int64_t total = n * BE_R * wrow;
+    const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gs) {
+        const int64_t rowi = idx / wrow;
+        const int col = (int)(idx - rowi * wrow) - 3;
+        const int64_t patch = first + rowi / BE_R;
+        const int row = (int)(rowi % BE_R);
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)col < (unsigned)BE_R) {
+            const int64_t pg = patch % P;
+            const float* s = v.base + (patch / P) * v.s_aperture + (pg / v.wp) * v.s_pi + (pg % v.wp) * v.s_pj +
+                             row * v.s_row + col * v.s_col;
+            o = make_float4(s[0], s[v.s_chan], s[2 * v.s_chan], 0.0f);
+        }
+        reinterpret_cast<float4*>(y)[idx] = o;
+    }
+}
+
 inline unsigned grid_cap(int64_t total, int block) {
     int64_t g = (total + block - 1) / block;
     return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -981,6 +1019,11 @@ static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2,
     static const bool no_rows = getenv("BE_NO_GEMM_ROWS") != nullptr;             // A/B knob
     if (d->ksize == 1 && !x2 && cp % 128 == 0 && M >= 4096 && a.nbatch <= 1 && !a.wb3 && !no_rows && d->cin % 16 == 0)
         return be::gemm_rows(x, M, d->cin, pw, d->cout, pb, res, d->act, y, ldy, stream);
+    // large batches of small images, 3x3: the pixel-major LDS-DMA kernel (be_conv_pm.hip; bit-identical)
+    if (d->ksize == 3 && d->n >= 512 && !res && a.nbatch <= 1 && !a.wb3 && conv_variant() == 0 && be::aligned16(y) && ldy % 4 == 0) {
+        const int rc = be::conv_pm(d, x, d->w, x2, cin2, pw, pb, y, ldy, a.Ktot, stream);
+        if (rc != 1) return rc;
+    }
     // large batches of small images: pixel-major tiles skip the taps that fall into the zero padding
     if (d->ksize > 1 && d->n >= 512 && conv_variant() != 99) {
         a.pixmaj = 1;
@@ -1036,6 +1079,32 @@ extern "C" int be_view_to_nhwc4_f32(const be_patch_view* view, int64_t patches_p
     hipLaunchKernelGGL(k_view_to_nhwc4, dim3(grid_cap(n * BE_NPIX, 256)), dim3(256), 0, be::as_stream(stream), *view,
                        patches_per_image, first, y, n);
     return be::check_launch("be_view_to_nhwc4_f32");
+}
+
+extern "C" int be_nchw3_to_nhwc4p_f32(const float* x, float* y, int64_t n, int h, int w, int wrow, void* stream) {
+    BE_REQUIRE(x && y && n > 0 && h > 0 && w > 0 && wrow >= w + 7, "be_nchw3_to_nhwc4p_f32: bad arguments (wrow >= w + 7)");
+    hipLaunchKernelGGL(k_nchw3_to_nhwc4p, dim3(grid_cap(n * h * wrow, 256)), dim3(256), 0, be::as_stream(stream), x, y, n, h, w, wrow);
+    return be::check_launch("be_nchw3_to_nhwc4p_f32");
+}
+
+extern "C" int be_view_to_nhwc4p_f32(const be_patch_view* view, int64_t patches_per_image, int64_t first, float* y,
+                                     int64_t n, int wrow, void* stream) {
+    BE_REQUIRE(view && view->base && y && n > 0 && first >= 0 && patches_per_image > 0 && view->wp > 0 && wrow >= BE_R + 7,
+               "be_view_to_nhwc4p_f32: bad arguments (wrow >= 28)");
+    hipLaunchKernelGGL(k_view_to_nhwc4p, dim3(grid_cap(n * BE_R * wrow, 256)), dim3(256), 0, be::as_stream(stream), *view,
+                       patches_per_image, first, y, n, wrow);
+    return be::check_launch("be_view_to_nhwc4p_f32");
+}
+
+extern "C" int be_conv7x7_nhwc4p_f32(const be_conv_desc* d, const float* x, int wrow, const float* pw, const float* pb, float* y,
+                                     int ldy, void* stream) {
+    BE_REQUIRE(d && x && pw && y, "be_conv7x7_nhwc4p_f32: null pointer");
+    BE_REQUIRE(d->ksize == 7 && d->cin == 4 && d->n >= 1 && wrow >= d->w + 7 && ldy >= d->cout,
+               "be_conv7x7_nhwc4p_f32: ksize 7, cin 4, wrow >= w + 7, ldy >= cout required");
+    BE_REQUIRE(be::aligned16(x) && be::aligned16(pw) && be::aligned16(y), "be_conv7x7_nhwc4p_f32: 16-byte alignment");
+    const int rc = be::conv_pm(d, x, wrow, nullptr, 0, pw, pb, y, ldy, 7 * BK, stream);
+    if (rc == 1) return be::fail(BE_EINVAL, "be_conv7x7_nhwc4p_f32: shape not supported (cout_pad must be 64)");
+    return rc;
 }
 
 extern "C" int be_nchw3_to_nhwc4_f32(const float* x, float* y, int64_t n, int hw, void* stream) {

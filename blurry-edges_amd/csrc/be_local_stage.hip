@@ -7,6 +7,7 @@
 // (input transform, 25 GEMMs, output+input transform, 25 GEMMs, output transform; be_wino.hip), fc.1, fc.4.  No allocation,
 // no synchronisation: graph-capturable.  be_local_stage_set_winograd(0) runs layers 1-3 as direct launches like layer0.
 #include "be_common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -184,10 +185,23 @@ int forward_impl(const float* packed, const float* x, const be_patch_view* view,
         // x4 -> RB ; conv1 -> RA ; pool -> RB(after x4 is dead: RB is big enough to hold both side by side)
         float* x4 = rb;                                   // nb*1764
         float* p1 = rb + (size_t)nb * 1764 * 2;           // nb*7744, placed behind x4 (1764*2 + 7744 <= 13824)
-        if (x) rc = be_nchw3_to_nhwc4_f32(x + first * 3 * BE_NPIX, x4, nb, BE_NPIX, stream);
-        else rc = be_view_to_nhwc4_f32(view, P, first, x4, nb, stream);
-        if (rc) return rc;
-        if ((rc = conv(packed, 0, x4, nullptr, ra, nb, 21, 1, 64, stream))) return rc;
+        // large sub-batches: conv1 on the pixel-major LDS-DMA kernel, which reads a staging with 28 pixels per row (3 zero
+        // pixels left, 4 right; 2352 floats per patch, still in front of p1)
+        static const bool no_pm = getenv("BE_NO_CONV_PM") != nullptr;
+        if (nb >= 512 && !no_pm && !be_conv_b3_active()) {
+            if (x) rc = be_nchw3_to_nhwc4p_f32(x + first * 3 * BE_NPIX, x4, nb, BE_R, BE_R, 28, stream);
+            else rc = be_view_to_nhwc4p_f32(view, P, first, x4, nb, 28, stream);
+            if (rc) return rc;
+            be_conv_desc d;
+            d.n = nb; d.h = 21; d.w = 21; d.cin = 4; d.cout = 64; d.ksize = 7; d.act = 1;
+            const PackedLayout& L = layout();
+            if ((rc = be_conv7x7_nhwc4p_f32(&d, x4, 28, packed + L.w_off[0], packed + L.b_off[0], ra, 64, stream))) return rc;
+        } else {
+            if (x) rc = be_nchw3_to_nhwc4_f32(x + first * 3 * BE_NPIX, x4, nb, BE_NPIX, stream);
+            else rc = be_view_to_nhwc4_f32(view, P, first, x4, nb, stream);
+            if (rc) return rc;
+            if ((rc = conv(packed, 0, x4, nullptr, ra, nb, 21, 1, 64, stream))) return rc;
+        }
         if ((rc = be_maxpool_nhwc_f32(ra, p1, nb, 21, 21, 64, 3, 2, 1, stream))) return rc;
         // layer0 @11x11: t in RA, out in RC
         if ((rc = block(packed, 1, p1, ra, rc_, nb, 11, stream))) return rc;

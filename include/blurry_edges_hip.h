@@ -315,6 +315,16 @@ int be_maxpool_nhwc_ld_f32(const float* x, int ldx, float* y, int n, int h, int 
                            void* stream);
 /* [N,3,21,21] NCHW -> [N,21,21,4] NHWC with a zero 4th channel (input staging of conv1). */
 int be_nchw3_to_nhwc4_f32(const float* x, float* y, int64_t n, int hw, void* stream);
+/* The padded form of that staging for large batches: [N,h,wrow,4], image column c at padded column c + 3, zeros in the
+ * other columns (wrow >= w + 7; LocalStage uses 28), so that the 8-pixel kernel rows of conv1 stay inside a row and the
+ * pixel-major LDS-DMA kernel needs no zero-fill (be_conv_pm.hip).  models/local_stage.py:34-37. */
+int be_nchw3_to_nhwc4p_f32(const float* x, float* y, int64_t n, int h, int w, int wrow, void* stream);
+int be_view_to_nhwc4p_f32(const be_patch_view* view_host, int64_t patches_per_image, int64_t first, float* y, int64_t n,
+                          int wrow, void* stream);
+/* conv1 (7x7, pad 3, cin 4 = rgb + zero, cout 64) + folded BatchNorm + activation on that padded staging; weights as packed
+ * by be_conv_pack_f32(ksize 7).  Bit-identical to be_conv_nhwc_f32 on the unpadded staging. */
+int be_conv7x7_nhwc4p_f32(const be_conv_desc* d, const float* x, int wrow, const float* packed_w, const float* packed_bias,
+                          float* y, int ldy, void* stream);
 /* Patches [first, first+n) of a view -> [n,21,21,4] (the staging be_local_stage_forward_view_f32 uses). */
 int be_view_to_nhwc4_f32(const be_patch_view* view_host, int64_t patches_per_image, int64_t first, float* y,
                          int64_t n, void* stream);
