@@ -88,10 +88,12 @@ __device__ __forceinline__ void bt5(const f32x4 d0, const f32x4 d1, const f32x4 
 
 // one thread = one tile (patch, ty, tx) x one channel quad
 __global__ __launch_bounds__(256)
-void k_wino_in(const float* __restrict__ x, float* __restrict__ V, int64_t n, int c4) {
+void k_wino_in(const float* __restrict__ x, float* __restrict__ V, int64_t n, int c4, int tm) {
     const int64_t total = n * 4 * c4;
     const int64_t gs = (int64_t)gridDim.x * blockDim.x;
-    const int64_t plane = n * 4 * c4;                          // float4 elements per transform-domain plane
+    // float4 elements between transform positions / between tiles: plane-major V [25][4n][C] (small batches) or
+    // tile-major V [4n][25][C] (large batches: a tile's 25 x C block is one contiguous piece of HBM for this kernel)
+    const int64_t plane = tm ? c4 : n * 4 * c4, ts = tm ? 25 * c4 : c4;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gs) {
         const int cq = (int)(idx % c4);
         const int64_t tile = idx / c4;
@@ -114,7 +116,7 @@ void k_wino_in(const float* __restrict__ x, float* __restrict__ V, int64_t n, in
 #pragma unroll
             for (int r = 0; r < 5; ++r) t[r][c] = o[r];
         }
-        f32x4* dst = reinterpret_cast<f32x4*>(V) + tile * c4 + cq;
+        f32x4* dst = reinterpret_cast<f32x4*>(V) + tile * ts + cq;
 #pragma unroll
         for (int r = 0; r < 5; ++r) {
             f32x4 o[5];
@@ -134,16 +136,16 @@ __device__ __forceinline__ void at5(const f32x4 m0, const f32x4 m1, const f32x4 
 
 __global__ __launch_bounds__(256)
 void k_wino_out(const float* __restrict__ M, const float* __restrict__ bias, const float* __restrict__ res,
-                float* __restrict__ y, int64_t n, int c4, int act) {
+                float* __restrict__ y, int64_t n, int c4, int act, int tm) {
     const int64_t total = n * 4 * c4;
     const int64_t gs = (int64_t)gridDim.x * blockDim.x;
-    const int64_t plane = n * 4 * c4;
+    const int64_t plane = tm ? c4 : n * 4 * c4, ts = tm ? 25 * c4 : c4;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gs) {
         const int cq = (int)(idx % c4);
         const int64_t tile = idx / c4;
         const int64_t img = tile >> 2;
         const int ty = (int)(tile >> 1) & 1, tx = (int)tile & 1;
-        const f32x4* src = reinterpret_cast<const f32x4*>(M) + tile * c4 + cq;
+        const f32x4* src = reinterpret_cast<const f32x4*>(M) + tile * ts + cq;
         f32x4 s[3][5];                                         // A^T m, column by column
 #pragma unroll
         for (int c = 0; c < 5; ++c) {
@@ -177,10 +179,12 @@ void k_wino_out(const float* __restrict__ M, const float* __restrict__ bias, con
 // 100 transform-domain values of conv1's result, forms the 6x6 map (+ bias, Smish) in registers and writes the 100
 // transform-domain values conv2's GEMMs read.  Saves the 36 values written and re-read (4x, tile overlap) per channel.
 __global__ __launch_bounds__(256, 1)
-void k_wino_out_in(const float* __restrict__ M, const float* __restrict__ bias, float* __restrict__ V, int64_t n, int c4, int act) {
+void k_wino_out_in(const float* __restrict__ M, const float* __restrict__ bias, float* __restrict__ V, int64_t n, int c4, int act,
+                   int tm_in, int tm_out) {
     const int64_t total = n * c4;
     const int64_t gs = (int64_t)gridDim.x * blockDim.x;
-    const int64_t plane = n * 4 * c4;
+    const int64_t plane = tm_in ? c4 : n * 4 * c4, ts = tm_in ? 25 * c4 : c4;          // M as conv1's GEMMs wrote it
+    const int64_t plane_o = tm_out ? c4 : n * 4 * c4, ts_o = tm_out ? 25 * c4 : c4;    // V as conv2's GEMMs read it
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gs) {
         const int cq = (int)(idx % c4);
         const int64_t img = idx / c4;
@@ -190,7 +194,7 @@ void k_wino_out_in(const float* __restrict__ M, const float* __restrict__ bias, 
         for (int ty = 0; ty < 2; ++ty)
 #pragma unroll
             for (int tx = 0; tx < 2; ++tx) {
-                const f32x4* src = reinterpret_cast<const f32x4*>(M) + (img * 4 + ty * 2 + tx) * c4 + cq;
+                const f32x4* src = reinterpret_cast<const f32x4*>(M) + (img * 4 + ty * 2 + tx) * ts + cq;
                 f32x4 s[3][5];
 #pragma unroll
                 for (int c = 0; c < 5; ++c) {
@@ -233,13 +237,13 @@ void k_wino_out_in(const float* __restrict__ M, const float* __restrict__ bias, 
 #pragma unroll
                     for (int r = 0; r < 5; ++r) t[r][c] = o[r];
                 }
-                f32x4* dst = reinterpret_cast<f32x4*>(V) + (img * 4 + ty * 2 + tx) * c4 + cq;
+                f32x4* dst = reinterpret_cast<f32x4*>(V) + (img * 4 + ty * 2 + tx) * ts_o + cq;
 #pragma unroll
                 for (int r = 0; r < 5; ++r) {
                     f32x4 o[5];
                     bt5(t[r][0], t[r][1], t[r][2], t[r][3], t[r][4], o);
 #pragma unroll
-                    for (int c = 0; c < 5; ++c) dst[(size_t)(5 * r + c) * plane] = o[c];
+                    for (int c = 0; c < 5; ++c) dst[(size_t)(5 * r + c) * plane_o] = o[c];
                 }
             }
     }
@@ -270,6 +274,7 @@ struct GemmArgs {
     float* y;             //            [M][ldy] at y + z * yb
     int M, K, N, ldy, nb, m_tiles, n_tiles;
     int64_t xb, wb, yb;
+    int lda;              // floats between rows of x (K for a plain matrix; 25 K for the tile-major Winograd V [4n][25][K])
     // the same kernel as a plain row GEMM (1x1 convolutions, linears: EPI = 1): the "problems" a workgroup walks are nb
     // consecutive 128-row tiles of ONE matrix (short K loops get the same continuous pipeline): mrows = 128 nb rows per
     // workgroup, zrows = 128 rows per problem, xb = 128 K, yb = 128 ldy, wb = 0.  Winograd: mrows = 128, zrows = 0.
@@ -303,10 +308,10 @@ void k_wino_gemm(GemmArgs a) {
     for (int p = 0; p < 2; ++p) {
         const int r = (2 * wave + p) * 16 + srow;
         // (walked tiles, zrows > 0, are launched only when every tile is full: M % (128 nb) == 0)
-        a_off[p] = (unsigned)((row_base + r < a.M ? r : 0) * a.K + 4 * sq) * 4u;
+        a_off[p] = (unsigned)((row_base + r < a.M ? r : 0) * a.lda + 4 * sq) * 4u;
         b_off[p] = (unsigned)(r * a.K + 4 * sq) * 4u;  // rows up to Npad exist (zero rows past N)
     }
-    const float* xt = a.x + (int64_t)row_base * a.K;   // uniform
+    const float* xt = a.x + (int64_t)row_base * a.lda; // uniform
     const float* wt = a.w + (int64_t)n0 * a.K;
     const int kchunks = a.K / BKT, total = kchunks * a.nb;
     // fragment reads: row = 64 wm + 32 i + li, quad (lh + 2 g) ^ ((li >> 2) & 3)
@@ -456,10 +461,15 @@ extern "C" size_t be_wino_workspace_floats(int64_t n, int cin, int cout) {
 
 namespace {
 
+// large batches take k_wino_gemm and the tile-major buffers, small ones the batched k_conv_igemm launch and plane-major buffers
+bool wino_large(int64_t n, int cout) {
+    static const bool no_persist = getenv("BE_WINO_NO_PERSIST") != nullptr;        // A/B knob
+    return ((cout + 31) / 32 * 32) % 128 == 0 && 4 * n >= 4096 && !no_persist && 100 * n * (int64_t)cout < ((int64_t)1 << 31);
+}
+
 int wino_gemms(const float* V, const float* packed_w, float* M, int64_t n, int cin, int cout, hipStream_t s, void* stream) {
     const int cp = (cout + 31) / 32 * 32;
-    static const bool no_persist = getenv("BE_WINO_NO_PERSIST") != nullptr;        // A/B knob
-    if (cp % 128 == 0 && 4 * n >= 4096 && !no_persist) {
+    if (wino_large(n, cout)) {
         // large batches: one workgroup per (M tile, N tile) walks the 25 problems back to back
         constexpr size_t lds = (size_t)2 * (128 + 128) * 16 * sizeof(float);
         static bool attr_set = false;
@@ -468,8 +478,9 @@ int wino_gemms(const float* V, const float* packed_w, float* M, int64_t n, int c
             if (e != hipSuccess) return be::fail(BE_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
             attr_set = true;
         }
-        GemmArgs g{V, packed_w, M, (int)(4 * n), cin, cout, cout, 25, (int)((4 * n + 127) / 128), cp / 128,
-                   (int64_t)4 * n * cin, (int64_t)cp * cin, (int64_t)4 * n * cout, 128, 0, nullptr, nullptr, 0};
+        // tile-major V [4n][25][cin] and M [4n][25][cout]: problem z = column block z of a row
+        GemmArgs g{V, packed_w, M, (int)(4 * n), cin, cout, 25 * cout, 25, (int)((4 * n + 127) / 128), cp / 128,
+                   (int64_t)cin, (int64_t)cp * cin, (int64_t)cout, 25 * cin, 128, 0, nullptr, nullptr, 0};
         const unsigned grid = (unsigned)(8 * ((g.m_tiles + 7) / 8) * g.n_tiles);
         {
             be::ProfileScope prof(s, BE_KERNEL_WINO_GEMM, 25.0 * 2.0 * 4 * n * cin * cout,
@@ -515,7 +526,7 @@ int be::gemm_rows(const float* x, int64_t M, int K, const float* packed_w, int N
         for (int c = 2; c <= 16; ++c)
             if (tiles % c == 0 && (tiles / c) * n_tiles >= 768) nb = c;
     GemmArgs g{x, packed_w, y, (int)M, K, N, ldy, nb, (int)(tiles / nb), n_tiles, (int64_t)128 * K, 0, (int64_t)128 * ldy,
-               128 * nb, nb > 1 ? 128 : 0, bias, res, act};
+               K, 128 * nb, nb > 1 ? 128 : 0, bias, res, act};
     const unsigned grid = (unsigned)(8 * ((g.m_tiles + 7) / 8) * g.n_tiles);
     {
         be::ProfileScope prof(s, BE_KERNEL_GEMM_ROWS, 2.0 * M * K * N, 4.0 * ((double)M * K + (double)K * N + (double)M * N),
@@ -536,11 +547,12 @@ extern "C" int be_wino_conv3x3_6x6_f32(const float* x, const float* packed_w, co
     hipStream_t s = be::as_stream(stream);
     float* V = workspace;
     float* M = workspace + (size_t)100 * n * cin;
-    hipLaunchKernelGGL(k_wino_in, dim3(grid_cap(n * 4 * (cin / 4), 256)), dim3(256), 0, s, x, V, n, cin / 4);
+    const int tm = wino_large(n, cout);
+    hipLaunchKernelGGL(k_wino_in, dim3(grid_cap(n * 4 * (cin / 4), 256)), dim3(256), 0, s, x, V, n, cin / 4, tm);
     if (int rc = be::check_launch("be_wino_conv3x3_6x6_f32(in)")) return rc;
     if (int rc = wino_gemms(V, packed_w, M, n, cin, cout, s, stream)) return rc;
     hipLaunchKernelGGL(k_wino_out, dim3(grid_cap(n * 4 * (cout / 4), 256)), dim3(256), 0, s, M, packed_bias, residual, y, n, cout / 4,
-                       act);
+                       act, tm);
     return be::check_launch("be_wino_conv3x3_6x6_f32(out)");
 }
 
@@ -565,13 +577,15 @@ extern "C" int be_wino_conv3x3_pair_6x6_f32(const float* x, const float* packed_
     const size_t big = (size_t)(cin > cmid ? cin : cmid);
     float* V = workspace;
     float* M = workspace + (size_t)100 * n * big;
-    hipLaunchKernelGGL(k_wino_in, dim3(grid_cap(n * 4 * (cin / 4), 256)), dim3(256), 0, s, x, V, n, cin / 4);
+    const int tm1 = wino_large(n, cmid), tm2 = wino_large(n, cout);
+    hipLaunchKernelGGL(k_wino_in, dim3(grid_cap(n * 4 * (cin / 4), 256)), dim3(256), 0, s, x, V, n, cin / 4, tm1);
     if (int rc = be::check_launch("be_wino_conv3x3_pair_6x6_f32(in)")) return rc;
     if (int rc = wino_gemms(V, packed_w1, M, n, cin, cmid, s, stream)) return rc;
-    hipLaunchKernelGGL(k_wino_out_in, dim3(grid_cap(n * (cmid / 4), 256)), dim3(256), 0, s, M, packed_bias1, V, n, cmid / 4, act1);
+    hipLaunchKernelGGL(k_wino_out_in, dim3(grid_cap(n * (cmid / 4), 256)), dim3(256), 0, s, M, packed_bias1, V, n, cmid / 4, act1,
+                       tm1, tm2);
     if (int rc = be::check_launch("be_wino_conv3x3_pair_6x6_f32(out_in)")) return rc;
     if (int rc = wino_gemms(V, packed_w2, M, n, cmid, cout, s, stream)) return rc;
     hipLaunchKernelGGL(k_wino_out, dim3(grid_cap(n * 4 * (cout / 4), 256)), dim3(256), 0, s, M, packed_bias2, residual, y, n, cout / 4,
-                       act2);
+                       act2, tm2);
     return be::check_launch("be_wino_conv3x3_pair_6x6_f32(out)");
 }
