@@ -101,6 +101,9 @@ _SIGNATURES = {
     "be_layernorm_bwd_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_uint32,
                                        C.c_uint32, _P]),
     "be_nchw3_to_nhwc4_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int, _P]),
+    "be_nchw3_to_nhwc4p_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P]),
+    "be_view_to_nhwc4p_f32": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int, _P]),
+    "be_conv7x7_nhwc4p_f32": (C.c_int, [C.POINTER(ConvDesc), _P, C.c_int, _P, _P, _P, C.c_int, _P]),
     "be_render_full_f32": (C.c_int, [C.POINTER(RenderOpts), C.POINTER(DepthConsts), C.c_float, C.c_int, _P,
                                      C.POINTER(PatchView), _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
     "be_fold_records_f32": (C.c_int, [C.POINTER(RenderOpts), _P] + [C.c_int] * 6 + [_P] * 6 + [_P]),
@@ -331,6 +334,26 @@ def nchw3_to_nhwc4(x):
         raise RuntimeError("nchw3_to_nhwc4: expected 3 channels")
     y = torch.empty(n, h, w, 4, dtype=torch.float32, device=x.device)
     check(lib().be_nchw3_to_nhwc4_f32(dptr(x, "x"), dptr(y), n, h * w, stream_ptr(x.device)), "be_nchw3_to_nhwc4_f32")
+    return y
+
+
+def nchw3_to_nhwc4p(x, wrow=28):
+    """[N,3,h,w] -> [N,h,wrow,4]: image column c at padded column c + 3, zeros elsewhere (staging of conv1 for large batches)."""
+    n, c, h, w = x.shape
+    if c != 3:
+        raise RuntimeError("nchw3_to_nhwc4p: expected 3 channels")
+    y = torch.empty(n, h, wrow, 4, dtype=torch.float32, device=x.device)
+    check(lib().be_nchw3_to_nhwc4p_f32(dptr(x, "x"), dptr(y), n, h, w, wrow, stream_ptr(x.device)), "be_nchw3_to_nhwc4p_f32")
+    return y
+
+
+def conv7x7_nhwc4p(xp, w_img, pw, pb, cout, act):
+    """conv1 on the padded staging xp [N,h,wrow,4] (image width w_img) -> [N,h,w_img,cout]."""
+    n, h, wrow, c4 = xp.shape
+    y = torch.empty(n, h, w_img, cout, dtype=torch.float32, device=xp.device)
+    d = ConvDesc(n, h, w_img, 4, cout, 7, int(act))
+    check(lib().be_conv7x7_nhwc4p_f32(C.byref(d), dptr(xp, "x"), wrow, dptr(pw), dptr(pb), dptr(y), cout, stream_ptr(xp.device)),
+          "be_conv7x7_nhwc4p_f32")
     return y
 
 

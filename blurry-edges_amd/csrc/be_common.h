@@ -44,6 +44,11 @@ int gemm_rows(const float* x, int64_t M, int K, const float* packed_w, int N, co
 int conv_pm(const be_conv_desc* d, const float* x, int wrow, const float* x2, int cin2, const float* pw, const float* pb,
             float* y, int ldy, int ktot, void* stream);
 
+// be_wino.hip: be_wino_conv3x3_pair_6x6_f32; pool2 = 1 writes the 2x2 max-pool of the block's output, [n,3,3,cout]
+int wino_pair(const float* x, const float* packed_w1, const float* packed_bias1, int act1, const float* packed_w2,
+              const float* packed_bias2, const float* residual, int act2, float* y, int64_t n, int cin, int cmid, int cout,
+              float* workspace, size_t workspace_floats, void* stream, int pool2);
+
 #define BE_REQUIRE(cond, ...) do { if (!(cond)) return be::fail(BE_EINVAL, __VA_ARGS__); } while (0)
 
 }  // namespace be

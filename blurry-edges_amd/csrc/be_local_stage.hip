@@ -145,15 +145,16 @@ int block(const float* packed, int l0, const float* x, float* t, float* o, int n
 
 // The same block on a 6x6 map with both 3x3 convolutions in Winograd F(3x3,3x3) form (be_wino.hip): 2.56x fewer multiplies
 // than the direct form; the 1x1 downsample runs as its own convolution into `r` and joins in the output transform of conv2.
-int block_wino(const float* packed, int l0, const float* x, float* t, float* o, float* r, float* w, int n, void* stream) {
+int block_wino(const float* packed, int l0, const float* x, float* t, float* o, float* r, float* w, int n, void* stream,
+               int pool2 = 0) {
     const PackedLayout& L = layout();
     const int c = kLayers[l0].cout;
     (void)t;                                          // conv1's 6x6 result only ever exists in registers (k_wino_out_in)
     be_conv_desc d;
     d.n = n; d.h = 6; d.w = 6; d.cin = kLayers[l0 + 2].cin; d.cout = c; d.ksize = 1; d.act = 0;
     if (int rc = be_conv_nhwc_f32(&d, x, packed + L.dw_off[l0 + 2], packed + L.db_off[l0 + 2], nullptr, r, c, stream)) return rc;
-    return be_wino_conv3x3_pair_6x6_f32(x, packed + L.uw_off[l0], packed + L.ub_off[l0], 1, packed + L.uw_off[l0 + 1],
-                                        packed + L.ub_off[l0 + 1], r, 1, o, n, kLayers[l0].cin, c, c, w, (size_t)n * RW, stream);
+    return be::wino_pair(x, packed + L.uw_off[l0], packed + L.ub_off[l0], 1, packed + L.uw_off[l0 + 1], packed + L.ub_off[l0 + 1], r,
+                         1, o, n, kLayers[l0].cin, c, c, w, (size_t)n * RW, stream, pool2);
 }
 
 }  // namespace
@@ -211,10 +212,17 @@ int forward_impl(const float* packed, const float* x, const be_patch_view* view,
         if ((rc = wino ? block_wino(packed, 4, p2, ra, rc_, rr, rw, nb, stream) : block(packed, 4, p2, ra, rc_, nb, 6, stream))) return rc;
         // layer2: in RC, t RA, out RB
         if ((rc = wino ? block_wino(packed, 7, rc_, ra, rb, rr, rw, nb, stream) : block(packed, 7, rc_, ra, rb, nb, 6, stream))) return rc;
-        // layer3: in RB, t RA, out RC
-        if ((rc = wino ? block_wino(packed, 10, rb, ra, rc_, rr, rw, nb, stream) : block(packed, 10, rb, ra, rc_, nb, 6, stream))) return rc;
-        float* p3 = rb;                                   // nb*2304  (H,W,C) flatten
-        if ((rc = be_maxpool_nhwc_f32(rc_, p3, nb, 6, 6, 256, 2, 2, 0, stream))) return rc;
+        // layer3: in RB, t RA, out RC; then maxpool(2,2) -> p3 [nb,3,3,256] = the (H,W,C) flatten.  Winograd path: the
+        // output transform pools in registers and writes p3 directly (into RC: RB is still the block's input)
+        float* p3;
+        if (wino) {
+            p3 = rc_;
+            if ((rc = block_wino(packed, 10, rb, ra, p3, rr, rw, nb, stream, 1))) return rc;
+        } else {
+            if ((rc = block(packed, 10, rb, ra, rc_, nb, 6, stream))) return rc;
+            p3 = rb;                                      // nb*2304
+            if ((rc = be_maxpool_nhwc_f32(rc_, p3, nb, 6, 6, 256, 2, 2, 0, stream))) return rc;
+        }
         float* f1 = ra;                                   // nb*1024
         if ((rc = conv(packed, 13, p3, nullptr, f1, nb, 1, 1, 1024, stream))) return rc;
         if ((rc = conv(packed, 14, f1, nullptr, out + first * BE_LOCAL_OUT, nb, 1, 0, BE_LOCAL_OUT, stream))) return rc;

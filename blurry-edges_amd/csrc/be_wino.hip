@@ -249,6 +249,61 @@ void k_wino_out_in(const float* __restrict__ M, const float* __restrict__ bias, 
     }
 }
 
+// Last block of LocalStage: output transform + bias + residual + activation + the 2x2 max-pool that follows it
+// (models/local_stage.py:42,67: maxpool after layer3), one thread per image and channel quad: the 6x6 map exists only in
+// registers, [N,3,3,C] is written (saves the map's round trip through HBM and the pooling launch).
+__global__ __launch_bounds__(256, 1)
+void k_wino_out_pool2(const float* __restrict__ M, const float* __restrict__ bias, const float* __restrict__ res,
+                      float* __restrict__ y, int64_t n, int c4, int act, int tm) {
+    const int64_t total = n * c4;
+    const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+    const int64_t plane = tm ? c4 : n * 4 * c4, ts = tm ? 25 * c4 : c4;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gs) {
+        const int cq = (int)(idx % c4);
+        const int64_t img = idx / c4;
+        const f32x4 bv = reinterpret_cast<const f32x4*>(bias)[cq];
+        f32x4 v[6][6];
+#pragma unroll
+        for (int ty = 0; ty < 2; ++ty)
+#pragma unroll
+            for (int tx = 0; tx < 2; ++tx) {
+                const f32x4* src = reinterpret_cast<const f32x4*>(M) + (img * 4 + ty * 2 + tx) * ts + cq;
+                f32x4 s[3][5];
+#pragma unroll
+                for (int c = 0; c < 5; ++c) {
+                    f32x4 o[3];
+                    at5(src[(size_t)c * plane], src[(size_t)(5 + c) * plane], src[(size_t)(10 + c) * plane],
+                        src[(size_t)(15 + c) * plane], src[(size_t)(20 + c) * plane], o);
+#pragma unroll
+                    for (int r = 0; r < 3; ++r) s[r][c] = o[r];
+                }
+#pragma unroll
+                for (int r = 0; r < 3; ++r) {
+                    f32x4 o[3];
+                    at5(s[r][0], s[r][1], s[r][2], s[r][3], s[r][4], o);
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) {
+                        f32x4 w = o[c] + bv;
+                        if (res) w += reinterpret_cast<const f32x4*>(res)[((size_t)img * 36 + (3 * ty + r) * 6 + 3 * tx + c) * c4 + cq];
+                        if (act == 1) { w[0] = be::smish(w[0]); w[1] = be::smish(w[1]); w[2] = be::smish(w[2]); w[3] = be::smish(w[3]); }
+                        else if (act == 2) { w[0] = fmaxf(w[0], 0.f); w[1] = fmaxf(w[1], 0.f); w[2] = fmaxf(w[2], 0.f); w[3] = fmaxf(w[3], 0.f); }
+                        v[3 * ty + r][3 * tx + c] = w;
+                    }
+                }
+            }
+#pragma unroll
+        for (int py = 0; py < 3; ++py)
+#pragma unroll
+            for (int px = 0; px < 3; ++px) {
+                f32x4 m;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    m[k] = fmaxf(fmaxf(v[2 * py][2 * px][k], v[2 * py][2 * px + 1][k]), fmaxf(v[2 * py + 1][2 * px][k], v[2 * py + 1][2 * px + 1][k]));
+                reinterpret_cast<f32x4*>(y)[((size_t)img * 9 + py * 3 + px) * c4 + cq] = m;
+            }
+    }
+}
+
 // ---- the 25 transform-domain GEMMs of one (M tile, N tile), walked by ONE workgroup --------------------------------
 // M[z] = V[z] U[z]^T for z = 0..24: each problem has a K loop of only Cin/16 = 6-24 chunks, so as separate tiles every
 // 12.6 MFLOP pay a prologue (first loads exposed), an epilogue and a workgroup turnover.  Here the software pipeline runs
@@ -562,10 +617,10 @@ extern "C" size_t be_wino_pair_workspace_floats(int64_t n, int cin, int cmid, in
     return (size_t)100 * n * (big + out);                       // V (cin, then cmid) + M (cmid, then cout)
 }
 
-extern "C" int be_wino_conv3x3_pair_6x6_f32(const float* x, const float* packed_w1, const float* packed_bias1, int act1,
-                                            const float* packed_w2, const float* packed_bias2, const float* residual, int act2,
-                                            float* y, int64_t n, int cin, int cmid, int cout, float* workspace,
-                                            size_t workspace_floats, void* stream) {
+// pool2 = 1: y is [n,3,3,cout], the 2x2 max-pool of the block's output (k_wino_out_pool2)
+int be::wino_pair(const float* x, const float* packed_w1, const float* packed_bias1, int act1, const float* packed_w2,
+                  const float* packed_bias2, const float* residual, int act2, float* y, int64_t n, int cin, int cmid, int cout,
+                  float* workspace, size_t workspace_floats, void* stream, int pool2) {
     BE_REQUIRE(x && packed_w1 && packed_bias1 && packed_w2 && packed_bias2 && y && workspace,
                "be_wino_conv3x3_pair_6x6_f32: null pointer");
     if (int rc = wino_args_ok("be_wino_conv3x3_pair_6x6_f32", n, cin, cmid)) return rc;
@@ -585,7 +640,19 @@ extern "C" int be_wino_conv3x3_pair_6x6_f32(const float* x, const float* packed_
                        tm1, tm2);
     if (int rc = be::check_launch("be_wino_conv3x3_pair_6x6_f32(out_in)")) return rc;
     if (int rc = wino_gemms(V, packed_w2, M, n, cmid, cout, s, stream)) return rc;
-    hipLaunchKernelGGL(k_wino_out, dim3(grid_cap(n * 4 * (cout / 4), 256)), dim3(256), 0, s, M, packed_bias2, residual, y, n, cout / 4,
-                       act2, tm2);
+    if (pool2)
+        hipLaunchKernelGGL(k_wino_out_pool2, dim3(grid_cap(n * (cout / 4), 256)), dim3(256), 0, s, M, packed_bias2, residual, y, n,
+                           cout / 4, act2, tm2);
+    else
+        hipLaunchKernelGGL(k_wino_out, dim3(grid_cap(n * 4 * (cout / 4), 256)), dim3(256), 0, s, M, packed_bias2, residual, y, n,
+                           cout / 4, act2, tm2);
     return be::check_launch("be_wino_conv3x3_pair_6x6_f32(out)");
+}
+
+extern "C" int be_wino_conv3x3_pair_6x6_f32(const float* x, const float* packed_w1, const float* packed_bias1, int act1,
+                                            const float* packed_w2, const float* packed_bias2, const float* residual, int act2,
+                                            float* y, int64_t n, int cin, int cmid, int cout, float* workspace,
+                                            size_t workspace_floats, void* stream) {
+    return be::wino_pair(x, packed_w1, packed_bias1, act1, packed_w2, packed_bias2, residual, act2, y, n, cin, cmid, cout, workspace,
+                         workspace_floats, stream, 0);
 }

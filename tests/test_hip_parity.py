@@ -263,6 +263,49 @@ def test_local_stage_ragged_batches_are_position_independent(native, n):
         assert torch.equal(y[n - 7:], tail)
 
 
+def test_large_batch_kernels_are_bit_identical_to_the_small_batch_kernels(native):
+    """The LDS-DMA kernels large batches take (be_conv_pm.hip: 3x3 / fused 1x1 / conv1 on the row-padded staging; the row GEMM
+    of be_wino.hip for 1x1 convolutions and linears, with and without walked row tiles) against k_conv_igemm, which the same
+    data takes in slices below the large-batch thresholds.  Ragged sizes: a partly empty last tile in each."""
+    g = torch.Generator().manual_seed(1869)
+    rnd = lambda *s: (torch.rand(*s, generator=g) - 0.5).to(DEV)
+
+    def sliced(f, n, step):
+        return torch.cat([f(i, min(i + step, n)) for i in range(0, n, step)])
+
+    # conv1: 7x7 on the padded staging (600 = 2 groups of 256 + 88)
+    x = rnd(600, 3, 21, 21)
+    pw, pb = native.conv_pack(rnd(64, 3, 7, 7), rnd(64))
+    new = native.conv7x7_nhwc4p(native.nchw3_to_nhwc4p(x), 21, pw, pb, 64, act=1)
+    old = sliced(lambda a, b: native.conv_nhwc(native.nchw3_to_nhwc4(x[a:b].contiguous()), pw, pb, 64, 7, act=1), 600, 200)
+    assert torch.equal(new, old)
+    # layer0-shaped 3x3 on 11x11, then conv2 with the 1x1 on x2 appended to its K loop
+    xin = rnd(600, 11, 11, 64)
+    pw1, pb1 = native.conv_pack(rnd(96, 64, 3, 3) * 0.1, rnd(96))
+    t_new = native.conv_nhwc(xin, pw1, pb1, 96, 3, act=1)
+    t_old = sliced(lambda a, b: native.conv_nhwc(xin[a:b].contiguous(), pw1, pb1, 96, 3, act=1), 600, 200)
+    assert torch.equal(t_new, t_old)
+    pwf, pbf = native.conv_pack_fused2(rnd(96, 96, 3, 3) * 0.1, rnd(96), None, rnd(96, 64, 1, 1) * 0.1, rnd(96), None)
+    o_new = native.conv_nhwc_fused2(t_new, xin, pwf, pbf, 96, 3, act=1)
+    o_old = sliced(lambda a, b: native.conv_nhwc_fused2(t_new[a:b].contiguous(), xin[a:b].contiguous(), pwf, pbf, 96, 3, act=1),
+                   600, 200)
+    assert torch.equal(o_new, o_old)
+    # 1x1 on 6x6 maps: 4096 images = 1152 row tiles, walked three at a time; slices of 100 images stay below the threshold
+    x6 = rnd(4096, 6, 6, 96)
+    pwd, pbd = native.conv_pack(rnd(256, 96, 1, 1) * 0.1, rnd(256))
+    d_new = native.conv_nhwc(x6, pwd, pbd, 256, 1, act=0)
+    d_old = sliced(lambda a, b: native.conv_nhwc(x6[a:b].contiguous(), pwd, pbd, 256, 1, act=0), 4096, 100)
+    assert torch.equal(d_new, d_old)
+    # linear with bias + Smish + a residual, ragged row count (4100 = 32 tiles + 4 rows)
+    xf = rnd(4100, 1, 1, 2304)
+    pwl, pbl = native.conv_pack(rnd(1024, 2304) * 0.05, rnd(1024))
+    res = rnd(4100, 1, 1, 1024)
+    f_new = native.conv_nhwc(xf, pwl, pbl, 1024, 1, act=1, residual=res)
+    f_old = sliced(lambda a, b: native.conv_nhwc(xf[a:b].contiguous(), pwl, pbl, 1024, 1, act=1, residual=res[a:b].contiguous()),
+                   4100, 1000)
+    assert torch.equal(f_new, f_old)
+
+
 def test_product_path_refuses_cpu_tensors(native):
     import models
     m = models.LocalStage().eval()
