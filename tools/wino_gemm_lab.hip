@@ -333,11 +333,12 @@ void k_wave(GemmArgs a) {
 // image is lane-linear per 1-KB piece (16 rows x 64 B) with the 16-byte quads of a row XOR-swizzled by (row >> 2) & 3 on
 // the SOURCE address and on the fragment read; interior tiles store without per-element bounds checks; a new problem starts
 // with C = 0 in its first MFMAs instead of clearing 64 registers.
-//   FLAGS: 1 = keep per-element checks everywhere (A/B of the fast epilogue), 2 = clear registers instead of C = 0
+//   FLAGS: 1 = keep per-element checks everywhere (A/B of the fast epilogue), 2 = clear registers instead of C = 0,
+//          knock-outs (timing only): 64 = the DMA always fetches chunk 0 (L2 hits), 4 = no DMA in the loop, 8 = store once at the end, 16 = no barrier, 32 = no ds_read
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 
-template <int FLAGS, int WGS>
+template <int FLAGS, int WGS, int NBUF = 2>
 __global__ __launch_bounds__(256, WGS)
 void k_glds(GemmArgs a) {
     constexpr int BM = 128, BN = 128, BKT = 16;
@@ -390,12 +391,13 @@ void k_glds(GemmArgs a) {
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(xs_ + a_off[p_]), (lds_ptr_t)(st_ + p_ * 256), 16, 0, 0);             \
             __builtin_amdgcn_global_load_lds((glb_ptr_t)(ws_ + b_off[p_]), (lds_ptr_t)(st_ + BM * BKT + p_ * 256), 16, 0, 0);  \
         }                                                                                                       \
-        if (lk + 1 < kchunks) ++lk; else if (lz + 1 < a.nb) { lk = 0; ++lz; }                                   \
+        if (!(FLAGS & 64)) { if (lk + 1 < kchunks) ++lk; else if (lz + 1 < a.nb) { lk = 0; ++lz; } }            \
     } while (0)
 #define G_MFMA(BUF, FIRST)                                                                                      \
     do {                                                                                                        \
         const float* sb_ = smem_w + (BUF) * STAGE;                                                              \
         f32x4 af[2][2], bf[2][2];                                                                               \
+        if (FLAGS & 32) { _Pragma("unroll") for (int g = 0; g < 2; ++g) _Pragma("unroll") for (int i = 0; i < 2; ++i) { af[g][i] = kaf; bf[g][i] = kbf; } } else { \
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                         \
             af[0][i] = *reinterpret_cast<const f32x4*>(sb_ + a_fr0 + i * 32 * BKT);                             \
             bf[0][i] = *reinterpret_cast<const f32x4*>(sb_ + b_fr0 + i * 32 * BKT);                             \
@@ -403,7 +405,7 @@ void k_glds(GemmArgs a) {
         _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                         \
             af[1][i] = *reinterpret_cast<const f32x4*>(sb_ + a_fr1 + i * 32 * BKT);                             \
             bf[1][i] = *reinterpret_cast<const f32x4*>(sb_ + b_fr1 + i * 32 * BKT);                             \
-        }                                                                                                       \
+        } }                                                                                                     \
         _Pragma("unroll") for (int g = 0; g < 2; ++g)                                                           \
         _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                           \
         _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                         \
@@ -418,18 +420,31 @@ void k_glds(GemmArgs a) {
         }                                                                                                       \
     } while (0)
     const bool interior = !(FLAGS & 1) && row_base + BM <= a.M && n0 + BN <= a.N;
+    f32x4 kaf = {1.f + tid, 2.f, 3.f, 4.f}, kbf = {0.5f, 0.25f * tid, 2.f, 1.f};
     const unsigned y_off = (unsigned)((wm * 64 + 4 * lh) * a.ldy + wn * 64 + li) * 4u;
     G_LOAD(0);
-    __syncthreads();
+    if (NBUF == 3) G_LOAD(1);
+    if (NBUF == 3) { __builtin_amdgcn_s_waitcnt(0x0F74); __builtin_amdgcn_s_barrier(); }   // vmcnt(4): chunk 0 has landed
+    else __syncthreads();
     int cz = 0, ck = 0;
+    int buf = 0, lbuf = NBUF == 3 ? 2 : 1;
     for (int kc = 0; kc < total; ++kc) {
-        const int buf = kc & 1;
-        G_LOAD(buf ^ 1);                               // past the end: re-reads the last chunk (harmless)
+        if (!(FLAGS & 4)) G_LOAD(lbuf);                // past the end: re-reads the last chunk (harmless)
         __builtin_amdgcn_sched_barrier(0);
         if (ck == 0 && !(FLAGS & 2)) G_MFMA(buf, 1); else G_MFMA(buf, 0);
         __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-        if (++ck == kchunks) {
+        if (NBUF == 3) {
+            // the four DMAs just issued may stay in flight across the barrier; everything older has landed
+            __builtin_amdgcn_s_waitcnt(0x0F74);
+            __builtin_amdgcn_s_barrier();
+            buf = buf == 2 ? 0 : buf + 1; lbuf = lbuf == 2 ? 0 : lbuf + 1;
+        } else {
+            if (!(FLAGS & 16)) __syncthreads();
+            buf ^= 1; lbuf ^= 1;
+        }
+        ++ck;
+        if (ck == kchunks && (FLAGS & 8) && kc + 1 < total) { ck = 0; ++cz; }
+        if (ck == kchunks) {
             char* yt = reinterpret_cast<char*>(a.y + (int64_t)cz * a.yb + (int64_t)row_base * a.ldy + n0);   // uniform
             if (interior) {
 #pragma unroll
@@ -472,33 +487,155 @@ void k_glds(GemmArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-struct Variant { const char* name; void (*fn)(GemmArgs); bool ko; };
+// variant family Wd: ONE workgroup per 128-row tile covers ALL N columns (N = 128 NW: 4 NW waves, wave tile 64 x 64 as before),
+// so the A tile is fetched into LDS once per M tile instead of once per N tile: 8 + 8 NW DMA pieces per chunk for 4 NW waves
+// (3 / 2.67 per wave where the 128 x 128 workgroups issue 4) - the DMA issue is what the knock-outs price at 11-13 %.
+template <int NW>
+__global__ __launch_bounds__(256 * NW, 1)
+void k_wide(GemmArgs a) {
+    constexpr int BM = 128, BN = 128 * NW, BKT = 16, NWAVE = 4 * NW, NPIECE = 8 + 8 * NW, PPW = (NPIECE + NWAVE - 1) / NWAVE;
+    constexpr int STAGE = (BM + BN) * BKT;
+    extern __shared__ __attribute__((aligned(16))) float smem_w[];
+    const int m_tile = blockIdx.x;
+    if (m_tile >= a.m_tiles) return;
+    const int row_base = m_tile * BM;
+    const int tid = threadIdx.x;
+    long long t0 = 0, w0 = 0;
+    if (m_tile == 0 && tid == 0) { t0 = clock64(); w0 = wall_clock64(); }
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int wm = wave & 1, wn = wave >> 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int srow = lane >> 2, sq = (lane & 3) ^ ((lane >> 4) & 3);
+    // piece p = wave + NWAVE i: p < 8 -> rows 16 p.. of the A tile, else rows 16 (p - 8).. of the B tile (LDS: A then B)
+    unsigned p_off[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int p = wave + NWAVE * i;
+        const int r = (p < 8 ? p : p - 8) * 16 + srow;
+        p_off[i] = p < 8 ? (unsigned)((row_base + r < a.M ? r : 0) * a.K + 4 * sq) * 4u : (unsigned)(r * a.K + 4 * sq) * 4u;
+    }
+    const float* xt = a.x + (int64_t)row_base * a.K;
+    const float* wt = a.w;
+    const int kchunks = a.K / BKT, total = kchunks * a.nb;
+    const int fsw = (li >> 2) & 3;
+    const int a_fr0 = (wm * 64 + li) * BKT + 4 * (lh ^ fsw);
+    const int a_fr1 = (wm * 64 + li) * BKT + 4 * ((lh + 2) ^ fsw);
+    const int b_fr0 = BM * BKT + (wn * 64 + li) * BKT + 4 * (lh ^ fsw);
+    const int b_fr1 = BM * BKT + (wn * 64 + li) * BKT + 4 * ((lh + 2) ^ fsw);
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    int lz = 0, lk = 0;
+#define WD_LOAD(BUF)                                                                                            \
+    do {                                                                                                        \
+        const char* xs_ = reinterpret_cast<const char*>(xt + (int64_t)lz * a.xb + lk * BKT);                     \
+        const char* ws_ = reinterpret_cast<const char*>(wt + (int64_t)lz * a.wb + lk * BKT);                     \
+        float* st_ = smem_w + (BUF) * STAGE;                                                                    \
+        _Pragma("unroll") for (int i_ = 0; i_ < PPW; ++i_) {                                                    \
+            const int p_ = wave + NWAVE * i_;                                                                   \
+            if (NPIECE % NWAVE == 0 || p_ < NPIECE)                                                             \
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)((p_ < 8 ? xs_ : ws_) + p_off[i_]), (lds_ptr_t)(st_ + p_ * 256), 16, 0, 0); \
+        }                                                                                                       \
+        if (lk + 1 < kchunks) ++lk; else if (lz + 1 < a.nb) { lk = 0; ++lz; }                                   \
+    } while (0)
+    const unsigned y_off = (unsigned)((wm * 64 + 4 * lh) * a.ldy + wn * 64 + li) * 4u;
+    const bool interior = row_base + BM <= a.M && BN <= a.N;
+    WD_LOAD(0);
+    __syncthreads();
+    int cz = 0, ck = 0;
+    for (int kc = 0; kc < total; ++kc) {
+        const int buf = kc & 1;
+        WD_LOAD(buf ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const float* sb = smem_w + buf * STAGE;
+            f32x4 af[2][2], bf[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[0][i] = *reinterpret_cast<const f32x4*>(sb + a_fr0 + i * 32 * BKT);
+                bf[0][i] = *reinterpret_cast<const f32x4*>(sb + b_fr0 + i * 32 * BKT);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[1][i] = *reinterpret_cast<const f32x4*>(sb + a_fr1 + i * 32 * BKT);
+                bf[1][i] = *reinterpret_cast<const f32x4*>(sb + b_fr1 + i * 32 * BKT);
+            }
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][i].x, bf[g][j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][i].y, bf[g][j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][i].z, bf[g][j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g][i].w, bf[g][j].w, acc[i][j], 0, 0, 0);
+                    }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        if (++ck == kchunks) {
+            char* yt = reinterpret_cast<char*>(a.y + (int64_t)cz * a.yb + (int64_t)row_base * a.ldy);
+            if (interior) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int ro = i * 32 + (r & 3) + 8 * (r >> 2);
+                        float* yr = reinterpret_cast<float*>(yt + (size_t)ro * a.ldy * 4 + y_off);
+                        yr[0] = acc[i][0][r];
+                        yr[32] = acc[i][1][r];
+                    }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const bool c_ok = wn * 64 + j * 32 + li < a.N;
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int ro = i * 32 + (r & 3) + 8 * (r >> 2);
+                            if (c_ok && row_base + wm * 64 + 4 * lh + ro < a.M)
+                                reinterpret_cast<float*>(yt + (size_t)ro * a.ldy * 4 + y_off)[j * 32] = acc[i][j][r];
+                        }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+            ck = 0; ++cz;
+        }
+    }
+#undef WD_LOAD
+    if (m_tile == 0 && tid == 0) { a.dbg[0] = clock64() - t0; a.dbg[1] = wall_clock64() - w0; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+struct Variant { const char* name; void (*fn)(GemmArgs); bool ko; int nw; };   // nw > 0: one workgroup of 256 nw threads per M tile, N = 128 nw only
 
 int main(int argc, char** argv) {
     const int M = argc > 1 ? atoi(argv[1]) : 32768;
     const int reps = 5;
     const Variant vars[] = {
-        {"B0 product               ", k_base<0>, false},
-        {"B1 KO no barrier         ", k_base<1>, true},
-        {"B2 epilogue after barrier", k_base<2>, false},
-        {"B3 B2 + loads 2 ahead    ", k_base<2, 2>, false},
-        {"B4 KO B2 no loads        ", k_base<2, 1, 1>, true},
-        {"B5 KO B2 no epilogue     ", k_base<2, 1, 0, 1>, true},
-        {"B6 KO B2 no loads no epi ", k_base<2, 1, 1, 1>, true},
-        {"G0 glds + fast epi + C=0 ", k_glds<0, 3>, false},
-        {"G1 glds, checked epilogue", k_glds<1, 3>, false},
-        {"G2 glds, clear registers ", k_glds<2, 3>, false},
-        {"G4 G0 at 4 workgroups/CU ", k_glds<0, 4>, false},
-        {"M0 KO B6 -bar -dsw -dsr  ", k_base<2, 1, 1, 1, 0, 7>, true},
-        {"M1 KO B6 -bar -dsw       ", k_base<2, 1, 1, 1, 0, 3>, true},
-        {"M2 KO B6 -bar            ", k_base<2, 1, 1, 1, 0, 1>, true},
-        {"M3 KO B6 -dsw            ", k_base<2, 1, 1, 1, 0, 2>, true},
-        {"M4 KO B6 -dsr            ", k_base<2, 1, 1, 1, 0, 4>, true},
+        {"B0 register-staged (old) ", k_base<0>, false, 0},
+        {"G2 LDS-DMA (product)     ", k_glds<2, 3>, false, 0},
+        {"Wd all N in one workgroup", k_wide<2>, false, 2},
+        {"Wd all N in one workgroup", k_wide<3>, false, 3},
+        {"G2 KO no DMA in loop     ", k_glds<2 | 4, 3>, true, 0},
     };
     const int nv = sizeof(vars) / sizeof(vars[0]);
-    constexpr size_t lds = (size_t)2 * (128 + 128) * 20 * sizeof(float);
+    constexpr size_t lds = (size_t)3 * (128 + 128) * 16 * sizeof(float);   // 48 KB: enough for the 256-thread variants
+    constexpr size_t lds_wide = 82 * 1024;                                 // > 80 KB: one wide workgroup per CU
     for (int v = 0; v < nv; ++v)
-        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(vars[v].fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CK(hipFuncSetAttribute(reinterpret_cast<const void*>(vars[v].fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)(vars[v].nw ? lds_wide : lds)));
     const int shapes[][2] = {{96, 256}, {256, 256}, {256, 384}, {384, 384}, {384, 256}};
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -519,11 +656,14 @@ int main(int argc, char** argv) {
         const double flop = 2.0 * nb * M * (double)K * N;
         std::vector<float> href(ny), hy(ny);
         printf("K %d N %d (grid %u)\n", K, N, grid);
+#define LAUNCH(V) do { if (vars[V].nw) hipLaunchKernelGGL(vars[V].fn, dim3(8 * ((g.m_tiles + 7) / 8)), dim3(256 * vars[V].nw), lds_wide, 0, g); \
+                       else hipLaunchKernelGGL(vars[V].fn, dim3(grid), dim3(256), lds, 0, g); } while (0)
         // correctness pass
         for (int v = 0; v < nv; ++v) {
+            if (vars[v].nw && vars[v].nw != N / 128) continue;
             g.y = v == 0 ? dref : dy;
             CK(hipMemset(g.y, 0xff, ny * 4));
-            hipLaunchKernelGGL(vars[v].fn, dim3(grid), dim3(256), lds, 0, g);
+            LAUNCH(v);
             CK(hipGetLastError());
             CK(hipDeviceSynchronize());
             if (v == 0) CK(hipMemcpy(href.data(), dref, ny * 4, hipMemcpyDeviceToHost));
@@ -546,14 +686,15 @@ int main(int argc, char** argv) {
         }
         // timing: warm clocks first, then rounds that walk the variants in turn
         g.y = dy;
-        for (int r = 0; r < 40; ++r) hipLaunchKernelGGL(vars[0].fn, dim3(grid), dim3(256), lds, 0, g);
+        for (int r = 0; r < 40; ++r) LAUNCH(0);
         CK(hipDeviceSynchronize());
         const int rounds = 4;
         std::vector<float> best(nv, 1e30f), sum(nv, 0.f); std::vector<double> ghz(nv, 0.0);
         for (int rd = 0; rd < rounds; ++rd)
             for (int v = 0; v < nv; ++v) {
+                if (vars[v].nw && vars[v].nw != N / 128) continue;
                 CK(hipEventRecord(e0, 0));
-                for (int r = 0; r < reps; ++r) hipLaunchKernelGGL(vars[v].fn, dim3(grid), dim3(256), lds, 0, g);
+                for (int r = 0; r < reps; ++r) LAUNCH(v);
                 CK(hipEventRecord(e1, 0));
                 CK(hipEventSynchronize(e1));
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
@@ -563,6 +704,7 @@ int main(int argc, char** argv) {
                 if (hd[1] > 0) ghz[v] = (double)hd[0] / hd[1] * 0.1;
             }
         for (int v = 0; v < nv; ++v)
+            if (!vars[v].nw || vars[v].nw == N / 128)
             printf("  %s best %8.4f ms %6.1f TF   mean %8.4f ms %6.1f TF  clock %.3f GHz -> %.1f%% of the MFMA rate at that clock %s\n",
                    vars[v].name, best[v], flop / best[v] / 1e9, sum[v] / rounds, flop / (sum[v] / rounds) / 1e9, ghz[v],
                    ghz[v] > 0 ? 100.0 * (flop / (sum[v] / rounds) / 1e9) / (65.536 * ghz[v]) : 0.0, vars[v].ko ? "(KO)" : "");
