@@ -2,10 +2,13 @@
 //   conv7x7+BN+Smish -> maxpool(3,2,1) -> block 64->96 @11^2 -> maxpool(3,2,1) -> blocks 96->256, 256->384,
 //   384->256 @6^2 -> maxpool(2,2) -> flatten -> Linear 2304->1024 + BN1d + Smish -> Linear 1024->10
 // Activations are NHWC in a caller-provided workspace; the batch is walked in sub-batches (default 8192 patches,
-// measured best) so the workspace stays bounded whatever N is.  Per sub-batch: staging, conv1, 3 pools, layer0 as two direct
+// measured best) so the workspace stays bounded whatever N is.  Per sub-batch: staging, conv1, 2-3 pools, layer0 as two direct
 // launches (conv1; conv2 with the downsample fused in), layers 1-3 each as a 1x1 downsample launch + the Winograd pair
-// (input transform, 25 GEMMs, output+input transform, 25 GEMMs, output transform; be_wino.hip), fc.1, fc.4.  No allocation,
-// no synchronisation: graph-capturable.  be_local_stage_set_winograd(0) runs layers 1-3 as direct launches like layer0.
+// (input transform, 25 GEMMs, output+input transform, 25 GEMMs, output transform - layer3's with the 2x2 max-pool in it;
+// be_wino.hip), fc.1, fc.4.  Sub-batches of 512 patches and more take the LDS-DMA kernels (be_conv_pm.hip for conv1 on a
+// row-padded staging and for layer0, the row GEMM of be_wino.hip for the 1x1s and fc.1); smaller ones k_conv_igemm - same
+// results bit for bit.  No allocation, no synchronisation: graph-capturable.  be_local_stage_set_winograd(0) runs layers 1-3
+// as direct launches like layer0.
 #include "be_common.h"
 #include <cstdlib>
 
