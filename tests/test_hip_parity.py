@@ -306,6 +306,19 @@ def test_large_batch_kernels_are_bit_identical_to_the_small_batch_kernels(native
     assert torch.equal(f_new, f_old)
 
 
+@pytest.mark.parametrize("n,h,w,cin,cout", [(512, 7, 7, 32, 96), (700, 5, 9, 64, 192), (1031, 3, 3, 32, 96)])
+def test_pixel_major_kernel_shapes(native, n, h, w, cin, cout):
+    """be_conv_pm.hip away from LocalStage's shapes: exactly two / a ragged number of 256-image groups, non-square and 3x3
+    images (every pixel on the border), two N tiles - against k_conv_igemm on slices below the large-batch threshold."""
+    g = torch.Generator().manual_seed(n)
+    rnd = lambda *s: (torch.rand(*s, generator=g) - 0.5).to(DEV)
+    x = rnd(n, h, w, cin)
+    pw, pb = native.conv_pack(rnd(cout, cin, 3, 3) * 0.2, rnd(cout))
+    new = native.conv_nhwc(x, pw, pb, cout, 3, act=2)
+    old = torch.cat([native.conv_nhwc(x[a:a + 300].contiguous(), pw, pb, cout, 3, act=2) for a in range(0, n, 300)])
+    assert torch.equal(new, old)
+
+
 def test_product_path_refuses_cpu_tensors(native):
     import models
     m = models.LocalStage().eval()
