@@ -441,7 +441,7 @@ void k_wino_gemm(GemmArgs a) {
             const int zrow = row_base + cz * a.zrows;
             const int64_t yo = (int64_t)cz * a.yb + (int64_t)row_base * a.ldy + n0;                           // uniform
             char* yt = reinterpret_cast<char*>(a.y + yo);
-            const char* rt = reinterpret_cast<const char*>(a.res + yo);
+            const char* rt = a.res ? reinterpret_cast<const char*>(a.res + yo) : nullptr;
             const bool interior = zrow + BM <= a.M && n0 + BN <= a.N;
 #define WG_VALUE(J)                                                                                             \
             float v_ = acc[i][J][r];                                                                            \
