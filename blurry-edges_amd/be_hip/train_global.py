@@ -71,7 +71,7 @@ def train_step(model, helper, dcal, opt, batch, gamma, flat=None, world=1, clip=
     """One iteration of global_training.py:207-213; batch: dict of stacked GPU tensors."""
     import utils
     est = model(batch["pm"])
-    opt.zero_grad(set_to_none=False)
+    opt.zero_grad(set_to_none=True)      # backward then SETS .grad (no fill, no accumulate launch per parameter)
     loss = utils.global_loss(helper, dcal, est, batch["img_gt"], batch["img_gt"], batch["bndry_dist"], batch["deri"],
                              batch["bndry_depth"], gamma)
     loss.backward()

@@ -39,7 +39,7 @@ def train_step(model, helper, opt, batch, beta_b, beta_s, flat=None, world=1, cl
     """One iteration of local_training.py:103-108.  batch: dict of GPU tensors (dataset layouts)."""
     import utils
     est = model(batch["img_ny"].permute(0, 3, 1, 2))
-    opt.zero_grad(set_to_none=False)
+    opt.zero_grad(set_to_none=True)      # backward then SETS .grad (no fill, no accumulate launch per parameter)
     loss = utils.local_loss(helper, est, batch["img_gt"], batch["img_gt"], batch["bndry_dist"], batch["deri"], beta_b, beta_s)
     loss.backward()
     if flat is not None:
