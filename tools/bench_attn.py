@@ -8,7 +8,7 @@ from be_hip import native, synth, train_global_stage as tg
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-L, H, p = 4096, 8, 0.1
+L, H, p = 4096, 8, (float(sys.argv[3]) if len(sys.argv) > 3 else 0.1)
 dev = "cuda:0"
 qkv = torch.from_numpy(synth.hash_normal(3, "attn_qkv", (B * L, 384)).astype(np.float32)).to(dev)
 dout = torch.from_numpy(synth.hash_normal(4, "attn_dout", (B * L, 128)).astype(np.float32)).to(dev)
