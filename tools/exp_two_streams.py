@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Experiment: do two half-batches on two streams overlap the matrix-bound and the HBM-bound kernels of LocalStage?"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "blurry-edges_amd")]
+import numpy as np, torch
+from be_hip import synth
+import models
+dev = "cuda:0"
+x_np, _ = synth.synthetic_patch_pairs(4096, seed=synth.SEED_DEFAULT)
+sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.local_stage_state_dict().items()}
+def mk():
+    m = models.LocalStage(); m.load_state_dict(sd); return m.to(dev).eval()
+m0, m1, m2 = mk(), mk(), mk()
+x = torch.from_numpy(x_np).to(dev)
+xa, xb = x[:4096].contiguous(), x[4096:].contiguous()
+s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+def one():
+    with torch.no_grad(): return m0(x)
+def two():
+    s1.wait_stream(torch.cuda.current_stream()); s2.wait_stream(torch.cuda.current_stream())
+    with torch.no_grad():
+        with torch.cuda.stream(s1): a = m1(xa)
+        with torch.cuda.stream(s2): b = m2(xb)
+    torch.cuda.current_stream().wait_stream(s1); torch.cuda.current_stream().wait_stream(s2)
+    return a, b
+def timed(f, n=20):
+    for _ in range(3): f()
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(n): f()
+    torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e3
+r1 = one(); ra, rb = two()
+print("identical:", torch.equal(r1[:4096], ra) and torch.equal(r1[4096:], rb))
+print(f"one stream, 8192 patches: {timed(one):.3f} ms   two streams x 4096: {timed(two):.3f} ms")
