@@ -47,3 +47,27 @@ def copy_grads_into(buf: torch.Tensor, params):
             view.copy_(p.grad)
             p.grad = view
         off += p.numel()
+
+
+def grads_as_flat(params, fallback: torch.Tensor | None = None):
+    """The gradients of `params` as ONE flat tensor to all-reduce.  The HIP backward (be_hip.train.backward_train) writes every
+    gradient into consecutive slices of one buffer, in parameter order, and autograd keeps those views as .grad: then this is
+    that buffer, zero-copy.  Otherwise (torch autograd allocated the gradients one by one) they are copied into `fallback`
+    (from flat_grad_buffer) and re-pointed at it, as copy_grads_into does."""
+    params = [p for p in params if p.requires_grad]
+    if params and all(p.grad is not None and p.grad.is_contiguous() for p in params):
+        g0 = params[0].grad
+        st, off, ok = g0.untyped_storage(), g0.storage_offset(), True
+        for p in params:
+            g = p.grad
+            if g.untyped_storage().data_ptr() != st.data_ptr() or g.storage_offset() != off or g.dtype != g0.dtype:
+                ok = False
+                break
+            off += g.numel()
+        if ok:
+            total = off - g0.storage_offset()
+            return torch.empty(0, dtype=g0.dtype, device=g0.device).set_(st, g0.storage_offset(), (total,))
+    if fallback is None:
+        raise RuntimeError("grads_as_flat: gradients are not one flat buffer and no fallback buffer was given")
+    copy_grads_into(fallback, params)
+    return fallback

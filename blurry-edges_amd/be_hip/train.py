@@ -58,12 +58,13 @@ def _bn_fwd(y, gamma, beta, rm, rv, res, act):
     return out, (y, mean, invstd, s_in)
 
 
-def _bn_bwd(dout, saved, gamma):
+def _bn_bwd(dout, saved, gamma, dgamma=None, dbeta=None):
     y, mean, invstd, s_in = saved
     m, c = y.numel() // y.shape[-1], y.shape[-1]
     dev = y.device
     ds, dy = torch.empty_like(y), torch.empty_like(y)
-    dgamma, dbeta = _new(c, dev), _new(c, dev)
+    dgamma = _new(c, dev) if dgamma is None else dgamma
+    dbeta = _new(c, dev) if dbeta is None else dbeta
     sc = _Scratch.get(dev)
     check(lib().be_bn_train_bwd_f32(dptr(dout), dptr(s_in), dptr(y), dptr(mean), dptr(invstd), dptr(gamma), dptr(ds),
                                     dptr(dy), dptr(dgamma), dptr(dbeta), m, c, dptr(sc), sc.numel() * 4, stream_ptr(dev)),
@@ -71,18 +72,18 @@ def _bn_bwd(dout, saved, gamma):
     return ds, dy, dgamma, dbeta
 
 
-def _col_sum(a):
+def _col_sum(a, out=None):
     m, c = a.numel() // a.shape[-1], a.shape[-1]
-    out = _new(c, a.device)
+    out = _new(c, a.device) if out is None else out
     sc = _Scratch.get(a.device)
     check(lib().be_col_sum_f32(dptr(a), dptr(out), m, c, dptr(sc), sc.numel() * 4, stream_ptr(a.device)), "be_col_sum_f32")
     return out
 
 
-def _wgrad(x, dy, w_shape, ks, chw_hw=0):
+def _wgrad(x, dy, w_shape, ks, chw_hw=0, out=None):
     n, h, w, cin = x.shape
     cout = dy.shape[-1]
-    dw = _new(w_shape, x.device)
+    dw = _new(w_shape, x.device) if out is None else out
     sc = _Scratch.get(x.device)
     check(lib().be_conv_wgrad_f32(dptr(x), dptr(dy), dptr(dw), n, h, w, cin, cout, ks, chw_hw, dptr(sc), sc.numel() * 4,
                                   stream_ptr(x.device)), "be_conv_wgrad_f32")
@@ -150,24 +151,34 @@ def forward_train(x, t):
     return out, S
 
 
+# trainable entries of the 86-tensor list, in order (= LocalStage.parameters() order): conv / linear weight + bias and
+# BatchNorm gamma + beta of every unit; running statistics (6i+4, 6i+5, 82, 83) have no gradient
+TRAINABLE = [6 * i + j for i in range(13) for j in range(4)] + [78, 79, 80, 81, 84, 85]
+
+
 def backward_train(dlogits, t, S):
-    """Returns the list of 86 gradients (None for running statistics) in the order of t."""
+    """Returns the list of 86 gradients (None for running statistics) in the order of t.  Every gradient is a view into ONE
+    flat buffer, in parameter order, written by the kernels directly: autograd then stores those views as .grad, so a
+    data-parallel run all-reduces that buffer as it stands (be_hip.dp.grads_as_flat) - no per-parameter copy."""
     n = dlogits.shape[0]
     dev = dlogits.device
     grads = [None] * 86
+    flat = torch.empty(sum(t[i].numel() for i in TRAINABLE), dtype=torch.float32, device=dev)
+    off = 0
+    for i in TRAINABLE:
+        grads[i] = flat[off:off + t[i].numel()].view(t[i].shape)
+        off += t[i].numel()
     w1, b1, g1, be1, rm1, rv1, w4, b4 = t[78:86]
     # fc.4
     f1 = S["fc4"].reshape(n, 1024)
-    dx, dw4, db4 = _new((n, 1024), dev), torch.empty_like(w4), torch.empty_like(b4)
-    check(lib().be_linear_small_bwd_f32(dptr(f1), dptr(w4.contiguous()), dptr(dlogits.contiguous()), dptr(dx), dptr(dw4),
-                                        dptr(db4), n, 1024, 10, stream_ptr(dev)), "be_linear_small_bwd_f32")
-    grads[84], grads[85] = dw4, db4
+    dx = _new((n, 1024), dev)
+    check(lib().be_linear_small_bwd_f32(dptr(f1), dptr(w4.contiguous()), dptr(dlogits.contiguous()), dptr(dx), dptr(grads[84]),
+                                        dptr(grads[85]), n, 1024, 10, stream_ptr(dev)), "be_linear_small_bwd_f32")
     # fc.1 + BN1d + Smish
     f_in, saved1 = S["fc1"]
-    ds, dy, dg, dbt = _bn_bwd(dx.reshape(n, 1, 1, 1024), saved1, g1)
-    grads[80], grads[81] = dg, dbt
-    grads[78] = _wgrad(f_in, dy, tuple(w1.shape), 1, chw_hw=9)
-    grads[79] = _col_sum(dy)
+    ds, dy, _, _ = _bn_bwd(dx.reshape(n, 1, 1, 1024), saved1, g1, grads[80], grads[81])
+    _wgrad(f_in, dy, tuple(w1.shape), 1, chw_hw=9, out=grads[78])
+    _col_sum(dy, out=grads[79])
     d = _dgrad(dy, w1, 2304, 1, chw_hw=9).reshape(n, 3, 3, 256)
     d = _pool_bwd(S["pool3"], d, 2, 2, 0)
 
@@ -176,10 +187,9 @@ def backward_train(dlogits, t, S):
         _, cout, cin, ks = CONVS[i]
         w, b, g = t[6 * i], t[6 * i + 1], t[6 * i + 2]
         xin, saved = S[name]
-        ds_, dy_, dg_, db_ = _bn_bwd(dout, saved, g)
-        grads[6 * i + 2], grads[6 * i + 3] = dg_, db_
-        grads[6 * i] = _wgrad(xin, dy_, tuple(w.shape), ks)
-        grads[6 * i + 1] = _col_sum(dy_)
+        ds_, dy_, _, _ = _bn_bwd(dout, saved, g, grads[6 * i + 2], grads[6 * i + 3])
+        _wgrad(xin, dy_, tuple(w.shape), ks, out=grads[6 * i])
+        _col_sum(dy_, out=grads[6 * i + 1])
         dxi = _dgrad(dy_, w, cin, ks) if need_dx else None
         return ds_, dxi
 

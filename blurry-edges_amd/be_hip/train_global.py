@@ -76,8 +76,7 @@ def train_step(model, helper, dcal, opt, batch, gamma, flat=None, world=1, clip=
                              batch["bndry_depth"], gamma)
     loss.backward()
     if flat is not None:
-        dp.copy_grads_into(flat, list(model.parameters()))
-        dp.allreduce_mean_(flat, world)
+        dp.allreduce_mean_(dp.grads_as_flat(list(model.parameters()), flat), world)      # zero-copy when the backward wrote one buffer
     torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=clip, norm_type=2)
     opt.step()
     return loss.detach()

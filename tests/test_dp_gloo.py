@@ -64,3 +64,28 @@ def test_two_rank_gradient_average_equals_full_batch_gradient():
     ((m(x) - y) ** 2).mean().backward()
     ref = torch.cat([p.grad.flatten() for p in m.parameters()]).numpy()
     assert np.allclose(got, ref, rtol=1e-5, atol=1e-7)
+
+
+def test_grads_as_flat_is_zero_copy_for_a_backward_that_writes_one_buffer():
+    """be_hip.dp.grads_as_flat: views into one buffer in parameter order come back as that buffer (what the HIP backward
+    produces); separately allocated gradients fall back to the copy into the flat buffer."""
+    from be_hip import dp
+    ps = [torch.nn.Parameter(torch.zeros(2, 3)), torch.nn.Parameter(torch.zeros(4)), torch.nn.Parameter(torch.zeros(5, 1))]
+    buf = torch.arange(20, dtype=torch.float32)
+    off = 3                                             # the buffer may start anywhere in its storage
+    for p in ps:
+        p.grad = buf[off:off + p.numel()].view_as(p)
+        off += p.numel()
+    flat = dp.grads_as_flat(ps)
+    assert flat.data_ptr() == buf[3:].data_ptr() and flat.numel() == 15 and torch.equal(flat, buf[3:18])
+    flat.mul_(2)                                        # the all-reduce works in place on the gradients themselves
+    assert torch.equal(ps[1].grad, buf[9:13]) and float(ps[1].grad[0]) == 18.0
+    # gradients allocated one by one: copied into the fallback buffer and re-pointed at it
+    for i, p in enumerate(ps):
+        p.grad = torch.full_like(p, float(i + 1))
+    fb = dp.flat_grad_buffer(ps)
+    for i, p in enumerate(ps):
+        p.grad = torch.full_like(p, float(i + 1))
+    got = dp.grads_as_flat(ps, fb)
+    assert got.data_ptr() == fb.data_ptr() and torch.equal(got, torch.tensor([1.0] * 6 + [2.0] * 4 + [3.0] * 5))
+    assert ps[2].grad.data_ptr() == fb[10:].data_ptr()

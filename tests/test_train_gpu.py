@@ -71,6 +71,30 @@ def test_training_loss_curve_matches_oracle_for_the_first_steps():
     assert all(np.isfinite(hip))
 
 
+def test_backward_leaves_the_gradients_as_one_flat_buffer_in_parameter_order():
+    """be_hip.train.backward_train writes every gradient into one buffer; autograd keeps the views as .grad, so the
+    data-parallel all-reduce (be_hip.dp.grads_as_flat) needs no per-parameter copy: 7 254 122 floats, zero-copy."""
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a GPU")
+    import models, utils
+    from be_hip import dp, train_local
+    args = utils.get_args("local_train", argv=[])
+    model = models.LocalStage().to(DEV)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.local_stage_state_dict().items()})
+    helper = utils.PostProcessLocalBase(args, DEV)
+    opt = torch.optim.AdamW(model.parameters(), lr=args.learning_rate)
+    model.train()
+    b = {k: torch.from_numpy(v).to(DEV) for k, v in synth.synthetic_training_patches(64, seed=5).items()}
+    train_local.train_step(model, helper, opt, b, args.beta_bndry_loc, args.beta_smthns)
+    params = list(model.parameters())
+    flat = dp.grads_as_flat(params)                      # raises if it would have to copy
+    assert flat.numel() == sum(p.numel() for p in params) == 7254122
+    off = 0
+    for p in params:
+        assert p.grad.data_ptr() == flat[off:].data_ptr() and torch.isfinite(p.grad).all()
+        off += p.numel()
+
+
 def test_global_loss_value_and_gradient_vs_fp64_golden():
     """be_global_loss_f32 (+ records / fold / Sobel of the current global image) against the reference's GlobalLoss
     under autograd, batch 1, final gammas (G11)."""
