@@ -9,6 +9,13 @@ from __future__ import annotations
 import torch
 
 
+def fused_adamw():
+    """`fused=` argument for torch.optim.AdamW in the training loops: the single-kernel implementation (the default foreach
+    one is eight multi-tensor launches per step: 0.4 ms of a 3.1 ms LocalStage step).  BE_FUSED_ADAMW=0: torch's default."""
+    import os
+    return True if os.environ.get("BE_FUSED_ADAMW", "1") != "0" else None
+
+
 def flat_grad_buffer(params):
     """One contiguous fp32 buffer holding every .grad (allocated once; grads become views into it)."""
     params = [p for p in params if p.requires_grad]

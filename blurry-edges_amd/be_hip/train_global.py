@@ -110,7 +110,7 @@ def main(argv=None):
     for p in model.parameters():
         if p.dim() > 1:
             torch.nn.init.xavier_normal_(p)
-    opt = torch.optim.AdamW(model.parameters(), lr=a.lr)
+    opt = torch.optim.AdamW(model.parameters(), lr=a.lr, fused=dp.fused_adamw())
     flat = dp.flat_grad_buffer(model.parameters()) if world > 1 else None
     sched = GammaSchedule(args)
     gamma = sched.final()

@@ -101,7 +101,7 @@ def main(argv=None):
     model = models.LocalStage().to(dev)
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)).to(dev) for k, v in synth.local_stage_state_dict().items()})
     helper = utils.PostProcessLocalBase(args, dev)
-    opt = torch.optim.AdamW(model.parameters(), lr=a.lr, capturable=a.graph)
+    opt = torch.optim.AdamW(model.parameters(), lr=a.lr, capturable=a.graph, fused=dp.fused_adamw())
     flat = dp.flat_grad_buffer(model.parameters()) if world > 1 else None
     data = {k: torch.from_numpy(v).to(dev) for k, v in synth.synthetic_training_patches(a.patches, seed=1869 + rank).items()}
     sched = BetaSchedule(args.beta_bndry_loc, args.beta_smthns, args.dynamic_epoch)

@@ -45,6 +45,7 @@ def local_train(args, quiet=False, graph=True):
     """graph: replay the training step as a hipGraph (train_local.GraphedStep); batches are gathered on the device
     (data.ShapeDataset.batches) instead of sample by sample."""
     import data, models, utils
+    from . import dp
     from .train_local import BetaSchedule, GraphedStep, train_step
     utils.set_seed(1869)
     utils.create_directory(args.log_path, overwrite=False)
@@ -54,7 +55,7 @@ def local_train(args, quiet=False, graph=True):
     va = data.ShapeDataset(dev, data_path=args.data_path, train=False)
     model = models.LocalStage().to(dev)
     _xavier_(model)
-    opt = torch.optim.AdamW(model.parameters(), lr=args.learning_rate, capturable=graph)
+    opt = torch.optim.AdamW(model.parameters(), lr=args.learning_rate, capturable=graph, fused=dp.fused_adamw())
     helper = utils.PostProcessLocalBase(args, dev)
     gstep = GraphedStep(model, helper, opt) if graph else None
     sampler = torch.Generator().manual_seed(1869)
@@ -125,6 +126,7 @@ def global_pre(args, local_weights=None, quiet=False):
 # ------------------------------------------------------------------------------------------------ global_training.py
 def global_train(args, quiet=False):
     import data, models, utils
+    from . import dp
     from .train_global import GammaSchedule, train_step
     utils.set_seed(1898)
     utils.create_directory(args.log_path, overwrite=False)
@@ -135,7 +137,7 @@ def global_train(args, quiet=False):
     sampler = torch.Generator().manual_seed(1898)
     model = models.GlobalStage(in_parameter_size=args.input_size, out_parameter_size=args.output_size, device=dev).to(dev)
     _xavier_(model)
-    opt = torch.optim.AdamW(model.parameters(), lr=args.learning_rate)
+    opt = torch.optim.AdamW(model.parameters(), lr=args.learning_rate, fused=dp.fused_adamw())
     helper = utils.PostProcessGlobalBase(args, dev)
     dcal = utils.DepthEtas(args, dev)
     gamma = GammaSchedule(args)
