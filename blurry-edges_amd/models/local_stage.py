@@ -123,9 +123,9 @@ class LocalStage(nn.Module):
                 raise RuntimeError("LocalStage: expected a tensor on the GPU; the HIP path has no CPU fallback")
             out = LocalStageTrainFn.apply(x, *self._tensor_list())
             self._packed_key = None          # running statistics changed under the packed (BN-folded) weights
-            for m in self.modules():
-                if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):
-                    m.num_batches_tracked += 1
+            # one multi-tensor launch for the 14 counters (a `+= 1` each was 14 launches of a 270-launch step)
+            torch._foreach_add_([m.num_batches_tracked for m in self.modules()
+                                 if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d))], 1)
             return out
         x = x.to(torch.float32).contiguous()
         native.check(native.lib().be_local_stage_set_winograd(int(bool(self.winograd))), "be_local_stage_set_winograd")
