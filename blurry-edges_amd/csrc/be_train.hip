@@ -352,8 +352,10 @@ inline unsigned cap_grid(int64_t total, int block, int64_t cap = 4096) {
 inline int pick_splits(int M, int col_blocks, int max_splits) {
     // enough blocks to cover the chip (~512) without making slices shorter than 32 rows; the finalize kernels walk
     // the splits with one wave per channel (fixed-order butterfly)
-    if (max_splits > 128) max_splits = 128;
-    int s = (512 + col_blocks - 1) / col_blocks;
+    // (narrow matrices - conv1's 64 channels are ONE column block over 28 224 rows - need many short slices: with 128 the
+    // reduction was 128 workgroups walking 55 dependent steps each, 55 us for 7 MB)
+    if (max_splits > 512) max_splits = 512;
+    int s = (1024 + col_blocks - 1) / col_blocks;
     const int by_rows = (M + 31) / 32;
     if (s > by_rows) s = by_rows;
     if (s > max_splits) s = max_splits;
@@ -371,7 +373,7 @@ extern "C" int be_bn_train_fwd_f32(const float* y, const float* gamma, const flo
     BE_REQUIRE(y && gamma && beta && mean && invstd && out && scratch, "be_bn_train_fwd_f32: null pointer");
     BE_REQUIRE(M > 0 && C > 0, "be_bn_train_fwd_f32: empty");
     const int cb = (C + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK;
-    const int S = pick_splits(M, cb, 256);
+    const int S = pick_splits(M, cb, 512);
     BE_REQUIRE((size_t)S * C * 2 * sizeof(double) <= scratch_bytes, "be_bn_train_fwd_f32: scratch too small");
     hipStream_t s = be::as_stream(stream);
     ColArgs a{y, nullptr, nullptr, nullptr, nullptr, nullptr, static_cast<double*>(scratch), M, C, (M + S - 1) / S};
@@ -390,7 +392,7 @@ extern "C" int be_bn_train_bwd_f32(const float* dout, const float* s_in, const f
     BE_REQUIRE(dout && y && mean && invstd && gamma && ds && dy && dgamma && dbeta && scratch, "be_bn_train_bwd_f32: null pointer");
     BE_REQUIRE(M > 0 && C > 0, "be_bn_train_bwd_f32: empty");
     const int cb = (C + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK;
-    const int S = pick_splits(M, cb, 256);
+    const int S = pick_splits(M, cb, 512);
     BE_REQUIRE((size_t)S * C * 2 * sizeof(double) <= scratch_bytes, "be_bn_train_bwd_f32: scratch too small");
     hipStream_t s = be::as_stream(stream);
     ColArgs a{y, dout, s_in, mean, invstd, ds, static_cast<double*>(scratch), M, C, (M + S - 1) / S};
@@ -406,7 +408,7 @@ extern "C" int be_bn_train_bwd_f32(const float* dout, const float* s_in, const f
 extern "C" int be_col_sum_f32(const float* a, float* out, int M, int C, void* scratch, size_t scratch_bytes, void* stream) {
     BE_REQUIRE(a && out && scratch && M > 0 && C > 0, "be_col_sum_f32: bad arguments");
     const int cb = (C + COLS_PER_BLOCK - 1) / COLS_PER_BLOCK;
-    const int S = pick_splits(M, cb, 256);
+    const int S = pick_splits(M, cb, 512);
     BE_REQUIRE((size_t)S * C * sizeof(double) <= scratch_bytes, "be_col_sum_f32: scratch too small");
     hipStream_t s = be::as_stream(stream);
     hipLaunchKernelGGL(k_col_sum, dim3(cb, S), dim3(256), 0, s, a, static_cast<double*>(scratch), M, C, (M + S - 1) / S);
