@@ -19,6 +19,14 @@ NPIX = 441
 NTENSORS = 86
 
 
+class PackJob(C.Structure):
+    """be_pack_job (include/blurry_edges_hip.h): one be_conv_pack_f32 / be_conv_pack_dgrad_f32 call of a job table."""
+    _fields_ = [("weight", C.c_void_p), ("bias", C.c_void_p), ("bn_gamma", C.c_void_p), ("bn_beta", C.c_void_p),
+                ("bn_mean", C.c_void_p), ("bn_var", C.c_void_p), ("packed_w", C.c_void_p), ("packed_bias", C.c_void_p),
+                ("bn_eps", C.c_float), ("cout", C.c_int), ("cin", C.c_int), ("ksize", C.c_int), ("layout_chw_hw", C.c_int),
+                ("dgrad", C.c_int)]
+
+
 class DepthConsts(C.Structure):
     _fields_ = [(n, C.c_float) for n in
                 ("s", "numerator", "den_const", "k", "k2", "intercept", "sin_w", "cos_w", "sin_m", "cos_m")]
@@ -61,6 +69,7 @@ _SIGNATURES = {
     "be_view_to_nhwc4_f32": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, _P]),
     "be_conv_packed_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "be_conv_pack_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "be_conv_pack_jobs_f32": (C.c_int, [_P, C.c_int, _P]),
     "be_conv_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, C.c_int, _P]),
     "be_conv_nhwc_splitk_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, C.c_int, _P, C.c_size_t, _P]),
     "be_conv_nhwc_batched_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, _P]),

@@ -39,9 +39,53 @@ def _new(shape, dev):
     return torch.empty(shape, dtype=torch.float32, device=dev)
 
 
-def _conv_fwd(x, w, b, cout, ks, chw_hw=0):
-    """plain conv / linear + bias (no BatchNorm fold): x NHWC -> y NHWC."""
-    pw, pb = native.conv_pack(w, b, bn=None, chw_hw=chw_hw)
+class _Packs:
+    """Packed weights of every unit for one training step - forward form and data-gradient form - written by ONE launch
+    (be_conv_pack_jobs_f32) at the top of the forward; buffers and the device job table are built once per parameter set."""
+    cache = {}
+
+    def __init__(self, t):
+        dev = t[0].device
+        units = [(6 * i, CONVS[i][1], CONVS[i][2], CONVS[i][3], 0) for i in range(13)] + [(78, 1024, 2304, 1, 9), (84, 10, 1024, 1, 0)]
+        self.fwd, self.dg, self.keep = {}, {}, [v for v in t]
+        jobs = []
+        for wi, cout, cin, ks, chw in units:
+            cin_k = 3 if ks == 7 else cin                               # conv1's weight has 3 input channels
+            nfl = lib().be_conv_packed_floats(cout, cin_k, ks)
+            pw, pb = _new(nfl, dev), _new((cout + 31) // 32 * 32, dev)
+            self.fwd[wi] = (pw, pb)
+            jobs.append(native.PackJob(dptr(t[wi]), dptr(t[wi + 1]), None, None, None, None, dptr(pw), dptr(pb), 0.0,
+                                       cout, cin_k, ks, chw, 0))
+            if ks != 7 and wi != 84:                                    # conv1 needs no input gradient; fc.4 has its own kernel
+                nd = lib().be_conv_dgrad_packed_floats(cout, cin, ks)
+                dw, db = _new(nd, dev), _new((cin + 31) // 32 * 32, dev)
+                self.dg[wi] = (dw, db)
+                jobs.append(native.PackJob(dptr(t[wi]), None, None, None, None, None, dptr(dw), dptr(db), 0.0, cout, cin, ks, chw, 1))
+        arr = (native.PackJob * len(jobs))(*jobs)
+        self.njobs = len(jobs)
+        self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+
+    @classmethod
+    def get(cls, t):
+        key = tuple(v.data_ptr() for v in t)
+        p = cls.cache.get(key)
+        if p is None:
+            for v in t:
+                if not v.is_contiguous():
+                    raise RuntimeError("LocalStage training: parameters must be contiguous")
+            cls.cache.clear()                                           # one model at a time keeps its buffers
+            p = cls.cache[key] = cls(t)
+        return p
+
+    def pack(self):
+        dev = self.table.device
+        check(lib().be_conv_pack_jobs_f32(dptr(self.table, "job table", (torch.uint8,)), self.njobs, stream_ptr(dev)),
+              "be_conv_pack_jobs_f32")
+
+
+def _conv_fwd(x, packs, wi, cout, ks):
+    """plain conv / linear + bias (no BatchNorm fold) with the step's packed weights: x NHWC -> y NHWC."""
+    pw, pb = packs.fwd[wi]
     return native.conv_nhwc(x, pw, pb, cout, ks, act=0, scratch=_Scratch.get(x.device))
 
 
@@ -90,15 +134,10 @@ def _wgrad(x, dy, w_shape, ks, chw_hw=0, out=None):
     return dw
 
 
-def _dgrad(dy, w, cin, ks, chw_hw=0):
-    """dy NHWC [.., cout] -> dx NHWC [.., cin] through the transposed / mirrored pack."""
-    cout = w.shape[0]
-    dev = dy.device
-    pw = _new(lib().be_conv_dgrad_packed_floats(cout, cin, ks), dev)
-    pb = _new((cin + 31) // 32 * 32, dev)
-    check(lib().be_conv_pack_dgrad_f32(dptr(w.contiguous()), cout, cin, ks, chw_hw, dptr(pw), dptr(pb), stream_ptr(dev)),
-          "be_conv_pack_dgrad_f32")
-    return native.conv_nhwc(dy, pw, pb, cin, ks, act=0, scratch=_Scratch.get(dev))
+def _dgrad(dy, packs, wi, cin, ks):
+    """dy NHWC [.., cout] -> dx NHWC [.., cin] through the transposed / mirrored pack of the step."""
+    pw, pb = packs.dg[wi]
+    return native.conv_nhwc(dy, pw, pb, cin, ks, act=0, scratch=_Scratch.get(dy.device))
 
 
 def _pool_bwd(x, dout, k, stride, pad):
@@ -112,12 +151,14 @@ def _pool_bwd(x, dout, k, stride, pad):
 def forward_train(x, t):
     """x [N,3,21,21]; t = the 86 tensors (native.local_stage_pack order).  Returns (logits [N,10], saved)."""
     n = x.shape[0]
-    S = {}
+    packs = _Packs.get(t)
+    packs.pack()                                          # this step's weights, forward and data-gradient forms: one launch
+    S = {"packs": packs}
 
     def unit(name, i, xin, res=None, act=True):
         _, cout, cin, ks = CONVS[i]
         w, b, g, be_, rm, rv = t[6 * i:6 * i + 6]
-        y = _conv_fwd(xin, w, b, cout, ks)
+        y = _conv_fwd(xin, packs, 6 * i, cout, ks)
         out, saved = _bn_fwd(y, g, be_, rm, rv, res, act)
         S[name] = (xin, saved)
         return out
@@ -142,10 +183,10 @@ def forward_train(x, t):
     S["pool3"] = l3
     f_in = p3.reshape(n, 1, 1, 2304)
     w1, b1, g1, be1, rm1, rv1, w4, b4 = t[78:86]
-    y1 = _conv_fwd(f_in, w1, b1, 1024, 1, chw_hw=9)
+    y1 = _conv_fwd(f_in, packs, 78, 1024, 1)
     f1, saved1 = _bn_fwd(y1, g1, be1, rm1, rv1, None, True)
     S["fc1"] = (f_in, saved1)
-    pw4, pb4 = native.conv_pack(w4, b4)
+    pw4, pb4 = packs.fwd[84]
     out = native.conv_nhwc(f1, pw4, pb4, 10, 1, act=0).reshape(n, 10)
     S["fc4"] = f1
     return out, S
@@ -179,7 +220,8 @@ def backward_train(dlogits, t, S):
     ds, dy, _, _ = _bn_bwd(dx.reshape(n, 1, 1, 1024), saved1, g1, grads[80], grads[81])
     _wgrad(f_in, dy, tuple(w1.shape), 1, chw_hw=9, out=grads[78])
     _col_sum(dy, out=grads[79])
-    d = _dgrad(dy, w1, 2304, 1, chw_hw=9).reshape(n, 3, 3, 256)
+    packs = S["packs"]
+    d = _dgrad(dy, packs, 78, 2304, 1).reshape(n, 3, 3, 256)
     d = _pool_bwd(S["pool3"], d, 2, 2, 0)
 
     def unit_bwd(name, i, dout, need_dx=True):
@@ -190,7 +232,7 @@ def backward_train(dlogits, t, S):
         ds_, dy_, _, _ = _bn_bwd(dout, saved, g, grads[6 * i + 2], grads[6 * i + 3])
         _wgrad(xin, dy_, tuple(w.shape), ks, out=grads[6 * i])
         _col_sum(dy_, out=grads[6 * i + 1])
-        dxi = _dgrad(dy_, w, cin, ks) if need_dx else None
+        dxi = _dgrad(dy_, packs, 6 * i, cin, ks) if need_dx else None
         return ds_, dxi
 
     def block_bwd(tag, base, dout):

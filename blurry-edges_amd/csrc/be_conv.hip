@@ -657,7 +657,7 @@ struct PackArgs {
     int dgrad;      // 1: pack W^T with mirrored taps: rows = input channels, K = (cout chunk, tap) -> data-gradient conv
 };
 
-__global__ void k_pack(PackArgs p) {
+__device__ __forceinline__ void pack_body(const PackArgs& p) {
     const int64_t total = (int64_t)p.cout_pad * p.ktot;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += stride) {
@@ -707,6 +707,22 @@ __global__ void k_pack(PackArgs p) {
         }
         if (p.bias_add) p.pb[co] += v; else p.pb[co] = v;
     }
+}
+
+__global__ void k_pack(PackArgs p) { pack_body(p); }
+
+// a table of pack jobs in ONE launch (blockIdx.y = job): a training step re-packs every layer's weights for the forward
+// and for the data-gradient convolution, 28 launches of a few microseconds otherwise
+__global__ void k_pack_jobs(const be_pack_job* __restrict__ jobs) {
+    const be_pack_job j = jobs[blockIdx.y];
+    PackArgs p;
+    p.w = j.weight; p.b = j.bias; p.gamma = j.bn_gamma; p.beta = j.bn_beta; p.mean = j.bn_mean; p.var = j.bn_var;
+    p.eps = j.bn_eps; p.cout = j.cout; p.cin = j.cin; p.ks = j.ksize; p.chw_hw = j.layout_chw_hw;
+    p.pw = j.packed_w; p.pb = j.packed_bias; p.col_off = 0; p.bias_add = 0; p.dgrad = j.dgrad;
+    if (j.dgrad) { p.cout_pad = (j.cin + 31) / 32 * 32; p.ktot = (j.cout / BK) * j.ksize * j.ksize * BK; }
+    else { p.cout_pad = (j.cout + 31) / 32 * 32; p.ktot = (j.ksize == 7 ? 7 : (j.cin / BK) * j.ksize * j.ksize) * BK; }
+    p.row_stride = p.ktot;
+    pack_body(p);
 }
 
 // ------------------------------------------------------------------------------------------- pooling / layout
@@ -871,6 +887,12 @@ extern "C" int be_conv_pack_dgrad_f32(const float* w, int cout, int cin, int ksi
                kt, 0, 0, 1};
     hipLaunchKernelGGL(k_pack, dim3(grid_cap((int64_t)p.cout_pad * p.ktot, 256)), dim3(256), 0, be::as_stream(stream), p);
     return be::check_launch("be_conv_pack_dgrad_f32");
+}
+
+extern "C" int be_conv_pack_jobs_f32(const be_pack_job* jobs_device, int njobs, void* stream) {
+    BE_REQUIRE(jobs_device && njobs > 0 && njobs <= 65535, "be_conv_pack_jobs_f32: bad arguments");
+    hipLaunchKernelGGL(k_pack_jobs, dim3(1024, njobs), dim3(256), 0, be::as_stream(stream), jobs_device);
+    return be::check_launch("be_conv_pack_jobs_f32");
 }
 
 // opt-in split-bf16 mode: convolutions whose packed weights lie inside [g_b3_base, g_b3_base + g_b3_plane) and that take the

@@ -253,6 +253,18 @@ size_t be_conv_packed_floats(int cout, int cin, int ksize);
 int be_conv_pack_f32(const float* weight_oihw, const float* bias, const float* bn_gamma, const float* bn_beta,
                      const float* bn_mean, const float* bn_var, float bn_eps, int cout, int cin, int ksize,
                      int layout_chw_hw, float* packed_w, float* packed_bias, void* stream);
+/* A table of pack jobs in ONE launch: job i = be_conv_pack_f32 (dgrad = 0; BatchNorm pointers may be NULL) or
+ * be_conv_pack_dgrad_f32 (dgrad = 1: bias / BatchNorm pointers ignored) with the same argument meaning and the same
+ * preconditions (the caller checks them: the table lives in DEVICE memory and is not inspected on the host).  A training step
+ * re-packs every layer for the forward and the data-gradient convolution (local_training.py:103-106 under autograd). */
+typedef struct be_pack_job {
+    const float *weight, *bias, *bn_gamma, *bn_beta, *bn_mean, *bn_var;
+    float* packed_w;
+    float* packed_bias;
+    float bn_eps;
+    int cout, cin, ksize, layout_chw_hw, dgrad;
+} be_pack_job;
+int be_conv_pack_jobs_f32(const be_pack_job* jobs_device, int njobs, void* stream);
 /* y[n,h,w,cout] = act(conv(x) + bias (+ residual)); residual may be NULL; ldy = row stride of y in floats. */
 int be_conv_nhwc_f32(const be_conv_desc* desc_host, const float* x, const float* packed_w,
                      const float* packed_bias, const float* residual, float* y, int ldy, void* stream);
