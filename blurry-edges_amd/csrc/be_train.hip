@@ -349,13 +349,13 @@ inline unsigned cap_grid(int64_t total, int block, int64_t cap = 4096) {
     return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
 }
 
-inline int pick_splits(int M, int col_blocks, int max_splits) {
+inline int pick_splits(int M, int col_blocks, int max_splits, int target_blocks = 1024) {
     // enough blocks to cover the chip (~512) without making slices shorter than 32 rows; the finalize kernels walk
     // the splits with one wave per channel (fixed-order butterfly)
     // (narrow matrices - conv1's 64 channels are ONE column block over 28 224 rows - need many short slices: with 128 the
     // reduction was 128 workgroups walking 55 dependent steps each, 55 us for 7 MB)
     if (max_splits > 512) max_splits = 512;
-    int s = (1024 + col_blocks - 1) / col_blocks;
+    int s = (target_blocks + col_blocks - 1) / col_blocks;
     const int by_rows = (M + 31) / 32;
     if (s > by_rows) s = by_rows;
     if (s > max_splits) s = max_splits;
@@ -450,7 +450,7 @@ extern "C" int be_conv_wgrad_f32(const float* x, const float* dy, float* dw, int
     const int taps = ksize * ksize;
     const int ct = (cout + 63) / 64, it = (cin + 63) / 64;
     const int64_t wsize = (int64_t)cout * cin * taps;
-    int S = pick_splits(M, ct * it * taps, 64);
+    int S = pick_splits(M, ct * it * taps, 64, 512);       // every split is another full copy of dW to sum
     while (S > 1 && (size_t)S * wsize * sizeof(float) > scratch_bytes) --S;
     BE_REQUIRE((size_t)S * wsize * sizeof(float) <= scratch_bytes, "be_conv_wgrad_f32: scratch too small");
     int rows = (M + S - 1) / S; rows = (rows + 31) / 32 * 32;
