@@ -237,8 +237,22 @@ void k_wgrad(WgradArgs a) {
             if (m < m_end) {
                 if (a_col_ok) a_st[i] = *reinterpret_cast<const f32x4*>(a.dy + (size_t)m * a.Cout + co0 + 4 * q);
                 const int pp = m % a.HW, yy = pp / a.W + tdy, xx = pp % a.W + tdx;
-                if (b_col_ok && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W)
-                    b_st[i] = *reinterpret_cast<const f32x4*>(a.x + ((int64_t)m + tdy * a.W + tdx) * a.Cin + ci0 + 4 * q);
+                if (b_col_ok && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) {
+                    const float* xr = a.x + ((int64_t)m + tdy * a.W + tdx) * a.Cin;
+                    if (a.chw_hw > 0) {
+                        // fc.1: the tile's columns run in the REFERENCE's (C,H,W) feature order so that dW is stored in
+                        // contiguous runs; our (H,W,C) activations are gathered instead (64 rows: nothing).  Column j =
+                        // c*HW + hw of the reference is our column hw*(Cin/HW) + c.
+                        const int cpl = a.Cin / a.chw_hw;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int j = ci0 + 4 * q + e;
+                            b_st[i][e] = xr[(j % a.chw_hw) * cpl + j / a.chw_hw];
+                        }
+                    } else {
+                        b_st[i] = *reinterpret_cast<const f32x4*>(xr + ci0 + 4 * q);
+                    }
+                }
             }
         }
     };
@@ -267,8 +281,7 @@ void k_wgrad(WgradArgs a) {
     float* out = a.partial + (size_t)blockIdx.z * a.Cout * a.Cin * taps;
     const int ci = ci0 + wn * 32 + li;
     if (ci < a.Cin) {
-        // features flattened from (C,H,W) in the reference, (H,W,C) here (fc.1): map our column back
-        const int ci_ref = a.chw_hw > 0 ? (ci % (a.Cin / a.chw_hw)) * a.chw_hw + ci / (a.Cin / a.chw_hw) : ci;
+        const int ci_ref = ci;       // (fc.1: the columns already run in the reference's order, see the gather above)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
@@ -296,10 +309,8 @@ __global__ void k_wgrad_conv1(const float* __restrict__ x4, const float* __restr
     if (e >= total) return;
     const int co = e % Cout, rest = e / Cout;
     const int ci = rest % 3, t = rest / 3, kh = t / 7, kw = t % 7;
-    // grid slice = (group of whole images, third of the rows): enough slices in flight for this latency-bound loop
-    const int yseg = blockIdx.y % 3, rows3 = (H + 2) / 3;
-    const int n0 = (blockIdx.y / 3) * imgs_per_split, n1 = min(N, n0 + imgs_per_split);
-    const int y_lo = max(max(0, 3 - kh), yseg * rows3), y_hi = min(min(H, H + 3 - kh), (yseg + 1) * rows3);   // rows with tap kh inside
+    const int n0 = blockIdx.y * imgs_per_split, n1 = min(N, n0 + imgs_per_split);
+    const int y_lo = max(0, 3 - kh), y_hi = min(H, H + 3 - kh);   // output rows whose tap (kh) falls inside the image
     const int x_lo = max(0, 3 - kw), x_hi = min(W, W + 3 - kw);
     // seven independent partial sums per row: the fourteen loads of a step are in flight together (a single running sum
     // made every step wait for its two loads: 182 us for 0.5 GFLOP); fixed order -> bitwise reproducible
@@ -435,8 +446,8 @@ extern "C" int be_conv_wgrad_f32(const float* x, const float* dy, float* dw, int
     if (ksize == 7) {
         BE_REQUIRE(cin == 4, "be_conv_wgrad_f32: ksize 7 takes the NHWC4 input (cin = 4); dW has 3 input channels");
         const int total = cout * 3 * 49;
-        const int per = (n + 63) / 64;                       // images per grid slice (<= 64 image groups x 3 row segments)
-        const int S = 3 * ((n + per - 1) / per);
+        const int per = (n + 63) / 64;                       // images per grid slice (<= 64 slices: k_sum_splits walks them serially)
+        const int S = (n + per - 1) / per;
         BE_REQUIRE((size_t)S * total * sizeof(float) <= scratch_bytes, "be_conv_wgrad_f32: scratch too small");
         hipLaunchKernelGGL(k_wgrad_conv1, dim3((total + 255) / 256, S), dim3(256), 0, s, x, dy, static_cast<float*>(scratch), n,
                            h, w, cout, per);
