@@ -95,6 +95,38 @@ def test_backward_leaves_the_gradients_as_one_flat_buffer_in_parameter_order():
         off += p.numel()
 
 
+def test_pack_job_table_equals_the_single_pack_calls():
+    """be_conv_pack_jobs_f32 (every layer's forward and data-gradient pack in one launch, what the training step uses)
+    against be_conv_pack_f32 / be_conv_pack_dgrad_f32 called one by one: bit-identical buffers."""
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a GPU")
+    import ctypes as C
+    import models
+    from be_hip import native, train
+    from be_hip.native import check, dptr, lib, stream_ptr
+    model = models.LocalStage().to(DEV)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.local_stage_state_dict().items()})
+    t = [v.detach() for v in model._tensor_list()]
+    packs = train._Packs.get(t)
+    packs.pack()
+    torch.cuda.synchronize()
+    assert packs.njobs == 28
+    for wi, (pw, pb) in packs.fwd.items():
+        chw = 9 if wi == 78 else 0
+        rw, rb = native.conv_pack(t[wi], t[wi + 1], bn=None, chw_hw=chw)
+        assert torch.equal(pw, rw) and torch.equal(pb, rb), wi
+    for wi, (dw, db) in packs.dg.items():
+        w = t[wi]
+        cout, cin = w.shape[0], w.shape[1]
+        ks = w.shape[2] if w.dim() == 4 else 1
+        chw = 9 if wi == 78 else 0
+        rw = torch.empty_like(dw)
+        rb = torch.empty_like(db)
+        check(lib().be_conv_pack_dgrad_f32(dptr(w.contiguous()), cout, cin, ks, chw, dptr(rw), dptr(rb), stream_ptr(w.device)),
+              "be_conv_pack_dgrad_f32")
+        assert torch.equal(dw, rw) and torch.equal(db, rb), wi
+
+
 def test_global_loss_value_and_gradient_vs_fp64_golden():
     """be_global_loss_f32 (+ records / fold / Sobel of the current global image) against the reference's GlobalLoss
     under autograd, batch 1, final gammas (G11)."""
