@@ -467,7 +467,7 @@ def local_stage_forward_view(packed, view, patches_per_image: int, n: int, devic
 KERNEL_NAMES = {0: "k_conv_igemm<2,2,2,2,TAPS> (128x128)", 1: "k_conv_igemm<4,1,1,3,TAPS> (128x96)",
                 2: "k_conv_igemm<4,1,1,2,TAPS> (128x64)", 3: "k_conv_igemm<4,1,1,1,TAPS> (128x32)",
                 4: "k_conv_igemm<4,1,1,2,ROW8> (conv1)", 5: "k_conv_igemm small-M tiles (64x64 / 128x32)",
-                6: "k_wino_gemm (128x128 tiles, 25 Winograd transform-domain GEMMs per launch)",
+                6: "k_wino_gemm_ws / k_wino_gemm (128x128 tiles, the 25 Winograd transform-domain GEMMs of a layer per launch; weight-stationary form for K = 96 / 256 / 384 and full tiles)",
                 7: "k_wino_gemm as a row GEMM (1x1 convolutions / linears of large batches)"}
 
 

@@ -489,6 +489,161 @@ void k_wino_gemm(GemmArgs a) {
 #undef WG_LOAD
 }
 
+// ---- weight-stationary form of the same GEMMs (large batches, K = 96 / 256 / 384) ------------------------------------------
+// A workgroup owns ONE (problem z, N tile), keeps that B tile [128 cols][K] in REGISTERS (K fragment registers per lane: 384
+// at K = 384, so one wave per SIMD) and walks a range of M tiles streaming only A: half the DMA pieces and half the fragment
+// reads per MFMA of k_wino_gemm.  The issue model of DESIGN 3.1d prices the loop at 2048 / (2048 + 64 + 120 + 60) = 89 %; with
+// one wave per SIMD every latency has to be hidden inside the wave: three LDS buffers for A, DMA two chunks ahead, the
+// fragments of chunk s+1 read while the MFMAs of chunk s run, one raw barrier per chunk, counted vmcnt (a tile's 64 stores
+// sit between the DMA and its wait: "all but the newest 63").  Same order of operations per output element as k_wino_gemm:
+// bit-identical.  Measured (tools/wino_gemm_lab.hip, weight_stationary_run13.log): +3...5 % over k_wino_gemm.
+template <int KCH>
+__global__ __launch_bounds__(256, 1)
+void k_wino_gemm_ws(GemmArgs a, int mgroups) {
+    constexpr int BM = 128, BKT = 16, ABUF = BM * BKT;     // floats per A stage (8 KB)
+    extern __shared__ __attribute__((aligned(16))) float smem_w[];
+    const int bid = blockIdx.x;
+    const int mg = bid % mgroups, pair = bid / mgroups;    // the N tiles of a (z, M range) are neighbours: they share A in L2
+    const int z = pair / a.n_tiles, n_tile = pair % a.n_tiles;
+    const int tiles_per = (a.m_tiles + mgroups - 1) / mgroups;
+    const int t0 = mg * tiles_per, t1 = min(a.m_tiles, t0 + tiles_per);
+    if (z >= a.nb || t0 >= t1) return;
+    const int n0 = n_tile * 128;
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int srow = lane >> 2, sq = (lane & 3) ^ ((lane >> 4) & 3);
+    const int fsw = (li >> 2) & 3;
+    const int fr0 = li * BKT + 4 * (lh ^ fsw), fr1 = li * BKT + 4 * ((lh + 2) ^ fsw);
+    // ---- B tile -> registers, chunk by chunk through LDS (two buffers, plain barriers: once per workgroup)
+    f32x4 breg[KCH][2][2];
+    {
+        const float* wt = a.w + (int64_t)z * a.wb + (int64_t)n0 * a.K;
+        unsigned b_off[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) b_off[p] = (unsigned)(((2 * wave + p) * 16 + srow) * a.K + 4 * sq) * 4u;
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+            float* st = smem_w + (c & 1) * ABUF;
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(reinterpret_cast<const char*>(wt + c * BKT) + b_off[p]),
+                                                 (lds_ptr_t)(st + (2 * wave + p) * 256), 16, 0, 0);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                breg[c][0][j] = *reinterpret_cast<const f32x4*>(st + (wn * 64 + j * 32) * BKT + fr0);
+                breg[c][1][j] = *reinterpret_cast<const f32x4*>(st + (wn * 64 + j * 32) * BKT + fr1);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- stream A over the M tiles [t0, t1): flat step s = (tile, chunk); every tile is full (the launcher checks M % 128 == 0)
+    unsigned a_off[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) a_off[p] = (unsigned)(((2 * wave + p) * 16 + srow) * a.lda + 4 * sq) * 4u;
+    const float* xz = a.x + (int64_t)z * a.xb;
+    int l_tile = t0, l_c = 0, l_buf = 0;                   // next DMA: (tile, chunk) into ring slot l_buf
+#define WS_DMA()                                                                                                \
+    do {                                                                                                        \
+        const int lt_ = l_tile < t1 ? l_tile : t1 - 1;                       /* past the end: a harmless re-read */  \
+        const char* xs_ = reinterpret_cast<const char*>(xz + (int64_t)lt_ * BM * a.lda + l_c * BKT);            \
+        float* st_ = smem_w + l_buf * ABUF + (2 * wave) * 256;                                                  \
+        _Pragma("unroll") for (int p_ = 0; p_ < 2; ++p_)                                                        \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(xs_ + a_off[p_]), (lds_ptr_t)(st_ + p_ * 256), 16, 0, 0); \
+        if (++l_c == KCH) { l_c = 0; ++l_tile; }                                                                \
+        l_buf = l_buf == 2 ? 0 : l_buf + 1;                                                                     \
+    } while (0)
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    f32x4 fa[2][2][2];                                     // [set][g][i]: the fragments of step s and of step s + 1
+    WS_DMA();                                              // step 0
+    WS_DMA();                                              // step 1
+    __builtin_amdgcn_s_waitcnt(0x0F72);                    // vmcnt(2): step 0 has landed
+    __builtin_amdgcn_s_barrier();
+    int r_buf = 0;                                         // ring slot whose fragments are read next
+#define WS_READ(SET)                                                                                            \
+    do {                                                                                                        \
+        const float* sb_ = smem_w + r_buf * ABUF + (wm * 64) * BKT;                                             \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                      \
+            fa[SET][0][i_] = *reinterpret_cast<const f32x4*>(sb_ + i_ * 32 * BKT + fr0);                        \
+            fa[SET][1][i_] = *reinterpret_cast<const f32x4*>(sb_ + i_ * 32 * BKT + fr1);                        \
+        }                                                                                                       \
+        r_buf = r_buf == 2 ? 0 : r_buf + 1;                                                                     \
+    } while (0)
+    WS_READ(0);
+    const unsigned y_off = (unsigned)((wm * 64 + 4 * lh) * a.ldy + wn * 64 + li) * 4u;
+    for (int t = t0; t < t1; ++t) {
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+            // the DMA of the NEXT step (issued one step ago) has to land before its fragments are read below; behind the 64
+            // stores of a finished tile that is vmcnt(63) (memory operations retire in issue order), otherwise vmcnt(0)
+            if (c == 0 && t != t0) __builtin_amdgcn_s_waitcnt(0xCF7F); else __builtin_amdgcn_s_waitcnt(0x0F70);
+            __builtin_amdgcn_s_barrier();                  // every wave's pieces of step + 1 are in LDS; slot (step + 2) % 3 is free
+            WS_DMA();                                      // step + 2
+            __builtin_amdgcn_sched_barrier(0);
+            WS_READ((c + 1) & 1);                          // fragments of step + 1 (KCH is even: the parity is static)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c & 1][g][i].x, breg[c][g][j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c & 1][g][i].y, breg[c][g][j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c & 1][g][i].z, breg[c][g][j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c & 1][g][i].w, breg[c][g][j].w, acc[i][j], 0, 0, 0);
+                    }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        char* yt = reinterpret_cast<char*>(a.y + (int64_t)z * a.yb + (int64_t)t * BM * a.ldy + n0);   // uniform; full tile, N % 128 == 0
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ro = i * 32 + (r & 3) + 8 * (r >> 2);
+                float* yr = reinterpret_cast<float*>(yt + (size_t)ro * a.ldy * 4 + y_off);
+                yr[0] = acc[i][0][r];
+                yr[32] = acc[i][1][r];
+                acc[i][0][r] = 0.0f; acc[i][1][r] = 0.0f;
+            }
+    }
+#undef WS_DMA
+#undef WS_READ
+}
+
+template <int KCH>
+int launch_ws(const GemmArgs& g, hipStream_t s, int64_t n, int cin, int cout) {
+    constexpr size_t lds = (size_t)3 * 128 * 16 * sizeof(float);
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+            cus = 256;
+    }
+    // about R rounds of one workgroup per CU (the kernel takes the whole register file of a CU)
+    const int pairs = g.nb * g.n_tiles;
+    int rounds = (int)((pairs + cus - 1) / cus);
+    while ((rounds * cus) / pairs < 8 && (int64_t)g.m_tiles * pairs > (int64_t)8 * rounds * cus) ++rounds;    // >= 8 M groups when there is work
+    int mgroups = rounds * cus / pairs;
+    if (mgroups < 1) mgroups = 1;
+    if (mgroups > g.m_tiles / 4) mgroups = g.m_tiles / 4 > 0 ? g.m_tiles / 4 : 1;     // >= 4 tiles per register fill
+    const unsigned grid = (unsigned)(pairs * mgroups);
+    {
+        be::ProfileScope prof(s, BE_KERNEL_WINO_GEMM, 25.0 * 2.0 * 4 * n * cin * cout,
+                              25.0 * 4.0 * (4.0 * n * cin + (double)cin * cout + 4.0 * n * cout),
+                              25.0 * 2.0 * g.m_tiles * g.n_tiles * 128.0 * 128.0 * cin);
+        hipLaunchKernelGGL(k_wino_gemm_ws<KCH>, dim3(grid), dim3(256), lds, s, g, mgroups);
+    }
+    return be::check_launch("be_wino_conv3x3_6x6_f32(gemm, weight-stationary)");
+}
+
 }  // namespace
 
 extern "C" size_t be_wino_packed_floats(int cout, int cin) {
@@ -536,6 +691,13 @@ int wino_gemms(const float* V, const float* packed_w, float* M, int64_t n, int c
         // tile-major V [4n][25][cin] and M [4n][25][cout]: problem z = column block z of a row
         GemmArgs g{V, packed_w, M, (int)(4 * n), cin, cout, 25 * cout, 25, (int)((4 * n + 127) / 128), cp / 128,
                    (int64_t)cin, (int64_t)cp * cin, (int64_t)cout, 25 * cin, 128, 0, nullptr, nullptr, 0};
+        // weight-stationary form: full tiles only, enough M tiles to amortise the register fill, cout a multiple of 128
+        static const bool no_ws = getenv("BE_WINO_NO_WS") != nullptr;               // A/B knob
+        if (!no_ws && (4 * n) % 128 == 0 && g.m_tiles >= 128 && cout % 128 == 0) {
+            if (cin == 96) return launch_ws<6>(g, s, n, cin, cout);
+            if (cin == 256) return launch_ws<16>(g, s, n, cin, cout);
+            if (cin == 384) return launch_ws<24>(g, s, n, cin, cout);
+        }
         const unsigned grid = (unsigned)(8 * ((g.m_tiles + 7) / 8) * g.n_tiles);
         {
             be::ProfileScope prof(s, BE_KERNEL_WINO_GEMM, 25.0 * 2.0 * 4 * n * cin * cout,

@@ -486,7 +486,7 @@ int be_datagen_crop_f64(const double* const* in6, const double* bloc, const doub
 #define BE_KERNEL_CONV_128x32       3   /* fc.4                                                                */
 #define BE_KERNEL_CONV_ROW8_128x64  4   /* conv1 (7x7 row-gather)                                              */
 #define BE_KERNEL_CONV_SMALL        5   /* 64x64 / 128x32 tiles for small M (training batches)                 */
-#define BE_KERNEL_WINO_GEMM         6   /* k_wino_gemm: the 25 transform-domain GEMMs of the Winograd layers   */
+#define BE_KERNEL_WINO_GEMM         6   /* k_wino_gemm_ws / k_wino_gemm: the 25 transform-domain GEMMs of a Winograd layer */
 #define BE_KERNEL_GEMM_ROWS         7   /* k_wino_gemm as a row GEMM: 1x1 convolutions / linears, large batches */
 int be_profile_enable(int max_launches);
 int be_profile_reset(void);

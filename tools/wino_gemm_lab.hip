@@ -19,6 +19,7 @@ struct GemmArgs {
     int M, K, N, ldy, nb, m_tiles, n_tiles;
     int64_t xb, wb, yb;
     long long* dbg;       // [2]: shader-clock cycles and 100 MHz ticks of workgroup 0
+    int mgroups;          // WS variants: M-tile groups per (problem, N tile)
 };
 
 #define CK(e) do { hipError_t e_ = (e); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); exit(1); } } while (0)
@@ -618,6 +619,139 @@ void k_wide(GemmArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// variant family WS: weight-stationary.  A workgroup owns ONE (problem z, N tile) and keeps that B tile [128 cols][K] in
+// REGISTERS (K fragment registers per lane: 384 at K = 384, one wave per SIMD), then walks a range of M tiles streaming only
+// A: half the DMA pieces and half the fragment reads per MFMA.  The issue model prices it at 2048 / (2048 + 64 + 120 + 60) =
+// 89 %; with one wave per SIMD every latency has to be hidden inside the wave: three LDS buffers for A, DMA two chunks ahead,
+// the fragments of chunk s+1 read while the MFMAs of chunk s run, one raw barrier per chunk, counted vmcnt.
+template <int KCH>
+__global__ __launch_bounds__(256, 1)
+void k_ws(GemmArgs a) {
+    const int mgroups = a.mgroups;
+    constexpr int BM = 128, BKT = 16, ABUF = BM * BKT;     // floats per A stage (8 KB)
+    extern __shared__ __attribute__((aligned(16))) float smem_w[];
+    const int bid = blockIdx.x;
+    const int mg = bid % mgroups, pair = bid / mgroups;
+    const int z = pair / a.n_tiles, n_tile = pair % a.n_tiles;
+    if (z >= a.nb) return;
+    const int tiles_per = (a.m_tiles + mgroups - 1) / mgroups;
+    const int t0 = mg * tiles_per, t1 = min(a.m_tiles, t0 + tiles_per);
+    if (t0 >= t1) return;
+    const int n0 = n_tile * 128;
+    const int tid = threadIdx.x;
+    long long tc0 = 0, tw0 = 0;
+    if (bid == 0 && tid == 0) { tc0 = clock64(); tw0 = wall_clock64(); }
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, lh = lane >> 5;
+    const int srow = lane >> 2, sq = (lane & 3) ^ ((lane >> 4) & 3);
+    const int fsw = (li >> 2) & 3;
+    const int fr0 = li * BKT + 4 * (lh ^ fsw), fr1 = li * BKT + 4 * ((lh + 2) ^ fsw);
+    // ---- B tile -> registers, chunk by chunk through LDS (buffer 0/1 alternating, plain barriers: once per workgroup)
+    f32x4 breg[KCH][2][2];
+    {
+        const float* wt = a.w + (int64_t)z * a.wb + (int64_t)n0 * a.K;
+        unsigned b_off[2];
+#pragma unroll
+        for (int p = 0; p < 2; ++p) b_off[p] = (unsigned)(((2 * wave + p) * 16 + srow) * a.K + 4 * sq) * 4u;
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+            float* st = smem_w + (c & 1) * ABUF;
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(reinterpret_cast<const char*>(wt + c * BKT) + b_off[p]),
+                                                 (lds_ptr_t)(st + (2 * wave + p) * 256), 16, 0, 0);
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                breg[c][0][j] = *reinterpret_cast<const f32x4*>(st + (wn * 64 + j * 32) * BKT + fr0);
+                breg[c][1][j] = *reinterpret_cast<const f32x4*>(st + (wn * 64 + j * 32) * BKT + fr1);
+            }
+        }
+        __syncthreads();
+    }
+    // ---- stream A over the M tiles [t0, t1): flat step s = (tile, chunk)
+    const int nsteps = (t1 - t0) * KCH;
+    unsigned a_off[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) a_off[p] = (unsigned)(((2 * wave + p) * 16 + srow) * a.K + 4 * sq) * 4u;
+    const float* xz = a.x + (int64_t)z * a.xb;
+    int l_tile = t0, l_c = 0, l_buf = 0;                   // next DMA: (tile, chunk) into ring slot l_buf
+#define WS_DMA()                                                                                                \
+    do {                                                                                                        \
+        const int lt_ = l_tile < t1 ? l_tile : t1 - 1;                       /* past the end: harmless re-read */   \
+        const char* xs_ = reinterpret_cast<const char*>(xz + (int64_t)lt_ * BM * a.K + l_c * BKT);              \
+        float* st_ = smem_w + l_buf * ABUF + (2 * wave) * 256;                                                  \
+        _Pragma("unroll") for (int p_ = 0; p_ < 2; ++p_)                                                        \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(xs_ + a_off[p_]), (lds_ptr_t)(st_ + p_ * 256), 16, 0, 0); \
+        if (++l_c == KCH) { l_c = 0; ++l_tile; }                                                                \
+        l_buf = l_buf == 2 ? 0 : l_buf + 1;                                                                     \
+    } while (0)
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+    f32x4 fa[2][2][2];                                     // [set][g][i]
+    WS_DMA();                                              // step 0
+    WS_DMA();                                              // step 1
+    __builtin_amdgcn_s_waitcnt(0x0F72);                    // vmcnt(2): step 0 has landed
+    __builtin_amdgcn_s_barrier();
+    int r_buf = 0;                                         // ring slot of the step whose fragments are read NEXT
+#define WS_READ(SET)                                                                                            \
+    do {                                                                                                        \
+        const float* sb_ = smem_w + r_buf * ABUF + (wm * 64) * BKT;                                             \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                      \
+            fa[SET][0][i_] = *reinterpret_cast<const f32x4*>(sb_ + i_ * 32 * BKT + fr0);                        \
+            fa[SET][1][i_] = *reinterpret_cast<const f32x4*>(sb_ + i_ * 32 * BKT + fr1);                        \
+        }                                                                                                       \
+        r_buf = r_buf == 2 ? 0 : r_buf + 1;                                                                     \
+    } while (0)
+    WS_READ(0);
+    const unsigned y_off = (unsigned)((wm * 64 + 4 * lh) * a.ldy + wn * 64 + li) * 4u;
+    for (int t = t0; t < t1; ++t) {
+#pragma unroll
+        for (int c = 0; c < KCH; ++c) {
+            // the DMA of the NEXT step (issued one step ago) must have landed before its fragments are read below;
+            // behind a tile's 64 stores that is "all but the newest 63"
+            if (c == 0 && t != t0) __builtin_amdgcn_s_waitcnt(0xCF7F); else __builtin_amdgcn_s_waitcnt(0x0F70);
+            __builtin_amdgcn_s_barrier();
+            WS_DMA();                                      // step + 2
+            __builtin_amdgcn_sched_barrier(0);
+            WS_READ((c + 1) & 1);                          // fragments of step + 1 (KCH is even: the parity is static)
+#pragma unroll
+            for (int g = 0; g < 2; ++g)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c & 1][g][i].x, breg[c][g][j].x, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c & 1][g][i].y, breg[c][g][j].y, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c & 1][g][i].z, breg[c][g][j].z, acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c & 1][g][i].w, breg[c][g][j].w, acc[i][j], 0, 0, 0);
+                    }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        char* yt = reinterpret_cast<char*>(a.y + (int64_t)z * a.yb + (int64_t)t * BM * a.ldy + n0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ro = i * 32 + (r & 3) + 8 * (r >> 2);
+                float* yr = reinterpret_cast<float*>(yt + (size_t)ro * a.ldy * 4 + y_off);
+                yr[0] = acc[i][0][r];
+                yr[32] = acc[i][1][r];
+                acc[i][0][r] = 0.0f; acc[i][1][r] = 0.0f;
+            }
+    }
+#undef WS_DMA
+#undef WS_READ
+    if (bid == 0 && tid == 0) { a.dbg[0] = clock64() - tc0; a.dbg[1] = wall_clock64() - tw0; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 struct Variant { const char* name; void (*fn)(GemmArgs); bool ko; int nw; };   // nw > 0: one workgroup of 256 nw threads per M tile, N = 128 nw only
 
 int main(int argc, char** argv) {
@@ -629,13 +763,16 @@ int main(int argc, char** argv) {
         {"Wd all N in one workgroup", k_wide<2>, false, 2},
         {"Wd all N in one workgroup", k_wide<3>, false, 3},
         {"G2 KO no DMA in loop     ", k_glds<2 | 4, 3>, true, 0},
+        {"WS weight-stationary     ", k_ws<6>, false, -6},
+        {"WS weight-stationary     ", k_ws<16>, false, -16},
+        {"WS weight-stationary     ", k_ws<24>, false, -24},
     };
     const int nv = sizeof(vars) / sizeof(vars[0]);
     constexpr size_t lds = (size_t)3 * (128 + 128) * 16 * sizeof(float);   // 48 KB: enough for the 256-thread variants
     constexpr size_t lds_wide = 82 * 1024;                                 // > 80 KB: one wide workgroup per CU
     for (int v = 0; v < nv; ++v)
         CK(hipFuncSetAttribute(reinterpret_cast<const void*>(vars[v].fn), hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)(vars[v].nw ? lds_wide : lds)));
+                               (int)(vars[v].nw > 0 ? lds_wide : lds)));
     const int shapes[][2] = {{96, 256}, {256, 256}, {256, 384}, {384, 384}, {384, 256}};
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -651,16 +788,19 @@ int main(int argc, char** argv) {
         CK(hipMalloc(&dx, nx * 4)); CK(hipMalloc(&dw, nw * 4)); CK(hipMalloc(&dy, ny * 4)); CK(hipMalloc(&dref, ny * 4));
         CK(hipMemcpy(dx, hx.data(), nx * 4, hipMemcpyHostToDevice));
         CK(hipMemcpy(dw, hw.data(), nw * 4, hipMemcpyHostToDevice));
-        GemmArgs g{dx, dw, dref, M, K, N, N, nb, (M + 127) / 128, N / 128, (int64_t)M * K, (int64_t)N * K, (int64_t)M * N, ddbg};
+        GemmArgs g{dx, dw, dref, M, K, N, N, nb, (M + 127) / 128, N / 128, (int64_t)M * K, (int64_t)N * K, (int64_t)M * N, ddbg, 10};
         const unsigned grid = (unsigned)(8 * ((g.m_tiles + 7) / 8) * g.n_tiles);
         const double flop = 2.0 * nb * M * (double)K * N;
         std::vector<float> href(ny), hy(ny);
-        printf("K %d N %d (grid %u)\n", K, N, grid);
-#define LAUNCH(V) do { if (vars[V].nw) hipLaunchKernelGGL(vars[V].fn, dim3(8 * ((g.m_tiles + 7) / 8)), dim3(256 * vars[V].nw), lds_wide, 0, g); \
+        g.mgroups = (N == 384 ? 3 : 2) * 256 / (g.nb * g.n_tiles);
+        printf("K %d N %d (grid %u; WS: %d M groups per pair, %d workgroups)\n", K, N, grid, g.mgroups, g.nb * g.n_tiles * g.mgroups);
+#define LAUNCH(V) do { if (vars[V].nw < 0) hipLaunchKernelGGL(vars[V].fn, dim3(g.nb * g.n_tiles * g.mgroups), dim3(256), lds, 0, g); \
+                       else if (vars[V].nw) hipLaunchKernelGGL(vars[V].fn, dim3(8 * ((g.m_tiles + 7) / 8)), dim3(256 * vars[V].nw), lds_wide, 0, g); \
                        else hipLaunchKernelGGL(vars[V].fn, dim3(grid), dim3(256), lds, 0, g); } while (0)
         // correctness pass
         for (int v = 0; v < nv; ++v) {
-            if (vars[v].nw && vars[v].nw != N / 128) continue;
+            if (vars[v].nw > 0 && vars[v].nw != N / 128) continue;
+            if (vars[v].nw < 0 && -vars[v].nw != K / 16) continue;
             g.y = v == 0 ? dref : dy;
             CK(hipMemset(g.y, 0xff, ny * 4));
             LAUNCH(v);
@@ -692,7 +832,8 @@ int main(int argc, char** argv) {
         std::vector<float> best(nv, 1e30f), sum(nv, 0.f); std::vector<double> ghz(nv, 0.0);
         for (int rd = 0; rd < rounds; ++rd)
             for (int v = 0; v < nv; ++v) {
-                if (vars[v].nw && vars[v].nw != N / 128) continue;
+                if (vars[v].nw > 0 && vars[v].nw != N / 128) continue;
+                if (vars[v].nw < 0 && -vars[v].nw != K / 16) continue;
                 CK(hipEventRecord(e0, 0));
                 for (int r = 0; r < reps; ++r) LAUNCH(v);
                 CK(hipEventRecord(e1, 0));
@@ -704,7 +845,7 @@ int main(int argc, char** argv) {
                 if (hd[1] > 0) ghz[v] = (double)hd[0] / hd[1] * 0.1;
             }
         for (int v = 0; v < nv; ++v)
-            if (!vars[v].nw || vars[v].nw == N / 128)
+            if (vars[v].nw == 0 || vars[v].nw == N / 128 || -vars[v].nw == K / 16)
             printf("  %s best %8.4f ms %6.1f TF   mean %8.4f ms %6.1f TF  clock %.3f GHz -> %.1f%% of the MFMA rate at that clock %s\n",
                    vars[v].name, best[v], flop / best[v] / 1e9, sum[v] / rounds, flop / (sum[v] / rounds) / 1e9, ghz[v],
                    ghz[v] > 0 ? 100.0 * (flop / (sum[v] / rounds) / 1e9) / (65.536 * ghz[v]) : 0.0, vars[v].ko ? "(KO)" : "");
