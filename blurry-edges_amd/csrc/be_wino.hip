@@ -502,9 +502,13 @@ __global__ __launch_bounds__(256, 1)
 void k_wino_gemm_ws(GemmArgs a, int mgroups) {
     constexpr int BM = 128, BKT = 16, ABUF = BM * BKT;     // floats per A stage (8 KB)
     extern __shared__ __attribute__((aligned(16))) float smem_w[];
+    // workgroup -> (problem z, M range, N tile): the N tiles of one (z, M range) are consecutive slots of ONE XCD (ids congruent
+    // mod 8 share an XCD), so they run side by side and the A rows they all stream come from HBM once and from that L2 after
     const int bid = blockIdx.x;
-    const int mg = bid % mgroups, pair = bid / mgroups;    // the N tiles of a (z, M range) are neighbours: they share A in L2
-    const int z = pair / a.n_tiles, n_tile = pair % a.n_tiles;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int n_tile = slot % a.n_tiles;
+    const int unit = (slot / a.n_tiles) * 8 + xcd;
+    const int z = unit / mgroups, mg = unit % mgroups;
     const int tiles_per = (a.m_tiles + mgroups - 1) / mgroups;
     const int t0 = mg * tiles_per, t1 = min(a.m_tiles, t0 + tiles_per);
     if (z >= a.nb || t0 >= t1) return;
@@ -634,7 +638,8 @@ int launch_ws(const GemmArgs& g, hipStream_t s, int64_t n, int cin, int cout) {
     int mgroups = rounds * cus / pairs;
     if (mgroups < 1) mgroups = 1;
     if (mgroups > g.m_tiles / 4) mgroups = g.m_tiles / 4 > 0 ? g.m_tiles / 4 : 1;     // >= 4 tiles per register fill
-    const unsigned grid = (unsigned)(pairs * mgroups);
+    const int units = g.nb * mgroups;
+    const unsigned grid = (unsigned)(8 * ((units + 7) / 8) * g.n_tiles);
     {
         be::ProfileScope prof(s, BE_KERNEL_WINO_GEMM, 25.0 * 2.0 * 4 * n * cin * cout,
                               25.0 * 4.0 * (4.0 * n * cin + (double)cin * cout + 4.0 * n * cout),
