@@ -631,11 +631,16 @@ int launch_ws(const GemmArgs& g, hipStream_t s, int64_t n, int cin, int cout) {
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
             cus = 256;
     }
-    // about R rounds of one workgroup per CU (the kernel takes the whole register file of a CU)
-    const int pairs = g.nb * g.n_tiles;
-    int rounds = (int)((pairs + cus - 1) / cus);
-    while ((rounds * cus) / pairs < 8 && (int64_t)g.m_tiles * pairs > (int64_t)8 * rounds * cus) ++rounds;    // >= 8 M groups when there is work
-    int mgroups = rounds * cus / pairs;
+    // R rounds of ONE workgroup per CU (the kernel takes the whole register file of a CU).  Workgroup ids go round-robin over the
+    // 8 XCDs, so the count that has to fit is per XCD: ceil(units / 8) * n_tiles <= R * (CUs per XCD) - one workgroup too many
+    // on an XCD is a whole extra round for everybody.  At least 8 M ranges per problem when there is that much work.
+    const int per_xcd = cus / 8 > 0 ? cus / 8 : 1;
+    int mgroups = 1;
+    for (int rounds = 1; rounds <= 16; ++rounds) {
+        const int units_max = 8 * (per_xcd * rounds / g.n_tiles);
+        mgroups = units_max / g.nb;
+        if (mgroups >= 8 || mgroups >= g.m_tiles / 4) break;
+    }
     if (mgroups < 1) mgroups = 1;
     if (mgroups > g.m_tiles / 4) mgroups = g.m_tiles / 4 > 0 ? g.m_tiles / 4 : 1;     // >= 4 tiles per register fill
     const int units = g.nb * mgroups;
