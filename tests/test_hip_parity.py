@@ -243,10 +243,11 @@ def test_local_stage_full_batch_8192_properties(native):
     assert relmax(ys.cpu(), yo) <= 1e-5
 
 
-@pytest.mark.parametrize("n", [1, 3, 513, 1000, 1500, 8492])
+@pytest.mark.parametrize("n", [1, 3, 513, 1000, 1500, 4096, 6144, 8492])
 def test_local_stage_ragged_batches_are_position_independent(native, n):
-    """Edge sizes: a single patch, a ragged small batch, and ragged LARGE batches (pixel-major conv tiles with a
-    partly empty last tile) give bit-identical logits to the same patches run in another batch."""
+    """Edge sizes: a single patch, a ragged small batch, ragged LARGE batches (pixel-major conv tiles with a partly empty
+    last tile; k_wino_gemm) and full-tile large batches (4096, 6144: the weight-stationary k_wino_gemm_ws with 128 / 192 row
+    tiles) give bit-identical logits to the same patches run in another batch."""
     import models
     m = models.LocalStage()
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.local_stage_state_dict().items()})
