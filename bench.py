@@ -149,7 +149,8 @@ def main():
         elapsed = float(t.item())
 
     # ---- roofline leg: the same K steps again with a hipEvent pair around every conv launch (on the launch
-    #      stream = torch's current stream); dominant kernel = the 128x128 fp32-MFMA implicit-GEMM conv
+    #      stream = torch's current stream); dominant kernel = whichever kernel id takes the most time in the step (since v10
+    #      the 25 transform-domain GEMMs of the Winograd layers, k_wino_gemm_ws / k_wino_gemm)
     roof = None
     if rank == 0:
         per_step = 15 * ((2 * PAIRS + 1023) // 1024 + 1)
