@@ -320,6 +320,20 @@ def test_pixel_major_kernel_shapes(native, n, h, w, cin, cout):
     assert torch.equal(new, old)
 
 
+def test_forward_of_a_large_batch_is_run_to_run_bit_identical(native):
+    """The large-batch kernels synchronise by hand (LDS-DMA, counted vmcnt, raw barriers: be_wino.hip, be_conv_pm.hip): a race
+    would show as a run-to-run difference.  40 forwards of one 8192-patch batch (tools/stress_determinism.py runs 500)."""
+    import models
+    m = models.LocalStage()
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.local_stage_state_dict().items()})
+    m = m.to(DEV).eval()
+    x = T(synth.uniform_patches(8192, name="stress")).to(DEV)
+    with torch.no_grad():
+        ref = m(x).clone()
+        for _ in range(40):
+            assert torch.equal(m(x), ref)
+
+
 def test_product_path_refuses_cpu_tensors(native):
     import models
     m = models.LocalStage().eval()
