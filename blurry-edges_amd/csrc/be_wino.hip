@@ -520,28 +520,38 @@ void k_wino_gemm_ws(GemmArgs a, int mgroups) {
     const int srow = lane >> 2, sq = (lane & 3) ^ ((lane >> 4) & 3);
     const int fsw = (li >> 2) & 3;
     const int fr0 = li * BKT + 4 * (lh ^ fsw), fr1 = li * BKT + 4 * ((lh + 2) ^ fsw);
-    // ---- B tile -> registers, chunk by chunk through LDS (two buffers, plain barriers: once per workgroup)
+    // ---- B tile -> registers through LDS, eight K chunks (64 KB) per pass: all the DMAs of a pass are in flight together, ONE
+    //      wait per pass (chunk by chunk the fill was 24 dependent DMA round trips: ~36 us of a ~530 us workgroup)
     f32x4 breg[KCH][2][2];
     {
+        constexpr int PASS = 8;
         const float* wt = a.w + (int64_t)z * a.wb + (int64_t)n0 * a.K;
         unsigned b_off[2];
 #pragma unroll
         for (int p = 0; p < 2; ++p) b_off[p] = (unsigned)(((2 * wave + p) * 16 + srow) * a.K + 4 * sq) * 4u;
 #pragma unroll
-        for (int c = 0; c < KCH; ++c) {
-            float* st = smem_w + (c & 1) * ABUF;
+        for (int c0 = 0; c0 < KCH; c0 += PASS) {
 #pragma unroll
-            for (int p = 0; p < 2; ++p)
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)(reinterpret_cast<const char*>(wt + c * BKT) + b_off[p]),
-                                                 (lds_ptr_t)(st + (2 * wave + p) * 256), 16, 0, 0);
+            for (int cc = 0; cc < PASS; ++cc)
+                if (c0 + cc < KCH) {
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+                        __builtin_amdgcn_global_load_lds((glb_ptr_t)(reinterpret_cast<const char*>(wt + (c0 + cc) * BKT) + b_off[p]),
+                                                         (lds_ptr_t)(smem_w + cc * ABUF + (2 * wave + p) * 256), 16, 0, 0);
+                }
             __syncthreads();
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                breg[c][0][j] = *reinterpret_cast<const f32x4*>(st + (wn * 64 + j * 32) * BKT + fr0);
-                breg[c][1][j] = *reinterpret_cast<const f32x4*>(st + (wn * 64 + j * 32) * BKT + fr1);
-            }
+            for (int cc = 0; cc < PASS; ++cc)
+                if (c0 + cc < KCH) {
+                    const float* st = smem_w + cc * ABUF;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        breg[c0 + cc][0][j] = *reinterpret_cast<const f32x4*>(st + (wn * 64 + j * 32) * BKT + fr0);
+                        breg[c0 + cc][1][j] = *reinterpret_cast<const f32x4*>(st + (wn * 64 + j * 32) * BKT + fr1);
+                    }
+                }
+            __syncthreads();                               // everyone has its fragments before the next pass / the A ring overwrites
         }
-        __syncthreads();
     }
     // ---- stream A over the M tiles [t0, t1): flat step s = (tile, chunk); every tile is full (the launcher checks M % 128 == 0)
     unsigned a_off[2];
@@ -624,7 +634,13 @@ void k_wino_gemm_ws(GemmArgs a, int mgroups) {
 
 template <int KCH>
 int launch_ws(const GemmArgs& g, hipStream_t s, int64_t n, int cin, int cout) {
-    constexpr size_t lds = (size_t)3 * 128 * 16 * sizeof(float);
+    constexpr size_t lds = (size_t)8 * 128 * 16 * sizeof(float);     // 64 KB: eight chunks of the B fill (the A ring uses three)
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino_gemm_ws<KCH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return be::fail(BE_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_set = true;
+    }
     static int cus = 0;
     if (!cus) {
         int dev = 0;
