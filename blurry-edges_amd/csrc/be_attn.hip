@@ -28,6 +28,14 @@ __host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
 __host__ __device__ __forceinline__ uint32_t site_key(uint32_t seed, uint32_t site) {
     return mix32(seed + 0x9e3779b9U * (site + 1U));
 }
+// Attention dropout: ONE hash decides the two neighbouring keys 2j, 2j+1 of a query, 16 bits each (the hash was a third of
+// the training forward: two 32-bit multiplies per probability).  Element idx = query * L + key of head-batch `hkey` is
+// dropped iff its half of mix32((idx >> 1) ^ hkey) is below p * 2^16; the forward and dQ kernels hold four consecutive keys
+// per lane (two hashes for four elements), the dK/dV kernel and the mask kernel take the half that belongs to their key.
+__host__ __device__ __forceinline__ uint32_t pair_hash(uint32_t idx, uint32_t hkey) { return mix32((idx >> 1) ^ hkey); }
+__host__ __device__ __forceinline__ bool pair_dropped(uint32_t idx, uint32_t hkey, uint32_t t16) {
+    return ((pair_hash(idx, hkey) >> (16U * (idx & 1U))) & 0xffffU) < t16;
+}
 // raw v_exp_f32: exp2f() wraps it in denormal-range scaling (5 instructions); results below 2^-126 flush to zero here,
 // which a softmax weight may
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
@@ -156,6 +164,7 @@ void k_attention(const float* __restrict__ Q, const float* __restrict__ K, const
     const float* Kh = K + (size_t)bh * L * DH;
     const float* Vh = Vt + (size_t)bh * DH * L;
     const uint32_t hkey = site_key(seed, (uint32_t)bh);
+    const uint32_t t16 = thresh >> 16;                 // p * 2^16: the 16-bit threshold of the pair hash
 
     f32x4v qf[2], o[2];
     float m[2], lsum[2];
@@ -211,8 +220,11 @@ void k_attention(const float* __restrict__ Q, const float* __restrict__ K, const
 #pragma unroll
                 for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        if (mix32((base + 16 * kt + r) ^ hkey) < thresh) s[kt][qc][r] = 0.f;
+                    for (int r = 0; r < 4; r += 2) {                  // base is even: (r, r + 1) share a hash
+                        const uint32_t h = pair_hash(base + 16 * kt + r, hkey);
+                        if ((h & 0xffffU) < t16) s[kt][qc][r] = 0.f;
+                        if ((h >> 16) < t16) s[kt][qc][r + 1] = 0.f;
+                    }
             }
             o[qc] *= alpha;
         }
@@ -290,6 +302,7 @@ void k_attn_bwd_dq(const float* __restrict__ Q, const float* __restrict__ K, con
     const float* Vh = V + hb;
     const float* Kth = Kt + hb;
     const uint32_t hkey = site_key(seed, (uint32_t)bh);
+    const uint32_t t16 = thresh >> 16;                 // p * 2^16: the 16-bit threshold of the pair hash
 
     f32x4v qf[2], gf[2], dq[2];
     float lse_q[2], d_q[2];
@@ -339,11 +352,23 @@ void k_attn_bwd_dq(const float* __restrict__ Q, const float* __restrict__ K, con
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
+                for (int r = 0; r < 4; ++r) dp[kt][qc][r] *= inv_keep;
+            if (thresh) {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; r += 2) {                  // base is even: (r, r + 1) share a hash
+                        const uint32_t h = pair_hash(base + 16 * kt + r, hkey);
+                        if ((h & 0xffffU) < t16) dp[kt][qc][r] = 0.f;
+                        if ((h >> 16) < t16) dp[kt][qc][r + 1] = 0.f;
+                    }
+            }
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float p = fast_exp2(s[kt][qc][r] - lse_q[qc]);
-                    float gd = dp[kt][qc][r] * inv_keep;
-                    if (thresh && mix32((base + 16 * kt + r) ^ hkey) < thresh) gd = 0.f;
-                    s[kt][qc][r] = p * (gd - d_q[qc]);                           // dS
+                    s[kt][qc][r] = p * (dp[kt][qc][r] - d_q[qc]);                // dS
                 }
         }
 #pragma unroll
@@ -377,6 +402,7 @@ void k_attn_bwd_dkv(const float* __restrict__ Q, const float* __restrict__ K, co
     const float* lse_h = lse + (size_t)bh * L;
     const float* d_h = Drow + (size_t)bh * L;
     const uint32_t hkey = site_key(seed, (uint32_t)bh);
+    const uint32_t t16 = thresh >> 16;                 // p * 2^16: the 16-bit threshold of the pair hash
 
     f32x4v kf[2], vf[2], dv[2], dk[2];
 #pragma unroll
@@ -428,18 +454,28 @@ void k_attn_bwd_dkv(const float* __restrict__ Q, const float* __restrict__ K, co
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-            for (int kc = 0; kc < 2; ++kc)
+            for (int kc = 0; kc < 2; ++kc) {
+                // Here a lane holds four QUERIES of one key, so the pair hash (keys 2j, 2j+1 of a query) is shared with the
+                // neighbouring lane c ^ 1, not inside the lane: the even lane hashes queries r = 0, 1, the odd lane r = 2, 3,
+                // and they swap (one DPP move each): two hashes per lane for four elements here too.
+                uint32_t hq[4] = {0xffffffffU, 0xffffffffU, 0xffffffffU, 0xffffffffU};
+                if (thresh) {
+                    const int odd = c & 1;
+                    const uint32_t ih0 = (uint32_t)(qblk * KB + 16 * qt + 4 * g + 2 * odd) * (uint32_t)(L >> 1) +
+                                         (uint32_t)((k0 + 16 * kc + c) >> 1);      // idx >> 1 = query * (L / 2) + key / 2
+                    const uint32_t ha = mix32(ih0 ^ hkey), hb = mix32((ih0 + (uint32_t)(L >> 1)) ^ hkey);
+                    const uint32_t pa = (uint32_t)__shfl_xor((int)ha, 1, 64), pb = (uint32_t)__shfl_xor((int)hb, 1, 64);
+                    hq[0] = odd ? pa : ha; hq[1] = odd ? pb : hb; hq[2] = odd ? ha : pa; hq[3] = odd ? hb : pb;
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float p = fast_exp2(s[qt][kc][r] - ls[qt][r]);
                     float pd = p, gd = dp[qt][kc][r] * inv_keep;
-                    if (thresh) {
-                        const uint32_t idx = (uint32_t)(qblk * KB + 16 * qt + 4 * g + r) * (uint32_t)L + (uint32_t)(k0 + 16 * kc + c);
-                        if (mix32(idx ^ hkey) < thresh) { pd = 0.f; gd = 0.f; }
-                    }
+                    if (thresh && __builtin_amdgcn_ubfe(hq[r], 16U * (c & 1), 16U) < t16) { pd = 0.f; gd = 0.f; }
                     s[qt][kc][r] = p * (gd - dr[qt][r]);       // dS
                     dp[qt][kc][r] = pd;                         // Pd (the 1/keep factor is applied once at the end)
                 }
+            }
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
@@ -468,7 +504,7 @@ __global__ void k_attn_dropout_mask(float* __restrict__ mask, int64_t BH, int L,
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gs) {
         const int64_t bh = i / ((int64_t)L * L);
         const uint32_t idx = (uint32_t)(i - bh * (int64_t)L * L);
-        mask[i] = mix32(idx ^ site_key(seed, (uint32_t)bh)) < thresh ? 0.f : 1.f;
+        mask[i] = pair_dropped(idx, site_key(seed, (uint32_t)bh), thresh >> 16) ? 0.f : 1.f;
     }
 }
 
