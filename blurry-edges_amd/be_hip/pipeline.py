@@ -16,6 +16,12 @@ import torch
 from . import native
 
 
+def params_src_layout(pm):
+    """pm [P,38] = [P, (aperture, 19)] -> [2,P,19], the per-image layout global_data_pre_cal.py:27-32 saves in
+    params_src_*.npy (and global_training.py reads back)."""
+    return pm.view(-1, 2, 19).permute(1, 0, 2)
+
+
 class DepthPipeline:
     def __init__(self, local_module, global_module, helper, depth_cal, rho_prime=10.39, densify=None, stride=2,
                  densify_pp_module=None):

@@ -133,6 +133,16 @@ def plausible_params10(n: int, seed: int = SEED_DEFAULT, name: str = "params10")
     return f32(p)
 
 
+def glue_params10(p: int, seed: int = SEED_DEFAULT, name: str = "g15_params10") -> np.ndarray:
+    """[2p,10] raw LocalStage outputs as the CNN emits them BEFORE the eval glue wraps them: plausible_params10 with
+    every angle moved by a whole number of turns in [-3, 3] (blurry_edges_test.py:124 `remainder(., 2 pi)` must undo it).
+    Rows 0..p-1 aperture 1, p..2p-1 aperture 2 (golden g15)."""
+    q = plausible_params10(2 * p, seed, name).astype(np.float64)
+    turns = np.floor(7.0 * hash_uniform(seed, name + ".turns", (2 * p, 4))) - 3.0
+    q[:, 4:8] += 2.0 * math.pi * turns
+    return f32(q)
+
+
 def plausible_params12(n: int, seed: int = SEED_DEFAULT, name: str = "params12") -> np.ndarray:
     """[n,12]: 8 shared geometry + eta coefficients (w1,img1),(w2,img1),(w1,img2),(w2,img2)
     (layout of blurry_edges_test.py:36-37,44-45)."""

@@ -35,8 +35,9 @@ class BetaSchedule:
         self.beta_b, self.beta_s = self.max_b, self.max_s
 
 
-def train_step(model, helper, opt, batch, beta_b, beta_s, flat=None, world=1, clip=1.0):
-    """One iteration of local_training.py:103-108.  batch: dict of GPU tensors (dataset layouts)."""
+def train_step(model, helper, opt, batch, beta_b, beta_s, flat=None, world=1, clip=1.0, stats=None):
+    """One iteration of local_training.py:103-108.  batch: dict of GPU tensors (dataset layouts).
+    stats: optional dict that receives `grad_norm` (the total norm clip_grad_norm_ measured, a device scalar)."""
     import utils
     est = model(batch["img_ny"].permute(0, 3, 1, 2))
     opt.zero_grad(set_to_none=True)      # backward then SETS .grad (no fill, no accumulate launch per parameter)
@@ -44,7 +45,9 @@ def train_step(model, helper, opt, batch, beta_b, beta_s, flat=None, world=1, cl
     loss.backward()
     if flat is not None:
         dp.allreduce_mean_(dp.grads_as_flat(list(model.parameters()), flat), world)      # zero-copy when the backward wrote one buffer
-    torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=clip, norm_type=2)
+    norm = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=clip, norm_type=2)
+    if stats is not None:
+        stats["grad_norm"] = norm
     opt.step()
     return loss.detach()
 
@@ -78,6 +81,8 @@ class GraphedStep:
             for k in self.static:
                 self.static[k].copy_(batch[k])
         self.graph.replay()
+        # the replay moved weights and BatchNorm statistics on the device; no tensor version changed
+        self.model.invalidate_packed()
         return self.loss.clone()
 
 

@@ -103,7 +103,7 @@ def global_pre(args, local_weights=None, quiet=False):
     """params_src_{train,val}.npy [n, 2, P, 19] float64: the normalised local-stage output + colours of every image."""
     import data, models, utils
     from . import native
-    from .pipeline import DepthPipeline
+    from .pipeline import DepthPipeline, params_src_layout
     dev = _device(args)
     model = models.LocalStage().to(dev)
     model.load_state_dict(torch.load(local_weights or f'{args.model_path}/pretrained_local_stage.pth', map_location=dev))
@@ -117,7 +117,7 @@ def global_pre(args, local_weights=None, quiet=False):
             pm = pipe.local_pass(img)[3]                                      # [P,38] = [P, (aperture, 19)]
             if out is None:
                 out = np.zeros((len(ds), 2, pm.shape[0], 19), dtype=np.float64)
-            out[j] = pm.view(-1, 2, 19).permute(1, 0, 2).cpu().numpy()
+            out[j] = params_src_layout(pm).cpu().numpy()
         np.save(f'{args.data_path}/params_src_{part}.npy', out)
         if not quiet:
             print(f'{part}: {len(ds)} images -> params_src_{part}.npy')
@@ -185,8 +185,11 @@ def evaluate(args, big=False, local_weights=None, global_weights=None, pp_weight
     dev = _device(args)
     load = lambda m, path: (m.load_state_dict(torch.load(path, map_location=dev)), m.eval())[1]
     local = load(models.LocalStage().to(dev), local_weights or f'{args.model_path}/pretrained_local_stage.pth')
+    # blurry_edges_test.py:187-190 loads pretrained_global_stage_w.pth for `--densify w`; the big-image script
+    # (blurry_edges_test_big.py) always loads the plain name
+    gname = 'pretrained_global_stage_w.pth' if (args.densify == 'w' and not big) else 'pretrained_global_stage.pth'
     globl = load(models.GlobalStage(in_parameter_size=38, out_parameter_size=12, device=dev).to(dev),
-                 global_weights or f'{args.model_path}/pretrained_global_stage.pth')
+                 global_weights or f'{args.model_path}/{gname}')
     pp = None
     if args.densify == 'pp':
         pp = load(models.DepthCompletion().to(dev), pp_weights or f'{args.model_path}/pretrained_depth_completion_pp.pth')

@@ -103,6 +103,18 @@ class LocalStage(nn.Module):
     # products; be_wino.hip).  False: direct implicit-GEMM convolutions everywhere (be_local_stage_set_winograd).
     winograd = os.environ.get("BE_WINOGRAD", "1") != "0"
 
+    def invalidate_packed(self):
+        """Drop the cached BN-folded weight pack.  Needed whenever parameters or running statistics change on the device
+        without Python seeing it: a replayed hipGraph of the training step (be_hip.train_local.GraphedStep) updates them
+        without bumping any tensor's `_version`, which is what the cache key is made of."""
+        self._packed_key = None
+
+    def train(self, mode: bool = True):
+        # every train() / eval() switch re-packs on the next eval forward (one ~55 us launch): the pack folds the running
+        # statistics, and those move under it during training whether or not autograd's version counters notice
+        self._packed_key = None
+        return super().train(mode)
+
     def _packed_weights(self):
         tensors = [t.detach() for t in self._tensor_list()]
         key = tuple((t.data_ptr(), t._version) for t in tensors) + (self.conv_precision,)

@@ -1,5 +1,7 @@
 """Oracle: feature normalisation between LocalStage and GlobalStage and its inverse (TEST INFRASTRUCTURE).
-Restates blurry_edges_test.py:123-138."""
+Restates blurry_edges_test.py:123-138 and its second copy global_data_pre_cal.py:21-31.
+Pinned by golden g15 (tools/make_golden.py:G15 - the reference's own depth_estimator / ref_data_gen run with stub
+modules): tests/test_oracle_golden.py::test_g15_glue_is_the_references_own_ordering, bit-exact in float32."""
 import torch
 
 
@@ -16,3 +18,8 @@ def local_features(params10, colors):
 def global_denorm(y):
     """y [P,12] -> est12 [P,12]."""
     return torch.cat([y[:, :4] * 3, torch.remainder((y[:, 4:8] + 1) * torch.pi, 2 * torch.pi), y[:, 8:] + 0.5], dim=1)
+
+
+def params_src(pm):
+    """pm [P,38] -> the per-image layout global_data_pre_cal.py:27-32 stores: [2,P,19] (aperture-major)."""
+    return pm.view(pm.shape[0], 2, 19).permute(1, 0, 2)

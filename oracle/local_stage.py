@@ -26,10 +26,15 @@ def smish(x):
     return x * torch.tanh(torch.log(1 + torch.sigmoid(x)))
 
 
+_RUNNING_OUT = None    # dict filled with the updated running statistics of a training forward (see local_stage_forward)
+
+
 def _bn(y, sd, p, training):
     rm, rv = sd[p + ".running_mean"], sd[p + ".running_var"]
     if training:      # batch statistics; running buffers are updated on clones so the oracle stays pure
-        rm, rv = rm.clone(), rv.clone()
+        rm, rv = rm.detach().clone(), rv.detach().clone()
+        if _RUNNING_OUT is not None:
+            _RUNNING_OUT[p + ".running_mean"], _RUNNING_OUT[p + ".running_var"] = rm, rv
     return F.batch_norm(y, rm, rv, sd[p + ".weight"], sd[p + ".bias"], training, BN_MOMENTUM, BN_EPS)
 
 
@@ -46,9 +51,20 @@ def residual_block(x, sd, p, training=False):
     return smish(out + res)
 
 
-def local_stage_forward(sd, x, training=False, taps=None):
+def local_stage_forward(sd, x, training=False, taps=None, running_out=None):
     """x [N,3,21,21] -> [N,10]  (models/local_stage.py:63-73).
-    taps: optional dict filled with intermediate activations (NCHW) for layer-by-layer parity."""
+    taps: optional dict filled with intermediate activations (NCHW) for layer-by-layer parity.
+    running_out: optional dict; a training forward stores the running statistics nn.BatchNorm would have written
+    (momentum 0.1, unbiased variance) under their state-dict keys - sd itself is never modified."""
+    global _RUNNING_OUT
+    _RUNNING_OUT = running_out if training else None
+    try:
+        return _forward(sd, x, training, taps)
+    finally:
+        _RUNNING_OUT = None
+
+
+def _forward(sd, x, training, taps):
     def tap(name, t):
         if taps is not None:
             taps[name] = t

@@ -116,6 +116,9 @@ def test_render_pass_a_4096_patches_vs_fp64_oracle(native, args):
     assert relmax(ex["dists"].cpu(), r64["dists"]) <= 1e-5
     assert relmax(col.cpu(), r64["colors"]) <= 1e-4
     assert relmax(ex["recon"].cpu(), r64["recon"]) <= 1e-4
+    # the float64 run of the REFERENCE's eval-time helper on the same inputs (golden g16, global layout [3,3,64,64])
+    g64 = load_golden("g16_postprocess_147_f64")
+    assert relmax(col.cpu(), g64["colors_a"][0].reshape(3, 3, 4096).transpose(2, 0, 1)) <= 1e-4
     # wrap_angles=True on unwrapped angles == wrapping first (blurry_edges_test.py:123-127)
     shifted = p10.clone()
     shifted[:, 4:8] += 2 * torch.pi * torch.tensor([1.0, -1.0, 2.0, -3.0])

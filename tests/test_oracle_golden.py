@@ -283,3 +283,75 @@ def test_g14_datagen_oracle_matches_reference_generator():
     assert np.allclose(gen.get_blur_kernel(2.0), g["kernel_s2"], rtol=1e-14, atol=1e-300)
     assert np.array_equal(gen.get_blur_kernel(0.0), g["kernel_tiny"])
     assert np.allclose(odg.blur_kernel(2.0), g["kernel_s2"], rtol=1e-15, atol=0)
+
+
+# ------------------------------------------------------------------ G15: LocalStage -> GlobalStage feature glue (row a18)
+def _g15_inputs(g):
+    H, W, hp, wp = (int(v) for v in g["grid"])
+    P = hp * wp
+    S = synth.SEED_DEFAULT
+    p10 = T(synth.glue_params10(P))                                                     # [2P,10], unwrapped angles
+    col = T(synth.f32(synth.hash_uniform(S, "g15_colors", (2, 3, 3, hp, wp))))          # the helper stub's return
+    y12 = T(synth.f32(-1.5 + 3.0 * synth.hash_uniform(S, "g15_global_out", (1, P, 12))))
+    imgs, _ = synth.synthetic_image_pair(H, W)
+    return (H, W, hp, wp, P), p10, col, y12, T(imgs)
+
+
+def test_g15_glue_is_the_references_own_ordering():
+    """oracle/glue.py against what the reference's depth_estimator (blurry_edges_test.py:117-138) handed to its helper and
+    to GlobalStage when run with stub modules, and against ref_data_gen's params_src (global_data_pre_cal.py:21-31)."""
+    from oracle import glue
+    g = load_golden("g15_glue")
+    (H, W, hp, wp, P), p10, col, y12, img = _g15_inputs(g)
+    assert (hp, wp) == (13, 21)                                                          # non-square: a transposed grid fails
+    # what pass A received: wrapped angles, [2,P,10] aperture-major
+    assert np.array_equal(orr.wrap_angles10(p10).view(2, P, 10).numpy(), g["params_a"])
+    # colours [2,3(rgb),3(wedge),hp,wp] -> per patch [3(rgb),3(wedge)] -> 9 features rgb-major / wedge-minor
+    colp = col.permute(0, 3, 4, 1, 2).reshape(2, P, 3, 3)
+    pm = glue.local_features(p10.view(2, P, 10), colp)
+    assert pm.shape == (P, 38) and np.array_equal(pm.numpy(), g["pm"][0])                # bit-exact: same fp32 operations
+    # a wrong wedge/rgb order or aperture interleave would not be: check the test has teeth
+    assert not np.array_equal(glue.local_features(p10.view(2, P, 10), colp.transpose(2, 3)).numpy(), g["pm"][0])
+    assert np.array_equal(glue.global_denorm(y12[0]).numpy(), g["est"][0])
+    # second copy of the glue: colours from the LOCAL-layout helper, float64, [1,2,P,19]
+    pat = ot.unfold_patches(img.double())                                                # [2,P,3,21,21]
+    q = orr.wrap_angles10(p10.double())
+    c64 = torch.stack([orr.render_pass_a(q[i * P:(i + 1) * P], pat[i])["colors"] for i in range(2)])
+    src = glue.params_src(glue.local_features(p10.double().view(2, P, 10), c64))
+    assert src.shape == (2, P, 19) and relmax(src.numpy(), g["params_src_f64"][0]) <= 1e-10   # measured 1.2e-12
+
+
+# ------------------------------------------------------------------ G16: float64 run of the eval-time PostProcess
+def test_g16_fp64_postprocess_pass_a_pass_b_and_folds():
+    g = load_golden("g16_postprocess_147_f64")                                           # float64 results stored as float32
+    _, pat = _g6_inputs()
+    pat = pat.double()
+    tol = 2e-7
+    for i, nm in enumerate(("g6_img1", "g6_img2")):
+        r = orr.render_pass_a(T(synth.plausible_params10(4096, name=nm)).double(), pat[i])
+        assert relmax(r["colors"], g["colors_a"][i].reshape(3, 3, 4096).transpose(2, 0, 1)) <= tol
+    c = od.depth_consts()
+    p12 = T(synth.plausible_params12(4096, name="g6_est")).double()
+    ii, jj = np.meshgrid(np.arange(20, 24), np.arange(30, 34), indexing="ij")
+    sel = (ii * 64 + jj).ravel()
+    for densify, tag in ((None, ""), ("w", "w_")):
+        r = orr.render_pass_b(c, p12, pat[0], pat[1], densify=densify)
+
+        def sub(key):
+            a = g[key]
+            return np.moveaxis(a.reshape(a.shape[:-2] + (16,)), -1, 0)
+        assert np.array_equal(r["depth_mask"][sel].numpy(), sub(tag + "sub_dmask"))
+        assert np.array_equal(np.bincount(r["depth_mask"].numpy().ravel(), minlength=3), g[tag + "mask_hist"])
+        assert relmax(r["depth_map"][sel], sub(tag + "sub_dmap")) <= tol
+        assert relmax(r["refoc"][sel], sub(tag + "sub_refoc")) <= tol
+        fd, conf = ot.fold_depth(r["depth_map"][None], r["depth_mask"][None], 147, 147)
+        assert relmax(conf[0], g[tag + "fold_conf"][0]) <= tol and relmax(fd[0], g[tag + "fold_depth"][0]) <= tol
+        assert relmax(ot.fold_mean(r["refoc"][None], 147, 147)[0], g[tag + "fold_refoc"][0]) <= tol
+        if densify is None:
+            assert relmax(r["colors"], g["colors_b"][0].reshape(3, 3, 4096).transpose(2, 0, 1)) <= tol
+            assert relmax(torch.stack([r["patches1"], r["patches2"]], dim=1)[sel], sub("sub_patches")) <= tol
+            assert relmax(r["shpd"][sel], sub("sub_shpd")) <= tol
+            assert relmax(r["boundary"][sel], sub("sub_bnd")) <= tol
+            assert relmax(ot.fold_mean(torch.stack([r["patches1"], r["patches2"]]), 147, 147), g["fold_image"][0]) <= tol
+            assert relmax(ot.fold_mean(r["shpd"][None], 147, 147)[0], g["fold_shpd"][0]) <= tol
+            assert relmax(ot.fold_mean(r["boundary"][None, :, None], 147, 147)[0, 0], g["fold_bndry"][0, 0]) <= tol

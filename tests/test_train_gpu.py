@@ -10,65 +10,153 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
 
-def test_training_loss_curve_matches_oracle_for_the_first_steps():
+def test_twenty_training_steps_teacher_forced_against_the_fp64_oracle():
+    """configs[2], SURVEY 8d "loss-curve parity for the first 20 steps" (local_training.py:99-108), drift-free:
+    before EVERY step the HIP model's current parameters + BatchNorm running statistics are copied into the float64
+    oracle, which then takes the same step on the same batch.  Compared per step: the loss, the total gradient norm,
+    every parameter's (clipped) gradient norm-wise, the updated running statistics, and the AdamW update itself -
+    recomputed in float64 from the optimizer state the HIP run held before the step.  Nothing free-runs, so a gradient
+    that is wrong by a fraction of a per cent in any layer shows at the step where it happens."""
     if not torch.cuda.is_available():
         pytest.fail("gpu-marked test run without a GPU")
     import models, utils
     from be_hip import train_local
     from oracle import local_stage as ols, render as orr
-    steps, B = 6, 64
+    steps, B = 20, 64
+    lr, b1, b2, eps, wd = 6e-5, 0.9, 0.999, 1e-8, 1e-2          # local_training.py:86 (AdamW defaults)
     data = synth.synthetic_training_patches(B * steps, seed=5)
     args = utils.get_args("local_train", argv=[])
-    # ---- HIP
+    assert args.learning_rate == lr
+    torch.set_num_threads(min(16, torch.get_num_threads() or 1) or 1)
     model = models.LocalStage().to(DEV)
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.local_stage_state_dict().items()})
     helper = utils.PostProcessLocalBase(args, DEV)
-    opt = torch.optim.AdamW(model.parameters(), lr=args.learning_rate)
+    opt = torch.optim.AdamW(model.parameters(), lr=lr)
     model.train()
+    names = [k for k, _ in model.named_parameters()]
     gdata = {k: torch.from_numpy(v).to(DEV) for k, v in data.items()}
-    hip = []
+    cdata = {k: torch.from_numpy(v).double() for k, v in data.items()}
+    worst = dict(loss=0.0, norm=0.0, grad=0.0, grad_name="", upd=0.0, upd_name="", run=0.0, free=0.0)
+    hip_curve, ora_curve = [], []
+    # free-running float64 oracle next to it: a printed diagnostic only (it drifts, as any two arithmetic variants do)
+    free_sd = ols.to_torch_sd(synth.local_stage_state_dict(), torch.float64)
+    free_params = [v.requires_grad_(True) for k, v in free_sd.items() if v.is_floating_point() and "running_" not in k]
+    free_opt = torch.optim.AdamW(free_params, lr=lr)
+    free_curve = []
     for it in range(steps):
+        # ---- snapshot of the HIP state BEFORE the step
+        sd64 = {k: (v.detach().cpu().double() if v.is_floating_point() else v.detach().cpu()) for k, v in model.state_dict().items()}
+        before = {k: p.detach().clone() for k, p in model.named_parameters()}
+        st = {k: {kk: (vv.detach().clone() if torch.is_tensor(vv) else vv) for kk, vv in opt.state[p].items()}
+              for k, p in model.named_parameters() if p in opt.state}
+        # ---- HIP step
         b = {k: v[it * B:(it + 1) * B] for k, v in gdata.items()}
-        hip.append(float(train_local.train_step(model, helper, opt, b, args.beta_bndry_loc, args.beta_smthns)))
-    # ---- oracle: CPU autograd over the restated reference math, in float64 (ground truth) AND float32: the gap
-    #      between the two is the trajectory's own sensitivity to rounding, the yardstick for the HIP curve.
-    def oracle_curve(dt):
-        sd = ols.to_torch_sd(synth.local_stage_state_dict(), dt)
-        params = [v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running_" not in k]
-        oopt = torch.optim.AdamW(params, lr=args.learning_rate)
-        out = []
-        cdata = {k: torch.from_numpy(v).to(dt) for k, v in data.items()}
-        for it in range(steps):
-            b = {k: v[it * B:(it + 1) * B] for k, v in cdata.items()}
-            est = ols.local_stage_forward(sd, b["img_ny"].permute(0, 3, 1, 2), training=True)
-            oopt.zero_grad()
-            loss, _, _ = orr.local_loss(est, b["img_gt"], b["img_gt"], b["bndry_dist"], b["deri"], args.beta_bndry_loc,
-                                        args.beta_smthns, inverse="solve")
-            loss.backward()
-            torch.nn.utils.clip_grad_norm_(params, 1.0)
-            oopt.step()
-            out.append(float(loss.detach()))
-        return out
-    ref = oracle_curve(torch.float64)
-    ref32 = oracle_curve(torch.float32)
-    print("hip   ", ["%.6f" % v for v in hip])
-    print("oracle", ["%.6f" % v for v in ref])
-    print("orac32", ["%.6f" % v for v in ref32])
-    # step 0: identical weights -> pure forward parity
-    assert abs(hip[0] - ref[0]) <= 1e-5 * abs(ref[0])
-    # later steps.  Two effects make ANY two arithmetic variants of this training step drift apart within a few
-    # iterations (the reference's own fp32 and fp64 runs do: orac32 vs oracle above):
-    #  (1) the loss of a patch whose edge is far sharper than the pixel pitch (eta ~ 1e-3 against 0.1) is
-    #      ill-conditioned in the logits: measured on this batch, the 7e-6 difference between the fp32 HIP logits and
-    #      the fp64 oracle logits changes d loss/d est by 1.4e-3, although the loss kernel matches the fp64 autograd
-    #      gradient to 1.4e-7 AT EQUAL INPUT (tools/dbg_grad.py);
-    #  (2) AdamW's first updates are lr*sign(g) for EVERY parameter, so the sign of each gradient element below the
-    #      accumulation noise (~1e-5 of the largest, for fp32 sums over up to 28 224 pixels) is arbitrary.
-    # Step-0 parity and the gradient test against G2 are the strict checks; here the curves must overlay.
-    for h, r in zip(hip, ref):
-        assert abs(h - r) <= 0.10 * abs(r), (hip, ref, ref32)
-    assert hip[-1] < hip[0] and ref[-1] < ref[0]
-    assert all(np.isfinite(hip))
+        stats = {}
+        loss_h = float(train_local.train_step(model, helper, opt, b, args.beta_bndry_loc, args.beta_smthns, stats=stats))
+        norm_h = float(stats["grad_norm"])
+        hip_curve.append(loss_h)
+        # ---- oracle step from the same state
+        params = {k: sd64[k].requires_grad_(True) for k in names}
+        cb = {k: v[it * B:(it + 1) * B] for k, v in cdata.items()}
+        run = {}
+        est = ols.local_stage_forward(sd64, cb["img_ny"].permute(0, 3, 1, 2), training=True, running_out=run)
+        loss_o, _, _ = orr.local_loss(est, cb["img_gt"], cb["img_gt"], cb["bndry_dist"], cb["deri"], args.beta_bndry_loc,
+                                      args.beta_smthns, inverse="solve")
+        grads = torch.autograd.grad(loss_o, [params[k] for k in names])
+        norm_o = float(torch.sqrt(sum((g ** 2).sum() for g in grads)))
+        coef = min(1.0, 1.0 / (norm_o + 1e-6))                   # clip_grad_norm_(max_norm=1)
+        ora_curve.append(float(loss_o))
+        worst["loss"] = max(worst["loss"], abs(loss_h - float(loss_o)) / abs(float(loss_o)))
+        worst["norm"] = max(worst["norm"], abs(norm_h - norm_o) / norm_o)
+        t = it + 1
+        for k, g64 in zip(names, grads):
+            p = dict(model.named_parameters())[k]
+            gh = p.grad.detach().cpu().double()                   # clipped in place by clip_grad_norm_
+            e = float((gh - coef * g64).norm() / (coef * g64).norm())
+            if e > worst["grad"]:
+                worst["grad"], worst["grad_name"] = e, f"{k}@{it}"
+            # AdamW arithmetic in float64 from the HIP run's own clipped gradient and its state before the step
+            m0 = st[k]["exp_avg"].cpu().double() if k in st else torch.zeros_like(gh)
+            v0 = st[k]["exp_avg_sq"].cpu().double() if k in st else torch.zeros_like(gh)
+            m1, v1 = b1 * m0 + (1 - b1) * gh, b2 * v0 + (1 - b2) * gh * gh
+            p0 = before[k].cpu().double()
+            p1 = p0 * (1 - lr * wd) - lr * (m1 / (1 - b1 ** t)) / ((v1 / (1 - b2 ** t)).sqrt() + eps)
+            d_ref, d_hip = p1 - p0, p.detach().cpu().double() - p0
+            e = float((d_hip - d_ref).norm() / d_ref.norm())
+            if e > worst["upd"]:
+                worst["upd"], worst["upd_name"] = e, f"{k}@{it}"
+        sd_after = model.state_dict()
+        for k, v in run.items():
+            worst["run"] = max(worst["run"], float((sd_after[k].cpu().double() - v).abs().max() / v.abs().max()))
+        assert int(sd_after["conv1.1.num_batches_tracked"]) == t
+        # ---- the free-running diagnostic
+        fest = ols.local_stage_forward(free_sd, cb["img_ny"].permute(0, 3, 1, 2), training=True)
+        free_opt.zero_grad()
+        fl, _, _ = orr.local_loss(fest, cb["img_gt"], cb["img_gt"], cb["bndry_dist"], cb["deri"], args.beta_bndry_loc,
+                                  args.beta_smthns, inverse="solve")
+        fl.backward()
+        torch.nn.utils.clip_grad_norm_(free_params, 1.0)
+        free_opt.step()
+        free_curve.append(float(fl.detach()))
+        worst["free"] = max(worst["free"], abs(loss_h - free_curve[-1]) / abs(free_curve[-1]))
+    print("hip            ", ["%.6f" % v for v in hip_curve])
+    print("oracle (forced)", ["%.6f" % v for v in ora_curve])
+    print("oracle (free)  ", ["%.6f" % v for v in free_curve])
+    print("teacher-forced worst over %d steps: %s" % (steps, worst))
+    # tolerances: measured on MI355X (see the printed line), with ~3x margin; never widened to make a run pass
+    assert worst["loss"] <= 1e-5                                  # measured TBD: forward parity at every visited state
+    assert worst["norm"] <= 5e-4                                  # measured TBD
+    assert worst["grad"] <= 5e-3, worst                           # measured TBD ( App. C: the loss of sharp
+    #                                                               edges is ill-conditioned in the fp32 logits)
+    assert worst["upd"] <= 1e-3, worst                            # measured TBD: fp32 AdamW + the rounding of p + dp
+    assert worst["run"] <= 1e-5
+    assert all(np.isfinite(hip_curve)) and hip_curve[-1] < hip_curve[0]
+
+
+def test_graph_replayed_training_steps_are_seen_by_the_next_eval_forward():
+    """ADVICE r1 (high): a replayed hipGraph moves weights and running statistics without touching any tensor version;
+    the eval forward's BN-folded weight pack must not survive it.  Train with GraphedStep at constant beta / lr (so the
+    graph is captured once and only replayed), switch to eval, and compare with a FRESH model loaded from state_dict()."""
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a GPU")
+    import models, utils
+    from be_hip import dp, train_local
+    args = utils.get_args("local_train", argv=[])
+    B = 64
+    data = {k: torch.from_numpy(v).to(DEV) for k, v in synth.synthetic_training_patches(B * 6, seed=9).items()}
+    model = models.LocalStage().to(DEV)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.local_stage_state_dict().items()})
+    helper = utils.PostProcessLocalBase(args, DEV)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-3, capturable=True, fused=dp.fused_adamw())
+    gstep = train_local.GraphedStep(model, helper, opt)
+    x_eval = torch.from_numpy(synth.uniform_patches(32, name="graph_eval")).to(DEV)
+    logits = []
+    for epoch in range(3):
+        model.train()
+        for it in range(6):
+            gstep({k: v[it * B:(it + 1) * B] for k, v in data.items()}, args.beta_bndry_loc, args.beta_smthns)
+        model.eval()
+        with torch.no_grad():
+            y = model(x_eval).clone()
+        fresh = models.LocalStage().to(DEV)
+        fresh.load_state_dict(model.state_dict())
+        fresh.eval()
+        with torch.no_grad():
+            assert torch.equal(y, fresh(x_eval)), f"epoch {epoch}: eval ran on a stale weight pack"
+        logits.append(y)
+    assert gstep.graph is not None
+    assert not torch.equal(logits[0], logits[1]) and not torch.equal(logits[1], logits[2])
+    # and without the train()/eval() switch in between: replay, then straight to an inference entry point
+    model.train()
+    gstep({k: v[:B] for k, v in data.items()}, args.beta_bndry_loc, args.beta_smthns)
+    model.training = False                                         # bypasses LocalStage.train(): only the replay hook is left
+    with torch.no_grad():
+        y = model(x_eval).clone()
+    fresh = models.LocalStage().to(DEV)
+    fresh.load_state_dict(model.state_dict())
+    fresh.eval()
+    with torch.no_grad():
+        assert torch.equal(y, fresh(x_eval))
 
 
 def test_backward_leaves_the_gradients_as_one_flat_buffer_in_parameter_order():

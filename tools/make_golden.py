@@ -487,7 +487,130 @@ def G14():
     save("g14_datagen", **out)
 
 
-GROUPS = dict(G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G8=G8, G9=G9, G10=G10, G11=G11, G12=G12, G13=G13, G14=G14)
+def _as_double_global(helper, dcal):
+    """the reference's eval-time helper with every constant tensor cast to float64 (as G11 does for GlobalLoss)"""
+    helper.x, helper.y, helper.ridge = helper.x.double(), helper.y.double(), helper.ridge.double()
+    helper.sobel_x, helper.sobel_y = helper.sobel_x.double(), helper.sobel_y.double()
+    helper.num_patches = helper.num_patches.double()
+    dcal.intercept, dcal.theta_mid, dcal.theta_wng = dcal.intercept.double(), dcal.theta_mid.double(), dcal.theta_wng.double()
+
+
+def G15():
+    """LocalStage -> GlobalStage feature glue, read out of the reference's OWN drivers run with stub modules:
+    (a) depth_estimator (blurry_edges_test.py:102-145): stub local module (fixed raw params incl. unwrapped angles), stub
+        helper (fixed pass-A colours [2,3,3,Hp,Wp] with distinct rgb/wedge values; records the `est` it is handed for pass B),
+        stub global module (records `pm`, returns a fixed [1,P,12]); a 13 x 21 patch grid (45 x 61 image) so that a
+        row/column transposition cannot pass;
+    (b) ref_data_gen (global_data_pre_cal.py:10-33) with the same stub local module and the reference's real
+        local-layout PostProcess cast to float64 -> params_src [1,2,P,19] (colours flattened from the LOCAL layout)."""
+    import shutil
+    import tempfile
+    sys.modules["cv2"].imwrite = lambda *a, **k: True
+    sys.modules.setdefault("tqdm", types.ModuleType("tqdm"))
+    if not hasattr(sys.modules["tqdm"], "tqdm"):
+        sys.modules["tqdm"].tqdm = lambda it, **k: it
+    import global_data_pre_cal as ref_pre
+    H, W = 45, 61
+    hp, wp = (H - 21) // 2 + 1, (W - 21) // 2 + 1           # 13 x 21
+    P = hp * wp
+    S = synth.SEED_DEFAULT
+    p10 = synth.glue_params10(P)                              # [2P,10], angles unwrapped by whole turns, both signs
+    col = synth.f32(synth.hash_uniform(S, "g15_colors", (2, 3, 3, hp, wp)))
+    y12 = synth.f32(-1.5 + 3.0 * synth.hash_uniform(S, "g15_global_out", (1, P, 12)))
+    imgs, _ = synth.synthetic_image_pair(H, W)                # [2,3,H,W]
+    rec = {}
+
+    class Helper:
+        device = torch.device("cpu")
+        H_patches, W_patches = hp, wp
+
+        def __call__(self, params, img_patches, colors_only):
+            if colors_only:
+                rec["params_a"] = params.clone()
+                rec["img_patches_shape"] = np.array(img_patches.shape)
+                return torch.from_numpy(col)
+            rec["est"] = params.clone()
+            z = lambda *s: np.full(s, 0.9, np.float32)
+            return z(1, 2, 3, H, W), z(1, 3, H, W), z(1, 3, H, W), z(1, 1, H, W), z(1, H, W), z(1, H, W)
+
+    class Vis:
+        def visualize(self, *a):
+            return np.zeros((2, 2, 3), np.uint8)
+
+    def local_stub(vec):
+        rec["vec_shape"] = np.array(vec.shape)
+        return torch.from_numpy(p10).to(vec.dtype)
+
+    def global_stub(pm):
+        rec["pm"] = pm.clone()
+        return torch.from_numpy(y12)
+
+    a = ref_args("eval")
+    tmp = tempfile.mkdtemp(dir=os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else ROOT)
+    a.log_path, a.crop = tmp, 2
+    loader = [(torch.from_numpy(imgs).permute(0, 2, 3, 1)[None].contiguous(), torch.ones(1, H, W))]
+    try:
+        with np.errstate(all="ignore"):
+            ref_test.depth_estimator(a, local_stub, global_stub, None, Helper(), Vis(), loader)
+        # (b) the second copy of the glue, with the real local-layout colour solve in float64
+        b = ref_args("global_pre")
+        b.img_size, b.data_path = [H, W], tmp
+        hl = ref_pre.PostProcess(b, torch.device("cpu"))
+        hl.x, hl.y, hl.ridge = hl.x.double(), hl.y.double(), hl.ridge.double()
+        ref_pre.ref_data_gen(b, lambda vec: torch.from_numpy(p10).to(vec.dtype), hl,
+                             [torch.from_numpy(imgs).double().permute(0, 2, 3, 1)[None].contiguous()], "g15")
+        params_src = np.load(os.path.join(tmp, "params_src_g15.npy"))
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    assert tuple(rec["vec_shape"]) == (2 * P, 3, 21, 21) and rec["pm"].shape == (1, P, 38) and rec["est"].shape == (1, P, 12)
+    save("g15_glue", grid=np.array([H, W, hp, wp]), params_a=n(rec["params_a"]), pm=n(rec["pm"]), est=n(rec["est"]),
+         params_src_f64=params_src)
+
+
+def G16():
+    """float64 run of the eval-time PostProcess of G6 (same inputs; helper tensors cast to double as in G11): pass-A
+    colours, pass-B colours, the 4x4 sub-grid outputs and the six folded maps.  Stored as float32 (6e-8 relative - far
+    below the 1e-4 they are compared at) except where noted."""
+    a = ref_args("eval")
+    dev = torch.device("cpu")
+    imgs, _ = synth.synthetic_image_pair(147, 147)
+    t_img = torch.from_numpy(imgs).double()
+    img_patches = torch.nn.Unfold(a.R, stride=a.stride)(t_img).view(2, 3, a.R, a.R, 64, 64)
+    p10 = torch.from_numpy(np.stack([synth.plausible_params10(4096, name="g6_img1"),
+                                     synth.plausible_params10(4096, name="g6_img2")])).double()
+    p12 = torch.from_numpy(synth.plausible_params12(4096, name="g6_est"))[None].double()
+    sub = (slice(20, 24), slice(30, 34))
+    f32 = lambda t: n(t).astype(np.float32) if torch.is_tensor(t) else np.asarray(t).astype(np.float32)
+    out = {}
+    for densify in (None, "w"):
+        a.densify = densify
+        dcal = ref_utils.DepthEtas(a, dev)
+        helper = ref_test.PostProcess(a, dcal, dev)
+        _as_double_global(helper, dcal)
+        tag = "w_" if densify == "w" else ""
+        helper.img_patches = img_patches.unsqueeze(0)
+        est = p12.permute(0, 2, 1).view(1, 12, 64, 64)
+        etas = helper.params2etas(est[:, 8:])
+        patches, shpd, refoc, bnd, dmap, dmask = helper.get_patches(est[:, :8], etas, False)
+        dists = helper.params2dists(est[:, :8])
+        w1 = helper.dists2indicators(dists, etas[:, :2])
+        w2 = helper.dists2indicators(dists, etas[:, 2:])
+        colors_b = helper.get_colors(torch.cat([w1.unsqueeze(1), w2.unsqueeze(1)], dim=1), helper.img_patches, False)
+        folded = helper(p12, img_patches, colors_only=False)
+        if densify is None:
+            out["colors_a"] = f32(helper(p10, img_patches, colors_only=True))          # [2,3,3,64,64]
+            out["colors_b"] = f32(colors_b)                                            # [1,3,3,64,64]
+            out.update(sub_patches=f32(patches[0][..., sub[0], sub[1]]), sub_shpd=f32(shpd[0][..., sub[0], sub[1]]),
+                       sub_bnd=f32(bnd[0, 0][..., sub[0], sub[1]]),
+                       fold_image=f32(folded[0]), fold_shpd=f32(folded[1]), fold_bndry=f32(folded[3]))
+        out.update({tag + "sub_refoc": f32(refoc[0][..., sub[0], sub[1]]), tag + "sub_dmap": f32(dmap[0][..., sub[0], sub[1]]),
+                    tag + "sub_dmask": n(dmask[0][..., sub[0], sub[1]]),
+                    tag + "mask_hist": np.bincount(n(dmask).ravel(), minlength=3),
+                    tag + "fold_refoc": f32(folded[2]), tag + "fold_depth": f32(folded[4]), tag + "fold_conf": f32(folded[5])})
+    save("g16_postprocess_147_f64", **out)
+
+
+GROUPS = dict(G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G8=G8, G9=G9, G10=G10, G11=G11, G12=G12, G13=G13, G14=G14, G15=G15, G16=G16)
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)

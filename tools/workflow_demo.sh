@@ -14,6 +14,7 @@ T2=$(t); python -m be_hip.workflow global_pre --data_path $D/data --model_path $
 T3=$(t); python -m be_hip.workflow global_train --data_path $D/data --model_path $D/w --log_path $D/logs --epoch_num 12 > $O/4_global_train.log 2>&1
 cp $D/logs/exp_global_stage_training.txt $O/4_global_train_epochs.txt
 cp $D/w/best_run_exp_global_stage.pth $D/w/pretrained_global_stage.pth
+cp $D/w/best_run_exp_global_stage.pth $D/w/pretrained_global_stage_w.pth   # the name blurry_edges_test.py:187-188 loads for --densify w
 T4=$(t); mkdir -p $D/test
 python - <<PY
 import numpy as np
