@@ -13,10 +13,18 @@ DEV = "cuda:0"
 def test_twenty_training_steps_teacher_forced_against_the_fp64_oracle():
     """configs[2], SURVEY 8d "loss-curve parity for the first 20 steps" (local_training.py:99-108), drift-free:
     before EVERY step the HIP model's current parameters + BatchNorm running statistics are copied into the float64
-    oracle, which then takes the same step on the same batch.  Compared per step: the loss, the total gradient norm,
-    every parameter's (clipped) gradient norm-wise, the updated running statistics, and the AdamW update itself -
-    recomputed in float64 from the optimizer state the HIP run held before the step.  Nothing free-runs, so a gradient
-    that is wrong by a fraction of a per cent in any layer shows at the step where it happens."""
+    oracle, which then takes the same step on the same batch; nothing free-runs.  Compared per step:
+      (1) the loss;
+      (2) d loss / d logits at the HIP logits (the loss kernel's backward at equal input);
+      (3) every parameter gradient with the SAME cotangent pushed through the oracle CNN (the CNN backward alone);
+      (4) the chain (2)+(3) in one piece - the oracle's parameter gradients had its logits been the HIP logits - and the
+          train-mode logits themselves; what is left between that and the plain end-to-end comparison is the sensitivity of
+          d loss / d logits to a 5e-6 logit difference, a property of the LOSS (a patch whose edge is far sharper than the
+          pixel pitch is ill-conditioned, App. C): it moves the gradient by up to 4e-2 in some batches, and the float32 run
+          of the oracle from the same state by 1e-2 ... 6e-2 depending on its thread count.  That figure is printed for
+          both, not asserted beyond a sanity bound;
+      (5) the updated running statistics and num_batches_tracked;
+      (6) clipping + AdamW, recomputed in float64 from the HIP run's own gradient and optimizer state before the step."""
     if not torch.cuda.is_available():
         pytest.fail("gpu-marked test run without a GPU")
     import models, utils
@@ -27,90 +35,122 @@ def test_twenty_training_steps_teacher_forced_against_the_fp64_oracle():
     data = synth.synthetic_training_patches(B * steps, seed=5)
     args = utils.get_args("local_train", argv=[])
     assert args.learning_rate == lr
-    torch.set_num_threads(min(16, torch.get_num_threads() or 1) or 1)
     model = models.LocalStage().to(DEV)
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.local_stage_state_dict().items()})
     helper = utils.PostProcessLocalBase(args, DEV)
     opt = torch.optim.AdamW(model.parameters(), lr=lr)
     model.train()
     names = [k for k, _ in model.named_parameters()]
+    hp = dict(model.named_parameters())
+    # a bias in front of a BatchNorm has gradient exactly 0 in exact arithmetic: what either side computes is rounding noise
+    live = [k for k in names if not (k.endswith(".0.bias") or k == "fc.1.bias")]
     gdata = {k: torch.from_numpy(v).to(DEV) for k, v in data.items()}
-    cdata = {k: torch.from_numpy(v).double() for k, v in data.items()}
-    worst = dict(loss=0.0, norm=0.0, grad=0.0, grad_name="", upd=0.0, upd_name="", run=0.0, free=0.0)
-    hip_curve, ora_curve = [], []
-    # free-running float64 oracle next to it: a printed diagnostic only (it drifts, as any two arithmetic variants do)
-    free_sd = ols.to_torch_sd(synth.local_stage_state_dict(), torch.float64)
-    free_params = [v.requires_grad_(True) for k, v in free_sd.items() if v.is_floating_point() and "running_" not in k]
-    free_opt = torch.optim.AdamW(free_params, lr=lr)
-    free_curve = []
+    W = dict(loss=0.0, logits=0.0, dest_same=0.0, cnn=0.0, cnn_name="", chain=0.0, chain_name="", e2e_hip=0.0, e2e_f32=0.0,
+             norm=0.0, run=0.0, upd_ulp=0.0, upd_name="", dead=0.0)
+    cnn_all, hip_curve, ora_curve = [], [], []
+
+    def loss_of(est, cb):
+        return orr.local_loss(est, cb["img_gt"], cb["img_gt"], cb["bndry_dist"], cb["deri"], args.beta_bndry_loc,
+                              args.beta_smthns, inverse="solve")[0]
+    rel = lambda a, r: float((a - r).norm() / r.norm())
     for it in range(steps):
-        # ---- snapshot of the HIP state BEFORE the step
-        sd64 = {k: (v.detach().cpu().double() if v.is_floating_point() else v.detach().cpu()) for k, v in model.state_dict().items()}
-        before = {k: p.detach().clone() for k, p in model.named_parameters()}
-        st = {k: {kk: (vv.detach().clone() if torch.is_tensor(vv) else vv) for kk, vv in opt.state[p].items()}
-              for k, p in model.named_parameters() if p in opt.state}
-        # ---- HIP step
-        b = {k: v[it * B:(it + 1) * B] for k, v in gdata.items()}
-        stats = {}
-        loss_h = float(train_local.train_step(model, helper, opt, b, args.beta_bndry_loc, args.beta_smthns, stats=stats))
-        norm_h = float(stats["grad_norm"])
-        hip_curve.append(loss_h)
-        # ---- oracle step from the same state
-        params = {k: sd64[k].requires_grad_(True) for k in names}
-        cb = {k: v[it * B:(it + 1) * B] for k, v in cdata.items()}
-        run = {}
-        est = ols.local_stage_forward(sd64, cb["img_ny"].permute(0, 3, 1, 2), training=True, running_out=run)
-        loss_o, _, _ = orr.local_loss(est, cb["img_gt"], cb["img_gt"], cb["bndry_dist"], cb["deri"], args.beta_bndry_loc,
-                                      args.beta_smthns, inverse="solve")
-        grads = torch.autograd.grad(loss_o, [params[k] for k in names])
-        norm_o = float(torch.sqrt(sum((g ** 2).sum() for g in grads)))
-        coef = min(1.0, 1.0 / (norm_o + 1e-6))                   # clip_grad_norm_(max_norm=1)
-        ora_curve.append(float(loss_o))
-        worst["loss"] = max(worst["loss"], abs(loss_h - float(loss_o)) / abs(float(loss_o)))
-        worst["norm"] = max(worst["norm"], abs(norm_h - norm_o) / norm_o)
         t = it + 1
-        for k, g64 in zip(names, grads):
-            p = dict(model.named_parameters())[k]
-            gh = p.grad.detach().cpu().double()                   # clipped in place by clip_grad_norm_
-            e = float((gh - coef * g64).norm() / (coef * g64).norm())
-            if e > worst["grad"]:
-                worst["grad"], worst["grad_name"] = e, f"{k}@{it}"
-            # AdamW arithmetic in float64 from the HIP run's own clipped gradient and its state before the step
-            m0 = st[k]["exp_avg"].cpu().double() if k in st else torch.zeros_like(gh)
-            v0 = st[k]["exp_avg_sq"].cpu().double() if k in st else torch.zeros_like(gh)
-            m1, v1 = b1 * m0 + (1 - b1) * gh, b2 * v0 + (1 - b2) * gh * gh
-            p0 = before[k].cpu().double()
-            p1 = p0 * (1 - lr * wd) - lr * (m1 / (1 - b1 ** t)) / ((v1 / (1 - b2 ** t)).sqrt() + eps)
-            d_ref, d_hip = p1 - p0, p.detach().cpu().double() - p0
-            e = float((d_hip - d_ref).norm() / d_ref.norm())
-            if e > worst["upd"]:
-                worst["upd"], worst["upd_name"] = e, f"{k}@{it}"
-        sd_after = model.state_dict()
-        for k, v in run.items():
-            worst["run"] = max(worst["run"], float((sd_after[k].cpu().double() - v).abs().max() / v.abs().max()))
+        sd_cpu = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+        st = {k: {kk: (vv.detach().cpu().double() if torch.is_tensor(vv) else vv) for kk, vv in opt.state[hp[k]].items()}
+              for k in names if hp[k] in opt.state}
+        # ---- the HIP step, opened up so that d loss / d logits and the unclipped gradients can be read
+        b = {k: v[it * B:(it + 1) * B] for k, v in gdata.items()}
+        est = model(b["img_ny"].permute(0, 3, 1, 2))
+        est.retain_grad()
+        opt.zero_grad(set_to_none=True)
+        loss = utils.local_loss(helper, est, b["img_gt"], b["img_gt"], b["bndry_dist"], b["deri"], args.beta_bndry_loc, args.beta_smthns)
+        loss.backward()
+        gh = {k: hp[k].grad.detach().cpu().double() for k in names}
+        dest_h = est.grad.detach().cpu().double()
+        norm_h = float(torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=1.0, norm_type=2))
+        gclip = {k: hp[k].grad.detach().cpu().double() for k in names}
+        opt.step()
+        hip_curve.append(float(loss.detach()))
+        # ---- float64 and float32 oracle from the same state
+        res = {}
+        for dt in (torch.float64, torch.float32):
+            sdd = {k: (v.to(dt) if v.is_floating_point() else v) for k, v in sd_cpu.items()}
+            P = [sdd[k].requires_grad_(True) for k in names]
+            cb = {k: torch.from_numpy(v[it * B:(it + 1) * B]).to(dt) for k, v in data.items()}
+            run = {}
+            esto = ols.local_stage_forward(sdd, cb["img_ny"].permute(0, 3, 1, 2), training=True, running_out=run)
+            lo = loss_of(esto, cb)
+            dest_o, = torch.autograd.grad(lo, esto, retain_graph=True)
+            res[dt] = dict(loss=float(lo.detach()), dest=dest_o.double(), run=run)
+            if dt == torch.float64:
+                go = dict(zip(names, torch.autograd.grad(lo, P, retain_graph=True)))
+                e_same = est.detach().cpu().double().requires_grad_(True)
+                dest_same, = torch.autograd.grad(loss_of(e_same, cb), e_same)
+                gb = dict(zip(names, torch.autograd.grad(esto, P, grad_outputs=dest_h, retain_graph=True)))
+                gc = dict(zip(names, torch.autograd.grad(esto, P, grad_outputs=dest_same.detach())))
+                logits_o = esto.detach()
+        o = res[torch.float64]
+        ora_curve.append(o["loss"])
+        W["loss"] = max(W["loss"], abs(hip_curve[-1] - o["loss"]) / abs(o["loss"]))                          # (1)
+        W["dest_same"] = max(W["dest_same"], rel(dest_h, dest_same))                                           # (2)
+        for k in live:                                                                                         # (3)
+            e = rel(gh[k], gb[k])
+            cnn_all.append(e)
+            if e > W["cnn"]:
+                W["cnn"], W["cnn_name"] = e, f"{k}@{it}"
+        W["dead"] = max(W["dead"], max(float(gh[k].norm()) for k in names if k not in live))
+        W["logits"] = max(W["logits"], float((est.detach().cpu().double() - logits_o).abs().max() / logits_o.abs().max()))
+        for k in live:                                                                                         # (4)
+            e = rel(gh[k], gc[k])
+            if e > W["chain"]:
+                W["chain"], W["chain_name"] = e, f"{k}@{it}"
+        e_hip, e_f32 = rel(dest_h, o["dest"]), rel(res[torch.float32]["dest"], o["dest"])
+        if e_hip > W["e2e_hip"]:
+            W["e2e_hip"], W["e2e_f32"] = e_hip, e_f32
+        norm_o = float(torch.sqrt(sum((g ** 2).sum() for g in go.values())))
+        W["norm"] = max(W["norm"], abs(norm_h - norm_o) / norm_o)
+        sd_after = model.state_dict()                                                                          # (5)
+        for k, v in o["run"].items():
+            W["run"] = max(W["run"], float((sd_after[k].cpu().double() - v).abs().max() / v.abs().max()))
         assert int(sd_after["conv1.1.num_batches_tracked"]) == t
-        # ---- the free-running diagnostic
-        fest = ols.local_stage_forward(free_sd, cb["img_ny"].permute(0, 3, 1, 2), training=True)
-        free_opt.zero_grad()
-        fl, _, _ = orr.local_loss(fest, cb["img_gt"], cb["img_gt"], cb["bndry_dist"], cb["deri"], args.beta_bndry_loc,
-                                  args.beta_smthns, inverse="solve")
-        fl.backward()
-        torch.nn.utils.clip_grad_norm_(free_params, 1.0)
-        free_opt.step()
-        free_curve.append(float(fl.detach()))
-        worst["free"] = max(worst["free"], abs(loss_h - free_curve[-1]) / abs(free_curve[-1]))
+        coef = min(1.0, 1.0 / (norm_h + 1e-6))                                                                 # (6)
+        for k in live:
+            assert rel(gclip[k], coef * gh[k]) <= 1e-6, k
+            m0 = st[k]["exp_avg"] if k in st else torch.zeros_like(gh[k])
+            v0 = st[k]["exp_avg_sq"] if k in st else torch.zeros_like(gh[k])
+            m1, v1 = b1 * m0 + (1 - b1) * gclip[k], b2 * v0 + (1 - b2) * gclip[k] ** 2
+            p0 = sd_cpu[k].detach().double()
+            d_ref = p0 * (-lr * wd) - lr * (m1 / (1 - b1 ** t)) / ((v1 / (1 - b2 ** t)).sqrt() + eps)
+            # the new parameter is a float32: it can carry the update only to its own spacing (a BatchNorm gamma near 1
+            # takes a 6e-5 step in units of 1.2e-7), so the yardstick is ulps of the result, plus the fp32 rounding of the
+            # step itself
+            p1 = (p0 + d_ref).numpy()
+            # ... and of the moment m1 = 0.9 m0 + 0.1 g where the two terms cancel
+            cancel = lr * (b1 * m0.abs() + (1 - b1) * gclip[k].abs()) / (1 - b1 ** t) / ((v1 / (1 - b2 ** t)).sqrt() + eps)
+            tol = np.spacing(np.abs(p1).astype(np.float32)).astype(np.float64) + 3e-6 * np.abs(d_ref.numpy()) + 3e-7 * cancel.numpy()
+            ratio = np.abs(hp[k].detach().cpu().double().numpy() - p1) / tol
+            e = float(ratio.max())
+            if e > W["upd_ulp"]:
+                j = np.unravel_index(int(ratio.argmax()), ratio.shape)
+                W["upd_ulp"], W["upd_name"] = e, f"{k}@{it}"
+                W["upd_detail"] = dict(p0=float(p0[j]), g=float(gclip[k][j]), m0=float(m0[j]), v0=float(v0[j]), d_ref=float(d_ref[j]),
+                                       d_hip=float(hp[k].detach().cpu().double()[j] - p0[j]))
+    cnn_med = float(np.median(cnn_all))
     print("hip            ", ["%.6f" % v for v in hip_curve])
     print("oracle (forced)", ["%.6f" % v for v in ora_curve])
-    print("oracle (free)  ", ["%.6f" % v for v in free_curve])
-    print("teacher-forced worst over %d steps: %s" % (steps, worst))
-    # tolerances: measured on MI355X (see the printed line), with ~3x margin; never widened to make a run pass
-    assert worst["loss"] <= 1e-5                                  # measured TBD: forward parity at every visited state
-    assert worst["norm"] <= 5e-4                                  # measured TBD
-    assert worst["grad"] <= 5e-3, worst                           # measured TBD ( App. C: the loss of sharp
-    #                                                               edges is ill-conditioned in the fp32 logits)
-    assert worst["upd"] <= 1e-3, worst                            # measured TBD: fp32 AdamW + the rounding of p + dp
-    assert worst["run"] <= 1e-5
-    assert all(np.isfinite(hip_curve)) and hip_curve[-1] < hip_curve[0]
+    print("teacher-forced, worst over %d steps: %s  cnn median %.2e" % (steps, W, cnn_med))
+    # tolerances written from the measurement on MI355X quoted next to each (about 3x margin)
+    assert W["loss"] <= 3e-6                 # measured 8.9e-7
+    assert W["dest_same"] <= 1.5e-6          # measured 4.2e-7
+    assert W["cnn"] <= 1e-2 and cnn_med <= 1e-5, W     # measured 2.6e-3 (conv1.1.weight, step 8) / 2.5e-6: worst / median over 20 steps x 46 tensors; the worst cases
+    #                                          are discrete fp32 events (a max-pool tie broken the other way), the fp32 oracle has them too
+    assert W["chain"] <= 1e-2, W             # measured 2.6e-3 (the same event)
+    assert W["logits"] <= 1e-5               # measured 3.5e-6: train-mode logits (batch statistics) at every visited state
+    assert W["e2e_hip"] <= 0.2, W            # sanity only, see (4): measured 4.0e-2 (step 5) with the fp32 oracle at 1.7e-2 ... 5.8e-2 at that step
+    assert W["run"] <= 1e-6                  # measured 1.4e-7
+    assert W["upd_ulp"] <= 2.0, W            # measured 1.06 in units of the yardstick above (1 = one spacing of the updated fp32 parameter)
+    assert W["dead"] <= 1e-6                 # measured 8.1e-8: the exactly-zero gradients stay at rounding noise
+    assert all(np.isfinite(hip_curve)) and np.mean(hip_curve[-5:]) < np.mean(hip_curve[:5])
 
 
 def test_graph_replayed_training_steps_are_seen_by_the_next_eval_forward():
