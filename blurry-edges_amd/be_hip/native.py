@@ -100,8 +100,8 @@ _SIGNATURES = {
     "be_datagen_candidates_f64": (C.c_int, [_P, _P] + [C.c_int] * 5 + [_P]),
     "be_datagen_crop_f64": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64] + [C.c_int] * 4 + [_P, _P]),
     "be_attention_train_workspace_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
-    "be_attention_train_fwd_f32": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint32, _P]),
-    "be_attention_bwd_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint32, _P]),
+    "be_attention_train_fwd_f32": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint32, _P]),
+    "be_attention_bwd_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint32, _P]),
     "be_attention_dropout_mask_f32": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint32, _P]),
     "be_dropout_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_float, C.c_uint32, C.c_uint32, _P]),
     "be_add_layernorm_train_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_float, C.c_float, C.c_uint32,
@@ -137,7 +137,7 @@ _SIGNATURES = {
     "be_image_derivative_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, _P]),
     "be_fold_patches_f32": (C.c_int, [_P, _P, _P] + [C.c_int] * 7 + [C.c_int64] * 6 + [C.c_int, _P]),
     "be_attention_workspace_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
-    "be_attention_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, _P]),
+    "be_attention_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "be_add_layernorm_f32": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_float, _P]),
     "be_add_pe_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int64, _P]),
     "be_global_loss_f32": (C.c_int, [C.POINTER(RenderOpts), C.POINTER(DepthConsts)] + [_P] * 9 + [C.POINTER(C.c_float)]
@@ -613,14 +613,15 @@ def linear(x2d, pw, pb, cout, act=0, residual=None):
     return y.view(t, cout)
 
 
-def attention(qkv, B, L, H, workspace=None):
-    """qkv [B*L, 3*H*16] -> [B*L, H*16]."""
+def attention(qkv, B, L, H, workspace=None, l_valid=None):
+    """qkv [B*L, 3*H*16] -> [B*L, H*16].  l_valid: real tokens per sequence when L is padded to a multiple of 128."""
     dev = qkv.device
     need = lib().be_attention_workspace_floats(B, L, H)
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(need, dtype=torch.float32, device=dev)
     out = torch.empty(B * L, H * 16, dtype=torch.float32, device=dev)
-    check(lib().be_attention_f32(dptr(qkv, "qkv"), dptr(out), dptr(workspace), B, L, H, stream_ptr(dev)), "be_attention_f32")
+    check(lib().be_attention_f32(dptr(qkv, "qkv"), dptr(out), dptr(workspace), B, L, L if l_valid is None else int(l_valid), H,
+                                 stream_ptr(dev)), "be_attention_f32")
     return out, workspace
 
 

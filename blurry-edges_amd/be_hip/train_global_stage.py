@@ -56,19 +56,19 @@ def _wgrad_lin(x, dy, w_shape):
     return _wgrad(x.view(t, 1, 1, x.shape[1]), dy.view(t, 1, 1, dy.shape[1]), tuple(w_shape), 1)
 
 
-def attention_train_fwd(qkv, B, L, H, p, seed, ws=None):
+def attention_train_fwd(qkv, B, L, H, p, seed, ws=None, l_valid=None):
     dev = qkv.device
     need = lib().be_attention_train_workspace_floats(B, L, H)
     if ws is None or ws.numel() < need:
         ws = _new(need, dev)
     out = _new((B * L, H * 16), dev)
     lse = _new((B * H, L), dev)
-    check(lib().be_attention_train_fwd_f32(dptr(qkv, "qkv"), dptr(out), dptr(lse), dptr(ws), B, L, H, float(p),
-                                           int(seed) & 0xffffffff, stream_ptr(dev)), "be_attention_train_fwd_f32")
+    check(lib().be_attention_train_fwd_f32(dptr(qkv, "qkv"), dptr(out), dptr(lse), dptr(ws), B, L, L if l_valid is None else int(l_valid),
+                                           H, float(p), int(seed) & 0xffffffff, stream_ptr(dev)), "be_attention_train_fwd_f32")
     return out, lse, ws
 
 
-def attention_bwd(qkv, out, lse, dout, B, L, H, p, seed, ws=None, operands_ready=False):
+def attention_bwd(qkv, out, lse, dout, B, L, H, p, seed, ws=None, operands_ready=False, l_valid=None):
     """operands_ready: ws is the workspace attention_train_fwd returned for THIS qkv and is untouched since."""
     dev = qkv.device
     need = lib().be_attention_train_workspace_floats(B, L, H)
@@ -76,8 +76,8 @@ def attention_bwd(qkv, out, lse, dout, B, L, H, p, seed, ws=None, operands_ready
         ws, operands_ready = _new(need, dev), False
     dqkv = torch.empty_like(qkv)
     check(lib().be_attention_bwd_f32(dptr(qkv, "qkv"), dptr(out), dptr(lse), dptr(dout.contiguous(), "dout"), dptr(dqkv),
-                                     dptr(ws), int(bool(operands_ready)), B, L, H, float(p), int(seed) & 0xffffffff,
-                                     stream_ptr(dev)), "be_attention_bwd_f32")
+                                     dptr(ws), int(bool(operands_ready)), B, L, L if l_valid is None else int(l_valid), H, float(p),
+                                     int(seed) & 0xffffffff, stream_ptr(dev)), "be_attention_bwd_f32")
     return dqkv, ws
 
 
@@ -118,8 +118,9 @@ def layernorm_bwd(dy, v, gamma, eps, p, seed, site, want_dv=True, want_dx=True):
     return dv, dx, gb[:d].clone(), gb[d:].clone()
 
 
-def forward_train(src, pe, seed, p, H, eps, t):
-    """src [B,L,cin]; t = parameter_list order (detached).  -> (out [B,L,cout], saved)."""
+def forward_train(src, pe, seed, p, H, eps, t, l_valid=None):
+    """src [B,L,cin]; t = parameter_list order (detached).  -> (out [B,L,cout], saved).
+    l_valid: real tokens per sequence when the caller padded L up to a multiple of 128 (keys beyond are masked)."""
     B, L, cin = src.shape
     T = B * L
     dev = src.device
@@ -132,11 +133,11 @@ def forward_train(src, pe, seed, p, H, eps, t):
     w_in = torch.cat([t[0], t[0].new_zeros(t[0].shape[0], pad)], dim=1) if pad else t[0]
     h = _linear(x0, w_in, t[1])
     native.add_pe_(h, pe[:L].contiguous(), B)
-    S = dict(x0=x0, layers=[], shape=(B, L, cin))
+    S = dict(x0=x0, layers=[], shape=(B, L, cin), l_valid=l_valid)
     for i in range(nl):
         wqkv, bqkv, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2 = t[2 + PER_LAYER * i:2 + PER_LAYER * (i + 1)]
         qkv = _linear(h, wqkv, bqkv)
-        a, lse, ws = attention_train_fwd(qkv, B, L, H, p, seed + 16 * i)      # one workspace per layer: the split q/k/v
+        a, lse, ws = attention_train_fwd(qkv, B, L, H, p, seed + 16 * i, l_valid=l_valid)   # one workspace per layer: the split q/k/v
                                                                               # (6 x 16 B per token and head) are reused by the backward
         sa = _linear(a, wo, bo)
         v1, h1 = add_layernorm_train(sa, h, g1, be1, eps, p, seed, 16 * i + 1)
@@ -190,7 +191,7 @@ def backward_train(dout, seed, p, H, eps, t, S):
         grads[base + 2] = _wgrad_lin(a, dsa, wo.shape)
         grads[base + 3] = _col_sum(dsa)
         da = _dgrad_lin(dsa, wo)
-        dqkv, _ = attention_bwd(qkv, a, lse, da, B, L, H, p, seed + 16 * i, ws, operands_ready=True)
+        dqkv, _ = attention_bwd(qkv, a, lse, da, B, L, H, p, seed + 16 * i, ws, operands_ready=True, l_valid=S["l_valid"])
         grads[base] = _wgrad_lin(h_in, dqkv, wqkv.shape)
         grads[base + 1] = _col_sum(dqkv)
         dh = _dgrad_lin(dqkv, wqkv, residual=dv1)
@@ -202,9 +203,9 @@ def backward_train(dout, seed, p, H, eps, t, S):
 
 class GlobalStageTrainFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, src, pe, seed, p, nhead, eps, *params):
+    def forward(ctx, src, pe, seed, p, nhead, eps, l_valid, *params):
         t = [v.detach() for v in params]
-        out, S = forward_train(src.detach(), pe, int(seed), float(p), int(nhead), float(eps), t)
+        out, S = forward_train(src.detach(), pe, int(seed), float(p), int(nhead), float(eps), t, l_valid=l_valid)
         ctx.S, ctx.t, ctx.cfg = S, t, (int(seed), float(p), int(nhead), float(eps))
         return out
 
@@ -213,4 +214,4 @@ class GlobalStageTrainFn(torch.autograd.Function):
         seed, p, nhead, eps = ctx.cfg
         grads = backward_train(dout.contiguous(), seed, p, nhead, eps, ctx.t, ctx.S)
         ctx.S = None
-        return (None,) * 6 + tuple(grads)
+        return (None,) * 7 + tuple(grads)

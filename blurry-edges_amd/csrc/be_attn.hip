@@ -149,10 +149,13 @@ __device__ __forceinline__ float quad_sum(float v) {
 
 // TRAIN: dropout on the probabilities (nn.MultiheadAttention's dropout, models/global_stage.py:28) and the log2-sum-exp
 // of every query row saved for the backward
-template <bool TRAIN>
+// RAGGED: only the first Lv (< L) tokens are real, the rest pads the sequence to a multiple of 128: keys >= Lv get the score
+// -inf (probability exactly 0), fully padded key blocks are never visited.  Padded QUERY rows are computed like any other
+// (their output is discarded by the caller; in training their upstream gradient is exactly 0).
+template <bool TRAIN, bool RAGGED>
 __global__ __launch_bounds__(256)
 void k_attention(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
-                 float* __restrict__ out, float* __restrict__ lse, int L, int H, uint32_t seed, uint32_t thresh,
+                 float* __restrict__ out, float* __restrict__ lse, int L, int Lv, int H, uint32_t seed, uint32_t thresh,
                  float inv_keep, float* __restrict__ part) {
     // grid.x = L/128 query blocks (4 waves x 32 queries), grid.y = B*H, grid.z = key slices (inference at small batch:
     // 256 workgroups cannot fill 256 CUs x 4 SIMDs; each slice then leaves un-normalised partials for k_attn_combine)
@@ -174,14 +177,15 @@ void k_attention(const float* __restrict__ Q, const float* __restrict__ K, const
         o[qc] = f32x4v{0.f, 0.f, 0.f, 0.f};
         m[qc] = -INFINITY; lsum[qc] = 0.f;
     }
-    const int kb0 = (L / KB) * blockIdx.z / gridDim.z;
+    const int nblk = RAGGED ? (Lv + KB - 1) / KB : L / KB;               // key blocks that hold at least one real key
+    const int kb0 = nblk * blockIdx.z / gridDim.z;
     f32x4v kn[2], vn[2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
         kn[kt] = *reinterpret_cast<const f32x4v*>(Kh + (size_t)(kb0 * KB + 16 * kt + c) * DH + 4 * g);
         vn[kt] = *reinterpret_cast<const f32x4v*>(Vh + (size_t)c * L + kb0 * KB + 16 * kt + 4 * g);
     }
-    const int nkb = (L / KB) * (blockIdx.z + 1) / gridDim.z;              // this slice: key blocks [kb0, nkb)
+    const int nkb = nblk * (blockIdx.z + 1) / gridDim.z;                  // this slice: key blocks [kb0, nkb)
     for (int kblk = kb0; kblk < nkb; ++kblk) {
         const f32x4v kf[2] = {kn[0], kn[1]}, vf[2] = {vn[0], vn[1]};
         const int nx = kblk + 1 < nkb ? kblk + 1 : kblk;                 // prefetch (clamped on the last block)
@@ -201,6 +205,13 @@ void k_attention(const float* __restrict__ Q, const float* __restrict__ K, const
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int qc = 0; qc < 2; ++qc) s[kt][qc] = MFMA16(kf[kt][t], qf[qc][t], s[kt][qc]);
+        if (RAGGED && (kblk + 1) * KB > Lv) {                            // the one partial block (wave-uniform branch)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kblk * KB + 16 * kt + 4 * g + r >= Lv) { s[kt][0][r] = -INFINITY; s[kt][1][r] = -INFINITY; }
+        }
 #pragma unroll
         for (int qc = 0; qc < 2; ++qc) {
             float mloc = fmaxf(fmaxf(fmaxf(s[0][qc][0], s[0][qc][1]), fmaxf(s[0][qc][2], s[0][qc][3])),
@@ -288,10 +299,11 @@ __global__ void k_attn_combine(const float* __restrict__ part, float* __restrict
 // per wave and streams the queries.  Same register trick as the forward: a [16x16] tile of dS (or Pd) sits in the
 // accumulator layout and is fed back as the B operand of the next product, whose A operand is a 16-byte load of the
 // transposed tensor ([16][L]).
+template <bool RAGGED>
 __global__ __launch_bounds__(256)
 void k_attn_bwd_dq(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
                    const float* __restrict__ Kt, const float* __restrict__ dOh, const float* __restrict__ lse,
-                   const float* __restrict__ Drow, float* __restrict__ dqkv, int L, int H, uint32_t seed,
+                   const float* __restrict__ Drow, float* __restrict__ dqkv, int L, int Lv, int H, uint32_t seed,
                    uint32_t thresh, float inv_keep) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = lane & 15, g = lane >> 4;
@@ -322,7 +334,7 @@ void k_attn_bwd_dq(const float* __restrict__ Q, const float* __restrict__ K, con
         vn[kt] = *reinterpret_cast<const f32x4v*>(Vh + (size_t)(16 * kt + c) * DH + 4 * g);
         tn[kt] = *reinterpret_cast<const f32x4v*>(Kth + (size_t)c * L + 16 * kt + 4 * g);
     }
-    const int nkb = L / KB;
+    const int nkb = RAGGED ? (Lv + KB - 1) / KB : L / KB;
     for (int kblk = 0; kblk < nkb; ++kblk) {
         const f32x4v kf[2] = {kn[0], kn[1]}, vf[2] = {vn[0], vn[1]}, tf[2] = {tn[0], tn[1]};
         const int nx = kblk + 1 < nkb ? kblk + 1 : kblk;
@@ -346,6 +358,13 @@ void k_attn_bwd_dq(const float* __restrict__ Q, const float* __restrict__ K, con
                     s[kt][qc] = MFMA16(kf[kt][t], qf[qc][t], s[kt][qc]);        // S^T[key][query]
                     dp[kt][qc] = MFMA16(vf[kt][t], gf[qc][t], dp[kt][qc]);      // dPd^T[key][query]
                 }
+        if (RAGGED && (kblk + 1) * KB > Lv) {                            // padded keys: P = exp2(-inf) = 0, so dS = 0
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kblk * KB + 16 * kt + 4 * g + r >= Lv) { s[kt][0][r] = -INFINITY; s[kt][1][r] = -INFINITY; }
+        }
 #pragma unroll
         for (int qc = 0; qc < 2; ++qc) {
             const uint32_t base = (uint32_t)(q0 + 16 * qc + c) * (uint32_t)L + (uint32_t)(kblk * KB + 4 * g);
@@ -385,11 +404,12 @@ void k_attn_bwd_dq(const float* __restrict__ Q, const float* __restrict__ K, con
         *reinterpret_cast<f32x4v*>(dqkv + ((size_t)b * L + q0 + 16 * qc + c) * 3 * Dm + hd * DH + 4 * g) = dq[qc] * 0.25f;
 }
 
+template <bool RAGGED>
 __global__ __launch_bounds__(256)
 void k_attn_bwd_dkv(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
                     const float* __restrict__ Qt, const float* __restrict__ dOh, const float* __restrict__ dOt,
-                    const float* __restrict__ lse, const float* __restrict__ Drow, float* __restrict__ dqkv, int L, int H,
-                    uint32_t seed, uint32_t thresh, float inv_keep) {
+                    const float* __restrict__ lse, const float* __restrict__ Drow, float* __restrict__ dqkv, int L, int Lv,
+                    int H, uint32_t seed, uint32_t thresh, float inv_keep) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = lane & 15, g = lane >> 4;
     const int bh = blockIdx.y;
@@ -420,7 +440,10 @@ void k_attn_bwd_dkv(const float* __restrict__ Q, const float* __restrict__ K, co
         qtn[qt] = *reinterpret_cast<const f32x4v*>(Qth + (size_t)c * L + 16 * qt + 4 * g);
         gtn[qt] = *reinterpret_cast<const f32x4v*>(Gth + (size_t)c * L + 16 * qt + 4 * g);
     }
-    const int nqb = L / KB;
+    // RAGGED: a padded query row has dO = 0 and Drow = 0 (nothing downstream reads its output), so it adds nothing to dK / dV
+    // and its blocks are skipped; a padded KEY column of this wave's tile gets P = 0 through a -inf score
+    const int nqb = RAGGED ? (Lv + KB - 1) / KB : L / KB;
+    const bool kdead[2] = {RAGGED && k0 + c >= Lv, RAGGED && k0 + 16 + c >= Lv};
     for (int qblk = 0; qblk < nqb; ++qblk) {
         const f32x4v qf[2] = {qn[0], qn[1]}, gf[2] = {gn[0], gn[1]}, qtf[2] = {qtn[0], qtn[1]}, gtf[2] = {gtn[0], gtn[1]};
         f32x4v ls[2], dr[2];                                             // per query row 16 qt + 4g + r
@@ -469,7 +492,7 @@ void k_attn_bwd_dkv(const float* __restrict__ Q, const float* __restrict__ K, co
                 }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = fast_exp2(s[qt][kc][r] - ls[qt][r]);
+                    const float p = (RAGGED && kdead[kc]) ? 0.f : fast_exp2(s[qt][kc][r] - ls[qt][r]);
                     float pd = p, gd = dp[qt][kc][r] * inv_keep;
                     if (thresh && __builtin_amdgcn_ubfe(hq[r], 16U * (c & 1), 16U) < t16) { pd = 0.f; gd = 0.f; }
                     s[qt][kc][r] = p * (gd - dr[qt][r]);       // dS
@@ -630,9 +653,10 @@ __global__ void k_add_pe(float* __restrict__ x, const float* __restrict__ pe, in
 
 }  // namespace
 
-extern "C" int be_attention_f32(const float* qkv, float* out, float* workspace, int B, int L, int H, void* stream) {
+extern "C" int be_attention_f32(const float* qkv, float* out, float* workspace, int B, int L, int l_valid, int H, void* stream) {
     BE_REQUIRE(qkv && out && workspace, "be_attention_f32: null pointer");
     BE_REQUIRE(B > 0 && H > 0 && L > 0 && L % 128 == 0, "be_attention_f32: L must be a multiple of 128 (got %d)", L);
+    BE_REQUIRE(l_valid > L - 128 && l_valid <= L, "be_attention_f32: l_valid %d outside (L - 128, L] for L = %d", l_valid, L);
     BE_REQUIRE(be::aligned16(qkv) && be::aligned16(out) && be::aligned16(workspace), "be_attention_f32: 16-byte alignment");
     hipStream_t s = be::as_stream(stream);
     const size_t n = (size_t)B * H * L * DH;
@@ -644,8 +668,12 @@ extern "C" int be_attention_f32(const float* qkv, float* out, float* workspace, 
     const int wgs = (L / 128) * B * H;
     const int nz = (L >= 2048 && wgs < 512) ? (wgs <= 256 ? 4 : 2) : 1;
     float* part = workspace + 3 * n;
-    hipLaunchKernelGGL(k_attention<false>, dim3(L / 128, B * H, nz), dim3(256), 0, s, Q, K, Vt, out, (float*)nullptr, L, H, 0u,
-                       0u, 1.0f, part);
+    if (l_valid == L)
+        hipLaunchKernelGGL((k_attention<false, false>), dim3(L / 128, B * H, nz), dim3(256), 0, s, Q, K, Vt, out, (float*)nullptr,
+                           L, L, H, 0u, 0u, 1.0f, part);
+    else
+        hipLaunchKernelGGL((k_attention<false, true>), dim3(L / 128, B * H, nz), dim3(256), 0, s, Q, K, Vt, out, (float*)nullptr,
+                           L, l_valid, H, 0u, 0u, 1.0f, part);
     if (nz > 1) {
         const int64_t total = (int64_t)B * H * L * 4;
         hipLaunchKernelGGL(k_attn_combine, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256), 0, s,
@@ -660,8 +688,9 @@ TrainWs train_ws(float* w, int B, int L, int H) {
     const size_t n = (size_t)B * H * L * DH;
     return {w, w + n, w + 2 * n, w + 3 * n, w + 4 * n, w + 5 * n, w + 6 * n, w + 7 * n, w + 8 * n};
 }
-int attn_args_ok(const char* who, int B, int L, int H, float p) {
+int attn_args_ok(const char* who, int B, int L, int H, float p, int l_valid = -1) {
     BE_REQUIRE(B > 0 && H > 0 && L > 0 && L % 128 == 0 && L <= 65536, "%s: L must be a multiple of 128, <= 65536 (got %d)", who, L);
+    BE_REQUIRE(l_valid == -1 || (l_valid > L - 128 && l_valid <= L), "%s: l_valid %d outside (L - 128, L] for L = %d", who, l_valid, L);
     BE_REQUIRE(p >= 0.f && p < 1.f, "%s: dropout probability %g outside [0,1)", who, (double)p);
     return BE_OK;
 }
@@ -671,26 +700,30 @@ extern "C" size_t be_attention_train_workspace_floats(int B, int L, int H) {
     return (size_t)8 * B * H * L * DH + (size_t)B * H * L;
 }
 
-extern "C" int be_attention_train_fwd_f32(const float* qkv, float* out, float* lse, float* workspace, int B, int L, int H,
-                                          float dropout_p, uint32_t seed, void* stream) {
+extern "C" int be_attention_train_fwd_f32(const float* qkv, float* out, float* lse, float* workspace, int B, int L, int l_valid,
+                                          int H, float dropout_p, uint32_t seed, void* stream) {
     BE_REQUIRE(qkv && out && lse && workspace, "be_attention_train_fwd_f32: null pointer");
-    if (int rc = attn_args_ok("be_attention_train_fwd_f32", B, L, H, dropout_p)) return rc;
+    if (int rc = attn_args_ok("be_attention_train_fwd_f32", B, L, H, dropout_p, l_valid)) return rc;
     BE_REQUIRE(be::aligned16(qkv) && be::aligned16(out) && be::aligned16(workspace), "be_attention_train_fwd_f32: 16-byte alignment");
     hipStream_t s = be::as_stream(stream);
     const TrainWs w = train_ws(workspace, B, L, H);
     int64_t g = ((int64_t)B * H * L + 255) / 256; if (g > 8192) g = 8192;
     hipLaunchKernelGGL(k_qkv_split_train, dim3((unsigned)g), dim3(256), 0, s, qkv, w.Q, w.K, w.V, w.Qt, w.Kt, w.Vt, B, L, H,
                        0.25f * 1.44269504088896340736f);
-    hipLaunchKernelGGL(k_attention<true>, dim3(L / 128, B * H), dim3(256), 0, s, w.Q, w.K, w.Vt, out, lse, L, H, seed,
-                       drop_threshold(dropout_p), 1.0f / (1.0f - dropout_p), (float*)nullptr);
+    if (l_valid == L)
+        hipLaunchKernelGGL((k_attention<true, false>), dim3(L / 128, B * H), dim3(256), 0, s, w.Q, w.K, w.Vt, out, lse, L, L, H, seed,
+                           drop_threshold(dropout_p), 1.0f / (1.0f - dropout_p), (float*)nullptr);
+    else
+        hipLaunchKernelGGL((k_attention<true, true>), dim3(L / 128, B * H), dim3(256), 0, s, w.Q, w.K, w.Vt, out, lse, L, l_valid, H,
+                           seed, drop_threshold(dropout_p), 1.0f / (1.0f - dropout_p), (float*)nullptr);
     return be::check_launch("be_attention_train_fwd_f32");
 }
 
 extern "C" int be_attention_bwd_f32(const float* qkv, const float* out, const float* lse, const float* dout, float* dqkv,
-                                    float* workspace, int operands_ready, int B, int L, int H, float dropout_p,
+                                    float* workspace, int operands_ready, int B, int L, int l_valid, int H, float dropout_p,
                                     uint32_t seed, void* stream) {
     BE_REQUIRE(qkv && out && lse && dout && dqkv && workspace, "be_attention_bwd_f32: null pointer");
-    if (int rc = attn_args_ok("be_attention_bwd_f32", B, L, H, dropout_p)) return rc;
+    if (int rc = attn_args_ok("be_attention_bwd_f32", B, L, H, dropout_p, l_valid)) return rc;
     BE_REQUIRE(be::aligned16(qkv) && be::aligned16(dqkv) && be::aligned16(workspace) && be::aligned16(lse),
                "be_attention_bwd_f32: 16-byte alignment");
     hipStream_t s = be::as_stream(stream);
@@ -703,10 +736,17 @@ extern "C" int be_attention_bwd_f32(const float* qkv, const float* out, const fl
     hipLaunchKernelGGL(k_dout_prep, dim3((unsigned)g2), dim3(256), 0, s, dout, out, w.dOh, w.dOt, w.Drow, B, L, H);
     const uint32_t th = drop_threshold(dropout_p);
     const float ik = 1.0f / (1.0f - dropout_p);
-    hipLaunchKernelGGL(k_attn_bwd_dq, dim3(L / 128, B * H), dim3(256), 0, s, w.Q, w.K, w.V, w.Kt, w.dOh, lse, w.Drow, dqkv, L,
-                       H, seed, th, ik);
-    hipLaunchKernelGGL(k_attn_bwd_dkv, dim3(L / 128, B * H), dim3(256), 0, s, w.Q, w.K, w.V, w.Qt, w.dOh, w.dOt, lse, w.Drow,
-                       dqkv, L, H, seed, th, ik);
+    if (l_valid == L) {
+        hipLaunchKernelGGL(k_attn_bwd_dq<false>, dim3(L / 128, B * H), dim3(256), 0, s, w.Q, w.K, w.V, w.Kt, w.dOh, lse, w.Drow, dqkv,
+                           L, L, H, seed, th, ik);
+        hipLaunchKernelGGL(k_attn_bwd_dkv<false>, dim3(L / 128, B * H), dim3(256), 0, s, w.Q, w.K, w.V, w.Qt, w.dOh, w.dOt, lse,
+                           w.Drow, dqkv, L, L, H, seed, th, ik);
+    } else {
+        hipLaunchKernelGGL(k_attn_bwd_dq<true>, dim3(L / 128, B * H), dim3(256), 0, s, w.Q, w.K, w.V, w.Kt, w.dOh, lse, w.Drow, dqkv,
+                           L, l_valid, H, seed, th, ik);
+        hipLaunchKernelGGL(k_attn_bwd_dkv<true>, dim3(L / 128, B * H), dim3(256), 0, s, w.Q, w.K, w.V, w.Qt, w.dOh, w.dOt, lse,
+                           w.Drow, dqkv, L, l_valid, H, seed, th, ik);
+    }
     return be::check_launch("be_attention_bwd_f32");
 }
 

@@ -4,9 +4,12 @@ Boundary kept exactly (constructor signature, forward(src [B,L,38]) -> [B,L,12],
 sinusoidal position table held as a plain tensor that is NOT part of the state-dict): models/global_stage.py:6-38
 of the reference.  Inference on the GPU runs on libblurry_edges_hip: the linears on the implicit-GEMM kernel, a
 flash-style fp32-MFMA attention kernel whose scores never leave registers, fused residual + LayerNorm.
-Training on the GPU (model.train(), grad enabled) runs the HIP training kernels as well: counter-based dropout at the
-four sites of every layer, flash-style attention backward, LayerNorm / linear backward (be_hip/train_global_stage.py).
-CPU tensors use stock PyTorch ops (math SDPA backend: the flash / mem-efficient backends on ROCm are Triton-built).  The stage is ~2.4 % of the FLOPs of the path (18.9 of 794 MFLOP per pair).
+Training on the GPU (model.train()) runs the HIP training kernels as well: counter-based dropout at the four sites of
+every layer (with or without grad mode, as the reference module), flash-style attention backward, LayerNorm / linear
+backward (be_hip/train_global_stage.py).  A GPU tensor never reaches stock PyTorch ops: any sequence length up to the
+position table (4096) runs on the kernels (padded to 128-token tiles, padded keys masked), other configurations raise.
+CPU tensors run the module tree as it stands, which is the reference's own nn.TransformerEncoder (BASELINE configs[0]).
+The stage is ~2.4 % of the FLOPs of the path (18.9 of 794 MFLOP per pair).
 """
 import math
 
@@ -52,27 +55,45 @@ class GlobalStage(nn.Module):
         self.generator = nn.Linear(d_model, out_parameter_size)
 
     def forward(self, src):
-        if src.is_cuda and src.shape[1] % 128 == 0 and self._hip_shapes_ok():
-            if not (self.training and torch.is_grad_enabled()):
-                return self._forward_hip(src)
-            # model.train(): dropout + autograd on the HIP training kernels (be_hip/train_global_stage.py); the dropout
-            # seed is drawn from torch's CPU generator, so torch.manual_seed makes a run repeatable
+        if not src.is_cuda:
+            # CPU tensors (BASELINE configs[0], "plumbing, no GPU"): the module tree IS the reference's nn.TransformerEncoder,
+            # so this is the reference's own computation (math SDPA backend; the flash / mem-efficient ones are Triton-built)
+            from torch.nn.attention import sdpa_kernel, SDPBackend
+            with sdpa_kernel(SDPBackend.MATH):
+                h = self.positional_encoding(self.in_src_projection(src))
+                return self.generator(self.encoder(h))
+        # GPU tensors: the HIP kernels or an error - never stock PyTorch ops
+        self._require_hip_shapes()
+        B, L, cin = src.shape
+        if L > self.positional_encoding.pe.shape[1]:
+            raise ValueError(f"GlobalStage: {L} tokens, the position table has {self.positional_encoding.pe.shape[1]} "
+                             f"(models/global_stage.py:19 fails the same way)")
+        # any L <= max_len^2 is legal for the reference; the kernels work on 128-token tiles: pad the sequence with zero
+        # tokens and mask the padded KEYS inside the attention kernels (l_valid); every other op is per token
+        Lp = (L + 127) // 128 * 128
+        if Lp != L:
+            src = torch.cat([src, src.new_zeros(B, Lp - L, cin)], dim=1)
+        if not self.training:
+            out = self._forward_hip(src, L)
+        else:
+            # model.train(): dropout at the four sites of every layer whatever the grad mode, as nn.TransformerEncoder does;
+            # under autograd the HIP backward kernels (be_hip/train_global_stage.py).  The dropout seed is drawn from
+            # torch's CPU generator, so torch.manual_seed makes a run repeatable
             from be_hip.train_global_stage import GlobalStageTrainFn, parameter_list
             lyr = self.encoder.layers[0]
             seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
-            return GlobalStageTrainFn.apply(src, self.positional_encoding.pe[0], seed, lyr.dropout.p, lyr.self_attn.num_heads,
-                                            lyr.norm1.eps, *parameter_list(self))
-        # CPU / other shapes: stock PyTorch ops (boundary kept; no Triton-built attention kernels)
-        from torch.nn.attention import sdpa_kernel, SDPBackend
-        with sdpa_kernel(SDPBackend.MATH):
-            h = self.positional_encoding(self.in_src_projection(src))
-            return self.generator(self.encoder(h))
+            out = GlobalStageTrainFn.apply(src, self.positional_encoding.pe[0], seed, lyr.dropout.p, lyr.self_attn.num_heads,
+                                           lyr.norm1.eps, L, *parameter_list(self))
+        return out if Lp == L else out[:, :L]
 
-    def _hip_shapes_ok(self):
+    def _require_hip_shapes(self):
         lyr = self.encoder.layers[0]
         d = self.in_src_projection.out_features
-        return (d == 128 and d // lyr.self_attn.num_heads == 16 and lyr.linear1.out_features % 32 == 0
-                and lyr.self_attn.dropout == lyr.dropout.p == lyr.dropout1.p == lyr.dropout2.p)
+        ok = (d == 128 and d // lyr.self_attn.num_heads == 16 and lyr.linear1.out_features % 32 == 0
+              and lyr.self_attn.dropout == lyr.dropout.p == lyr.dropout1.p == lyr.dropout2.p)
+        if not ok:
+            raise NotImplementedError("GlobalStage on the GPU is built for the reference configuration: d_model 128, heads of 16, "
+                                      "dim_feedforward a multiple of 32, one dropout probability (models/global_stage.py:23-32)")
 
     # ------------------------------------------------------------------ inference on the HIP library
     def _packed(self):
@@ -100,7 +121,7 @@ class GlobalStage(nn.Module):
         self._pk, self._pk_key = pk, key
         return pk
 
-    def _forward_hip(self, src):
+    def _forward_hip(self, src, l_valid):
         from be_hip import native
         B, L, cin = src.shape
         pk = self._packed()
@@ -114,7 +135,7 @@ class GlobalStage(nn.Module):
         ws = getattr(self, "_attn_ws", None)
         for lyr, p in zip(self.encoder.layers, pk["layers"]):
             qkv = native.linear(h, *p["qkv"], 3 * d)
-            a, ws = native.attention(qkv, B, L, H, ws)
+            a, ws = native.attention(qkv, B, L, H, ws, l_valid=l_valid)
             y = native.linear(a, *p["out"], d, residual=h)                       # x + SA(x)
             h = native.add_layernorm(y, None, lyr.norm1.weight.detach(), lyr.norm1.bias.detach(), lyr.norm1.eps)
             f = native.linear(h, *p["l1"], lyr.linear1.out_features, act=2)      # ReLU

@@ -402,9 +402,11 @@ int be_upconv2x2_scatter_f32(const float* t, float* y, int64_t n, int h, int w, 
  * ------------------------------------------------------------------------------------------------- */
 /* Multi-head self-attention with head dim 16: qkv [B*L, 3*H*16] (rows = tokens, columns q|k|v as
  * nn.MultiheadAttention's in_proj produces them) -> out [B*L, H*16] = softmax(q k^T / 4) v per head.
- * workspace: be_attention_workspace_floats(B,L,H) floats.  L % 128 == 0. */
+ * workspace: be_attention_workspace_floats(B,L,H) floats.  L % 128 == 0; l_valid in (L - 128, L]: the number of real
+ * tokens when the caller padded the sequence up to L (keys >= l_valid get probability exactly 0; output rows >= l_valid
+ * are computed and meaningless).  nn.TransformerEncoder takes any L <= max_len^2 (models/global_stage.py:18-20). */
 size_t be_attention_workspace_floats(int B, int L, int H);
-int be_attention_f32(const float* qkv, float* out, float* workspace, int B, int L, int H, void* stream);
+int be_attention_f32(const float* qkv, float* out, float* workspace, int B, int L, int l_valid, int H, void* stream);
 /* y = LayerNorm(x + res) over the last dimension D in {64,128,192,256}; res may be NULL; y may alias x. */
 int be_add_layernorm_f32(const float* x, const float* res, const float* gamma, const float* beta, float* y,
                          int64_t rows, int D, float eps, void* stream);
@@ -419,14 +421,15 @@ int be_add_pe_f32(float* x, const float* pe, int64_t batches, int64_t per_batch,
 /* Attention forward for training: out as be_attention_f32 with dropout on the probabilities (site = batch*H + head,
  * element = query*L + key), lse [B*H, L] = log2-sum-exp of each score row (saved for the backward). */
 size_t be_attention_train_workspace_floats(int B, int L, int H);
-int be_attention_train_fwd_f32(const float* qkv, float* out, float* lse, float* workspace, int B, int L, int H,
+int be_attention_train_fwd_f32(const float* qkv, float* out, float* lse, float* workspace, int B, int L, int l_valid, int H,
                                float dropout_p, uint32_t seed, void* stream);
 /* Attention backward: dout [B*L, H*16] -> dqkv [B*L, 3*H*16]; probabilities are recomputed from qkv and lse
  * (no [L,L] tensor is ever stored); deterministic (no atomics).  Same workspace size as the forward.
  * operands_ready != 0: `workspace` is the buffer the forward call of this layer used and nothing wrote to it since
- * (its split q/k/v are reused); 0: they are split again from qkv. */
+ * (its split q/k/v are reused); 0: they are split again from qkv.  l_valid as in be_attention_f32: rows >= l_valid of
+ * dout must be zero (they are when the caller slices the padded output), and dqkv comes out zero there. */
 int be_attention_bwd_f32(const float* qkv, const float* out, const float* lse, const float* dout, float* dqkv,
-                         float* workspace, int operands_ready, int B, int L, int H, float dropout_p, uint32_t seed,
+                         float* workspace, int operands_ready, int B, int L, int l_valid, int H, float dropout_p, uint32_t seed,
                          void* stream);
 /* The keep mask the two functions above apply, [B*H, L, L] in {0,1} (test hook; small L only). */
 int be_attention_dropout_mask_f32(float* mask, int B, int L, int H, float dropout_p, uint32_t seed, void* stream);
