@@ -1,9 +1,14 @@
 """Data-parallel gradient exchange for LocalStage training (one process per GPU, torch.distributed).
 
-The only collective of the training path: ONE all-reduce (sum, then / world) of the flat fp32
-gradient buffer (7 254 122 elements = 29.0 MB) before clip_grad_norm_ and the optimizer step.  With RCCL over
-xGMI (7 point-to-point links x ~153 GB/s per GPU) the buffer is sent as a few large buckets so every link carries
-several MB per phase; BatchNorm statistics stay per replica (the reference's batch-64 semantics)."""
+The only collective of the training path: an all-reduce (sum, then / world) of the flat fp32
+gradient buffer (7 254 122 elements = 29.0 MB) before clip_grad_norm_ and the optimizer step.  The HIP backward writes
+the gradients of one layer group after another into consecutive slices of that buffer (fc first, conv1 last), so the
+exchange runs as FIVE buckets (`bucket_ranges`: fc 9.5 MB, layer3 6.3, layer2 9.2, layer1 3.3, conv1 + layer0 0.6), each
+launched on a side stream the moment its slice is final (`GradSync`): the collective of a bucket overlaps the backward of
+the layers in front of it, and only the last, smallest bucket is exposed.  With RCCL over xGMI (7 point-to-point links x
+~153 GB/s per GPU) buckets of several MB keep every link busy; BatchNorm statistics stay per replica during training (the
+reference's batch-64 semantics); `broadcast_parameters` aligns the replicas at the start and `broadcast_bn_stats` hands
+rank 0's running statistics to everyone before a checkpoint is written."""
 from __future__ import annotations
 
 import torch
@@ -78,3 +83,101 @@ def grads_as_flat(params, fallback: torch.Tensor | None = None):
         raise RuntimeError("grads_as_flat: gradients are not one flat buffer and no fallback buffer was given")
     copy_grads_into(fallback, params)
     return fallback
+
+
+# ------------------------------------------------------------------------------- overlapped, bucketed gradient exchange
+def bucket_ranges(numels, groups=((78, 86), (60, 78), (42, 60), (24, 42), (0, 24)), trainable=None):
+    """[(lo, hi)] float offsets into the flat gradient buffer, in the order the LocalStage backward completes them.
+    numels: element count of each of the 86 tensors (native.local_stage_pack order); groups: tensor-index ranges
+    (fc.1/fc.2/fc.4, layer3, layer2, layer1, conv1 + layer0); trainable: be_hip.train.TRAINABLE."""
+    if trainable is None:
+        from .train import TRAINABLE as trainable
+    off, start = 0, {}
+    for i in trainable:
+        start[i] = off
+        off += numels[i]
+    start[86] = off
+    first = lambda a: start[min(i for i in list(trainable) + [86] if i >= a)]
+    return [(first(a), first(b)) for a, b in groups]
+
+
+class GradSync:
+    """All-reduce of the flat gradient buffer in buckets that start while the backward is still running.
+
+        sync = GradSync(world)                       # once
+        train.set_grad_hook(sync.bucket_ready)       # the backward calls it with (flat, lo, hi) as each slice becomes final
+        loss.backward(); sync.finish()               # all buckets reduced and divided by world; .grad views are the means
+
+    GPU tensors + RCCL ("nccl"): every bucket is issued under a side stream that waits for an event recorded on the compute
+    stream right behind the kernels that wrote the slice; finish() makes the compute stream wait for the collectives.
+    gloo (CPU rehearsal, tests): the same calls, synchronous; GPU tensors are staged through the host because gloo has no
+    device transport on this build."""
+
+    def __init__(self, world, group=None):
+        self.world, self.group = world, group
+        self.handles, self.flat, self.side = [], None, None
+        self.bytes = 0
+
+    def bucket_ready(self, flat, lo, hi):
+        if self.world == 1 or hi <= lo:
+            return
+        import torch.distributed as dist
+        self.flat = flat
+        piece = flat[lo:hi]
+        self.bytes += piece.numel() * 4
+        if piece.is_cuda and dist.get_backend(self.group) == "nccl":
+            if self.side is None:
+                self.side = torch.cuda.Stream(device=flat.device)
+            ev = torch.cuda.Event()
+            ev.record()                                               # behind the last kernel that wrote flat[lo:hi]
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(ev)
+                self.handles.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        elif piece.is_cuda:
+            host = piece.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            piece.copy_(host)
+        else:
+            self.handles.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def finish(self):
+        """-> the averaged flat buffer (None if nothing was exchanged)."""
+        for h in self.handles:
+            h.wait()                                                  # nccl: the current stream waits for the collective
+        self.handles = []
+        flat, self.flat = self.flat, None
+        if flat is not None and self.world > 1:
+            flat.div_(self.world)
+        return flat
+
+
+def broadcast_parameters(model, src=0, group=None):
+    """Every parameter AND buffer (BatchNorm statistics, counters) of rank `src` to all ranks: replicas start identical
+    (SURVEY 8e).  One-off, ~100 small broadcasts."""
+    import torch.distributed as dist
+    with torch.no_grad():
+        for t in list(model.parameters()) + list(model.buffers()):
+            if t.is_cuda and dist.get_backend(group) != "nccl":
+                host = t.detach().cpu()
+                dist.broadcast(host, src, group=group)
+                t.copy_(host)
+            else:
+                dist.broadcast(t.detach(), src, group=group)
+    if hasattr(model, "invalidate_packed"):
+        model.invalidate_packed()
+
+
+def broadcast_bn_stats(model, src=0, group=None):
+    """Rank `src`'s BatchNorm running statistics to every rank (before torch.save: all replicas then write the same
+    checkpoint; during training the statistics stay per replica)."""
+    import torch.distributed as dist
+    with torch.no_grad():
+        for b in model.buffers():
+            if b.is_cuda and dist.get_backend(group) != "nccl":
+                host = b.detach().cpu()
+                dist.broadcast(host, src, group=group)
+                b.copy_(host)
+            else:
+                dist.broadcast(b.detach(), src, group=group)
+    if hasattr(model, "invalidate_packed"):
+        model.invalidate_packed()

@@ -197,6 +197,17 @@ def forward_train(x, t):
 TRAINABLE = [6 * i + j for i in range(13) for j in range(4)] + [78, 79, 80, 81, 84, 85]
 
 
+_GRAD_HOOK = None
+
+
+def set_grad_hook(fn):
+    """fn(flat, lo, hi) is called by backward_train each time a layer group's slice flat[lo:hi] of the gradient buffer is
+    final (all kernels that write it are enqueued on the current stream): fc, layer3, layer2, layer1, conv1 + layer0, in that
+    order.  be_hip.dp.GradSync.bucket_ready starts that bucket's all-reduce there.  None removes the hook."""
+    global _GRAD_HOOK
+    _GRAD_HOOK = fn
+
+
 def backward_train(dlogits, t, S):
     """Returns the list of 86 gradients (None for running statistics) in the order of t.  Every gradient is a view into ONE
     flat buffer, in parameter order, written by the kernels directly: autograd then stores those views as .grad, so a
@@ -209,6 +220,14 @@ def backward_train(dlogits, t, S):
     for i in TRAINABLE:
         grads[i] = flat[off:off + t[i].numel()].view(t[i].shape)
         off += t[i].numel()
+    hook = _GRAD_HOOK
+    if hook is not None:
+        from .dp import bucket_ranges
+        buckets = bucket_ranges([v.numel() for v in t])
+
+    def done(k):
+        if hook is not None:
+            hook(flat, *buckets[k])
     w1, b1, g1, be1, rm1, rv1, w4, b4 = t[78:86]
     # fc.4
     f1 = S["fc4"].reshape(n, 1024)
@@ -220,6 +239,7 @@ def backward_train(dlogits, t, S):
     ds, dy, _, _ = _bn_bwd(dx.reshape(n, 1, 1, 1024), saved1, g1, grads[80], grads[81])
     _wgrad(f_in, dy, tuple(w1.shape), 1, chw_hw=9, out=grads[78])
     _col_sum(dy, out=grads[79])
+    done(0)                                                            # fc.1 / fc.2 / fc.4: the tail of the buffer
     packs = S["packs"]
     d = _dgrad(dy, packs, 78, 2304, 1).reshape(n, 3, 3, 256)
     d = _pool_bwd(S["pool3"], d, 2, 2, 0)
@@ -242,12 +262,16 @@ def backward_train(dlogits, t, S):
         return dx_c1 + dx_ds                                           # elementwise add: torch op on GPU buffers
 
     d = block_bwd("layer3", 10, d)
+    done(1)
     d = block_bwd("layer2", 7, d)
+    done(2)
     d = block_bwd("layer1", 4, d)
+    done(3)
     d = _pool_bwd(S["pool2"], d, 3, 2, 1)
     d = block_bwd("layer0", 1, d)
     d = _pool_bwd(S["pool1"], d, 3, 2, 1)
     unit_bwd("conv1", 0, d, need_dx=False)
+    done(4)                                                            # conv1 + layer0: the head of the buffer
     return grads
 
 

@@ -35,16 +35,28 @@ class BetaSchedule:
         self.beta_b, self.beta_s = self.max_b, self.max_s
 
 
-def train_step(model, helper, opt, batch, beta_b, beta_s, flat=None, world=1, clip=1.0, stats=None):
+def train_step(model, helper, opt, batch, beta_b, beta_s, flat=None, world=1, clip=1.0, stats=None, sync=None):
     """One iteration of local_training.py:103-108.  batch: dict of GPU tensors (dataset layouts).
+    world > 1: the gradients are averaged over the ranks before clipping.  sync = a be_hip.dp.GradSync: five buckets, each
+    all-reduced on a side stream as soon as the backward has finished its slice (overlap); without one, `flat` selects
+    the older path - one bucketed all-reduce after the whole backward.
     stats: optional dict that receives `grad_norm` (the total norm clip_grad_norm_ measured, a device scalar)."""
     import utils
+    from . import train
     est = model(batch["img_ny"].permute(0, 3, 1, 2))
     opt.zero_grad(set_to_none=True)      # backward then SETS .grad (no fill, no accumulate launch per parameter)
     loss = utils.local_loss(helper, est, batch["img_gt"], batch["img_gt"], batch["bndry_dist"], batch["deri"], beta_b, beta_s)
-    loss.backward()
-    if flat is not None:
-        dp.allreduce_mean_(dp.grads_as_flat(list(model.parameters()), flat), world)      # zero-copy when the backward wrote one buffer
+    if sync is not None and world > 1:
+        train.set_grad_hook(sync.bucket_ready)
+        try:
+            loss.backward()
+        finally:
+            train.set_grad_hook(None)
+        sync.finish()                    # the compute stream waits for the last bucket; .grad now holds the mean
+    else:
+        loss.backward()
+        if flat is not None and world > 1:
+            dp.allreduce_mean_(dp.grads_as_flat(list(model.parameters()), flat), world)      # zero-copy when the backward wrote one buffer
     norm = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=clip, norm_type=2)
     if stats is not None:
         stats["grad_norm"] = norm
@@ -107,7 +119,10 @@ def main(argv=None):
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)).to(dev) for k, v in synth.local_stage_state_dict().items()})
     helper = utils.PostProcessLocalBase(args, dev)
     opt = torch.optim.AdamW(model.parameters(), lr=a.lr, capturable=a.graph, fused=dp.fused_adamw())
-    flat = dp.flat_grad_buffer(model.parameters()) if world > 1 else None
+    flat = None
+    sync = dp.GradSync(world) if world > 1 else None       # five buckets, each all-reduced while the backward goes on
+    if world > 1:
+        dp.broadcast_parameters(model, src=0)               # replicas start from rank 0's weights and statistics
     data = {k: torch.from_numpy(v).to(dev) for k, v in synth.synthetic_training_patches(a.patches, seed=1869 + rank).items()}
     sched = BetaSchedule(args.beta_bndry_loc, args.beta_smthns, args.dynamic_epoch)
     sched.final()
@@ -122,11 +137,11 @@ def main(argv=None):
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(3):
-                train_step(model, helper, opt, static, sched.beta_b, sched.beta_s, flat, world)
+                train_step(model, helper, opt, static, sched.beta_b, sched.beta_s, flat, world, sync=sync)
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph):
-            static_loss = train_step(model, helper, opt, static, sched.beta_b, sched.beta_s, flat, world)
+            static_loss = train_step(model, helper, opt, static, sched.beta_b, sched.beta_s, flat, world, sync=sync)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for it in range(a.steps):
@@ -138,9 +153,11 @@ def main(argv=None):
             graph.replay()
             losses.append(static_loss.clone())
         else:
-            losses.append(train_step(model, helper, opt, batch, sched.beta_b, sched.beta_s, flat, world))
+            losses.append(train_step(model, helper, opt, batch, sched.beta_b, sched.beta_s, flat, world, sync=sync))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    if world > 1:
+        dp.broadcast_bn_stats(model, src=0)                 # what a checkpoint written now would hold on every rank
     if rank == 0:
         print(json.dumps({"metric": "local training patches/s", "value": world * a.batch * a.steps / dt, "n_gpus": world,
                           "ms_per_step": dt / a.steps * 1e3, "graph": bool(a.graph), "first_loss": float(losses[0]), "last_loss": float(losses[-1])}))

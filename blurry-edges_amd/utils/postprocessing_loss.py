@@ -222,7 +222,7 @@ class _GlobalLossFn(torch.autograd.Function):
                                                  deri.contiguous(), bndry_depth.contiguous(), g6, hp, wp, st)
         t = partial.double().sum(dim=0)
         n1, n3, n4 = B * 2 * 441 * P, B * 441 * P, B * 2 * 361 * P
-        msum = torch.clamp(t[7], min=1.0)
+        msum = t[7]          # NOT clamped: an empty mask gives 0 / 0 = NaN, exactly as `.sum() / mask.sum()` at global_training.py:127
         loss = (g6[0] * t[0] + g6[1] * t[1]) / n1 + (g6[2] * t[2] + g6[5] * t[5]) / n3 + (g6[3] * t[3] + g6[4] * t[4]) / n4 \
             + gam["depth"] * t[6] / msum
         grad[:, 8:12] += (gam["depth"] / msum).to(torch.float32) * gdep

@@ -89,3 +89,67 @@ def test_grads_as_flat_is_zero_copy_for_a_backward_that_writes_one_buffer():
     got = dp.grads_as_flat(ps, fb)
     assert got.data_ptr() == fb.data_ptr() and torch.equal(got, torch.tensor([1.0] * 6 + [2.0] * 4 + [3.0] * 5))
     assert ps[2].grad.data_ptr() == fb[10:].data_ptr()
+
+
+# ------------------------------------------------------------------ the real buffer: 7 254 122 floats in the five buckets
+def _sync_worker(rank, world, port, q):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    import models
+    from be_hip import dp, synth
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    m = models.LocalStage()                                           # module tree only: no HIP call on the CPU
+    t = m._tensor_list()
+    ranges = dp.bucket_ranges([v.numel() for v in t])
+    n = sum(p.numel() for p in m.parameters())
+    flat = torch.from_numpy(synth.f32(synth.hash_normal(100 + rank, "dp_flat", (n,))))
+    sync = dp.GradSync(world)
+    for lo, hi in ranges:                                             # the order the backward completes them: tail first
+        sync.bucket_ready(flat, lo, hi)
+    out = sync.finish()
+    assert out.data_ptr() == flat.data_ptr() and sync.bytes == 4 * n
+    # replicas are aligned from rank 0, and rank 0's BatchNorm statistics reach everyone before a checkpoint
+    with torch.no_grad():
+        for prm in m.parameters():
+            prm.fill_(float(rank + 1))
+        for b in m.buffers():
+            b.fill_(rank + 7)
+    dp.broadcast_parameters(m, src=0)
+    ok = all(float(prm.flatten()[0]) == 1.0 for prm in m.parameters()) and all(float(b.flatten()[0]) == 7.0 for b in m.buffers())
+    with torch.no_grad():
+        m.conv1[1].running_mean.fill_(float(10 + rank))
+    dp.broadcast_bn_stats(m, src=0)
+    ok = ok and float(m.conv1[1].running_mean[0]) == 10.0
+    if rank == 1:
+        q.put((ranges, flat[::1009].clone().numpy(), float(flat.double().sum()), ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_five_bucket_gradient_sync_on_the_real_local_stage_buffer():
+    """be_hip.dp.GradSync on the 7 254 122-float buffer the LocalStage backward writes, bucket by bucket in completion
+    order (fc, layer3, layer2, layer1, conv1 + layer0), two gloo ranks: every element is the mean, nothing is skipped or
+    reduced twice; parameter / BatchNorm-statistics broadcasts align the replicas."""
+    from be_hip import synth
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ranges, sub, total, ok = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    n = 7254122
+    assert sorted(ranges) == [(0, 154848), (154848, 992736), (992736, 3306336), (3306336, 4881504), (4881504, n)]
+    assert ranges[0] == (4881504, n) and ranges[-1] == (0, 154848)      # completion order: the tail (fc) first
+    a = synth.f32(synth.hash_normal(100, "dp_flat", (n,)))
+    b = synth.f32(synth.hash_normal(101, "dp_flat", (n,)))
+    ref = (a + b) / np.float32(2)
+    assert np.array_equal(sub, ref[::1009]) and abs(total - float(ref.astype(np.float64).sum())) < 1e-6 * n ** 0.5
+    assert ok

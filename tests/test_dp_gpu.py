@@ -1,0 +1,91 @@
+"""configs[4] rehearsed on one GPU: two fresh processes share cuda:0, run the REAL LocalStage training step with world = 2
+(be_hip.train_local.train_step + be_hip.dp.GradSync over gloo) on different batches, and the synchronised gradient buffer
+must be the mean of the two single-rank gradients, bit for bit."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT, PKG
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _setup(rank):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import models, utils
+    from be_hip import synth
+    args = utils.get_args("local_train", argv=[])
+    model = models.LocalStage().to(DEV)
+    model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.local_stage_state_dict().items()})
+    helper = utils.PostProcessLocalBase(args, DEV)
+    model.train()
+    batch = {k: torch.from_numpy(v).to(DEV) for k, v in synth.synthetic_training_patches(64, seed=40 + rank).items()}
+    return args, model, helper, batch
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    args, model, helper, batch = _setup(rank)
+    from be_hip import dp, train_local
+    if rank == 1:                                                   # a replica that starts somewhere else ...
+        with torch.no_grad():
+            for p in model.parameters():
+                p.add_(0.5)
+    dp.broadcast_parameters(model, src=0)                           # ... is aligned with rank 0 first
+    opt = torch.optim.SGD(model.parameters(), lr=0.0)               # lr 0: the step leaves the (clipped) means in .grad
+    sync = dp.GradSync(world)
+    stats = {}
+    train_local.train_step(model, helper, opt, batch, args.beta_bndry_loc, args.beta_smthns, world=world, clip=1e9, stats=stats,
+                           sync=sync)
+    flat = dp.grads_as_flat(list(model.parameters()))               # still the backward's one buffer: zero-copy
+    torch.cuda.synchronize()
+    q.put((rank, flat.cpu().numpy(), float(stats["grad_norm"]), sync.bytes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_processes_on_one_gpu_train_step_world_2_gives_the_mean_gradient():
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(2):
+        r, flat, norm, nbytes = q.get(timeout=600)
+        got[r] = (flat, norm, nbytes)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    # single-rank gradients of the two batches, computed here with the same kernels
+    from be_hip import dp, train_local
+    single = []
+    for rank in range(2):
+        args, model, helper, batch = _setup(rank)
+        opt = torch.optim.SGD(model.parameters(), lr=0.0)
+        train_local.train_step(model, helper, opt, batch, args.beta_bndry_loc, args.beta_smthns, clip=1e9)
+        single.append(dp.grads_as_flat(list(model.parameters())).cpu().numpy().copy())
+    assert single[0].size == 7254122 and not np.array_equal(single[0], single[1])
+    mean = (single[0] + single[1]) / np.float32(2)                  # fp32 sum then an exact halving, as the ranks did
+    assert np.array_equal(got[0][0], mean) and np.array_equal(got[1][0], mean)
+    assert got[0][2] == got[1][2] == 4 * 7254122                    # every bucket went through the exchange, once
+    assert abs(got[0][1] - float(np.sqrt((mean.astype(np.float64) ** 2).sum()))) <= 1e-5 * got[0][1]
