@@ -73,7 +73,8 @@ def train_step(model, helper, dcal, opt, batch, gamma, flat=None, world=1, clip=
     est = model(batch["pm"])
     opt.zero_grad(set_to_none=True)      # backward then SETS .grad (no fill, no accumulate launch per parameter)
     loss = utils.global_loss(helper, dcal, est, batch["img_gt"], batch["img_gt"], batch["bndry_dist"], batch["deri"],
-                             batch["bndry_depth"], gamma)
+                             batch["bndry_depth"], gamma, empty_mask="zero")      # a batch without depth-mask pixels skips the term
+    #                                                     (the reference's 0 / 0 = NaN there would end the run)
     loss.backward()
     if flat is not None:
         dp.allreduce_mean_(dp.grads_as_flat(list(model.parameters()), flat), world)      # zero-copy when the backward wrote one buffer

@@ -159,7 +159,7 @@ def global_train(args, quiet=False):
             with torch.no_grad():
                 for param, img_ny, img_gt, bndry_dist, deri, bndry_depth in va.batches(args.batch_size, shuffle=False, drop_last=True):
                     est = model(feats(param))
-                    total += float(utils.global_loss(helper, dcal, est, img_ny, img_gt, bndry_dist, deri, bndry_depth, gf))
+                    total += float(utils.global_loss(helper, dcal, est, img_ny, img_gt, bndry_dist, deri, bndry_depth, gf, empty_mask="zero"))
             gamma.step(idx_update=False)
             curve[epoch] = total / max(len(va) // args.batch_size, 1)
             print(f'{epoch + 1:<10} {curve[epoch]:<20.10f} {sched.patience:<20} {opt.param_groups[0]["lr"]:.4e}', file=f, flush=True)

@@ -49,10 +49,14 @@ __device__ __forceinline__ float remainder_2pi(float a) {
 // exp through v_exp_f32 and the quotient through v_rcp_f32 (1 ulp each): the epilogue evaluates this once per output
 // element, and with the IEEE expf + correctly-rounded division it was a quarter of the short-K launches.
 __device__ __forceinline__ float smish(float x) {
+    // branch-free: both cases are num = t (n2 t + 2) + n0, den = t (d2 t + 6) + d0 with (n2, n0, d2, d0) = (0, 3, 2, 5) for
+    // x >= 0 and (3, 0, 5, 2) for x < 0 - the same fmaf chains as the two-branch form (bit-identical), four selects instead
+    // of a divergent branch per element (the epilogues evaluate this once per output value)
     const float t = __expf(-fabsf(x));
-    float num, den;
-    if (x >= 0.0f) { num = fmaf(2.0f, t, 3.0f);        den = fmaf(t, fmaf(2.0f, t, 6.0f), 5.0f); }
-    else           { num = t * fmaf(3.0f, t, 2.0f);    den = fmaf(t, fmaf(5.0f, t, 6.0f), 2.0f); }
+    const bool pos = x >= 0.0f;
+    const float n2 = pos ? 0.0f : 3.0f, n0 = pos ? 3.0f : 0.0f, d2 = pos ? 2.0f : 5.0f, d0 = pos ? 5.0f : 2.0f;
+    const float num = fmaf(t, fmaf(n2, t, 2.0f), n0);
+    const float den = fmaf(t, fmaf(d2, t, 6.0f), d0);
     return x * (num * __frcp_rn(den));
 }
 

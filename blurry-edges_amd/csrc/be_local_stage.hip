@@ -148,14 +148,27 @@ int block(const float* packed, int l0, const float* x, float* t, float* o, int n
 
 // The same block on a 6x6 map with both 3x3 convolutions in Winograd F(3x3,3x3) form (be_wino.hip): 2.56x fewer multiplies
 // than the direct form; the 1x1 downsample runs as its own convolution into `r` and joins in the output transform of conv2.
+// chain: 0 = stand-alone block; 1 = x's input transform is already in the first transform buffer (the block before wrote it);
+// 2 = also write the NEXT block's input transform (into that first buffer again: it is dead after conv1).  Large sub-batches
+// only (be::wino_pair_chained returns 1 otherwise and the block runs stand-alone).
 int block_wino(const float* packed, int l0, const float* x, float* t, float* o, float* r, float* w, int n, void* stream,
-               int pool2 = 0) {
+               int pool2 = 0, int chain_in = 0, int chain_out = 0, bool* chained = nullptr) {
     const PackedLayout& L = layout();
     const int c = kLayers[l0].cout;
     (void)t;                                          // conv1's 6x6 result only ever exists in registers (k_wino_out_in)
     be_conv_desc d;
     d.n = n; d.h = 6; d.w = 6; d.cin = kLayers[l0 + 2].cin; d.cout = c; d.ksize = 1; d.act = 0;
     if (int rc = be_conv_nhwc_f32(&d, x, packed + L.dw_off[l0 + 2], packed + L.db_off[l0 + 2], nullptr, r, c, stream)) return rc;
+    {
+        float* va = w;                                // two transform-domain buffers of 100 x 384 floats per patch each
+        float* vb = w + (size_t)n * 100 * 384;
+        const int rc = be::wino_pair_chained(chain_in ? nullptr : x, packed + L.uw_off[l0], packed + L.ub_off[l0], 1,
+                                             packed + L.uw_off[l0 + 1], packed + L.ub_off[l0 + 1], r, 1, o, n, kLayers[l0].cin, c, c,
+                                             va, vb, chain_out ? va : nullptr, stream, pool2);
+        if (chained) *chained = rc == 0 && chain_out;
+        if (rc <= 0) return rc;                       // done (0) or a real error (< 0); 1 = not a fused shape
+        if (chain_in) return be::fail(BE_EINVAL, "block_wino: chained input but the block cannot run fused");
+    }
     return be::wino_pair(x, packed + L.uw_off[l0], packed + L.ub_off[l0], 1, packed + L.uw_off[l0 + 1], packed + L.ub_off[l0 + 1], r,
                          1, o, n, kLayers[l0].cin, c, c, w, (size_t)n * RW, stream, pool2);
 }
@@ -211,16 +224,18 @@ int forward_impl(const float* packed, const float* x, const be_patch_view* view,
         if ((rc = block(packed, 1, p1, ra, rc_, nb, 11, stream))) return rc;
         float* p2 = rb;                                   // nb*3456
         if ((rc = be_maxpool_nhwc_f32(rc_, p2, nb, 11, 11, 96, 3, 2, 1, stream))) return rc;
-        // layer1: in RB, t RA, out RC
-        if ((rc = wino ? block_wino(packed, 4, p2, ra, rc_, rr, rw, nb, stream) : block(packed, 4, p2, ra, rc_, nb, 6, stream))) return rc;
+        // layer1: in RB, t RA, out RC.  Large sub-batches (fused Winograd kernels): every block's conv2 also writes the next
+        // block's input transform from its epilogue (ch1 / ch2), so k_wino_in runs for layer1 only
+        bool ch1 = false, ch2 = false;
+        if ((rc = wino ? block_wino(packed, 4, p2, ra, rc_, rr, rw, nb, stream, 0, 0, 1, &ch1) : block(packed, 4, p2, ra, rc_, nb, 6, stream))) return rc;
         // layer2: in RC, t RA, out RB
-        if ((rc = wino ? block_wino(packed, 7, rc_, ra, rb, rr, rw, nb, stream) : block(packed, 7, rc_, ra, rb, nb, 6, stream))) return rc;
+        if ((rc = wino ? block_wino(packed, 7, rc_, ra, rb, rr, rw, nb, stream, 0, ch1, 1, &ch2) : block(packed, 7, rc_, ra, rb, nb, 6, stream))) return rc;
         // layer3: in RB, t RA, out RC; then maxpool(2,2) -> p3 [nb,3,3,256] = the (H,W,C) flatten.  Winograd path: the
         // output transform pools in registers and writes p3 directly (into RC: RB is still the block's input)
         float* p3;
         if (wino) {
             p3 = rc_;
-            if ((rc = block_wino(packed, 10, rb, ra, p3, rr, rw, nb, stream, 1))) return rc;
+            if ((rc = block_wino(packed, 10, rb, ra, p3, rr, rw, nb, stream, 1, ch2, 0))) return rc;
         } else {
             if ((rc = block(packed, 10, rb, ra, rc_, nb, 6, stream))) return rc;
             p3 = rb;                                      // nb*2304

@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include "be_common.h"
 #include "be_device_math.h"
+#include "be_wino_math.h"
 
 namespace {
 
@@ -77,16 +78,7 @@ __global__ void k_wino_pack(const float* __restrict__ w, const float* __restrict
     }
 }
 
-// B^T (5x5) applied to a 5-vector
-__device__ __forceinline__ void bt5(const f32x4 d0, const f32x4 d1, const f32x4 d2, const f32x4 d3, const f32x4 d4, f32x4 o[5]) {
-    o[0] = 2.0f * d0 - d1 - 2.0f * d2 + d3;
-    o[1] = d3 - 2.0f * d1 - d2;
-    o[2] = 2.0f * d1 - 3.0f * d2 + d3;
-    o[3] = d3 - d1;
-    o[4] = 2.0f * d1 - d2 - 2.0f * d3 + d4;
-}
-
-// one thread = one tile (patch, ty, tx) x one channel quad
+// one thread = one tile (patch, ty, tx) x one channel quad; arithmetic: be_wino_math.h (shared with the fused GEMM epilogue)
 __global__ __launch_bounds__(256)
 void k_wino_in(const float* __restrict__ x, float* __restrict__ V, int64_t n, int c4, int tm) {
     const int64_t total = n * 4 * c4;
@@ -101,37 +93,25 @@ void k_wino_in(const float* __restrict__ x, float* __restrict__ V, int64_t n, in
         const int ty = (int)(tile >> 1) & 1, tx = (int)tile & 1;
         const f32x4* src = reinterpret_cast<const f32x4*>(x) + img * 36 * c4 + cq;
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        f32x4 t[5][5];                                         // B^T d  (rows transformed), column by column
+        f32x4 d[5][5], v[25];
 #pragma unroll
-        for (int c = 0; c < 5; ++c) {
-            const int xx = 3 * tx - 1 + c;
-            f32x4 d[5];
+        for (int r = 0; r < 5; ++r)
 #pragma unroll
-            for (int r = 0; r < 5; ++r) {
-                const int yy = 3 * ty - 1 + r;
-                d[r] = ((unsigned)xx < 6u && (unsigned)yy < 6u) ? src[(size_t)(yy * 6 + xx) * c4] : zero;
+            for (int c = 0; c < 5; ++c) {
+                const int yy = 3 * ty - 1 + r, xx = 3 * tx - 1 + c;
+                d[r][c] = ((unsigned)xx < 6u && (unsigned)yy < 6u) ? src[(size_t)(yy * 6 + xx) * c4] : zero;
             }
-            f32x4 o[5];
-            bt5(d[0], d[1], d[2], d[3], d[4], o);
-#pragma unroll
-            for (int r = 0; r < 5; ++r) t[r][c] = o[r];
-        }
+        be::wino_in25(d, v);
         f32x4* dst = reinterpret_cast<f32x4*>(V) + tile * ts + cq;
 #pragma unroll
-        for (int r = 0; r < 5; ++r) {
-            f32x4 o[5];
-            bt5(t[r][0], t[r][1], t[r][2], t[r][3], t[r][4], o);                  // (B^T d) B
-#pragma unroll
-            for (int c = 0; c < 5; ++c) dst[(size_t)(5 * r + c) * plane] = o[c];
-        }
+        for (int z = 0; z < 25; ++z) dst[(size_t)z * plane] = v[z];
     }
 }
 
-// A^T (3x5) applied to a 5-vector
-__device__ __forceinline__ void at5(const f32x4 m0, const f32x4 m1, const f32x4 m2, const f32x4 m3, const f32x4 m4, f32x4 o[3]) {
-    o[0] = m0 + m1 + m2 + m3;
-    o[1] = m1 - m2 + 2.0f * m3;
-    o[2] = m1 + m2 + 4.0f * m3 + m4;
+__device__ __forceinline__ f32x4 wino_act(f32x4 v, int act) {
+    if (act == 1) { v[0] = be::smish(v[0]); v[1] = be::smish(v[1]); v[2] = be::smish(v[2]); v[3] = be::smish(v[3]); }
+    else if (act == 2) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+    return v;
 }
 
 __global__ __launch_bounds__(256)
@@ -146,34 +126,22 @@ void k_wino_out(const float* __restrict__ M, const float* __restrict__ bias, con
         const int64_t img = tile >> 2;
         const int ty = (int)(tile >> 1) & 1, tx = (int)tile & 1;
         const f32x4* src = reinterpret_cast<const f32x4*>(M) + tile * ts + cq;
-        f32x4 s[3][5];                                         // A^T m, column by column
+        f32x4 m[25], o[9];
 #pragma unroll
-        for (int c = 0; c < 5; ++c) {
-            f32x4 o[3];
-            at5(src[(size_t)c * plane], src[(size_t)(5 + c) * plane], src[(size_t)(10 + c) * plane], src[(size_t)(15 + c) * plane],
-                src[(size_t)(20 + c) * plane], o);
-#pragma unroll
-            for (int r = 0; r < 3; ++r) s[r][c] = o[r];
-        }
+        for (int z = 0; z < 25; ++z) m[z] = src[(size_t)z * plane];
+        be::wino_out9(m, o);
         const f32x4 bv = reinterpret_cast<const f32x4*>(bias)[cq];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            f32x4 o[3];
-            at5(s[r][0], s[r][1], s[r][2], s[r][3], s[r][4], o);
+        for (int r = 0; r < 3; ++r)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const size_t e = ((size_t)img * 36 + (3 * ty + r) * 6 + 3 * tx + c) * c4 + cq;
-                f32x4 v = o[c] + bv;
+                f32x4 v = o[3 * r + c] + bv;
                 if (res) v += reinterpret_cast<const f32x4*>(res)[e];
-                if (act == 1) { v[0] = be::smish(v[0]); v[1] = be::smish(v[1]); v[2] = be::smish(v[2]); v[3] = be::smish(v[3]); }
-                else if (act == 2) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-                reinterpret_cast<f32x4*>(y)[e] = v;
+                reinterpret_cast<f32x4*>(y)[e] = wino_act(v, act);
             }
-        }
     }
 }
-
-
 
 // conv1 -> conv2 of a residual block without the intermediate map in HBM: one thread = one image x one channel quad reads the
 // 100 transform-domain values of conv1's result, forms the 6x6 map (+ bias, Smish) in registers and writes the 100
@@ -195,56 +163,32 @@ void k_wino_out_in(const float* __restrict__ M, const float* __restrict__ bias, 
 #pragma unroll
             for (int tx = 0; tx < 2; ++tx) {
                 const f32x4* src = reinterpret_cast<const f32x4*>(M) + (img * 4 + ty * 2 + tx) * ts + cq;
-                f32x4 s[3][5];
+                f32x4 m[25], o[9];
 #pragma unroll
-                for (int c = 0; c < 5; ++c) {
-                    f32x4 o[3];
-                    at5(src[(size_t)c * plane], src[(size_t)(5 + c) * plane], src[(size_t)(10 + c) * plane],
-                        src[(size_t)(15 + c) * plane], src[(size_t)(20 + c) * plane], o);
+                for (int z = 0; z < 25; ++z) m[z] = src[(size_t)z * plane];
+                be::wino_out9(m, o);
 #pragma unroll
-                    for (int r = 0; r < 3; ++r) s[r][c] = o[r];
-                }
+                for (int r = 0; r < 3; ++r)
 #pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    f32x4 o[3];
-                    at5(s[r][0], s[r][1], s[r][2], s[r][3], s[r][4], o);
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) {
-                        f32x4 v = o[c] + bv;
-                        if (act == 1) { v[0] = be::smish(v[0]); v[1] = be::smish(v[1]); v[2] = be::smish(v[2]); v[3] = be::smish(v[3]); }
-                        else if (act == 2) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
-                        y[3 * ty + r][3 * tx + c] = v;
-                    }
-                }
+                    for (int c = 0; c < 3; ++c) y[3 * ty + r][3 * tx + c] = wino_act(o[3 * r + c] + bv, act);
             }
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int ty = 0; ty < 2; ++ty)
 #pragma unroll
             for (int tx = 0; tx < 2; ++tx) {
-                f32x4 t[5][5];
+                f32x4 d[5][5], v[25];
 #pragma unroll
-                for (int c = 0; c < 5; ++c) {
-                    const int xx = 3 * tx - 1 + c;
-                    f32x4 d[5];
+                for (int r = 0; r < 5; ++r)
 #pragma unroll
-                    for (int r = 0; r < 5; ++r) {
-                        const int yy = 3 * ty - 1 + r;
-                        d[r] = (xx >= 0 && xx < 6 && yy >= 0 && yy < 6) ? y[yy < 0 ? 0 : (yy > 5 ? 5 : yy)][xx < 0 ? 0 : (xx > 5 ? 5 : xx)] : zero;
+                    for (int c = 0; c < 5; ++c) {
+                        const int yy = 3 * ty - 1 + r, xx = 3 * tx - 1 + c;
+                        d[r][c] = (xx >= 0 && xx < 6 && yy >= 0 && yy < 6) ? y[yy < 0 ? 0 : (yy > 5 ? 5 : yy)][xx < 0 ? 0 : (xx > 5 ? 5 : xx)] : zero;
                     }
-                    f32x4 o[5];
-                    bt5(d[0], d[1], d[2], d[3], d[4], o);
-#pragma unroll
-                    for (int r = 0; r < 5; ++r) t[r][c] = o[r];
-                }
+                be::wino_in25(d, v);
                 f32x4* dst = reinterpret_cast<f32x4*>(V) + (img * 4 + ty * 2 + tx) * ts_o + cq;
 #pragma unroll
-                for (int r = 0; r < 5; ++r) {
-                    f32x4 o[5];
-                    bt5(t[r][0], t[r][1], t[r][2], t[r][3], t[r][4], o);
-#pragma unroll
-                    for (int c = 0; c < 5; ++c) dst[(size_t)(5 * r + c) * plane_o] = o[c];
-                }
+                for (int z = 0; z < 25; ++z) dst[(size_t)z * plane_o] = v[z];
             }
     }
 }
@@ -268,28 +212,18 @@ void k_wino_out_pool2(const float* __restrict__ M, const float* __restrict__ bia
 #pragma unroll
             for (int tx = 0; tx < 2; ++tx) {
                 const f32x4* src = reinterpret_cast<const f32x4*>(M) + (img * 4 + ty * 2 + tx) * ts + cq;
-                f32x4 s[3][5];
+                f32x4 m[25], o[9];
 #pragma unroll
-                for (int c = 0; c < 5; ++c) {
-                    f32x4 o[3];
-                    at5(src[(size_t)c * plane], src[(size_t)(5 + c) * plane], src[(size_t)(10 + c) * plane],
-                        src[(size_t)(15 + c) * plane], src[(size_t)(20 + c) * plane], o);
+                for (int z = 0; z < 25; ++z) m[z] = src[(size_t)z * plane];
+                be::wino_out9(m, o);
 #pragma unroll
-                    for (int r = 0; r < 3; ++r) s[r][c] = o[r];
-                }
-#pragma unroll
-                for (int r = 0; r < 3; ++r) {
-                    f32x4 o[3];
-                    at5(s[r][0], s[r][1], s[r][2], s[r][3], s[r][4], o);
+                for (int r = 0; r < 3; ++r)
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        f32x4 w = o[c] + bv;
+                        f32x4 w = o[3 * r + c] + bv;
                         if (res) w += reinterpret_cast<const f32x4*>(res)[((size_t)img * 36 + (3 * ty + r) * 6 + 3 * tx + c) * c4 + cq];
-                        if (act == 1) { w[0] = be::smish(w[0]); w[1] = be::smish(w[1]); w[2] = be::smish(w[2]); w[3] = be::smish(w[3]); }
-                        else if (act == 2) { w[0] = fmaxf(w[0], 0.f); w[1] = fmaxf(w[1], 0.f); w[2] = fmaxf(w[2], 0.f); w[3] = fmaxf(w[3], 0.f); }
-                        v[3 * ty + r][3 * tx + c] = w;
+                        v[3 * ty + r][3 * tx + c] = wino_act(w, act);
                     }
-                }
             }
 #pragma unroll
         for (int py = 0; py < 3; ++py)
@@ -790,6 +724,11 @@ extern "C" int be_wino_conv3x3_6x6_f32(const float* x, const float* packed_w, co
     hipStream_t s = be::as_stream(stream);
     float* V = workspace;
     float* M = workspace + (size_t)100 * n * cin;
+    if (be::wino_fused_ok(n, cin, cout)) {              // large batches: output transform in the GEMM's epilogue, no M
+        hipLaunchKernelGGL(k_wino_in, dim3(grid_cap(n * 4 * (cin / 4), 256)), dim3(256), 0, s, x, V, n, cin / 4, 1);
+        if (int rc = be::check_launch("be_wino_conv3x3_6x6_f32(in)")) return rc;
+        return be::wino_fused(V, packed_w, packed_bias, residual, act, y, nullptr, n, cin, cout, 1, stream);
+    }
     const int tm = wino_large(n, cout);
     hipLaunchKernelGGL(k_wino_in, dim3(grid_cap(n * 4 * (cin / 4), 256)), dim3(256), 0, s, x, V, n, cin / 4, tm);
     if (int rc = be::check_launch("be_wino_conv3x3_6x6_f32(in)")) return rc;
@@ -820,6 +759,14 @@ int be::wino_pair(const float* x, const float* packed_w1, const float* packed_bi
     const size_t big = (size_t)(cin > cmid ? cin : cmid);
     float* V = workspace;
     float* M = workspace + (size_t)100 * n * big;
+    if (be::wino_fused_ok(n, cin, cmid) && be::wino_fused_ok(n, cmid, cout)) {
+        // large batches (be_wino_fused.hip): conv1's GEMM writes conv2's transform-domain input straight from its epilogue,
+        // conv2's GEMM writes the block's output (or its 2x2 max-pool); no M buffer, no separate output transforms
+        hipLaunchKernelGGL(k_wino_in, dim3(grid_cap(n * 4 * (cin / 4), 256)), dim3(256), 0, s, x, V, n, cin / 4, 1);
+        if (int rc = be::check_launch("be_wino_conv3x3_pair_6x6_f32(in)")) return rc;
+        if (int rc = be::wino_fused(V, packed_w1, packed_bias1, nullptr, act1, nullptr, M, n, cin, cmid, 2, stream)) return rc;
+        return be::wino_fused(M, packed_w2, packed_bias2, residual, act2, y, nullptr, n, cmid, cout, pool2 ? 4 : 1, stream);
+    }
     const int tm1 = wino_large(n, cmid), tm2 = wino_large(n, cout);
     hipLaunchKernelGGL(k_wino_in, dim3(grid_cap(n * 4 * (cin / 4), 256)), dim3(256), 0, s, x, V, n, cin / 4, tm1);
     if (int rc = be::check_launch("be_wino_conv3x3_pair_6x6_f32(in)")) return rc;
@@ -835,6 +782,21 @@ int be::wino_pair(const float* x, const float* packed_w1, const float* packed_bi
         hipLaunchKernelGGL(k_wino_out, dim3(grid_cap(n * 4 * (cout / 4), 256)), dim3(256), 0, s, M, packed_bias2, residual, y, n,
                            cout / 4, act2, tm2);
     return be::check_launch("be_wino_conv3x3_pair_6x6_f32(out)");
+}
+
+int be::wino_pair_chained(const float* x, const float* packed_w1, const float* packed_bias1, int act1, const float* packed_w2,
+                          const float* packed_bias2, const float* residual, int act2, float* y, int64_t n, int cin, int cmid, int cout,
+                          float* v_in, float* v_mid, float* v_next, void* stream, int pool2) {
+    if (!be::wino_fused_ok(n, cin, cmid) || !be::wino_fused_ok(n, cmid, cout)) return 1;
+    BE_REQUIRE(packed_w1 && packed_bias1 && packed_w2 && packed_bias2 && y && v_in && v_mid, "wino_pair_chained: null pointer");
+    BE_REQUIRE(!(pool2 && v_next), "wino_pair_chained: the pooled block is the last one");
+    hipStream_t s = be::as_stream(stream);
+    if (x) {
+        hipLaunchKernelGGL(k_wino_in, dim3(grid_cap(n * 4 * (cin / 4), 256)), dim3(256), 0, s, x, v_in, n, cin / 4, 1);
+        if (int rc = be::check_launch("wino_pair_chained(in)")) return rc;
+    }
+    if (int rc = be::wino_fused(v_in, packed_w1, packed_bias1, nullptr, act1, nullptr, v_mid, n, cin, cmid, 2, stream)) return rc;
+    return be::wino_fused(v_mid, packed_w2, packed_bias2, residual, act2, y, v_next, n, cmid, cout, pool2 ? 4 : (v_next ? 3 : 1), stream);
 }
 
 extern "C" int be_wino_conv3x3_pair_6x6_f32(const float* x, const float* packed_w1, const float* packed_bias1, int act1,

@@ -201,7 +201,7 @@ class _GlobalLossFn(torch.autograd.Function):
     """GlobalLoss(est) with the analytic gradient from the same HIP launch (be_global_loss_f32)."""
 
     @staticmethod
-    def forward(ctx, est, helper, dcal, img_fit, img_gt, bndry_dist, deri, bndry_depth, gam):
+    def forward(ctx, est, helper, dcal, img_fit, img_gt, bndry_dist, deri, bndry_depth, gam, empty_mask="nan"):
         e = est.detach().to(torch.float32).contiguous()
         B, P = e.shape[:2]
         H, W = img_gt.shape[2], img_gt.shape[3]
@@ -222,7 +222,10 @@ class _GlobalLossFn(torch.autograd.Function):
                                                  deri.contiguous(), bndry_depth.contiguous(), g6, hp, wp, st)
         t = partial.double().sum(dim=0)
         n1, n3, n4 = B * 2 * 441 * P, B * 441 * P, B * 2 * 361 * P
-        msum = t[7]          # NOT clamped: an empty mask gives 0 / 0 = NaN, exactly as `.sum() / mask.sum()` at global_training.py:127
+        # an empty depth mask: the reference computes `.sum() / mask.sum()` = 0 / 0 = NaN (global_training.py:127) and so does
+        # this operator by default; empty_mask="zero" drops the term instead (the build's own training loops ask for that:
+        # a NaN there ends a run, and a small synthetic set can produce an image whose mask is empty)
+        msum = t[7] if empty_mask == "nan" else torch.clamp(t[7], min=1.0)
         loss = (g6[0] * t[0] + g6[1] * t[1]) / n1 + (g6[2] * t[2] + g6[5] * t[5]) / n3 + (g6[3] * t[3] + g6[4] * t[4]) / n4 \
             + gam["depth"] * t[6] / msum
         grad[:, 8:12] += (gam["depth"] / msum).to(torch.float32) * gdep
@@ -233,11 +236,15 @@ class _GlobalLossFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (grad,) = ctx.saved_tensors
-        return (g * grad,) + (None,) * 8
+        return (g * grad,) + (None,) * 9
 
 
-def global_loss(helper, depth_cal, est, img_ny, img_gt, bndry_dist, deri, bndry_depth, gamma):
+def global_loss(helper, depth_cal, est, img_ny, img_gt, bndry_dist, deri, bndry_depth, gamma, empty_mask="nan"):
     """GlobalLoss.forward (global_training.py:147-157) as fused HIP launches; differentiable w.r.t. est [B,P,12].
     helper: a PostProcessGlobalBase; gamma: dict with the seven weights color, color_cons, bndry_cons,
-    smthns, smthns_cons, bndry_loc, depth (the --gamma_* arguments of utils/args.py:53-59)."""
-    return _GlobalLossFn.apply(est, helper, depth_cal, img_ny, img_gt, bndry_dist, deri, bndry_depth, dict(gamma))
+    smthns, smthns_cons, bndry_loc, depth (the --gamma_* arguments of utils/args.py:53-59).
+    empty_mask: "nan" (default, the reference's arithmetic: depth term = 0 / 0 when no pixel is in the depth mask) or "zero"
+    (the term and its gradient are dropped for that batch)."""
+    if empty_mask not in ("nan", "zero"):
+        raise ValueError("global_loss: empty_mask must be 'nan' or 'zero'")
+    return _GlobalLossFn.apply(est, helper, depth_cal, img_ny, img_gt, bndry_dist, deri, bndry_depth, dict(gamma), empty_mask)

@@ -529,3 +529,22 @@ def test_global_stage_in_train_mode_applies_dropout_with_and_without_grad_mode()
     assert float((y1 - y_eval).abs().max()) > 1e-3          # dropout at p = 0.1 moves the output visibly
     torch.manual_seed(5)
     assert torch.equal(m(src).detach(), y1)                  # the same masks with grad mode on
+
+
+def test_global_loss_with_an_empty_depth_mask_is_nan_like_the_reference_unless_asked_otherwise():
+    """global_training.py:127 divides by mask.sum(): no depth-mask pixel -> 0 / 0 = NaN.  The operator reproduces that;
+    empty_mask="zero" (what the build's own training loops pass) drops the term."""
+    import utils
+    from oracle import global_loss as ogl
+    args = utils.get_args("global_train", argv=[])
+    args.batch_size = 1
+    helper, dcal = utils.PostProcessGlobalBase(args, DEV), utils.DepthEtas(args, DEV)
+    smp = {k: torch.from_numpy(v).to(DEV)[None] for k, v in synth.synthetic_global_sample(147, 147).items()}
+    est = torch.from_numpy(synth.plausible_global_output(4096)).to(DEV)[None].requires_grad_(True)
+    none = torch.zeros_like(smp["bndry_depth"])                      # no ground-truth boundary depth anywhere -> empty mask
+    a = utils.global_loss(helper, dcal, est, smp["img_gt"], smp["img_gt"], smp["bndry_dist"], smp["deri"], none, ogl.GAMMA_FINAL)
+    assert torch.isnan(a)
+    b = utils.global_loss(helper, dcal, est, smp["img_gt"], smp["img_gt"], smp["bndry_dist"], smp["deri"], none, ogl.GAMMA_FINAL,
+                          empty_mask="zero")
+    b.backward()
+    assert torch.isfinite(b) and torch.isfinite(est.grad).all()
