@@ -302,8 +302,6 @@ def main():
     from be_hip import native, synth
     import models, utils
     native.lib()                                   # fails loudly if the HIP library is missing
-    if args.chunk:
-        native.check(native.lib().be_local_stage_set_chunk(args.chunk))
 
     # ---- synthetic workload, resident in HBM before the timed region (each rank: its own shard)
     x_np, z_gt = synth.synthetic_patch_pairs(PAIRS, seed=synth.SEED_DEFAULT + rank)
@@ -311,6 +309,7 @@ def main():
     model = models.LocalStage()
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()})
     model = model.to(dev).eval()
+    model.chunk = args.chunk                       # per-call option of the C ABI (be_local_stage_opts)
     helper = utils.PostProcessLocalBase(utils.get_args("local_train", argv=[]), dev)
     dcal = utils.DepthEtas(utils.get_args("eval", argv=[]), dev)
     x = torch.from_numpy(x_np).to(dev)

@@ -60,10 +60,9 @@ _SIGNATURES = {
     "be_render_colors_f32": (C.c_int, [C.POINTER(RenderOpts), _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
     "be_local_stage_packed_floats": (C.c_size_t, []),
     "be_local_stage_pack_f32": (C.c_int, [C.POINTER(_P), C.c_float, _P, _P]),
-    "be_local_stage_workspace_bytes": (C.c_size_t, [C.c_int64]),
-    "be_local_stage_set_chunk": (C.c_int, [C.c_int]),
-    "be_local_stage_forward_f32": (C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_size_t, _P]),
-    "be_local_stage_forward_view_f32": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, _P, C.c_size_t, _P]),
+    "be_local_stage_workspace_bytes": (C.c_size_t, [C.c_int64, C.c_int]),
+    "be_local_stage_forward_f32": (C.c_int, [_P, _P, _P, C.c_int64, _P, C.c_size_t, _P, _P]),
+    "be_local_stage_forward_view_f32": (C.c_int, [_P, _P, C.c_int64, _P, C.c_int64, _P, C.c_size_t, _P, _P]),
     "be_render_colors_view_f32": (C.c_int, [C.POINTER(RenderOpts), _P, _P, C.c_int64, _P, _P, _P, _P, _P, _P, _P,
                                             C.c_int64, _P]),
     "be_view_to_nhwc4_f32": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, _P]),
@@ -83,7 +82,6 @@ _SIGNATURES = {
     "be_conv_split_b3_f32": (C.c_int, [_P, C.c_size_t, _P, _P]),
     "be_conv_use_b3": (C.c_int, [_P, _P, C.c_size_t]),
     "be_conv_b3_active": (C.c_int, []),
-    "be_local_stage_set_winograd": (C.c_int, [C.c_int]),
     "be_conv_fused2_packed_floats": (C.c_size_t, [C.c_int] * 4),
     "be_conv_pack_fused2_f32": (C.c_int, [_P] * 12 + [C.c_float] + [C.c_int] * 4 + [_P, _P, _P]),
     "be_conv_nhwc_fused2_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, C.c_int, _P, _P, _P, C.c_int, _P]),
@@ -378,18 +376,24 @@ def local_stage_pack(tensors, eps=1e-5):
     return packed
 
 
-def local_stage_forward(packed, x, out=None, workspace=None):
+class LocalStageOpts(C.Structure):
+    """be_local_stage_opts: per-call options of the LocalStage forward (no process-wide state in the library)."""
+    _fields_ = [("winograd", C.c_int), ("chunk", C.c_int)]
+
+
+def local_stage_forward(packed, x, out=None, workspace=None, winograd=True, chunk=0):
     n = x.shape[0]
     if tuple(x.shape[1:]) != (3, BE_R, BE_R):
         raise RuntimeError(f"LocalStage input must be [N,3,21,21], got {tuple(x.shape)}")
     dev = x.device
     if out is None:
         out = torch.empty(n, 10, dtype=torch.float32, device=dev)
-    need = lib().be_local_stage_workspace_bytes(n)
+    need = lib().be_local_stage_workspace_bytes(n, int(chunk))
     if workspace is None or workspace.numel() * 4 < need:
         workspace = torch.empty((need + 3) // 4, dtype=torch.float32, device=dev)
+    opts = LocalStageOpts(int(bool(winograd)), int(chunk))
     check(lib().be_local_stage_forward_f32(dptr(packed, "packed"), dptr(x, "x"), dptr(out), n, dptr(workspace),
-                                           workspace.numel() * 4, stream_ptr(dev)), "be_local_stage_forward_f32")
+                                           workspace.numel() * 4, C.byref(opts), stream_ptr(dev)), "be_local_stage_forward_f32")
     return out, workspace
 
 
@@ -451,15 +455,17 @@ def conv_use_b3(packed=None):
     return planes
 
 
-def local_stage_forward_view(packed, view, patches_per_image: int, n: int, device, out=None, workspace=None):
+def local_stage_forward_view(packed, view, patches_per_image: int, n: int, device, out=None, workspace=None, winograd=True,
+                             chunk=0):
     """LocalStage eval forward over the n = A*P patches of a PatchView (no unfolded copy) -> [n,10]."""
     if out is None:
         out = torch.empty(n, 10, dtype=torch.float32, device=device)
-    need = lib().be_local_stage_workspace_bytes(n)
+    need = lib().be_local_stage_workspace_bytes(n, int(chunk))
     if workspace is None or workspace.numel() * 4 < need:
         workspace = torch.empty((need + 3) // 4, dtype=torch.float32, device=device)
+    opts = LocalStageOpts(int(bool(winograd)), int(chunk))
     check(lib().be_local_stage_forward_view_f32(dptr(packed, "packed"), C.byref(view), patches_per_image, dptr(out), n,
-                                                dptr(workspace), workspace.numel() * 4, stream_ptr(device)),
+                                                dptr(workspace), workspace.numel() * 4, C.byref(opts), stream_ptr(device)),
           "be_local_stage_forward_view_f32")
     return out, workspace
 

@@ -25,6 +25,14 @@ inline int check_launch(const char* what) {
 
 inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// per-device caches (function attributes, CU counts) are indexed by the current device id: one process may drive several GPUs
+constexpr int kMaxDevices = 64;
+inline int current_device() {
+    int d = 0;
+    if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) d = 0;
+    return d;
+}
+
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 // Opt-in per-launch timing (be_profile_* in the C ABI): when enabled, every conv launch is bracketed by two

@@ -7,8 +7,8 @@
 // (input transform, 25 GEMMs, output+input transform, 25 GEMMs, output transform - layer3's with the 2x2 max-pool in it;
 // be_wino.hip), fc.1, fc.4.  Sub-batches of 512 patches and more take the LDS-DMA kernels (be_conv_pm.hip for conv1 on a
 // row-padded staging and for layer0, the row GEMM of be_wino.hip for the 1x1s and fc.1); smaller ones k_conv_igemm - same
-// results bit for bit.  No allocation, no synchronisation: graph-capturable.  be_local_stage_set_winograd(0) runs layers 1-3
-// as direct launches like layer0.
+// results bit for bit.  No allocation, no synchronisation, no process-wide state: graph-capturable, re-entrant.  opts->winograd = 0
+// runs layers 1-3 as direct launches like layer0.
 #include "be_common.h"
 #include <cstdlib>
 
@@ -66,22 +66,16 @@ constexpr size_t RA = 28224, RB = 13824, RC = 13824;
 // 384 + 384 channels), RR = the block's downsample branch [6,6,384]
 constexpr size_t RW = 100 * (384 + 384), RR = 13824;
 constexpr size_t WS_FLOATS_PER_PATCH = RA + RB + RC + RW + RR;
-int g_wino = 1;       // be_local_stage_set_winograd: 0 = direct convolutions on the 6x6 maps (the pre-Winograd path)
-int g_chunk = 8192;   // measured: 8192 > 4096 > 2048 (fewer partial rounds of the 512 resident blocks)
+constexpr int kDefaultChunk = 8192;   // measured: 8192 > 4096 > 2048 (fewer partial rounds of the 512 resident blocks)
+inline int chunk_of(int chunk) { return chunk > 0 ? chunk : kDefaultChunk; }
 
 }  // namespace
 
 extern "C" size_t be_local_stage_packed_floats(void) { return layout().total; }
 
-extern "C" int be_local_stage_set_chunk(int patches) {
-    BE_REQUIRE(patches >= 1, "be_local_stage_set_chunk: chunk must be >= 1");
-    g_chunk = patches;
-    return BE_OK;
-}
-
-extern "C" size_t be_local_stage_workspace_bytes(int64_t n) {
+extern "C" size_t be_local_stage_workspace_bytes(int64_t n, int chunk) {
     if (n <= 0) return 0;
-    const int64_t nb = n < g_chunk ? n : g_chunk;
+    const int64_t nb = n < chunk_of(chunk) ? n : chunk_of(chunk);
     return (size_t)nb * WS_FLOATS_PER_PATCH * sizeof(float);
 }
 
@@ -175,20 +169,21 @@ int block_wino(const float* packed, int l0, const float* x, float* t, float* o, 
 
 }  // namespace
 
-extern "C" int be_local_stage_set_winograd(int on) { g_wino = on ? 1 : 0; return BE_OK; }
-
 namespace {
 
 // x != nullptr: flat patches [n,3,21,21]; else the patches are gathered from `view` (image pair, f2)
 int forward_impl(const float* packed, const float* x, const be_patch_view* view, int64_t P, float* out, int64_t n,
-                 void* workspace, size_t workspace_bytes, void* stream, const char* who) {
+                 void* workspace, size_t workspace_bytes, const be_local_stage_opts* opts, void* stream, const char* who) {
     BE_REQUIRE(n >= 0, "%s: n < 0", who);
+    BE_REQUIRE(!opts || opts->chunk >= 0, "%s: opts->chunk < 0", who);
+    const int g_wino = opts ? (opts->winograd != 0) : 1;
+    const int g_chunk = chunk_of(opts ? opts->chunk : 0);
     if (n == 0) return BE_OK;
     BE_REQUIRE(packed && (x || view) && out && workspace, "%s: null pointer", who);
     BE_REQUIRE(be::aligned16(workspace) && be::aligned16(packed), "%s: workspace / packed must be 16-byte aligned", who);
-    if (workspace_bytes < be_local_stage_workspace_bytes(n))
+    if (workspace_bytes < be_local_stage_workspace_bytes(n, g_chunk))
         return be::fail(BE_EWORKSPACE, "%s: workspace %zu B < %zu B needed", who, workspace_bytes,
-                        be_local_stage_workspace_bytes(n));
+                        be_local_stage_workspace_bytes(n, g_chunk));
     float* ws = static_cast<float*>(workspace);
     for (int64_t first = 0; first < n; first += g_chunk) {
         const int nb = (int)((n - first) < g_chunk ? (n - first) : g_chunk);
@@ -251,16 +246,16 @@ int forward_impl(const float* packed, const float* x, const be_patch_view* view,
 }  // namespace
 
 extern "C" int be_local_stage_forward_f32(const float* packed, const float* x, float* out, int64_t n,
-                                          void* workspace, size_t workspace_bytes, void* stream) {
+                                          void* workspace, size_t workspace_bytes, const be_local_stage_opts* opts, void* stream) {
     BE_REQUIRE(x || n == 0, "be_local_stage_forward_f32: null pointer");
-    return forward_impl(packed, x, nullptr, 1, out, n, workspace, workspace_bytes, stream, "be_local_stage_forward_f32");
+    return forward_impl(packed, x, nullptr, 1, out, n, workspace, workspace_bytes, opts, stream, "be_local_stage_forward_f32");
 }
 
 extern "C" int be_local_stage_forward_view_f32(const float* packed, const be_patch_view* view, int64_t patches_per_image,
                                                float* out, int64_t n, void* workspace, size_t workspace_bytes,
-                                               void* stream) {
+                                               const be_local_stage_opts* opts, void* stream) {
     BE_REQUIRE((view && view->base && view->wp > 0 && patches_per_image > 0) || n == 0,
                "be_local_stage_forward_view_f32: bad view");
-    return forward_impl(packed, nullptr, view, patches_per_image, out, n, workspace, workspace_bytes, stream,
+    return forward_impl(packed, nullptr, view, patches_per_image, out, n, workspace, workspace_bytes, opts, stream,
                         "be_local_stage_forward_view_f32");
 }

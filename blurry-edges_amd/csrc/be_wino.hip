@@ -428,8 +428,8 @@ void k_wino_gemm(GemmArgs a) {
 // at K = 384, so one wave per SIMD) and walks a range of M tiles streaming only A: half the DMA pieces and half the fragment
 // reads per MFMA of k_wino_gemm.  The issue model of DESIGN 3.1d prices the loop at 2048 / (2048 + 64 + 120 + 60) = 89 %; with
 // one wave per SIMD every latency has to be hidden inside the wave: three LDS buffers for A, DMA two chunks ahead, the
-// fragments of chunk s+1 read while the MFMAs of chunk s run, one raw barrier per chunk, counted vmcnt (a tile's 64 stores
-// sit between the DMA and its wait: "all but the newest 63").  Same order of operations per output element as k_wino_gemm:
+// fragments of chunk s+1 read while the MFMAs of chunk s run, one raw barrier per chunk, explicit vmcnt waits (the wait for a tile's
+// successor DMA sits in FRONT of that tile's stores, so no count depends on the number of store instructions).  Same order of operations per output element as k_wino_gemm:
 // bit-identical.  Measured (tools/wino_gemm_lab.hip, weight_stationary_run13.log): +3...5 % over k_wino_gemm.
 template <int KCH>
 __global__ __launch_bounds__(256, 1)
@@ -530,9 +530,11 @@ void k_wino_gemm_ws(GemmArgs a, int mgroups) {
     for (int t = t0; t < t1; ++t) {
 #pragma unroll
         for (int c = 0; c < KCH; ++c) {
-            // the DMA of the NEXT step (issued one step ago) has to land before its fragments are read below; behind the 64
-            // stores of a finished tile that is vmcnt(63) (memory operations retire in issue order), otherwise vmcnt(0)
-            if (c == 0 && t != t0) __builtin_amdgcn_s_waitcnt(0xCF7F); else __builtin_amdgcn_s_waitcnt(0x0F70);
+            // the DMA of the NEXT step (issued one step ago) has to land before its fragments are read below: vmcnt(0) - it is
+            // the only vector-memory operation in flight here.  After a finished tile that wait has already happened, in front
+            // of the tile's stores (below), so nothing here depends on how many store instructions the compiler emitted (round 1
+            // waited "all but the newest 63" behind the 64 stores: right only for exactly that store count)
+            if (!(c == 0 && t != t0)) __builtin_amdgcn_s_waitcnt(0x0F70);
             __builtin_amdgcn_s_barrier();                  // every wave's pieces of step + 1 are in LDS; slot (step + 2) % 3 is free
             WS_DMA();                                      // step + 2
             __builtin_amdgcn_sched_barrier(0);
@@ -550,6 +552,10 @@ void k_wino_gemm_ws(GemmArgs a, int mgroups) {
                     }
             __builtin_amdgcn_sched_barrier(0);
         }
+        // the first step of the next tile needs its DMA (issued at the top of the step that just ended, a whole chunk of MFMAs
+        // ago) in LDS: wait for it HERE, while it is still the only thing in flight, then issue the tile's stores
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_sched_barrier(0);
         char* yt = reinterpret_cast<char*>(a.y + (int64_t)z * a.yb + (int64_t)t * BM * a.ldy + n0);   // uniform; full tile, N % 128 == 0
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -569,18 +575,20 @@ void k_wino_gemm_ws(GemmArgs a, int mgroups) {
 template <int KCH>
 int launch_ws(const GemmArgs& g, hipStream_t s, int64_t n, int cin, int cout) {
     constexpr size_t lds = (size_t)8 * 128 * 16 * sizeof(float);     // 64 KB: eight chunks of the B fill (the A ring uses three)
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[be::kMaxDevices] = {};
+    const int dev_ = be::current_device();          // the attribute is per device
+    if (!attr_set[dev_]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino_gemm_ws<KCH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return be::fail(BE_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
+        attr_set[dev_] = true;
     }
-    static int cus = 0;
-    if (!cus) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-            cus = 256;
+    static int cus_of[be::kMaxDevices] = {};               // CU count, per device
+    if (!cus_of[dev_]) {
+        int c = 0;
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev_) != hipSuccess || c <= 0) c = 256;
+        cus_of[dev_] = c;
     }
+    const int cus = cus_of[dev_];
     // R rounds of ONE workgroup per CU (the kernel takes the whole register file of a CU).  Workgroup ids go round-robin over the
     // 8 XCDs, so the count that has to fit is per XCD: ceil(units / 8) * n_tiles <= R * (CUs per XCD) - one workgroup too many
     // on an XCD is a whole extra round for everybody.  At least 8 M ranges per problem when there is that much work.
@@ -642,11 +650,12 @@ int wino_gemms(const float* V, const float* packed_w, float* M, int64_t n, int c
     if (wino_large(n, cout)) {
         // large batches: one workgroup per (M tile, N tile) walks the 25 problems back to back
         constexpr size_t lds = (size_t)2 * (128 + 128) * 16 * sizeof(float);
-        static bool attr_set = false;
-        if (!attr_set) {
+        static bool attr_set[be::kMaxDevices] = {};
+        const int dev_ = be::current_device();          // the attribute is per device
+        if (!attr_set[dev_]) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino_gemm<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
             if (e != hipSuccess) return be::fail(BE_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-            attr_set = true;
+            attr_set[dev_] = true;
         }
         // tile-major V [4n][25][cin] and M [4n][25][cout]: problem z = column block z of a row
         GemmArgs g{V, packed_w, M, (int)(4 * n), cin, cout, 25 * cout, 25, (int)((4 * n + 127) / 128), cp / 128,
@@ -688,11 +697,12 @@ int be::gemm_rows(const float* x, int64_t M, int K, const float* packed_w, int N
                   float* y, int ldy, void* stream) {
     hipStream_t s = be::as_stream(stream);
     constexpr size_t lds = (size_t)2 * (128 + 128) * 16 * sizeof(float);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[be::kMaxDevices] = {};
+    const int dev_ = be::current_device();          // the attribute is per device
+    if (!attr_set[dev_]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino_gemm<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return be::fail(BE_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set = true;
+        attr_set[dev_] = true;
     }
     const int cp = (N + 127) / 128 * 128, n_tiles = cp / 128;
     const int64_t tiles = (M + 127) / 128;

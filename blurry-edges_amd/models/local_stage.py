@@ -100,8 +100,11 @@ class LocalStage(nn.Module):
     # per product with fp32 accumulation (include/blurry_edges_hip.h, be_conv_use_b3).
     conv_precision = os.environ.get("BE_CONV_PRECISION", "f32")
     # True (default): the 3x3 convolutions on the 6x6 maps run as Winograd F(3x3,3x3) (2.56x fewer multiplies, exact fp32
-    # products; be_wino.hip).  False: direct implicit-GEMM convolutions everywhere (be_local_stage_set_winograd).
+    # products; be_wino.hip).  False: direct implicit-GEMM convolutions everywhere.  A per-call option of the C ABI
+    # (be_local_stage_opts): instances with different settings coexist in one process.
     winograd = os.environ.get("BE_WINOGRAD", "1") != "0"
+    # sub-batch (patches) the forward walks a large batch in; 0 = the library default (8192)
+    chunk = 0
 
     def invalidate_packed(self):
         """Drop the cached BN-folded weight pack.  Needed whenever parameters or running statistics change on the device
@@ -140,8 +143,8 @@ class LocalStage(nn.Module):
                                  if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d))], 1)
             return out
         x = x.to(torch.float32).contiguous()
-        native.check(native.lib().be_local_stage_set_winograd(int(bool(self.winograd))), "be_local_stage_set_winograd")
-        out, self._workspace = native.local_stage_forward(self._packed_weights(), x, workspace=self._workspace)
+        out, self._workspace = native.local_stage_forward(self._packed_weights(), x, workspace=self._workspace,
+                                                          winograd=self.winograd, chunk=self.chunk)
         return out
 
     @torch.no_grad()
@@ -152,9 +155,8 @@ class LocalStage(nn.Module):
         if self.training:
             raise RuntimeError("LocalStage.forward_image_pair is an inference entry point; call .eval() first")
         img = img.to(torch.float32).contiguous()
-        native.check(native.lib().be_local_stage_set_winograd(int(bool(self.winograd))), "be_local_stage_set_winograd")
         view = native.view_image_pair(img, stride, window)
         P = (((window[2] if window is not None else img.shape[2]) - native.BE_R) // stride + 1) * view.wp
         out, self._workspace = native.local_stage_forward_view(self._packed_weights(), view, P, 2 * P, img.device,
-                                                               workspace=self._workspace)
+                                                               workspace=self._workspace, winograd=self.winograd, chunk=self.chunk)
         return out

@@ -219,25 +219,29 @@ size_t be_local_stage_packed_floats(void);
 int be_local_stage_pack_f32(const float* const* tensors_host /* [86] device ptrs */, float bn_eps,
                             float* packed, void* stream);
 
-/* The batch is walked in sub-batches of `patches` (default 8192) so that inter-layer activations stay in
- * the Infinity Cache and the workspace is bounded; affects be_local_stage_workspace_bytes(). */
-int be_local_stage_set_chunk(int patches);
+/* Per-call options of the forward (NULL = the defaults).  They travel with the call - no process-wide state, so two models
+ * with different settings, or two host threads, do not interfere.
+ *   winograd  1 (default): the 3x3 convolutions on the 6x6 maps (layers 1-3) run in Winograd F(3x3,3x3) form; 0: direct
+ *             implicit GEMM (the form the split-bf16 experiment and A/B runs use).  Both read the same packed buffer.
+ *   chunk     the batch is walked in sub-batches of this many patches (0 = default 8192) so that the workspace stays bounded
+ *             whatever N is; the same value must be given to be_local_stage_workspace_bytes(). */
+typedef struct be_local_stage_opts {
+    int winograd;
+    int chunk;
+} be_local_stage_opts;
 
-/* 1 (default): the 3x3 convolutions on the 6x6 maps (layers 1-3) run in Winograd F(3x3,3x3) form; 0: direct implicit GEMM
- * (the form the split-bf16 experiment and A/B runs use).  Both read the same packed buffer. */
-int be_local_stage_set_winograd(int on);
-
-/* Workspace (activations) for a batch of n patches, in bytes. */
-size_t be_local_stage_workspace_bytes(int64_t n);
+/* Workspace (activations) for a batch of n patches walked in sub-batches of `chunk` (0 = default), in bytes. */
+size_t be_local_stage_workspace_bytes(int64_t n, int chunk);
 
 /* LocalStage.forward in eval mode: x [N,3,21,21] (NCHW as the reference feeds it) -> out [N,10]. */
 int be_local_stage_forward_f32(const float* packed, const float* x, float* out, int64_t n,
-                               void* workspace, size_t workspace_bytes, void* stream);
+                               void* workspace, size_t workspace_bytes, const be_local_stage_opts* opts, void* stream);
 
 /* The same forward with the 21x21 windows gathered from a view (e.g. straight from the image pair [2,3,H,W]) in
  * place of nn.Unfold + permute (blurry_edges_test.py:120-121); patch numbering as be_render_colors_view_f32. */
 int be_local_stage_forward_view_f32(const float* packed, const be_patch_view* view_host, int64_t patches_per_image,
-                                    float* out, int64_t n, void* workspace, size_t workspace_bytes, void* stream);
+                                    float* out, int64_t n, void* workspace, size_t workspace_bytes,
+                                    const be_local_stage_opts* opts, void* stream);
 
 /* Layer-level entry points (used by the layer-by-layer parity tests and by the training path).
  * Activations are NHWC.  act: 0 none, 1 Smish (models/local_stage.py:4-6), 2 ReLU (GlobalStage FFN). */

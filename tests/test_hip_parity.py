@@ -514,6 +514,19 @@ def test_split_bf16_conv_mode_is_opt_in_and_stays_within_the_fp32_tolerance(nati
     ed = relmax(yd[:256].cpu(), ref)
     print("logits vs fp64 oracle: direct %.2e, winograd %.2e" % (ed, e32))
     assert torch.equal(yw, y32) and not torch.equal(yd, y32) and ed <= 1e-5
+    # the settings are per-call options of the C ABI, not process state: two instances with different
+    # settings - Winograd on / off, different sub-batch sizes - interleave in one process without disturbing each other
+    import models
+    m2 = models.LocalStage()
+    m2.load_state_dict(m.state_dict())
+    m2 = m2.to(DEV).eval()
+    m2.winograd, m2.chunk = False, 1000                                  # ragged sub-batches of 1000 patches
+    with torch.no_grad():
+        a1 = m(x).clone()
+        b1 = m2(x).clone()
+        a2 = m(x).clone()
+        b2 = m2(x)
+    assert torch.equal(a1, y32) and torch.equal(a2, y32) and torch.equal(b1, yd) and torch.equal(b2, yd)
 
 
 def test_entry_points_reject_bad_arguments_before_launching(native):
@@ -533,7 +546,7 @@ def test_entry_points_reject_bad_arguments_before_launching(native):
     with pytest.raises(RuntimeError, match="workspace"):
         n.check(n.lib().be_local_stage_forward_f32(n.dptr(torch.zeros(int(n.lib().be_local_stage_packed_floats()), device=DEV)),
                                                    n.dptr(torch.zeros(64, 3, 21, 21, device=DEV)), n.dptr(torch.zeros(64, 10, device=DEV)),
-                                                   64, n.dptr(torch.zeros(16, device=DEV)), 64, None), "be_local_stage_forward_f32")
+                                                   64, n.dptr(torch.zeros(16, device=DEV)), 64, None, None), "be_local_stage_forward_f32")
     with pytest.raises(RuntimeError, match="ldx"):
         n.check(n.lib().be_maxpool_nhwc_ld_f32(n.dptr(z), 6, n.dptr(torch.zeros(64, device=DEV)), 1, 4, 4, 8, 2, 2, 0, None), "pool")
     with pytest.raises(RuntimeError, match="channels must be multiples of 4"):

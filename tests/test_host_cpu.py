@@ -21,7 +21,7 @@ def test_library_exports_every_symbol_in_the_header():
         assert hasattr(lib, name), f"{name} declared in the header but not exported"
     assert declared == set(native.EXPORTED)
     assert lib.be_version() >= 1
-    assert lib.be_local_stage_workspace_bytes(0) == 0
+    assert lib.be_local_stage_workspace_bytes(0, 0) == 0
     assert lib.be_local_stage_packed_floats() > 7254122          # >= parameter count (padding only adds)
 
 
