@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Summarise the rocprofv3 --pmc passes written by tools/pmc_passes.sh into profiles/<tag>_pmc_summary.json and
-profiles/r01_pmc_traffic.json (HBM bytes per launch of the dominant kernel, corrected as MI355X_MICROARCH.md's HBM
+profiles/<tag>_pmc_traffic.json (usage: summarize_pmc.py <dir> <tag> [git head]; HBM bytes per launch of the dominant kernel, corrected as MI355X_MICROARCH.md's HBM
 section prescribes: FETCH_SIZE is in KiB and reads exactly half of a wide coalesced stream on gfx950 -> x2;
 WRITE_SIZE in KiB is exact for 16-B streaming stores; our epilogue stores are 4-B per lane, 128-B segments, so the
 write side is 'uncalibrated width' and reported as is)."""
@@ -44,11 +44,18 @@ for k, cs in out.items():
         h, m = cs["TCC_HIT_sum"]["mean_per_launch"], cs["TCC_MISS_sum"]["mean_per_launch"]
         cs.setdefault("derived", {})["l2_hit_rate"] = h / (h + m)
 json.dump(out, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
+head = sys.argv[3] if len(sys.argv) > 3 else None
 dom = out.get("wino_gemm") or out.get("conv128x128", {})
 if "FETCH_SIZE" in dom and "WRITE_SIZE" in dom:
     rd = dom["FETCH_SIZE"]["mean_per_launch"] * 1024 * 2
     wr = dom["WRITE_SIZE"]["mean_per_launch"] * 1024
-    json.dump({"kernel": "k_wino_gemm" if "wino_gemm" in out else "k_conv_igemm<2,2,2,2,TAPS>", "bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr,
-               "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes; FETCH_SIZE x2 (gfx950), KiB -> B",
-               "launches_averaged": dom["FETCH_SIZE"]["launches"]}, open("profiles/r01_pmc_traffic.json", "w"), indent=1)
+    wino = "wino_gemm" in out
+    # bench.py reports this under roofline.traffic_recorded only while kernel_id still names its dominant kernel
+    json.dump({"kernel": "k_wino_gemm_ws<6|16|24> (be_wino.hip)" if wino else "k_conv_igemm<2,2,2,2,TAPS>", "kernel_id": 6 if wino else 0,
+               "bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr,
+               # 25 x 4 B x (4n x cin + cin x cout + 4n x cout) averaged over the six launches of a step, n = 8192
+               "algo_bytes_per_launch": 1878289066.67 if wino else None, "git_head": head,
+               "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/pmc_passes.sh); FETCH_SIZE x2 (gfx950), KiB -> B; "
+                         "counts L2 misses, i.e. Infinity-Cache hits too",
+               "launches_averaged": dom["FETCH_SIZE"]["launches"]}, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
 print(json.dumps({k: v.get("derived") for k, v in out.items()}, indent=1))
