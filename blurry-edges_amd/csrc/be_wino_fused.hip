@@ -51,7 +51,7 @@ struct FusedArgs {
 template <bool WY, bool WV, bool POOL>
 __global__ __launch_bounds__(256, 2)
 void k_wino_fused(FusedArgs a) {
-    constexpr int BM = 64, BN = 64, BKT = 16, NWAVES = 4, G = 2, R = 3;
+    constexpr int BM = 64, BN = 64, BKT = 16, G = 2, R = 3;               // four waves
     constexpr int CHUNK = (BM + BN) * BKT;                            // floats per K-chunk of a stage (8 KB): A 64 x 16, B 64 x 16
     constexpr int STAGE = CHUNK * G;
     extern __shared__ __attribute__((aligned(16))) float smem_f[];

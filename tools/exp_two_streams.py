@@ -17,11 +17,14 @@ xa, xb = x[:4096].contiguous(), x[4096:].contiguous()
 s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
 def one():
     with torch.no_grad(): return m0(x)
+LAG = int(os.environ.get("LAG_KCYCLES", "0")) * 1000       # stream 2 starts this many GPU cycles later (staggers MFMA / HBM phases)
 def two():
     s1.wait_stream(torch.cuda.current_stream()); s2.wait_stream(torch.cuda.current_stream())
     with torch.no_grad():
         with torch.cuda.stream(s1): a = m1(xa)
-        with torch.cuda.stream(s2): b = m2(xb)
+        with torch.cuda.stream(s2):
+            if LAG: torch.cuda._sleep(LAG)
+            b = m2(xb)
     torch.cuda.current_stream().wait_stream(s1); torch.cuda.current_stream().wait_stream(s2)
     return a, b
 def timed(f, n=20):
