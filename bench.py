@@ -214,8 +214,19 @@ def leg_dp(dev, native, dist, rank, world, steps):
     opt = torch.optim.AdamW(model.parameters(), lr=args.learning_rate, fused=dp.fused_adamw())
     data = {k: torch.from_numpy(v).to(dev) for k, v in synth.synthetic_training_patches(B * 8, seed=1869 + rank).items()}
     model.train()
-    sync = dp.GradSync(world) if world > 1 else None
-    if world > 1:
+    own_group = False
+    if world == 1 and dist is None and os.environ.get("BE_BENCH_NO_RCCL") is None:
+        # N = 1: a one-rank RCCL group, so that the exchange code the N > 1 runs depend on (side stream, events, async handles,
+        # broadcasts) runs on every box; the sum over one rank is the identity
+        import socket
+        import torch.distributed as dist1
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist1.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
+        own_group = True
+    sync = dp.GradSync(world, always=own_group) if (world > 1 or own_group) else None
+    if world > 1 or own_group:
         dp.broadcast_parameters(model, src=0)
     it = [0]
 
@@ -248,7 +259,7 @@ def leg_dp(dev, native, dist, rank, world, steps):
                       "five gradient buckets all-reduced on a side stream while the backward runs",
                world=world, global_batch=B * world, steps=steps, dp_step_ms=round(ms, 4),
                patches_per_s=round(B * world / ms * 1e3, 1), allreduce_bytes=4 * sum(p.numel() for p in model.parameters()),
-               allreduce_buckets=5 if world > 1 else 0)
+               allreduce_buckets=5 if sync is not None else 0)
     if world > 1:
         res["compute_only_step_ms"] = round(clock(lambda: step(False), steps), 4)
         flat = torch.zeros(res["allreduce_bytes"] // 4, dtype=torch.float32, device=dev)
@@ -262,6 +273,11 @@ def leg_dp(dev, native, dist, rank, world, steps):
         res["exposed_comm_ms"] = round(res["dp_step_ms"] - res["compute_only_step_ms"], 4)
         res["allreduce_busbw_GBps"] = round(2 * (world - 1) / world * res["allreduce_bytes"] / (res["allreduce_ms"] * 1e-3) / 1e9, 1)
         dp.broadcast_bn_stats(model, src=0)
+    if own_group:
+        res["rccl_one_rank_group"] = True
+        res["compute_only_step_ms"] = round(clock(lambda: step(False), steps), 4)
+        dp.broadcast_bn_stats(model, src=0)
+        dist1.destroy_process_group()
     return res
 
 
@@ -392,6 +408,24 @@ def main():
 
     # ---- the other configurations, each on its own clock (never part of `value`)
     extra, dp_leg = None, None
+    head = git_head()
+
+    def headline(dp_result, cpu=None, more=None):
+        """the one JSON line, from whatever has been measured so far"""
+        out = {
+            "metric": "patch-pairs/s (local CNN + render + depth) on 21x21 synth",
+            "value": round(pairs_per_s, 1), "unit": "patch-pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if model.conv_precision == "f32" else "f32 operands split exactly into 3 bf16 pieces, 6 bf16 MFMAs per product, f32 accumulate (opt-in experiment)", "data": "synthetic",
+            "config": {"workload": "configs[1]: batch of 4096 synthetic 21x21 two-aperture patch pairs per GPU "
+                                   "(8192 CNN patches): LocalStage inference + pass-A colour solve + depth solve",
+                       "pairs_per_gpu": PAIRS, "weights": "portable-generator random init (no checkpoint offline)",
+                       "sharding": "independent pairs per rank, no data-path collective"},
+            "roofline": roof, "cpu_baseline": cpu, "extra_configs": extra, "dp": dp_result, "git_head": head,
+        }
+        out.update(more or {})
+        return out
+
     if not args.no_extra:
         if rank == 0:
             extra = []
@@ -401,12 +435,30 @@ def main():
                 except Exception as e:                    # a broken side leg must not take the headline number with it
                     extra.append(dict(error=f"{type(e).__name__}: {e}"))
         barrier()
+        # N > 1: the dp leg is the first code of this build that moves real data over RCCL between GPUs and it runs AFTER the
+        # measurement of `value`: a rank that fails or hangs in it must not cost the run its headline line.  A watchdog on every
+        # rank: past the deadline rank 0 prints the line it has (dp: timeout) and every rank leaves without waiting for the others.
+        watchdog = None
+        if world > 1:
+            import threading
+
+            def bail():
+                if rank == 0:
+                    print(json.dumps(headline(dict(error="dp leg did not finish within 180 s (watchdog)"))), flush=True)
+                os._exit(0)
+            watchdog = threading.Timer(180.0, bail)
+            watchdog.daemon = True
+            watchdog.start()
         try:
             dp_leg = leg_dp(dev, native, dist, rank, world, max(10, args.steps))
         except Exception as e:
-            if world > 1:
-                raise                                     # ranks would otherwise wait for each other
             dp_leg = dict(error=f"{type(e).__name__}: {e}")
+            if world > 1:                                 # the other ranks may be waiting inside a collective: do not join them
+                if rank == 0:
+                    print(json.dumps(headline(dp_leg)), flush=True)
+                os._exit(0)
+        if watchdog is not None:
+            watchdog.cancel()
 
     cpu = None
     more = {}
@@ -426,20 +478,7 @@ def main():
                                                   / est_o.abs().max()))
 
     if rank == 0:
-        ms = elapsed / args.steps * 1e3
-        out = {
-            "metric": "patch-pairs/s (local CNN + render + depth) on 21x21 synth",
-            "value": round(pairs_per_s, 1), "unit": "patch-pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if model.conv_precision == "f32" else "f32 operands split exactly into 3 bf16 pieces, 6 bf16 MFMAs per product, f32 accumulate (opt-in experiment)", "data": "synthetic",
-            "config": {"workload": "configs[1]: batch of 4096 synthetic 21x21 two-aperture patch pairs per GPU "
-                                   "(8192 CNN patches): LocalStage inference + pass-A colour solve + depth solve",
-                       "pairs_per_gpu": PAIRS, "weights": "portable-generator random init (no checkpoint offline)",
-                       "sharding": "independent pairs per rank, no data-path collective"},
-            "roofline": roof, "cpu_baseline": cpu, "extra_configs": extra, "dp": dp_leg, "git_head": git_head(),
-        }
-        out.update(more)
-        print(json.dumps(out), flush=True)
+        print(json.dumps(headline(dp_leg, cpu, more)), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -113,13 +113,15 @@ class GradSync:
     gloo (CPU rehearsal, tests): the same calls, synchronous; GPU tensors are staged through the host because gloo has no
     device transport on this build."""
 
-    def __init__(self, world, group=None):
-        self.world, self.group = world, group
+    def __init__(self, world, group=None, always=False):
+        """always: run the exchange even for world == 1 (a one-rank group: the sum is the identity) - how the RCCL path is
+        exercised on a single GPU (tests, bench.py at N = 1)."""
+        self.world, self.group, self.always = world, group, always
         self.handles, self.flat, self.side = [], None, None
         self.bytes = 0
 
     def bucket_ready(self, flat, lo, hi):
-        if self.world == 1 or hi <= lo:
+        if (self.world == 1 and not self.always) or hi <= lo:
             return
         import torch.distributed as dist
         self.flat = flat

@@ -89,3 +89,43 @@ def test_two_processes_on_one_gpu_train_step_world_2_gives_the_mean_gradient():
     assert np.array_equal(got[0][0], mean) and np.array_equal(got[1][0], mean)
     assert got[0][2] == got[1][2] == 4 * 7254122                    # every bucket went through the exchange, once
     assert abs(got[0][1] - float(np.sqrt((mean.astype(np.float64) ** 2).sum()))) <= 1e-5 * got[0][1]
+
+
+def _nccl_worker(port, q):
+    """One rank, backend nccl (= RCCL): the side-stream / event / async-handle mechanics of GradSync with the real library."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    args, model, helper, batch = _setup(0)
+    from be_hip import dp, train_local
+    res = []
+    for sync in (None, dp.GradSync(1, always=True)):
+        model.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in __import__("be_hip.synth", fromlist=["x"]).local_stage_state_dict().items()})
+        model.train()
+        opt = torch.optim.SGD(model.parameters(), lr=0.0)
+        for _ in range(3):                                           # several steps: handles / events are reused correctly
+            train_local.train_step(model, helper, opt, batch, args.beta_bndry_loc, args.beta_smthns, clip=1e9, sync=sync)
+        torch.cuda.synchronize()
+        res.append((dp.grads_as_flat(list(model.parameters())).cpu().numpy().copy(), None if sync is None else sync.bytes))
+    dp.broadcast_parameters(model, src=0)
+    dp.broadcast_bn_stats(model, src=0)
+    torch.cuda.synchronize()
+    q.put(res)
+    dist.destroy_process_group()
+
+
+def test_gradsync_over_rccl_one_rank_group_leaves_the_gradients_untouched():
+    """bench.py --gpus N > 1 and the driver's scaling run use backend nccl, which no 1-GPU box can run with two ranks; a ONE-rank
+    RCCL group can: the five bucket all-reduces are issued on the side stream behind their events while the backward runs,
+    finish() joins them, and (sum over one rank, / 1) every gradient must come out bit-identical to the run without exchange."""
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a GPU")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
+    p.start()
+    (g0, _), (g1, nbytes) = q.get(timeout=600)
+    p.join(timeout=120)
+    assert p.exitcode == 0
+    assert np.array_equal(g0, g1) and np.isfinite(g0).all() and nbytes == 3 * 4 * 7254122
