@@ -38,6 +38,12 @@ def allreduce_mean_(buf: torch.Tensor, world: int, group=None, bucket_bytes: int
     if world == 1:
         return buf
     import torch.distributed as dist
+    if buf.is_cuda and dist.get_backend(group) != "nccl":      # gloo rehearsal on one GPU: no device transport in this build
+        host = buf.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        buf.copy_(host)
+        buf.div_(world)
+        return buf
     n = max(1, bucket_bytes // 4)
     handles = [dist.all_reduce(buf[i:i + n], op=dist.ReduceOp.SUM, group=group, async_op=True)
                for i in range(0, buf.numel(), n)]

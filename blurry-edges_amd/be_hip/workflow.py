@@ -7,6 +7,11 @@ formats (argument names and defaults = utils/args.py of the reference):
     python -m be_hip.workflow global_train     global_training.py:168-224   (ShapeDataset 'global' -> best_run_exp_global_stage.pth)
     python -m be_hip.workflow eval [--big]     blurry_edges_test.py:102-176 / blurry_edges_test_big.py (TestDataset -> metrics)
 
+Data parallel (BASELINE configs[4]): the two training commands run under torchrun, one process per GPU -
+    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 -m be_hip.workflow local_train ...
+every rank keeps a replica, takes every world-th batch of the epoch, gradients are averaged over RCCL (be_hip.dp), rank 0 logs and
+writes the checkpoints (the reference has no distributed code at all: this part is the build's own).
+
 Checkpoints are `torch.save(model.state_dict())` files in the reference's key layout, so they are interchangeable with
 the reference's.  Epoch loops, schedules (beta / gamma ramps, ReduceLROnPlateau with the growing patience), xavier
 initialisation, clipping and AdamW settings follow the scripts cited above; the compute inside a step is the HIP path.
@@ -24,6 +29,26 @@ import torch
 
 def _device(args):
     return torch.device(args.cuda if torch.cuda.is_available() else "cpu")
+
+
+def _dist():
+    """(rank, world, dist module or None) for a run started by torchrun (one process per GPU, configs[4]); a plain `python -m
+    be_hip.workflow ...` is (0, 1, None).  Backend nccl (= RCCL); BE_DIST_BACKEND=gloo + BE_LOCAL_DEVICE=0 rehearse it on one GPU."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world == 1:
+        return 0, 1, None
+    import torch.distributed as dist
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("BE_DIST_BACKEND", "nccl")
+        lr = int(os.environ.get("BE_LOCAL_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+        if torch.cuda.is_available():
+            torch.cuda.set_device(lr)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", lr))
+        else:
+            dist.init_process_group(backend)
+    return dist.get_rank(), dist.get_world_size(), dist
 
 
 def _xavier_(model):
@@ -47,14 +72,25 @@ def local_train(args, quiet=False, graph=True):
     import data, models, utils
     from . import dp
     from .train_local import BetaSchedule, GraphedStep, train_step
+    rank, world, dist = _dist()
     utils.set_seed(1869)
-    utils.create_directory(args.log_path, overwrite=False)
-    os.makedirs(args.model_path, exist_ok=True)
-    dev = _device(args)
+    if rank == 0:
+        utils.create_directory(args.log_path, overwrite=False)
+        os.makedirs(args.model_path, exist_ok=True)
+    if dist is not None:
+        dist.barrier()
+    dev = _device(args) if world == 1 else torch.device("cuda", torch.cuda.current_device())
     tr = data.ShapeDataset(dev, data_path=args.data_path, train=True)
     va = data.ShapeDataset(dev, data_path=args.data_path, train=False)
     model = models.LocalStage().to(dev)
     _xavier_(model)
+    # data parallel (configs[4]): every rank keeps a replica, takes every world-th batch of the epoch's (identically shuffled)
+    # batch sequence - a global batch of batch_size x world - and the gradients are averaged by the five-bucket all-reduce that
+    # overlaps the backward (be_hip.dp.GradSync); eager launches (the hipGraph step is single-GPU)
+    graph = graph and world == 1
+    sync = dp.GradSync(world) if world > 1 else None
+    if world > 1:
+        dp.broadcast_parameters(model, src=0)
     opt = torch.optim.AdamW(model.parameters(), lr=args.learning_rate, capturable=graph, fused=dp.fused_adamw())
     helper = utils.PostProcessLocalBase(args, dev)
     gstep = GraphedStep(model, helper, opt) if graph else None
@@ -63,17 +99,27 @@ def local_train(args, quiet=False, graph=True):
     sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, 'min', factor=0.9, patience=2, min_lr=args.learning_rate * 0.1)
     curve = np.zeros((args.epoch_num,), dtype=float)
     best, best_epoch = np.inf, 0
-    with open(f'{args.log_path}/exp_local_stage_training.txt', 'wt') as f:
+    with open(f'{args.log_path}/exp_local_stage_training.txt' if rank == 0 else os.devnull, 'wt') as f:
         _log_header(f, args)
         for epoch in range(args.epoch_num):
             beta.step()
             model.train()
-            for img_ny, img_gt, bndry_dist, deri in tr.batches(args.batch_size, shuffle=True, drop_last=True, generator=sampler):
+            nb = len(tr) // args.batch_size
+            for i, (img_ny, img_gt, bndry_dist, deri) in enumerate(tr.batches(args.batch_size, shuffle=True, drop_last=True,
+                                                                             generator=sampler)):
+                if i >= nb - nb % world:
+                    break                                     # every rank takes the same number of steps (collectives pair up)
+                if i % world != rank:
+                    continue
                 b = dict(img_ny=img_ny, img_gt=img_gt, bndry_dist=bndry_dist, deri=deri)
                 if gstep is not None:
                     gstep(b, beta.beta_b, beta.beta_s)
                 else:
-                    train_step(model, helper, opt, b, beta.beta_b, beta.beta_s)
+                    train_step(model, helper, opt, b, beta.beta_b, beta.beta_s, world=world, sync=sync)
+            if world > 1:
+                # BatchNorm statistics are per replica during the epoch; rank 0's go to everyone before validation, so that every
+                # rank sees the same validation loss (same lr schedule everywhere) and the checkpoint is what was validated
+                dp.broadcast_bn_stats(model, src=0)
             # validation with the final betas (local_training.py:54-66)
             model.eval()
             total = 0.0
@@ -88,12 +134,16 @@ def local_train(args, quiet=False, graph=True):
             print(f'{epoch + 1:<10} {curve[epoch]:<20.10f} {sched.patience:<20} {opt.param_groups[0]["lr"]:.4e}', file=f, flush=True)
             if curve[epoch] < best:
                 best, best_epoch = curve[epoch], epoch
-                torch.save(model.state_dict(), f'{args.model_path}/best_run_exp_local_stage.pth')
-            if not quiet:
+                if rank == 0:
+                    torch.save(model.state_dict(), f'{args.model_path}/best_run_exp_local_stage.pth')
+            if not quiet and rank == 0:
                 print(f'epoch {epoch + 1}: validation loss {curve[epoch]:.6f}')
         print(f'\n-- Best epoch is the {best_epoch + 1:d}th, with average loss of {best:.10f}', file=f, flush=True)
-    np.save(f'{args.log_path}/loss_curve_exp_local_stage.npy', curve)
-    utils.showCurve(args, curve, 'loss_curve_exp_local_stage')
+    if rank == 0:
+        np.save(f'{args.log_path}/loss_curve_exp_local_stage.npy', curve)
+        utils.showCurve(args, curve, 'loss_curve_exp_local_stage')
+    if dist is not None:
+        dist.barrier()
     return curve
 
 
@@ -128,15 +178,25 @@ def global_train(args, quiet=False):
     import data, models, utils
     from . import dp
     from .train_global import GammaSchedule, train_step
+    rank, world, dist = _dist()
     utils.set_seed(1898)
-    utils.create_directory(args.log_path, overwrite=False)
-    os.makedirs(args.model_path, exist_ok=True)
-    dev = _device(args)
+    if rank == 0:
+        utils.create_directory(args.log_path, overwrite=False)
+        os.makedirs(args.model_path, exist_ok=True)
+    if dist is not None:
+        dist.barrier()
+    dev = _device(args) if world == 1 else torch.device("cuda", torch.cuda.current_device())
     tr = data.ShapeDataset(dev, data_path=args.data_path, train=True, mode='global')
     va = data.ShapeDataset(dev, data_path=args.data_path, train=False, mode='global')
     sampler = torch.Generator().manual_seed(1898)
     model = models.GlobalStage(in_parameter_size=args.input_size, out_parameter_size=args.output_size, device=dev).to(dev)
     _xavier_(model)
+    # data parallel: replicas aligned with rank 0, every world-th batch per rank, ONE all-reduce of the 4.27 MB gradient per step
+    flat = dp.flat_grad_buffer(model.parameters()) if world > 1 else None
+    if world > 1:
+        dp.broadcast_parameters(model, src=0)
+        for p_ in model.parameters():
+            p_.grad = None
     opt = torch.optim.AdamW(model.parameters(), lr=args.learning_rate, fused=dp.fused_adamw())
     helper = utils.PostProcessGlobalBase(args, dev)
     dcal = utils.DepthEtas(args, dev)
@@ -145,15 +205,20 @@ def global_train(args, quiet=False):
     curve = np.zeros((args.epoch_num,), dtype=float)
     best, best_epoch = np.inf, 0
     feats = lambda p: p.permute(0, 2, 1, 3).flatten(2, 3).contiguous()          # [B,2,P,19] -> [B,P,38]
-    with open(f'{args.log_path}/exp_global_stage_training.txt', 'wt') as f:
+    with open(f'{args.log_path}/exp_global_stage_training.txt' if rank == 0 else os.devnull, 'wt') as f:
         _log_header(f, args)
         for epoch in range(args.epoch_num):
             g = gamma.step()
             model.train()
-            for param, _, img_gt, bndry_dist, deri, bndry_depth in tr.batches(args.batch_size, shuffle=True, drop_last=True,
-                                                                              generator=sampler):
+            nb = len(tr) // args.batch_size
+            for i, (param, _, img_gt, bndry_dist, deri, bndry_depth) in enumerate(tr.batches(args.batch_size, shuffle=True,
+                                                                                           drop_last=True, generator=sampler)):
+                if i >= nb - nb % world:
+                    break
+                if i % world != rank:
+                    continue
                 train_step(model, helper, dcal, opt, dict(pm=feats(param), img_gt=img_gt, bndry_dist=bndry_dist, deri=deri,
-                                                          bndry_depth=bndry_depth), g)
+                                                          bndry_depth=bndry_depth), g, flat=flat, world=world)
             model.eval()
             total, gf = 0.0, gamma.final()
             with torch.no_grad():
@@ -165,14 +230,18 @@ def global_train(args, quiet=False):
             print(f'{epoch + 1:<10} {curve[epoch]:<20.10f} {sched.patience:<20} {opt.param_groups[0]["lr"]:.4e}', file=f, flush=True)
             if curve[epoch] < best:
                 best, best_epoch = curve[epoch], epoch
-                torch.save(model.state_dict(), f'{args.model_path}/best_run_exp_global_stage.pth')
+                if rank == 0:
+                    torch.save(model.state_dict(), f'{args.model_path}/best_run_exp_global_stage.pth')
             if epoch >= args.dynamic_epoch[1]:
                 sched.step(curve[epoch])
-            if not quiet:
+            if not quiet and rank == 0:
                 print(f'epoch {epoch + 1}: validation loss {curve[epoch]:.6f}')
         print(f'\n-- Best epoch is the {best_epoch + 1:d}th, with average loss of {best:.10f}.', file=f, flush=True)
-    np.save(f'{args.log_path}/loss_curve_exp_global_stage.npy', curve)
-    utils.showCurve(args, curve, 'loss_curve_exp_global_stage')
+    if rank == 0:
+        np.save(f'{args.log_path}/loss_curve_exp_global_stage.npy', curve)
+        utils.showCurve(args, curve, 'loss_curve_exp_global_stage')
+    if dist is not None:
+        dist.barrier()
     return curve
 
 

@@ -129,3 +129,66 @@ def test_gradsync_over_rccl_one_rank_group_leaves_the_gradients_untouched():
     p.join(timeout=120)
     assert p.exitcode == 0
     assert np.array_equal(g0, g1) and np.isfinite(g0).all() and nbytes == 3 * 4 * 7254122
+
+
+def _workflow_worker(rank, world, port, root, models_dir, logs, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      BE_DIST_BACKEND="gloo", BE_LOCAL_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import utils
+    from be_hip import workflow as wf
+    common = ["--model_path", models_dir, "--cuda", DEV]
+    a = utils.get_args("local_train", argv=common + ["--data_path", os.path.join(root, "patches"), "--log_path", logs,
+                                                     "--epoch_num", "2", "--batch_size", "16"])
+    c1 = wf.local_train(a, quiet=True)
+    import torch.distributed as dist
+    if rank == 0:
+        g = utils.get_args("global_pre", argv=common + ["--data_path", root])
+        wf.global_pre(g, local_weights=os.path.join(models_dir, "best_run_exp_local_stage.pth"), quiet=True)
+    dist.barrier()
+    a = utils.get_args("global_train", argv=common + ["--data_path", root, "--log_path", logs, "--epoch_num", "1", "--batch_size", "1"])
+    c2 = wf.global_train(a, quiet=True)
+    q.put((rank, c1.tolist(), c2.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_workflow_local_and_global_training_data_parallel_two_ranks(tmp_path):
+    """configs[4] through the drivers: `be_hip.workflow local_train` and `global_train` under a 2-rank process group (gloo, both
+    ranks on this GPU): every rank takes every second batch, gradients are averaged (five overlapped buckets for LocalStage, one
+    4.27 MB all-reduce for GlobalStage), rank 0's BatchNorm statistics are broadcast before validation - so both ranks must
+    report bit-identical validation curves - and rank 0 writes checkpoints that load."""
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a GPU")
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import models
+    from be_hip import datagen as dg
+    root = tmp_path / "data"
+    for part, n, seed in (("train", 8, 31), ("val", 4, 32)):
+        d = dg.generate(dg.draw_scenes(n, seed=seed, name="dpwf"), DEV, seed=seed)
+        dg.save(d, dg.crop_patches(d, 16 * n, seed=seed), str(root), part)
+    models_dir, logs = str(tmp_path / "weights"), str(tmp_path / "logs")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_workflow_worker, args=(r, 2, port, str(root), models_dir, logs, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(2):
+        r, c1, c2 = q.get(timeout=900)
+        got[r] = (c1, c2)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert got[0] == got[1]                                        # replicas stayed in step: identical validation losses
+    assert len(got[0][0]) == 2 and np.isfinite(got[0][0]).all() and np.isfinite(got[0][1]).all()
+    lm = models.LocalStage()
+    lm.load_state_dict(torch.load(os.path.join(models_dir, "best_run_exp_local_stage.pth"), map_location="cpu"))
+    gm = models.GlobalStage(device="cpu")
+    gm.load_state_dict(torch.load(os.path.join(models_dir, "best_run_exp_global_stage.pth"), map_location="cpu"))
+    assert os.path.exists(os.path.join(logs, "exp_local_stage_training.txt"))
