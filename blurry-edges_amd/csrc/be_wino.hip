@@ -662,7 +662,8 @@ int wino_gemms(const float* V, const float* packed_w, float* M, int64_t n, int c
                    (int64_t)cin, (int64_t)cp * cin, (int64_t)cout, 25 * cin, 128, 0, nullptr, nullptr, 0};
         // weight-stationary form: full tiles only, enough M tiles to amortise the register fill, cout a multiple of 128
         static const bool no_ws = getenv("BE_WINO_NO_WS") != nullptr;               // A/B knob
-        if (!no_ws && (4 * n) % 128 == 0 && g.m_tiles >= 128 && cout % 128 == 0) {
+        static const int ws_min_tiles = getenv("BE_WINO_WS_MIN_TILES") ? atoi(getenv("BE_WINO_WS_MIN_TILES")) : 128;   // A/B knob
+        if (!no_ws && (4 * n) % 128 == 0 && g.m_tiles >= ws_min_tiles && cout % 128 == 0) {
             if (cin == 96) return launch_ws<6>(g, s, n, cin, cout);
             if (cin == 256) return launch_ws<16>(g, s, n, cin, cout);
             if (cin == 384) return launch_ws<24>(g, s, n, cin, cout);

@@ -105,6 +105,13 @@ class LocalStage(nn.Module):
     winograd = os.environ.get("BE_WINOGRAD", "1") != "0"
     # sub-batch (patches) the forward walks a large batch in; 0 = the library default (8192)
     chunk = 0
+    # 2 (default): an eval batch of 8192 patches and more (or an image pair with 4096+ patch positions) runs as two halves
+    # on two side streams - patches are independent, the halves' kernels fill each other's tails and let HBM-bound transform
+    # kernels overlap matrix-bound ones: 14.0 -> 13.5 ms per 8192 patches, results bit-identical (tools/exp_two_streams.py,
+    # DESIGN 3.1f).  1: one stream (what the per-kernel roofline measurements use: a kernel's duration means something only
+    # when nothing else shares the chip).
+    streams = int(os.environ.get("BE_LOCAL_STREAMS", "2"))
+    _side = None
 
     def invalidate_packed(self):
         """Drop the cached BN-folded weight pack.  Needed whenever parameters or running statistics change on the device
@@ -143,9 +150,34 @@ class LocalStage(nn.Module):
                                  if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d))], 1)
             return out
         x = x.to(torch.float32).contiguous()
-        out, self._workspace = native.local_stage_forward(self._packed_weights(), x, workspace=self._workspace,
+        packed = self._packed_weights()
+        n = x.shape[0]
+        h = (n // 2) // 128 * 128
+        if self.streams >= 2 and h >= 4096 and x.is_cuda and not torch.cuda.is_current_stream_capturing():
+            out = torch.empty(n, 10, dtype=torch.float32, device=x.device)
+            ws = [self._workspace, getattr(self, "_workspace2", None)]
+
+            def half(i, lo, hi):
+                _, ws[i] = native.local_stage_forward(packed, x[lo:hi], out=out[lo:hi], workspace=ws[i], winograd=self.winograd,
+                                                      chunk=self.chunk)
+            self._on_two_streams(x.device, lambda: half(0, 0, h), lambda: half(1, h, n))
+            self._workspace, self._workspace2 = ws
+            return out
+        out, self._workspace = native.local_stage_forward(packed, x, workspace=self._workspace,
                                                           winograd=self.winograd, chunk=self.chunk)
         return out
+
+    def _on_two_streams(self, device, f0, f1):
+        """f0 / f1 enqueue independent work; each runs on its own side stream, forked from and joined into the current one."""
+        cur = torch.cuda.current_stream(device)
+        if self._side is None or self._side[0].device != cur.device:
+            self._side = (torch.cuda.Stream(device=device), torch.cuda.Stream(device=device))
+        for s_, f in zip(self._side, (f0, f1)):
+            s_.wait_stream(cur)
+            with torch.cuda.stream(s_):
+                f()
+        for s_ in self._side:
+            cur.wait_stream(s_)
 
     @torch.no_grad()
     def forward_image_pair(self, img, stride=2, window=None):
@@ -157,6 +189,20 @@ class LocalStage(nn.Module):
         img = img.to(torch.float32).contiguous()
         view = native.view_image_pair(img, stride, window)
         P = (((window[2] if window is not None else img.shape[2]) - native.BE_R) // stride + 1) * view.wp
-        out, self._workspace = native.local_stage_forward_view(self._packed_weights(), view, P, 2 * P, img.device,
+        packed = self._packed_weights()
+        if self.streams >= 2 and P >= 4096 and not torch.cuda.is_current_stream_capturing():
+            # one aperture per side stream: the second image's windows are the same view moved by one image
+            out = torch.empty(2 * P, 10, dtype=torch.float32, device=img.device)
+            v2 = native.PatchView(view.base + 4 * view.s_aperture, view.s_aperture, view.s_chan, view.s_row, view.s_col, view.s_pi,
+                                  view.s_pj, view.wp)
+            ws = [self._workspace, getattr(self, "_workspace2", None)]
+
+            def half(i, v):
+                _, ws[i] = native.local_stage_forward_view(packed, v, P, P, img.device, out=out[i * P:(i + 1) * P], workspace=ws[i],
+                                                           winograd=self.winograd, chunk=self.chunk)
+            self._on_two_streams(img.device, lambda: half(0, view), lambda: half(1, v2))
+            self._workspace, self._workspace2 = ws
+            return out
+        out, self._workspace = native.local_stage_forward_view(packed, view, P, 2 * P, img.device,
                                                                workspace=self._workspace, winograd=self.winograd, chunk=self.chunk)
         return out

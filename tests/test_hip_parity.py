@@ -529,6 +529,38 @@ def test_split_bf16_conv_mode_is_opt_in_and_stays_within_the_fp32_tolerance(nati
     assert torch.equal(a1, y32) and torch.equal(a2, y32) and torch.equal(b1, yd) and torch.equal(b2, yd)
 
 
+def test_two_stream_schedule_is_bit_identical_to_the_one_stream_schedule():
+    """LocalStage.streams = 2 (default): an eval batch of 8192+ patches runs as two halves on two side streams, an image pair as
+    one aperture per stream.  Patches are independent and every kernel's arithmetic is position-independent, so the logits
+    must equal the one-stream schedule's bit for bit - flat batches (even, ragged) and the gather-on-read image path."""
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a GPU")
+    import models
+    from be_hip import native
+    m = models.LocalStage()
+    m.load_state_dict({k: T(v) for k, v in synth.local_stage_state_dict().items()})
+    m = m.to(DEV).eval()
+    assert m.streams == 2
+    x = T(synth.uniform_patches(8192 + 777, name="two_streams")).to(DEV)
+    img = T(synth.synthetic_image_pair(147, 147)[0]).to(DEV)
+    with torch.no_grad():
+        two = [m(x).clone(), m(x[:8192]).clone(), m.forward_image_pair(img).clone()]
+        side = m._side
+        m.streams = 1
+        one = [m(x).clone(), m(x[:8192]).clone(), m.forward_image_pair(img).clone()]
+        m.streams = 2
+        again = m(x)
+    assert side is not None                                              # the two-stream branch really ran
+    for a, b in zip(two, one):
+        assert torch.equal(a, b)
+    assert torch.equal(again, two[0])
+    # work enqueued afterwards on the caller's stream sees the joined result (no missing dependency): consume it right away
+    with torch.no_grad():
+        y = m(x)
+        s = y.sum().item()
+    assert np.isfinite(s) and abs(s - two[0].sum().item()) <= 1e-3 * abs(s) + 1e-3
+
+
 def test_entry_points_reject_bad_arguments_before_launching(native):
     """Every C entry point validates on the host and returns an error code + message (BE_EINVAL / BE_EWORKSPACE) instead
     of launching with shapes its kernels do not support; the Python layer raises RuntimeError(be_last_error())."""

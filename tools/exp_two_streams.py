@@ -35,3 +35,24 @@ def timed(f, n=20):
 r1 = one(); ra, rb = two()
 print("identical:", torch.equal(r1[:4096], ra) and torch.equal(r1[4096:], rb))
 print(f"one stream, 8192 patches: {timed(one):.3f} ms   two streams x 4096: {timed(two):.3f} ms")
+
+# ---- N-way split (BE_WINO_WS_MIN_TILES lowers the weight-stationary kernel's minimum so that 2048-patch parts keep it)
+NW = int(os.environ.get("NWAY", "0"))
+if NW:
+    m0.streams = 1
+    ms = [mk() for _ in range(NW)]
+    for m in ms: m.streams = 1
+    ss = [torch.cuda.Stream() for _ in range(NW)]
+    per = 8192 // NW
+    xs = [x[i * per:(i + 1) * per].contiguous() for i in range(NW)]
+    def nway():
+        cur = torch.cuda.current_stream()
+        outs = []
+        with torch.no_grad():
+            for m, s, xx in zip(ms, ss, xs):
+                s.wait_stream(cur)
+                with torch.cuda.stream(s): outs.append(m(xx))
+        for s in ss: cur.wait_stream(s)
+        return outs
+    o = nway()
+    print("identical:", torch.equal(torch.cat(o), r1), f"  {NW} streams x {per}: {timed(nway):.3f} ms")
