@@ -277,6 +277,19 @@ def leg_dp(dev, native, dist, rank, world, steps):
         res["rccl_one_rank_group"] = True
         res["compute_only_step_ms"] = round(clock(lambda: step(False), steps), 4)
         dp.broadcast_bn_stats(model, src=0)
+    if sync is not None:
+        # the same step as six hipGraph segments with the RCCL calls between them (train_local.SegmentedGraphStep): what
+        # `be_hip.workflow local_train` runs under torchrun.  Last, because it is the newest code on the RCCL path.
+        opt2 = torch.optim.AdamW(model.parameters(), lr=args.learning_rate, capturable=True, fused=dp.fused_adamw())
+        seg = train_local.SegmentedGraphStep(model, helper, opt2, sync, world=world)
+
+        def seg_step():
+            lo = (it[0] % 8) * B
+            it[0] += 1
+            return seg({k: v[lo:lo + B] for k, v in data.items()}, args.beta_bndry_loc, args.beta_smthns)
+        res["segmented_graph_step_ms"] = round(clock(seg_step, steps), 4)
+        res["segmented_graph_patches_per_s"] = round(B * world / res["segmented_graph_step_ms"] * 1e3, 1)
+    if own_group:
         dist1.destroy_process_group()
     return res
 

@@ -98,6 +98,114 @@ class GraphedStep:
         return self.loss.clone()
 
 
+class SegmentedGraphStep:
+    """The data-parallel training step as SIX hipGraph segments with the gradient buckets' all-reduces issued between them.
+
+    The eager data-parallel step is bound by its ~232 host launches (3.3 ms against 2.6 ms for the single-GPU hipGraph step), and a
+    collective cannot be captured into a graph on this stack.  So the step is cut where the backward finishes a gradient bucket
+    (be_hip.train.set_grad_hook: fc, layer3, layer2, layer1, conv1 + layer0): segment k ends there, the host replays it and
+    issues bucket k's all-reduce on the side stream (GradSync.bucket_ready: event behind the segment, RCCL call), then replays
+    segment k + 1, which therefore overlaps that collective; the last segment is the division by the world size, the gradient
+    clipping and AdamW.  Host cost per step: six graph launches + five RCCL calls.
+    The step runs WITHOUT the autograd engine (forward_train / the fused loss kernel / backward_train called directly): the
+    engine would run the backward - and the hook that ends and begins captures - on another thread than the one that began the
+    capture.  Same kernels, same order, same results as train_step (tests/test_dp_gpu.py)."""
+
+    def __init__(self, model, helper, opt, sync, world=1, clip=1.0):
+        self.model, self.helper, self.opt, self.sync, self.world, self.clip = model, helper, opt, sync, world, clip
+        self.key = self.graphs = self.static = self.loss = self.flat = self.ranges = None
+        self.warm = 0
+        self.stream = None
+
+    def _step(self, batch, beta_b, beta_s, hook):
+        """forward + loss + backward (+ hook per finished bucket) + [sync.finish] + clip + AdamW, no autograd engine"""
+        from . import native, train
+        m = self.model
+        t = [v.detach() for v in m._tensor_list()]
+        x = batch["img_ny"].permute(0, 3, 1, 2).to(torch.float32).contiguous()
+        logits, S = train.forward_train(x, t)
+        m.invalidate_packed()
+        torch._foreach_add_([b for b in (mod.num_batches_tracked for mod in m.modules()
+                                         if isinstance(mod, (torch.nn.BatchNorm2d, torch.nn.BatchNorm1d)))], 1)
+        b = logits.shape[0]
+        partial, grad_est, _ = native.local_loss(self.helper.render_opts(False), logits, batch["img_gt"].contiguous(),
+                                                 batch["img_gt"].contiguous(), batch["bndry_dist"].contiguous(),
+                                                 batch["deri"].contiguous(), beta_b, beta_s, want_grad=True)
+        sm = partial.sum(dim=0)
+        loss = sm[0] / (b * 441) + beta_b * sm[1] / (b * 441) + beta_s * sm[2] / (b * 361)      # utils._LocalLossFn.forward
+        train.set_grad_hook(hook)
+        try:
+            grads = train.backward_train(grad_est, t, S)
+        finally:
+            train.set_grad_hook(None)
+        for p, i in zip(m.parameters(), train.TRAINABLE):
+            p.grad = grads[i]
+        return loss
+
+    def _tail(self):
+        flat = self.sync.finish() if self.sync is not None else None
+        torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=self.clip, norm_type=2)
+        self.opt.step()
+        return flat
+
+    def __call__(self, batch, beta_b, beta_s):
+        if self.warm < 2:                               # two eager steps: optimizer state, lazily allocated buffers, RCCL warm-up
+            self.warm += 1
+            loss = self._step(batch, beta_b, beta_s, self.sync.bucket_ready if self.sync is not None else None)
+            self._tail()
+            return loss.detach()
+        key = (float(beta_b), float(beta_s)) + tuple(float(g["lr"]) for g in self.opt.param_groups) + \
+            tuple(tuple(v.shape) for v in batch.values())
+        if key != self.key:
+            self._capture(batch, beta_b, beta_s)
+            self.key = key
+        else:
+            for k in self.static:
+                self.static[k].copy_(batch[k])
+        cur = torch.cuda.current_stream()
+        for k in range(5):
+            self.graphs[k].replay()
+            if self.sync is not None:
+                self.sync.bucket_ready(self.flat, *self.ranges[k])       # event behind segment k, all-reduce on the side stream
+        if self.sync is not None:
+            for h in self.sync.handles:
+                h.wait()                                 # the compute stream waits for the collectives (the division is captured)
+            self.sync.handles, self.sync.flat = [], None
+        self.graphs[5].replay()
+        return self.loss.clone()
+
+    def _capture(self, batch, beta_b, beta_s):
+        self.static = {k: v.clone() for k, v in batch.items()}
+        torch.cuda.synchronize()
+        graphs = [torch.cuda.CUDAGraph() for _ in range(6)]
+        pool = torch.cuda.graph_pool_handle()            # ONE memory pool: tensors made in one segment live on into the next
+        seen = []
+        state = dict(k=0)
+
+        def hook(flat, lo, hi):                          # bucket k is final: segment k ends here, segment k + 1 begins
+            seen.append((flat, lo, hi))
+            graphs[state["k"]].capture_end()
+            state["k"] += 1
+            graphs[state["k"]].capture_begin(pool=pool, capture_error_mode="thread_local")
+        if self.stream is None:
+            self.stream = torch.cuda.Stream()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            # thread_local: the process group's watchdog thread polls its events while this thread captures - legal for it,
+            # and only this thread's calls are policed
+            graphs[0].capture_begin(pool=pool, capture_error_mode="thread_local")
+            self.loss = self._step(self.static, beta_b, beta_s, hook)
+            assert state["k"] == 5, "the backward did not report its five gradient buckets"
+            flat = seen[0][0]
+            if self.sync is not None and (self.world > 1 or self.sync.always):
+                flat.div_(self.world)                    # GradSync.finish's division, captured
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=self.clip, norm_type=2)
+            self.opt.step()
+            graphs[5].capture_end()
+        torch.cuda.current_stream().wait_stream(self.stream)
+        self.graphs, self.flat, self.ranges = graphs, flat, [(lo, hi) for _, lo, hi in seen]
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=100)

@@ -86,14 +86,20 @@ def local_train(args, quiet=False, graph=True):
     _xavier_(model)
     # data parallel (configs[4]): every rank keeps a replica, takes every world-th batch of the epoch's (identically shuffled)
     # batch sequence - a global batch of batch_size x world - and the gradients are averaged by the five-bucket all-reduce that
-    # overlaps the backward (be_hip.dp.GradSync); eager launches (the hipGraph step is single-GPU)
-    graph = graph and world == 1
+    # overlaps the backward (be_hip.dp.GradSync).  graph=True: the step is six hipGraph segments with the RCCL calls between
+    # them (train_local.SegmentedGraphStep); one GPU: one hipGraph (GraphedStep)
     sync = dp.GradSync(world) if world > 1 else None
     if world > 1:
         dp.broadcast_parameters(model, src=0)
     opt = torch.optim.AdamW(model.parameters(), lr=args.learning_rate, capturable=graph, fused=dp.fused_adamw())
     helper = utils.PostProcessLocalBase(args, dev)
-    gstep = GraphedStep(model, helper, opt) if graph else None
+    if not graph:
+        gstep = None
+    elif world > 1:
+        from .train_local import SegmentedGraphStep
+        gstep = SegmentedGraphStep(model, helper, opt, sync, world=world)
+    else:
+        gstep = GraphedStep(model, helper, opt)
     sampler = torch.Generator().manual_seed(1869)
     beta = BetaSchedule(args.beta_bndry_loc, args.beta_smthns, args.dynamic_epoch)
     sched = torch.optim.lr_scheduler.ReduceLROnPlateau(opt, 'min', factor=0.9, patience=2, min_lr=args.learning_rate * 0.1)

@@ -111,6 +111,29 @@ def _nccl_worker(port, q):
     dp.broadcast_parameters(model, src=0)
     dp.broadcast_bn_stats(model, src=0)
     torch.cuda.synchronize()
+    # the step as six hipGraph segments with the RCCL calls between them (SegmentedGraphStep) against the eager step: same
+    # batches, same start -> bit-identical parameters, running statistics and losses after eight steps
+    from be_hip import synth
+    import models
+    data = {k: torch.from_numpy(v).to(DEV) for k, v in synth.synthetic_training_patches(64 * 4, seed=77).items()}
+    finals = []
+    for mode in ("eager", "segmented"):
+        mm = models.LocalStage().to(DEV)
+        mm.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.local_stage_state_dict().items()})
+        mm.train()
+        opt = torch.optim.AdamW(mm.parameters(), lr=1e-3, capturable=True, fused=dp.fused_adamw())
+        sync = dp.GradSync(1, always=True)
+        seg = train_local.SegmentedGraphStep(mm, helper, opt, sync, world=1) if mode == "segmented" else None
+        losses = []
+        for it in range(8):
+            b = {k: v[(it % 4) * 64:(it % 4 + 1) * 64] for k, v in data.items()}
+            if seg is not None:
+                losses.append(float(seg(b, args.beta_bndry_loc, args.beta_smthns)))
+            else:
+                losses.append(float(train_local.train_step(mm, helper, opt, b, args.beta_bndry_loc, args.beta_smthns, sync=sync)))
+        torch.cuda.synchronize()
+        finals.append((losses, {k: v.detach().cpu().numpy().copy() for k, v in mm.state_dict().items()}, seg is not None and seg.graphs is not None))
+    res.append(finals)
     q.put(res)
     dist.destroy_process_group()
 
@@ -125,10 +148,14 @@ def test_gradsync_over_rccl_one_rank_group_leaves_the_gradients_untouched():
     q = ctx.Queue()
     p = ctx.Process(target=_nccl_worker, args=(_free_port(), q))
     p.start()
-    (g0, _), (g1, nbytes) = q.get(timeout=600)
+    (g0, _), (g1, nbytes), finals = q.get(timeout=600)
     p.join(timeout=120)
     assert p.exitcode == 0
     assert np.array_equal(g0, g1) and np.isfinite(g0).all() and nbytes == 3 * 4 * 7254122
+    (l_e, sd_e, _), (l_s, sd_s, captured) = finals
+    assert captured and l_e == l_s and np.isfinite(l_e).all()
+    for k in sd_e:
+        assert np.array_equal(sd_e[k], sd_s[k]), k
 
 
 def _workflow_worker(rank, world, port, root, models_dir, logs, q):
