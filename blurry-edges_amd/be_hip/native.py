@@ -81,7 +81,7 @@ _SIGNATURES = {
                                                C.c_size_t, _P]),
     "be_conv_split_b3_f32": (C.c_int, [_P, C.c_size_t, _P, _P]),
     "be_conv_use_b3": (C.c_int, [_P, _P, C.c_size_t]),
-    "be_conv_b3_active": (C.c_int, []),
+    "be_conv_b3_active": (C.c_int, [_P]),
     "be_conv_fused2_packed_floats": (C.c_size_t, [C.c_int] * 4),
     "be_conv_pack_fused2_f32": (C.c_int, [_P] * 12 + [C.c_float] + [C.c_int] * 4 + [_P, _P, _P]),
     "be_conv_nhwc_fused2_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, C.c_int, _P, _P, _P, C.c_int, _P]),
@@ -439,11 +439,16 @@ def wino_conv3x3_pair(x, pw1, pb1, cmid, pw2, pb2, cout, act1=1, act2=1, residua
     return y, workspace
 
 
-def conv_use_b3(packed=None):
-    """Opt-in split-bf16 mode for the convolutions reading `packed` (a float32 GPU buffer of packed weights); None switches
-    it off.  Returns the bf16 planes tensor, which the caller must keep alive while the mode is on."""
+def conv_use_b3(packed=None, on=True):
+    """Opt-in split-bf16 mode for the convolutions reading `packed` (a float32 GPU buffer of packed weights).  on=False takes
+    that buffer back to exact fp32; packed=None forgets every registration.  Returns the bf16 planes tensor (None when
+    switching off), which the caller must keep alive while the mode is on.  The registration belongs to the buffer: other
+    models in the process are not affected."""
     if packed is None:
         check(lib().be_conv_use_b3(None, None, 0), "be_conv_use_b3")
+        return None
+    if not on:
+        check(lib().be_conv_use_b3(dptr(packed, "packed"), None, 0), "be_conv_use_b3")
         return None
     n = packed.numel()
     if n % 16:

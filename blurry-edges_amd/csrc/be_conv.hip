@@ -21,6 +21,7 @@
 //   - pixel-major M tiles for large batches (a tile = one pixel position of BM images): the taps that fall into the
 //     zero padding are skipped for the whole tile; an image group's tiles share one XCD (see the kernel)
 //   - an optional second input x2 appends a 1x1 conv to the K loop (residual block: downsample branch fused in)
+#include <mutex>
 #include "be_common.h"
 #include "be_device_math.h"
 #include <cstdlib>
@@ -898,13 +899,22 @@ extern "C" int be_conv_pack_jobs_f32(const be_pack_job* jobs_device, int njobs, 
 }
 
 // opt-in split-bf16 mode: convolutions whose packed weights lie inside [g_b3_base, g_b3_base + g_b3_plane) and that take the
-// 128x128 tile run k_conv_b3 on the bf16 planes registered for that buffer (not thread-safe, like the other knobs)
+// 128x128 tile run k_conv_b3 on the bf16 planes registered for that buffer
 struct BatchParams { int n; int64_t xb, wb, yb; };
 static thread_local BatchParams g_batch = {1, 0, 0, 0};   // set around one dispatch by be_conv_nhwc_batched_f32
 
-static const float* g_b3_base = nullptr;
-static const unsigned short* g_b3_planes = nullptr;
-static size_t g_b3_plane = 0;
+// registry of packed-weight buffers that run in split-bf16 mode: keyed by the buffer, so models with and without the mode (and
+// several models with it) coexist in one process; guarded by a mutex (registration is rare, lookup is a short scan)
+struct B3Entry { const float* base; const unsigned short* planes; size_t n; };
+constexpr int kB3Slots = 8;
+static B3Entry g_b3[kB3Slots] = {};
+static std::mutex g_b3_mu;
+static bool b3_lookup(const float* pw, B3Entry* out) {
+    std::lock_guard<std::mutex> lk(g_b3_mu);
+    for (int i = 0; i < kB3Slots; ++i)
+        if (g_b3[i].base && pw >= g_b3[i].base && pw < g_b3[i].base + g_b3[i].n) { *out = g_b3[i]; return true; }
+    return false;
+}
 
 extern "C" int be_conv_split_b3_f32(const float* packed, size_t n, void* planes, void* stream) {
     BE_REQUIRE(packed && planes && n > 0, "be_conv_split_b3_f32: bad arguments");
@@ -913,12 +923,28 @@ extern "C" int be_conv_split_b3_f32(const float* packed, size_t n, void* planes,
     return be::check_launch("be_conv_split_b3_f32");
 }
 
-extern "C" int be_conv_b3_active(void) { return g_b3_planes != nullptr; }
+extern "C" int be_conv_b3_active(const float* packed) {
+    B3Entry e;
+    return packed && b3_lookup(packed, &e) ? 1 : 0;
+}
 
 extern "C" int be_conv_use_b3(const float* packed, const void* planes, size_t n) {
-    BE_REQUIRE((packed && planes && n > 0) || (!packed && !planes), "be_conv_use_b3: pass (packed, planes, n) or (NULL, NULL, 0)");
-    BE_REQUIRE(!planes || (be::aligned16(planes) && n % 16 == 0), "be_conv_use_b3: planes must be 16-byte aligned, n %% 16 == 0");
-    g_b3_base = packed; g_b3_planes = static_cast<const unsigned short*>(planes); g_b3_plane = packed ? n : 0;
+    BE_REQUIRE(packed || (!planes && n == 0), "be_conv_use_b3: pass (packed, planes, n), (packed, NULL, 0) or (NULL, NULL, 0)");
+    BE_REQUIRE(!planes || (be::aligned16(planes) && n % 16 == 0 && n > 0), "be_conv_use_b3: planes must be 16-byte aligned, n %% 16 == 0");
+    std::lock_guard<std::mutex> lk(g_b3_mu);
+    if (!packed) {                                         // (NULL, NULL, 0): forget every registration
+        for (int i = 0; i < kB3Slots; ++i) g_b3[i] = B3Entry{};
+        return BE_OK;
+    }
+    int slot = -1;
+    for (int i = 0; i < kB3Slots; ++i) if (g_b3[i].base == packed) slot = i;
+    if (!planes) {                                         // (packed, NULL, 0): this buffer goes back to exact fp32
+        if (slot >= 0) g_b3[slot] = B3Entry{};
+        return BE_OK;
+    }
+    for (int i = 0; i < kB3Slots && slot < 0; ++i) if (!g_b3[i].base) slot = i;
+    if (slot < 0) return be::fail(BE_EINVAL, "be_conv_use_b3: all %d registration slots are taken", kB3Slots);
+    g_b3[slot] = B3Entry{packed, static_cast<const unsigned short*>(planes), n};
     return BE_OK;
 }
 
@@ -995,8 +1021,11 @@ static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2,
     a.pixmaj = 0; a.Nimg = d->n;
     a.ksplit = 1; a.ldp = 0; a.partial = nullptr;
     a.nbatch = g_batch.n; a.xb = g_batch.xb; a.wb = g_batch.wb; a.yb = g_batch.yb;
-    a.wb3 = nullptr; a.plane = g_b3_plane;
-    if (g_b3_planes && pw >= g_b3_base && pw < g_b3_base + g_b3_plane) a.wb3 = g_b3_planes + 3 * (pw - g_b3_base);
+    a.wb3 = nullptr; a.plane = 0;
+    {
+        B3Entry e;
+        if (b3_lookup(pw, &e)) { a.wb3 = e.planes + 3 * (pw - e.base); a.plane = e.n; }
+    }
     const int cp = round_up(d->cout, 32);
     hipStream_t s = be::as_stream(stream);
     // Small-M regime (training at batch 64: M = 2304 rows at 6x6): the 128-row tiles give a few dozen workgroups on

@@ -192,7 +192,8 @@ int forward_impl(const float* packed, const float* x, const be_patch_view* view,
         float* rc_ = rb + (size_t)nb * RB;
         float* rw = rc_ + (size_t)nb * RC;                // Winograd transform-domain buffers
         float* rr = rw + (size_t)nb * RW;                 // downsample branch of the current block
-        const bool wino = g_wino && !be_conv_b3_active(); // the split-bf16 experiment keeps the direct convolutions
+        const bool b3 = be_conv_b3_active(packed) != 0;   // this packed buffer runs the split-bf16 experiment: direct convolutions
+        const bool wino = g_wino && !b3;
         int rc;
         // x4 -> RB ; conv1 -> RA ; pool -> RB(after x4 is dead: RB is big enough to hold both side by side)
         float* x4 = rb;                                   // nb*1764
@@ -200,7 +201,7 @@ int forward_impl(const float* packed, const float* x, const be_patch_view* view,
         // large sub-batches: conv1 on the pixel-major LDS-DMA kernel, which reads a staging with 28 pixels per row (3 zero
         // pixels left, 4 right; 2352 floats per patch, still in front of p1)
         static const bool no_pm = getenv("BE_NO_CONV_PM") != nullptr;
-        if (nb >= 512 && !no_pm && !be_conv_b3_active()) {
+        if (nb >= 512 && !no_pm && !b3) {
             if (x) rc = be_nchw3_to_nhwc4p_f32(x + first * 3 * BE_NPIX, x4, nb, BE_R, BE_R, 28, stream);
             else rc = be_view_to_nhwc4p_f32(view, P, first, x4, nb, 28, stream);
             if (rc) return rc;

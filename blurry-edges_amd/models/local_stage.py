@@ -113,6 +113,14 @@ class LocalStage(nn.Module):
     streams = int(os.environ.get("BE_LOCAL_STREAMS", "2"))
     _side = None
 
+    def __del__(self):
+        # a split-bf16 registration is keyed by the packed buffer's address: take it back before the buffer is freed
+        try:
+            if getattr(self, "_b3_planes", None) is not None and self._packed is not None:
+                native.conv_use_b3(self._packed, on=False)
+        except Exception:
+            pass
+
     def invalidate_packed(self):
         """Drop the cached BN-folded weight pack.  Needed whenever parameters or running statistics change on the device
         without Python seeing it: a replayed hipGraph of the training step (be_hip.train_local.GraphedStep) updates them
@@ -131,8 +139,10 @@ class LocalStage(nn.Module):
         if self._packed is None or key != self._packed_key:
             if self.conv_precision not in ("f32", "bf16x3"):
                 raise ValueError(f"LocalStage.conv_precision must be 'f32' or 'bf16x3', got {self.conv_precision!r}")
+            if self._packed is not None:
+                native.conv_use_b3(self._packed, on=False)              # the old buffer's registration (if any) goes with it
             self._packed = native.local_stage_pack(tensors, eps=self.conv1[1].eps)
-            self._b3_planes = native.conv_use_b3(self._packed if self.conv_precision == "bf16x3" else None)
+            self._b3_planes = native.conv_use_b3(self._packed, on=self.conv_precision == "bf16x3")
             self._packed_key = key
         return self._packed
 

@@ -500,6 +500,19 @@ def test_split_bf16_conv_mode_is_opt_in_and_stays_within_the_fp32_tolerance(nati
         m.conv_precision = "f32"
         y32b = m(x)
     assert torch.equal(y32, y32b) and not torch.equal(y32, y3)          # the mode really switches, and switches back
+    # the registration belongs to the model's packed buffer: a second model in exact fp32 next to one in split-bf16 mode
+    import models as _models
+    mb = _models.LocalStage()
+    mb.load_state_dict(m.state_dict())
+    mb = mb.to(DEV).eval()
+    mb.conv_precision = "bf16x3"
+    with torch.no_grad():
+        yb = mb(x).clone()
+        ya = m(x).clone()
+        yb2 = mb(x)
+    assert torch.equal(ya, y32) and torch.equal(yb, y3) and torch.equal(yb2, y3)
+    assert native.lib().be_conv_b3_active(native.dptr(mb._packed)) == 1 and native.lib().be_conv_b3_active(native.dptr(m._packed)) == 0
+    del mb
     ref = ols.local_stage_forward(ols.to_torch_sd(synth.local_stage_state_dict(), torch.float64), x[:256].cpu().double())
     e32, e3 = relmax(y32[:256].cpu(), ref), relmax(y3[:256].cpu(), ref)
     print("logits vs fp64 oracle: fp32 MFMA %.2e, bf16x3 %.2e" % (e32, e3))
