@@ -5,7 +5,7 @@ renderer + ridge colour solve, DfD depth solve, unfold/fold tiling), every funct
 reference file:line it follows.  It is dtype-parametric (float32 reproduces the reference's
 arithmetic order; float64 is the ground truth for the ill-conditioned stages).
 
-Pinned: tools/make_golden.py imported the real reference (/root/reference, PyTorch-CPU) in the build
+Pinned: tests/golden/make_golden.py imported the real reference (/root/reference, PyTorch-CPU) in the build
 container and wrote tests/golden/*.npz; tests/test_oracle_golden.py checks this oracle against them.
 
 Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this package.

@@ -1,6 +1,6 @@
 """Oracle: feature normalisation between LocalStage and GlobalStage and its inverse (TEST INFRASTRUCTURE).
 Restates blurry_edges_test.py:123-138 and its second copy global_data_pre_cal.py:21-31.
-Pinned by golden g15 (tools/make_golden.py:G15 - the reference's own depth_estimator / ref_data_gen run with stub
+Pinned by golden g15 (tests/golden/make_golden.py:G15 - the reference's own depth_estimator / ref_data_gen run with stub
 modules): tests/test_oracle_golden.py::test_g15_glue_is_the_references_own_ordering, bit-exact in float32."""
 import torch
 

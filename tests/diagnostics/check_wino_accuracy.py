@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Logits of the Winograd path and of the direct path against the float64 oracle for several weight sets (GPU)."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))   # tests/diagnostics/ -> repo root
 sys.path[:0] = [ROOT, os.path.join(ROOT, "blurry-edges_amd")]
 import numpy as np, torch
 from be_hip import synth

@@ -1,5 +1,5 @@
 import os, sys
-ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")   # diagnostics live under tests/: they may import oracle/
 sys.path[:0] = [ROOT, os.path.join(ROOT, "blurry-edges_amd")]
 import numpy as np, torch
 from be_hip import synth, train_global

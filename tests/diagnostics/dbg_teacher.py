@@ -1,7 +1,7 @@
 """Teacher-forced per-step diagnostic of the LocalStage training step (HIP) against the fp64 and fp32 oracle.
 Splits the comparison at the logits: (a) d loss / d est at the HIP logits, (b) CNN backward at EQUAL cotangent."""
 import os, sys
-ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")   # diagnostics live under tests/: they may import oracle/
 sys.path[:0] = [ROOT, os.path.join(ROOT, "blurry-edges_amd")]
 import numpy as np, torch
 from be_hip import synth, train_local

@@ -9,7 +9,10 @@ OUTPUTS only (plus small inputs where that is cheaper than regenerating).
 Import recipe: `utils/__init__.py` star-imports visualization.py which needs cv2
 (absent, drawing only) -> register an empty stub module before importing.
 
-usage: python tools/make_golden.py [G1 G2 ...]      (default: all groups)
+usage: python tests/golden/make_golden.py [G1 G2 ...]      (default: all groups)
+
+Lives next to the fixtures it writes (tests/golden/*.npz): it is test infrastructure - it imports the reference and, for G14, the
+oracle's rasteriser stand-in - and nothing under blurry-edges_amd/ or bench.py uses it.
 """
 import os
 import sys
@@ -18,7 +21,7 @@ import types
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 REF = "/root/reference"
 OUT = os.path.join(ROOT, "tests", "golden")
 sys.dont_write_bytecode = True

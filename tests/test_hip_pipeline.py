@@ -36,7 +36,7 @@ def test_unfold_order_bit_exact(env):
 
 def test_feature_glue_vs_reference_golden(env):
     """Row a18: the HIP glue kernels against what the reference's own depth_estimator / ref_data_gen produced when run
-    with stub modules (golden g15, tools/make_golden.py:G15) - not against the oracle."""
+    with stub modules (golden g15, tests/golden/make_golden.py:G15) - not against the oracle."""
     from be_hip.pipeline import DepthPipeline, params_src_layout
     n = env["native"]
     g = load_golden("g15_glue")

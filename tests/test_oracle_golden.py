@@ -1,5 +1,5 @@
 """The CPU oracle (oracle/) against golden vectors captured from the real reference
-(tools/make_golden.py).  This is what pins the oracle; it runs without a GPU."""
+(tests/golden/make_golden.py).  This is what pins the oracle; it runs without a GPU."""
 import numpy as np
 import torch
 
