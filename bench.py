@@ -43,6 +43,7 @@ PAIRS = 4096                          # configs[1]
 FLOP_PER_PATCH = 387.716e6            # SURVEY.md A.2 (2*MAC, convs + linears)
 FLOP_PER_PAIR = 2 * FLOP_PER_PATCH    # 775.43 MFLOP, SURVEY.md 8d
 PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: dense fp32 matrix peak
+PEAK_HBM_TBPS = 8.0                   # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s is what a float4 copy reaches)
 # opt-in experiment (BE_CONV_PRECISION=bf16x3, never the default): six bf16 MFMAs per fp32 product -> the price is a
 # sixth of the dense bf16 peak (~2.5 PFLOP/s)
 PEAK_BF16X3_TFLOPS = 2500.0 / 6
@@ -89,7 +90,7 @@ def cpu_baseline(x_np, sd_np):
                        f"({', '.join('%.2f' % t for t in times)} s), torch {torch.__version__} CPU, {ncores} threads"), (est, col, z)
 
 
-def conv_profile(native, fn, iters, peak, per_iter=256):
+def conv_profile(native, fn, iters, peak, per_iter=320):
     """Run fn() `iters` times with a hipEvent pair around every matrix-kernel launch (on the launch stream); returns the
     dominant kernel (most time) with its algorithmic and executed rates, and the list of records.  per_iter: upper bound of
     the matrix-kernel launches of one fn() (two events are created for each)."""
@@ -103,6 +104,18 @@ def conv_profile(native, fn, iters, peak, per_iter=256):
     native.profile_enable(0)
     if not recs:
         return None, recs
+    # HBM-bound kernels (transforms, pools, pass A) carry their algorithmic bytes: GB/s against the 8 TB/s HBM peak
+    hbm = []
+    for kid in native.HBM_KERNEL_IDS:
+        rr = [r for r in recs if r[0] == kid]
+        if rr:
+            ms_k, by_k = sum(r[3] for r in rr), sum(r[2] for r in rr)
+            hbm.append(dict(kernel=native.KERNEL_NAMES[kid], launches_per_iter=len(rr) // iters, ms_per_iter=round(ms_k / iters, 4),
+                            algo_GB_per_iter=round(by_k / iters / 1e9, 3), achieved_TBps=round(by_k / ms_k / 1e9, 3),
+                            frac_of_hbm_peak=round(by_k / ms_k / 1e9 / PEAK_HBM_TBPS, 4)))
+    recs_all, recs = recs, [r for r in recs if r[0] not in native.HBM_KERNEL_IDS]
+    if not recs:
+        return None, recs_all
     by_id = {}
     for r in recs:
         by_id[r[0]] = by_id.get(r[0], 0.0) + r[3]
@@ -118,7 +131,7 @@ def conv_profile(native, fn, iters, peak, per_iter=256):
                 executed_tflops=round(execd / ms / 1e9, 2), executed_frac=round(execd / ms / 1e9 / peak, 4),
                 flop_per_launch=algo / len(dom), executed_flop_per_launch=execd / len(dom),
                 algo_bytes_per_launch=sum(r[2] for r in dom) / len(dom),
-                all_matrix_kernels_ms_per_iter=round(sum(r[3] for r in recs) / iters, 3)), recs
+                all_matrix_kernels_ms_per_iter=round(sum(r[3] for r in recs) / iters, 3), hbm_bound_kernels=hbm), recs
 
 
 def timed(fn, iters, warmup=2):
@@ -404,6 +417,8 @@ def main():
                         executed_flop_per_launch=prof["executed_flop_per_launch"],
                         algo_bytes_per_launch=prof["algo_bytes_per_launch"],
                         all_matrix_kernels_ms_per_step=prof["all_matrix_kernels_ms_per_iter"],
+                        # the HBM-bound kernels of the same pass: algorithmic bytes / hipEvent duration against the 8 TB/s peak
+                        hbm_bound_kernels=prof["hbm_bound_kernels"],
                         end_to_end_frac=round(pairs_per_s / world * FLOP_PER_PAIR / (peak * 1e12), 4),
                         end_to_end_executed_frac=round(pairs_per_s / world * executed_per_pair / (peak * 1e12), 4),
                         executed_mflop_per_pair=round(executed_per_pair / 1e6, 2),

@@ -479,7 +479,10 @@ KERNEL_NAMES = {0: "k_conv_igemm<2,2,2,2,TAPS> (128x128)", 1: "k_conv_igemm<4,1,
                 2: "k_conv_igemm<4,1,1,2,TAPS> (128x64)", 3: "k_conv_igemm<4,1,1,1,TAPS> (128x32)",
                 4: "k_conv_igemm<4,1,1,2,ROW8> (conv1)", 5: "k_conv_igemm small-M tiles (64x64 / 128x32)",
                 6: "k_wino_gemm_ws / k_wino_gemm (128x128 tiles, the 25 Winograd transform-domain GEMMs of a layer per launch; weight-stationary form for K = 96 / 256 / 384 and full tiles)",
-                7: "k_wino_gemm as a row GEMM (1x1 convolutions / linears of large batches)"}
+                7: "k_wino_gemm as a row GEMM (1x1 convolutions / linears of large batches)",
+                8: "k_wino_in / k_wino_out_in / k_wino_out / k_wino_out_pool2 (Winograd transforms)", 9: "k_maxpool_nhwc",
+                10: "k_render_colors (pass A)", 11: "conv1 input staging"}
+HBM_KERNEL_IDS = (8, 9, 10, 11)
 
 
 def profile_enable(max_launches: int):

@@ -1120,8 +1120,11 @@ extern "C" int be_maxpool_nhwc_ld_f32(const float* x, int ldx, float* y, int n, 
     const int oh = (h + 2 * pad - k) / stride + 1, ow = (w + 2 * pad - k) / stride + 1;
     BE_REQUIRE(oh > 0 && ow > 0, "be_maxpool_nhwc_f32: empty output");
     const int64_t total = (int64_t)n * oh * ow * (c / 4);
-    hipLaunchKernelGGL(k_maxpool_nhwc, dim3(grid_cap(total, 256)), dim3(256), 0, be::as_stream(stream), x, y, n, h, w,
-                       c / 4, oh, ow, k, stride, pad, ldx / 4);
+    {
+        be::ProfileScope prof(be::as_stream(stream), BE_KERNEL_MAXPOOL, 0.0, 4.0 * n * c * ((double)h * w + (double)oh * ow), 0.0);
+        hipLaunchKernelGGL(k_maxpool_nhwc, dim3(grid_cap(total, 256)), dim3(256), 0, be::as_stream(stream), x, y, n, h, w,
+                           c / 4, oh, ow, k, stride, pad, ldx / 4);
+    }
     return be::check_launch("be_maxpool_nhwc_f32");
 }
 

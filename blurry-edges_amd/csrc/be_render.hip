@@ -197,8 +197,12 @@ static int render_colors_impl(const be_render_opts* o, const float* params10, co
     RenderArgs a{params10, v, P, colors, recon, boundary, dists, wedges, gram, aty, n};
     const int64_t blocks = (n + WAVES_PER_BLOCK - 1) / WAVES_PER_BLOCK;
     BE_REQUIRE(blocks <= 0x7fffffff, "%s: n too large", who);
-    hipLaunchKernelGGL(k_render_colors, dim3((unsigned)blocks), dim3(64 * WAVES_PER_BLOCK), 0, be::as_stream(stream),
-                       *o, a);
+    {
+        // algorithmic bytes of pass A: 441 x 3 pixels + 10 parameters in, 9 colours out per patch (the optional outputs are test hooks)
+        be::ProfileScope prof(be::as_stream(stream), BE_KERNEL_RENDER_COLORS, 0.0, 4.0 * n * (1323.0 + 10.0 + 9.0), 0.0);
+        hipLaunchKernelGGL(k_render_colors, dim3((unsigned)blocks), dim3(64 * WAVES_PER_BLOCK), 0, be::as_stream(stream),
+                           *o, a);
+    }
     return be::check_launch(who);
 }
 

@@ -779,19 +779,28 @@ int be::wino_pair(const float* x, const float* packed_w1, const float* packed_bi
         return be::wino_fused(M, packed_w2, packed_bias2, residual, act2, y, nullptr, n, cmid, cout, pool2 ? 4 : 1, stream);
     }
     const int tm1 = wino_large(n, cmid), tm2 = wino_large(n, cout);
-    hipLaunchKernelGGL(k_wino_in, dim3(grid_cap(n * 4 * (cin / 4), 256)), dim3(256), 0, s, x, V, n, cin / 4, tm1);
+    {
+        be::ProfileScope prof(s, BE_KERNEL_WINO_TRANSFORM, 0.0, 4.0 * n * cin * (36.0 + 100.0), 0.0);
+        hipLaunchKernelGGL(k_wino_in, dim3(grid_cap(n * 4 * (cin / 4), 256)), dim3(256), 0, s, x, V, n, cin / 4, tm1);
+    }
     if (int rc = be::check_launch("be_wino_conv3x3_pair_6x6_f32(in)")) return rc;
     if (int rc = wino_gemms(V, packed_w1, M, n, cin, cmid, s, stream)) return rc;
-    hipLaunchKernelGGL(k_wino_out_in, dim3(grid_cap(n * (cmid / 4), 256)), dim3(256), 0, s, M, packed_bias1, V, n, cmid / 4, act1,
-                       tm1, tm2);
+    {
+        be::ProfileScope prof(s, BE_KERNEL_WINO_TRANSFORM, 0.0, 4.0 * n * cmid * (100.0 + 100.0), 0.0);
+        hipLaunchKernelGGL(k_wino_out_in, dim3(grid_cap(n * (cmid / 4), 256)), dim3(256), 0, s, M, packed_bias1, V, n, cmid / 4, act1,
+                           tm1, tm2);
+    }
     if (int rc = be::check_launch("be_wino_conv3x3_pair_6x6_f32(out_in)")) return rc;
     if (int rc = wino_gemms(V, packed_w2, M, n, cmid, cout, s, stream)) return rc;
-    if (pool2)
-        hipLaunchKernelGGL(k_wino_out_pool2, dim3(grid_cap(n * (cout / 4), 256)), dim3(256), 0, s, M, packed_bias2, residual, y, n,
-                           cout / 4, act2, tm2);
-    else
-        hipLaunchKernelGGL(k_wino_out, dim3(grid_cap(n * 4 * (cout / 4), 256)), dim3(256), 0, s, M, packed_bias2, residual, y, n,
-                           cout / 4, act2, tm2);
+    {
+        be::ProfileScope prof(s, BE_KERNEL_WINO_TRANSFORM, 0.0, 4.0 * n * cout * (100.0 + (residual ? 36.0 : 0.0) + (pool2 ? 9.0 : 36.0)), 0.0);
+        if (pool2)
+            hipLaunchKernelGGL(k_wino_out_pool2, dim3(grid_cap(n * (cout / 4), 256)), dim3(256), 0, s, M, packed_bias2, residual, y, n,
+                               cout / 4, act2, tm2);
+        else
+            hipLaunchKernelGGL(k_wino_out, dim3(grid_cap(n * 4 * (cout / 4), 256)), dim3(256), 0, s, M, packed_bias2, residual, y, n,
+                               cout / 4, act2, tm2);
+    }
     return be::check_launch("be_wino_conv3x3_pair_6x6_f32(out)");
 }
 

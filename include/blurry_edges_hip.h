@@ -486,7 +486,8 @@ int be_datagen_crop_f64(const double* const* in6, const double* bloc, const doub
                         int64_t n_patch, int n, int H, int W, int R, double* const* out9, void* stream);
 
 /* ---------------------------------------------------------------------------------------------------
- * Measurement hooks (bench.py's roofline leg): opt-in hipEvent pair around every conv launch, recorded on
+ * Measurement hooks (bench.py's roofline leg): opt-in hipEvent pair around every matrix-kernel launch and around the
+ * HBM-bound kernels of the LocalStage / pass-A step, recorded on
  * the launch stream.  be_profile_enable(0) turns it off and frees the events.  Not thread-safe.
  * ------------------------------------------------------------------------------------------------- */
 #define BE_KERNEL_CONV_128x128      0   /* k_conv_igemm<2,2,2,2,TAPS>: layers 1-3 + fc.1 (the dominant kernel) */
@@ -497,6 +498,11 @@ int be_datagen_crop_f64(const double* const* in6, const double* bloc, const doub
 #define BE_KERNEL_CONV_SMALL        5   /* 64x64 / 128x32 tiles for small M (training batches)                 */
 #define BE_KERNEL_WINO_GEMM         6   /* k_wino_gemm_ws / k_wino_gemm: the 25 transform-domain GEMMs of a Winograd layer */
 #define BE_KERNEL_GEMM_ROWS         7   /* k_wino_gemm as a row GEMM: 1x1 convolutions / linears, large batches */
+/* HBM-bound kernels: `bytes` = the algorithmic bytes the launch has to move, `flops` = 0 */
+#define BE_KERNEL_WINO_TRANSFORM    8   /* k_wino_in / k_wino_out / k_wino_out_in / k_wino_out_pool2 */
+#define BE_KERNEL_MAXPOOL           9   /* k_maxpool_nhwc */
+#define BE_KERNEL_RENDER_COLORS    10   /* k_render_colors (pass A: wedges + ridge colour solve) */
+#define BE_KERNEL_STAGING          11   /* NCHW / image view -> NHWC4 staging of conv1's input */
 int be_profile_enable(int max_launches);
 int be_profile_reset(void);
 /* Waits for the recorded events; fills up to cap records (launch order); returns the number filled (>= 0)
