@@ -56,3 +56,18 @@ if NW:
         return outs
     o = nway()
     print("identical:", torch.equal(torch.cat(o), r1), f"  {NW} streams x {per}: {timed(nway):.3f} ms")
+
+# ---- asymmetric two-way split (desynchronises the two streams' phases): SPLIT = patches of the first part
+SP = int(os.environ.get("SPLIT", "0"))
+if SP:
+    m1.streams = m2.streams = 1
+    xa2, xb2 = x[:SP].contiguous(), x[SP:].contiguous()
+    def asym():
+        s1.wait_stream(torch.cuda.current_stream()); s2.wait_stream(torch.cuda.current_stream())
+        with torch.no_grad():
+            with torch.cuda.stream(s1): a = m1(xa2)
+            with torch.cuda.stream(s2): b = m2(xb2)
+        torch.cuda.current_stream().wait_stream(s1); torch.cuda.current_stream().wait_stream(s2)
+        return a, b
+    a, b = asym()
+    print("identical:", torch.equal(torch.cat([a, b]), r1), f"  split {SP}/{8192 - SP}: {timed(asym):.3f} ms")
