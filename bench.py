@@ -310,8 +310,8 @@ def leg_dp(dev, native, dist, rank, world, steps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)      # 1.4 s of timed region: long enough for an outside observer to see the load
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs / dp legs (profiling runs)")
     ap.add_argument("--chunk", type=int, default=0, help="LocalStage sub-batch (patches); 0 = library default")
