@@ -104,6 +104,9 @@ def test_twenty_training_steps_teacher_forced_against_the_fp64_oracle():
             e = rel(gh[k], gc[k])
             if e > W["chain"]:
                 W["chain"], W["chain_name"] = e, f"{k}@{it}"
+        nh = float(torch.sqrt(sum((gh[k] ** 2).sum() for k in live)))
+        nc = float(torch.sqrt(sum((gc[k] ** 2).sum() for k in live)))
+        W["chain_norm"] = max(W.get("chain_norm", 0.0), abs(nh - nc) / nc)      # total gradient norm, teacher-forced at the logits
         e_hip, e_f32 = rel(dest_h, o["dest"]), rel(res[torch.float32]["dest"], o["dest"])
         if e_hip > W["e2e_hip"]:
             W["e2e_hip"], W["e2e_f32"] = e_hip, e_f32
@@ -145,6 +148,7 @@ def test_twenty_training_steps_teacher_forced_against_the_fp64_oracle():
     assert W["cnn"] <= 1e-2 and cnn_med <= 1e-5, W     # measured 2.6e-3 (conv1.1.weight, step 8) / 2.5e-6: worst / median over 20 steps x 46 tensors; the worst cases
     #                                          are discrete fp32 events (a max-pool tie broken the other way), the fp32 oracle has them too
     assert W["chain"] <= 1e-2, W             # measured 2.6e-3 (the same event)
+    assert W["chain_norm"] <= 1e-4, W        # measured 2.0e-5: the TOTAL gradient norm against the oracle's at the HIP logits
     assert W["logits"] <= 1e-5               # measured 3.5e-6: train-mode logits (batch statistics) at every visited state
     assert W["e2e_hip"] <= 0.2, W            # sanity only, see (4): measured 4.0e-2 (step 5) with the fp32 oracle at 1.7e-2 ... 5.8e-2 at that step
     assert W["run"] <= 1e-6                  # measured 1.4e-7
