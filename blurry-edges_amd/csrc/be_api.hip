@@ -60,3 +60,14 @@ extern "C" int be_profile_read(int* kernel_id, double* flops, double* bytes, dou
     }
     return n;
 }
+
+namespace {
+__global__ void k_vec_add(float* a, const float* b, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) a[i] += b[i];
+}
+}  // namespace
+int be::vec_add_inplace(float* a, const float* b, int n, void* stream) {
+    hipLaunchKernelGGL(k_vec_add, dim3((n + 255) / 256), dim3(256), 0, be::as_stream(stream), a, b, n);
+    return be::check_launch("vec_add_inplace");
+}

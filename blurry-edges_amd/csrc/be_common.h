@@ -47,6 +47,12 @@ struct ProfileScope {
 int gemm_rows(const float* x, int64_t M, int K, const float* packed_w, int N, const float* bias, const float* res, int act,
               float* y, int ldy, void* stream);
 
+// be_wino.hip: y[M][ldy] = x[M][K] w[Npad][K]^T, RAW accumulators (no bias, no activation) on the weight-stationary GEMM kernel;
+// returns 1 when the shape is not one it takes (K in {96, 256, 384}, M % 128 == 0, >= 128 row tiles, N % 128 == 0)
+int gemm_rows_ws(const float* x, int64_t M, int K, const float* packed_w, int N, float* y, int ldy, void* stream);
+// be_api.hip: a[i] += b[i], i < n (pack-time helper)
+int vec_add_inplace(float* a, const float* b, int n, void* stream);
+
 // be_conv_pm.hip: pixel-major LDS-DMA convolution for large batches (3x3 (+ fused 1x1 on x2), or the 7x7 conv1 on the padded
 // staging with `wrow` pixels per row); returns 1 when the shape is not one it is built for (the caller falls back)
 int conv_pm(const be_conv_desc* d, const float* x, int wrow, const float* x2, int cin2, const float* pw, const float* pb,

@@ -54,8 +54,10 @@ struct PackedLayout {
                 ub_off[i] = o; o += cout_pad(kLayers[i].cout);
             }
         }
+        zero_off = o; o += 384;            // a zero "bias" for the Winograd blocks' downsample convolutions (their bias lives in conv2's)
         total = o;
     }
+    size_t zero_off;
 };
 const PackedLayout& layout() { static PackedLayout l; return l; }
 
@@ -108,6 +110,14 @@ extern "C" int be_local_stage_pack_f32(const float* const* t, float bn_eps, floa
                                              packed + L.uw_off[i], packed + L.ub_off[i], stream);
         if (rc) return rc;
     }
+    // Winograd blocks: the downsample's (folded) bias moves into conv2's, so that the 1x1 downsample itself is a bias-free GEMM -
+    // raw accumulators, which the weight-stationary GEMM kernel can write (be::gemm_rows_ws) - and joins in conv2's output
+    // transform exactly as before: y = act(A^T M A + (b2 + b_ds) + x W_ds)
+    for (int l0 = 4; l0 < 13; l0 += 3) {
+        if (int rc = be::vec_add_inplace(packed + L.ub_off[l0 + 1], packed + L.db_off[l0 + 2], (int)cout_pad(kLayers[l0].cout), stream)) return rc;
+    }
+    if (hipMemsetAsync(packed + L.zero_off, 0, 384 * sizeof(float), be::as_stream(stream)) != hipSuccess)
+        return be::fail(BE_ELAUNCH, "be_local_stage_pack_f32: hipMemsetAsync failed");
     const float* const* f = t + 78;                   // fc.1.w, fc.1.b, fc.2.{gamma,beta,mean,var}, fc.4.w, fc.4.b
     int rc = be_conv_pack_f32(f[0], f[1], f[2], f[3], f[4], f[5], bn_eps, 1024, 2304, 1, 9,
                               packed + L.w_off[13], packed + L.b_off[13], stream);
@@ -150,9 +160,17 @@ int block_wino(const float* packed, int l0, const float* x, float* t, float* o, 
     const PackedLayout& L = layout();
     const int c = kLayers[l0].cout;
     (void)t;                                          // conv1's 6x6 result only ever exists in registers (k_wino_out_in)
-    be_conv_desc d;
-    d.n = n; d.h = 6; d.w = 6; d.cin = kLayers[l0 + 2].cin; d.cout = c; d.ksize = 1; d.act = 0;
-    if (int rc = be_conv_nhwc_f32(&d, x, packed + L.dw_off[l0 + 2], packed + L.db_off[l0 + 2], nullptr, r, c, stream)) return rc;
+    // the 1x1 downsample, bias-free (its bias sits in conv2's, see be_local_stage_pack_f32): large sub-batches on the
+    // weight-stationary GEMM (raw accumulators; 128 TFLOP/s where the row GEMM does 92-119), others on the general kernel with a zero bias
+    {
+        int rc = be::gemm_rows_ws(x, (int64_t)n * 36, kLayers[l0 + 2].cin, packed + L.dw_off[l0 + 2], c, r, c, stream);
+        if (rc < 0) return rc;
+        if (rc > 0) {
+            be_conv_desc d;
+            d.n = n; d.h = 6; d.w = 6; d.cin = kLayers[l0 + 2].cin; d.cout = c; d.ksize = 1; d.act = 0;
+            if ((rc = be_conv_nhwc_f32(&d, x, packed + L.dw_off[l0 + 2], packed + L.zero_off, nullptr, r, c, stream))) return rc;
+        }
+    }
     {
         float* va = w;                                // two transform-domain buffers of 100 x 384 floats per patch each
         float* vb = w + (size_t)n * 100 * 384;

@@ -572,8 +572,10 @@ void k_wino_gemm_ws(GemmArgs a, int mgroups) {
 #undef WS_READ
 }
 
+// kid = BE_KERNEL_WINO_GEMM: the 25 problems of a Winograd layer (n patches -> 4 n rows each);  BE_KERNEL_GEMM_ROWS: one plain GEMM
+// of n rows
 template <int KCH>
-int launch_ws(const GemmArgs& g, hipStream_t s, int64_t n, int cin, int cout) {
+int launch_ws(const GemmArgs& g, hipStream_t s, int64_t n, int cin, int cout, int kid = BE_KERNEL_WINO_GEMM) {
     constexpr size_t lds = (size_t)8 * 128 * 16 * sizeof(float);     // 64 KB: eight chunks of the B fill (the A ring uses three)
     static bool attr_set[be::kMaxDevices] = {};
     const int dev_ = be::current_device();          // the attribute is per device
@@ -604,9 +606,10 @@ int launch_ws(const GemmArgs& g, hipStream_t s, int64_t n, int cin, int cout) {
     const int units = g.nb * mgroups;
     const unsigned grid = (unsigned)(8 * ((units + 7) / 8) * g.n_tiles);
     {
-        be::ProfileScope prof(s, BE_KERNEL_WINO_GEMM, 25.0 * 2.0 * 4 * n * cin * cout,
-                              25.0 * 4.0 * (4.0 * n * cin + (double)cin * cout + 4.0 * n * cout),
-                              25.0 * 2.0 * g.m_tiles * g.n_tiles * 128.0 * 128.0 * cin);
+        const double rows = kid == BE_KERNEL_WINO_GEMM ? 4.0 * n : (double)n, probs = g.nb;
+        be::ProfileScope prof(s, kid, probs * 2.0 * rows * cin * cout,
+                              probs * 4.0 * (rows * cin + (double)cin * cout + rows * cout),
+                              probs * 2.0 * g.m_tiles * g.n_tiles * 128.0 * 128.0 * cin);
         hipLaunchKernelGGL(k_wino_gemm_ws<KCH>, dim3(grid), dim3(256), lds, s, g, mgroups);
     }
     return be::check_launch("be_wino_conv3x3_6x6_f32(gemm, weight-stationary)");
@@ -722,6 +725,19 @@ int be::gemm_rows(const float* x, int64_t M, int K, const float* packed_w, int N
         hipLaunchKernelGGL(k_wino_gemm<1>, dim3(grid), dim3(256), lds, s, g);
     }
     return be::check_launch("be_conv_nhwc_f32(gemm rows)");
+}
+
+// a plain row GEMM on the weight-stationary kernel: ONE "problem" (z = 0) of M / 128 row tiles
+int be::gemm_rows_ws(const float* x, int64_t M, int K, const float* packed_w, int N, float* y, int ldy, void* stream) {
+    static const bool off = getenv("BE_NO_ROWS_WS") != nullptr || getenv("BE_WINO_NO_WS") != nullptr;      // A/B knobs
+    if (off || M % 128 || M / 128 < 128 || N % 128 || ldy % 4 || M * (int64_t)ldy >= ((int64_t)1 << 31)) return 1;
+    if (!(K == 96 || K == 256 || K == 384) || !be::aligned16(x) || !be::aligned16(packed_w) || !be::aligned16(y)) return 1;
+    hipStream_t s = be::as_stream(stream);
+    GemmArgs g{x, packed_w, y, (int)M, K, N, ldy, 1, (int)(M / 128), N / 128, 0, 0, 0, K, 128, 0, nullptr, nullptr, 0};
+    // (n, cin, cout of the profile record: 2 M K N FLOPs = 25 x 2 x 4 n' x cin x cout with n' = M / 100)
+    if (K == 96) return launch_ws<6>(g, s, M, K, N, BE_KERNEL_GEMM_ROWS);
+    if (K == 256) return launch_ws<16>(g, s, M, K, N, BE_KERNEL_GEMM_ROWS);
+    return launch_ws<24>(g, s, M, K, N, BE_KERNEL_GEMM_ROWS);
 }
 
 extern "C" int be_wino_conv3x3_6x6_f32(const float* x, const float* packed_w, const float* packed_bias, const float* residual,
