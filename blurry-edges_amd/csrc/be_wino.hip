@@ -431,7 +431,9 @@ void k_wino_gemm(GemmArgs a) {
 // fragments of chunk s+1 read while the MFMAs of chunk s run, one raw barrier per chunk, explicit vmcnt waits (the wait for a tile's
 // successor DMA sits in FRONT of that tile's stores, so no count depends on the number of store instructions).  Same order of operations per output element as k_wino_gemm:
 // bit-identical.  Measured (tools/wino_gemm_lab.hip, weight_stationary_run13.log): +3...5 % over k_wino_gemm.
-template <int KCH>
+// KIND (0: the 25 problems of a Winograd layer, 1: a plain row GEMM - the blocks' 1x1 downsamples) changes nothing in the code: it
+// gives the two uses different kernel symbols, so that a profiler's per-kernel averages do not mix launches of different sizes
+template <int KCH, int KIND>
 __global__ __launch_bounds__(256, 1)
 void k_wino_gemm_ws(GemmArgs a, int mgroups) {
     constexpr int BM = 128, BKT = 16, ABUF = BM * BKT;     // floats per A stage (8 KB)
@@ -574,13 +576,13 @@ void k_wino_gemm_ws(GemmArgs a, int mgroups) {
 
 // kid = BE_KERNEL_WINO_GEMM: the 25 problems of a Winograd layer (n patches -> 4 n rows each);  BE_KERNEL_GEMM_ROWS: one plain GEMM
 // of n rows
-template <int KCH>
+template <int KCH, int KIND = 0>
 int launch_ws(const GemmArgs& g, hipStream_t s, int64_t n, int cin, int cout, int kid = BE_KERNEL_WINO_GEMM) {
     constexpr size_t lds = (size_t)8 * 128 * 16 * sizeof(float);     // 64 KB: eight chunks of the B fill (the A ring uses three)
     static bool attr_set[be::kMaxDevices] = {};
     const int dev_ = be::current_device();          // the attribute is per device
     if (!attr_set[dev_]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino_gemm_ws<KCH>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino_gemm_ws<KCH, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return be::fail(BE_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_set[dev_] = true;
     }
@@ -610,7 +612,7 @@ int launch_ws(const GemmArgs& g, hipStream_t s, int64_t n, int cin, int cout, in
         be::ProfileScope prof(s, kid, probs * 2.0 * rows * cin * cout,
                               probs * 4.0 * (rows * cin + (double)cin * cout + rows * cout),
                               probs * 2.0 * g.m_tiles * g.n_tiles * 128.0 * 128.0 * cin);
-        hipLaunchKernelGGL(k_wino_gemm_ws<KCH>, dim3(grid), dim3(256), lds, s, g, mgroups);
+        hipLaunchKernelGGL((k_wino_gemm_ws<KCH, KIND>), dim3(grid), dim3(256), lds, s, g, mgroups);
     }
     return be::check_launch("be_wino_conv3x3_6x6_f32(gemm, weight-stationary)");
 }
@@ -735,9 +737,9 @@ int be::gemm_rows_ws(const float* x, int64_t M, int K, const float* packed_w, in
     hipStream_t s = be::as_stream(stream);
     GemmArgs g{x, packed_w, y, (int)M, K, N, ldy, 1, (int)(M / 128), N / 128, 0, 0, 0, K, 128, 0, nullptr, nullptr, 0};
     // (n, cin, cout of the profile record: 2 M K N FLOPs = 25 x 2 x 4 n' x cin x cout with n' = M / 100)
-    if (K == 96) return launch_ws<6>(g, s, M, K, N, BE_KERNEL_GEMM_ROWS);
-    if (K == 256) return launch_ws<16>(g, s, M, K, N, BE_KERNEL_GEMM_ROWS);
-    return launch_ws<24>(g, s, M, K, N, BE_KERNEL_GEMM_ROWS);
+    if (K == 96) return launch_ws<6, 1>(g, s, M, K, N, BE_KERNEL_GEMM_ROWS);
+    if (K == 256) return launch_ws<16, 1>(g, s, M, K, N, BE_KERNEL_GEMM_ROWS);
+    return launch_ws<24, 1>(g, s, M, K, N, BE_KERNEL_GEMM_ROWS);
 }
 
 extern "C" int be_wino_conv3x3_6x6_f32(const float* x, const float* packed_w, const float* packed_bias, const float* residual,

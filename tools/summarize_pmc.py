@@ -15,6 +15,7 @@ tag = sys.argv[2] if len(sys.argv) > 2 else "r01"
 NAMES = {"k_conv_igemm<2, 2, 2, 2, 0,": "conv128x128", "k_conv_igemm<4, 1, 1, 3, 0,": "conv128x96",
          "k_conv_igemm<4, 1, 1, 2, 1,": "conv1_row8", "k_render_colors": "render_pass_a",
          "k_wino_in": "wino_in", "k_wino_out_in": "wino_out_in", "k_wino_out(": "wino_out", "k_wino_out_pool2": "wino_out_pool2",
+         "k_wino_gemm_ws<6, 1>": "gemm_rows_ws", "k_wino_gemm_ws<16, 1>": "gemm_rows_ws", "k_wino_gemm_ws<24, 1>": "gemm_rows_ws",
          "k_wino_gemm_ws": "wino_gemm", "k_wino_gemm<0>": "wino_gemm", "k_wino_gemm<1>": "gemm_rows", "k_wino_gemm(": "wino_gemm",
          "k_conv_pm<2, 3, 0>": "conv_pm_256x96", "k_conv_pm<2, 2, 1>": "conv_pm_conv1", "k_maxpool_nhwc": "maxpool"}
 
