@@ -513,6 +513,31 @@ def test_workflow_datagen_train_precalc_train_eval_end_to_end(env, tmp_path):
     assert all(np.isfinite(v) for v in res.values()) and 0 <= res["delta1"] <= res["delta2"] <= res["delta3"] <= 1
 
 
+def test_evaluate_loads_the_w_checkpoint_for_densify_w_like_the_reference(env, tmp_path):
+    """blurry_edges_test.py:187-190 loads pretrained_global_stage_w.pth for `--densify w`; only the big-image
+    script always takes the plain name.  The plain file here is NOT a GlobalStage checkpoint, so any path that opens it fails."""
+    import models, utils
+    from be_hip import datagen as dg, workflow as wf
+    d = dg.generate(dg.draw_scenes(2, seed=41, name="evw"), DEV, seed=41)
+    dg.save(d, dg.crop_patches(d, 8, seed=41), str(tmp_path / "data"), "val")
+    test_dir, wdir = tmp_path / "test", tmp_path / "w"
+    test_dir.mkdir(); wdir.mkdir()
+    for src, dst in (("images_ny_val", "images_ny"), ("image_depths_val", "depth_maps"), ("alphas_val", "alphas")):
+        np.save(test_dir / f"{dst}.npy", np.load(tmp_path / "data" / f"{src}.npy"))
+    lm = models.LocalStage()
+    lm.load_state_dict({k: T(v) for k, v in synth.local_stage_state_dict().items()})
+    torch.save(lm.state_dict(), wdir / "pretrained_local_stage.pth")
+    gm = models.GlobalStage(device="cpu")
+    gm.load_state_dict({k: T(v) for k, v in synth.global_stage_state_dict().items()})
+    torch.save(gm.state_dict(), wdir / "pretrained_global_stage_w.pth")
+    torch.save({"not": torch.zeros(1)}, wdir / "pretrained_global_stage.pth")
+    common = ["--model_path", str(wdir), "--data_path", str(test_dir), "--cuda", DEV]
+    res = wf.evaluate(utils.get_args("eval", argv=common + ["--densify", "w"]), quiet=True)       # takes the _w file
+    assert all(np.isfinite(v) for v in res.values())
+    with pytest.raises(RuntimeError):                                                              # default densify: the plain file
+        wf.evaluate(utils.get_args("eval", argv=common), quiet=True)
+
+
 def test_reference_style_postprocess_subclass_agrees_with_the_fused_pipeline(env):
     """A caller-written PostProcess(PostProcessGlobalBase) in the style of blurry_edges_test.py:12-100 - composed ONLY
     of the inherited methods, tensors in the reference's [B,.,21,21,Hp,Wp] layout - must give the maps of the fused
