@@ -143,6 +143,22 @@ def glue_params10(p: int, seed: int = SEED_DEFAULT, name: str = "g15_params10") 
     return f32(q)
 
 
+def big_block_params10(k: int, seed: int = SEED_DEFAULT) -> np.ndarray:
+    """[8192,10] raw LocalStage output for block k of the 36-block big-image golden (g17): rows 0..4095 aperture 1."""
+    return plausible_params10(8192, seed, f"g17_p10_{k}")
+
+
+def big_block_global_out(k: int, seed: int = SEED_DEFAULT) -> np.ndarray:
+    """[4096,12] GlobalStage output (normalised, as the network emits it) for block k of golden g17: the inverse of the eval glue's
+    de-normalisation (blurry_edges_test_big.py:161-165) applied to plausible wedge parameters."""
+    p = plausible_params12(4096, seed, f"g17_p12_{k}").astype(np.float64)
+    y = np.empty_like(p)
+    y[:, :4] = p[:, :4] / 3.0
+    y[:, 4:8] = p[:, 4:8] / math.pi - 1.0
+    y[:, 8:] = p[:, 8:] - 0.5
+    return f32(y)
+
+
 def plausible_params12(n: int, seed: int = SEED_DEFAULT, name: str = "params12") -> np.ndarray:
     """[n,12]: 8 shared geometry + eta coefficients (w1,img1),(w2,img1),(w1,img2),(w2,img2)
     (layout of blurry_edges_test.py:36-37,44-45)."""

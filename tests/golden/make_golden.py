@@ -613,7 +613,66 @@ def G16():
     save("g16_postprocess_147_f64", **out)
 
 
-GROUPS = dict(G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G8=G8, G9=G9, G10=G10, G11=G11, G12=G12, G13=G13, G14=G14, G15=G15, G16=G16)
+def G17():
+    """Big-image path end to end (blurry_edges_test_big.py:113-215): the reference's own depth_estimator on one 587 x 587 pair
+    with its REAL big-image PostProcess (float64 inside the helper; the script stores patches in float32), a stub local module
+    (fixed raw parameters per block) and a stub global module (fixed output per block): window extraction, the margin-dropping
+    stitch into the 284 x 284 patch grid, the six folds and the confidence threshold, at full size.  Stored: every map
+    subsampled by 7 in both directions + the row sums of the full maps."""
+    import shutil
+    import tempfile
+    sys.modules["cv2"].imwrite = lambda *a, **k: True
+    import blurry_edges_test_big as ref_big
+    argv, sys.argv = sys.argv, ["x"]
+    try:
+        a = ref_utils.get_args("eval", big=True)
+    finally:
+        sys.argv = argv
+    a.cuda = "cpu"
+    tmp = tempfile.mkdtemp(dir=os.path.join(ROOT, "gpurun_out") if os.path.isdir(os.path.join(ROOT, "gpurun_out")) else ROOT)
+    a.log_path = tmp
+    dev = torch.device("cpu")
+    dcal = ref_utils.DepthEtas(a, dev)
+    helper = ref_big.PostProcess(a, dcal, dev)
+    _as_double_global(helper, dcal)
+    H, W = a.big_img_size
+    imgs, _ = synth.synthetic_image_pair(H, W, nshape=14)
+    count = dict(local=0, glob=0)
+
+    def local_stub(vec):
+        k = count["local"]
+        count["local"] += 1
+        return torch.from_numpy(synth.big_block_params10(k))
+
+    def global_stub(pm):
+        k = count["glob"]
+        count["glob"] += 1
+        return torch.from_numpy(synth.big_block_global_out(k))[None]
+
+    seen = {}
+
+    class Vis:
+        def visualize(self, i1, i2, c1, c2, shpd, refoc, conf, bndry, gt, depth):
+            seen.update(image=np.stack([c1.transpose(2, 0, 1), c2.transpose(2, 0, 1)]), shpd=shpd.transpose(2, 0, 1),
+                        refoc=refoc.transpose(2, 0, 1), conf=conf, bndry=bndry, depth_map=depth)
+            return np.zeros((2, 2, 3), np.uint8)
+
+    loader = [(torch.from_numpy(imgs).double().permute(0, 2, 3, 1)[None].contiguous(), torch.ones(1, H, W))]
+    try:
+        with np.errstate(all="ignore"):
+            ref_big.depth_estimator(a, local_stub, global_stub, helper, Vis(), loader)
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    assert count["local"] == 36 and count["glob"] == 36
+    out = {}
+    for k, v in seen.items():
+        v = np.asarray(v, dtype=np.float32)
+        out[k + "_sub"] = v[..., ::7, ::7]
+        out[k + "_rowsum"] = v.astype(np.float64).sum(axis=-1)
+    save("g17_big_image", **out)
+
+
+GROUPS = dict(G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G8=G8, G9=G9, G10=G10, G11=G11, G12=G12, G13=G13, G14=G14, G15=G15, G16=G16, G17=G17)
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)

@@ -284,6 +284,46 @@ def test_big_image_tiler_and_fold_587(env):
     assert relmax(maps["image"].cpu()[:, :, 220:279], fi[:, :, 220:279]) <= 1e-4
 
 
+def test_big_image_path_matches_the_reference_run_g17(env):
+    """Golden g17: the reference's own big-image depth_estimator (blurry_edges_test_big.py:113-215; its PostProcess in float64,
+    stub networks with fixed outputs per block) on one 587 x 587 pair.  run_big with the same stub outputs must reproduce its
+    six folded maps: window extraction, the margin-dropping stitch, pass B, the folds and the 0.05 confidence threshold, full size."""
+    from be_hip.pipeline import DepthPipeline
+    g = load_golden("g17_big_image")
+
+    class FixedLocal:
+        k = 0
+
+        def forward_image_pair(self, img, stride, window):
+            est = T(synth.big_block_params10(self.k)).to(DEV)
+            self.k += 1
+            return est
+
+    class FixedGlobal:
+        k = 0
+
+        def __call__(self, pm):
+            ys = [T(synth.big_block_global_out(self.k + i)) for i in range(pm.shape[0])]
+            self.k += pm.shape[0]
+            return torch.stack(ys).to(DEV)
+
+    pipe = DepthPipeline(FixedLocal(), FixedGlobal(), env["helper"], env["dcal"])
+    imgs, _ = synth.synthetic_image_pair(587, 587, nshape=14)
+    maps = pipe.run_big(T(imgs).to(DEV))
+    assert pipe.local.k == 36 and pipe.globl.k == 36
+    got = {k: maps[k].double().cpu() for k in ("image", "shpd", "refoc", "bndry", "conf", "depth_map")}
+    for k in ("image", "shpd", "refoc", "bndry"):                       # fp32 kernels against the fp64 reference helper
+        assert relmax(got[k][..., ::7, ::7], g[k + "_sub"]) <= 1e-4, k
+        assert relmax(got[k].sum(-1), g[k + "_rowsum"]) <= 1e-4, k
+    # confidence: counts of depth-mask elements / 121; an element on its threshold may flip in fp32 (SURVEY 8c: counted)
+    flips = (got["conf"][::7, ::7] - T(g["conf_sub"], torch.float64)).abs() > 1e-6
+    assert float(flips.float().mean()) <= 2e-3, float(flips.float().mean())
+    dm = (got["depth_map"][::7, ::7] - T(g["depth_map_sub"], torch.float64)).abs()
+    assert float((dm[~flips] ** 2).mean().sqrt()) <= 1e-4
+    assert float((dm > 1e-3).float().mean()) <= 2e-3
+    assert relmax(got["conf"].sum(-1), g["conf_rowsum"]) <= 2e-3
+
+
 def test_base_class_methods_both_layouts_vs_oracle(env):
     """The reference's fine-grained PostProcess methods (what a subclass written against the reference calls)."""
     import utils
