@@ -88,6 +88,22 @@ def attention_dropout_mask(B, L, H, p, seed, dev):
     return m
 
 
+def attention_keep_bits(B, L, H, p, seed, dev):
+    """The attention dropout decisions in the packed layout the training forward leaves in its workspace, from the formula:
+    int16 [B*H, L/32, L/32, 64]."""
+    k = torch.empty((B * H, L // 32, L // 32, 32), dtype=torch.int32, device=dev)          # two halfwords per int32
+    check(lib().be_attention_keep_bits_u16(dptr(k), B, L, H, float(p), int(seed) & 0xffffffff, stream_ptr(dev)),
+          "be_attention_keep_bits_u16")
+    return k.view(torch.int16)
+
+
+def workspace_keep_bits(ws, B, L, H):
+    """View of the keep bits inside a workspace attention_train_fwd returned."""
+    off = lib().be_attention_train_keep_offset_floats(B, L, H)
+    n = B * H * (L // 32) ** 2 * 64
+    return ws[off:off + n // 2].view(torch.int16).view(B * H, L // 32, L // 32, 64)
+
+
 def dropout(x, p, seed, site, gate=None):
     y = torch.empty_like(x)
     check(lib().be_dropout_f32(dptr(x, "x"), dptr(gate), dptr(y), x.numel(), float(p), int(seed) & 0xffffffff, int(site),

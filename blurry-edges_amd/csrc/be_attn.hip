@@ -19,8 +19,9 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int DH = 16;       // head dim
 constexpr int KB = 32;       // keys per block
 
-// Counter-based dropout: element `idx` of dropout site `site` is kept iff mix32(idx ^ site_key) >= p * 2^32.
-// The same function is evaluated again in the backward kernels, so no mask is ever stored.
+// Counter-based dropout: element `idx` of dropout site `site` is kept iff mix32(idx ^ site_key) >= p * 2^32.  The elementwise
+// sites evaluate the same function again in their backward, so they store no mask; the attention forward leaves one keep BIT per
+// probability (L^2 / 8 bytes per head) because hashing costs the backward more than reading it (see k_attention).
 __host__ __device__ __forceinline__ uint32_t mix32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
     return x;
@@ -30,8 +31,8 @@ __host__ __device__ __forceinline__ uint32_t site_key(uint32_t seed, uint32_t si
 }
 // Attention dropout: ONE hash decides the two neighbouring keys 2j, 2j+1 of a query, 16 bits each (the hash was a third of
 // the training forward: two 32-bit multiplies per probability).  Element idx = query * L + key of head-batch `hkey` is
-// dropped iff its half of mix32((idx >> 1) ^ hkey) is below p * 2^16; the forward and dQ kernels hold four consecutive keys
-// per lane (two hashes for four elements), the dK/dV kernel and the mask kernel take the half that belongs to their key.
+// dropped iff its half of mix32((idx >> 1) ^ hkey) is below p * 2^16; the forward holds four consecutive keys per lane (two
+// hashes for four elements); k_attn_keep_bits and the mask kernel of the tests evaluate the same function.
 __host__ __device__ __forceinline__ uint32_t pair_hash(uint32_t idx, uint32_t hkey) { return mix32((idx >> 1) ^ hkey); }
 __host__ __device__ __forceinline__ bool pair_dropped(uint32_t idx, uint32_t hkey, uint32_t t16) {
     return ((pair_hash(idx, hkey) >> (16U * (idx & 1U))) & 0xffffU) < t16;
@@ -96,33 +97,6 @@ __global__ void k_qkv_split_train(const float* __restrict__ qkv, float* __restri
     }
 }
 
-// dout, out [T, D] token-major -> dOh [BH][L][16], dOt [BH][16][L], Drow [BH][L] = sum_d dO * O  (token fastest)
-__global__ void k_dout_prep(const float* __restrict__ dout, const float* __restrict__ out, float* __restrict__ dOh,
-                            float* __restrict__ dOt, float* __restrict__ Drow, int B, int L, int H) {
-    const int64_t total = (int64_t)B * L * H;
-    const int64_t gs = (int64_t)gridDim.x * blockDim.x;
-    const int D = H * DH;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gs) {
-        const int64_t l = idx % L, bh = idx / L;
-        const int64_t b = bh / H, h = bh % H;
-        const float* g = dout + (b * L + l) * D + h * DH;
-        const float* o = out + (b * L + l) * D + h * DH;
-        float acc = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f32x4 gv = *reinterpret_cast<const f32x4*>(g + 4 * i);
-            const f32x4 ov = *reinterpret_cast<const f32x4*>(o + 4 * i);
-            *reinterpret_cast<f32x4*>(dOh + (bh * L + l) * DH + 4 * i) = gv;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc = fmaf(gv[e], ov[e], acc);
-                dOt[(bh * DH + 4 * i + e) * L + l] = gv[e];
-            }
-        }
-        Drow[bh * L + l] = acc;
-    }
-}
-
 // ---- attention on v_mfma_f32_16x16x4_f32 -----------------------------------------------------------------------
 // With d_head = 16 every product here has a 16-wide side, so the 16x16x4 shape wastes nothing (the 32x32x2 shape
 // multiplied zeros in half of its rows for O^T = V^T P^T and the three backward products: 24 -> 16 MFMA-cycles per
@@ -147,18 +121,52 @@ __device__ __forceinline__ float quad_sum(float v) {
     return v + __shfl_xor(v, 32, 64);
 }
 
-// TRAIN: dropout on the probabilities (nn.MultiheadAttention's dropout, models/global_stage.py:28) and the log2-sum-exp
-// of every query row saved for the backward
+// TRAIN: dropout on the probabilities (nn.MultiheadAttention's dropout, models/global_stage.py:28); the log2-sum-exp of every query
+// row and the keep bits of every probability are saved for the backward
 // RAGGED: only the first Lv (< L) tokens are real, the rest pads the sequence to a multiple of 128: keys >= Lv get the score
 // -inf (probability exactly 0), fully padded key blocks are never visited.  Padded QUERY rows are computed like any other
 // (their output is discarded by the caller; in training their upstream gradient is exactly 0).
+// a, b: per-lane partial maxima of two independent quantities; on return every lane holds, for each of them, the maximum over its
+// four lanes c, c+16, c+32, c+48.  v_permlane32_swap exchanges rows 2,3 of the first operand with rows 0,1 of the second,
+// v_permlane16_swap the odd rows of the first with the even rows of the second: three swaps, two max, two moves - no LDS trip.
+// (Plain fmaxf on purpose: a swap that reads a register written by INLINE ASM gets none of the wait states the hazard
+// recognizer puts between a VALU write and v_permlane*_swap - seen as run-to-run differences in the softmax reference.)
+__device__ __forceinline__ void quad_max2(float& a, float& b) {
+    auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);   // [a0 a1 b0 b1], [a2 a3 b2 b3]
+    const float w = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));                                  // [a02 a13 b02 b13]
+    auto q = __builtin_amdgcn_permlane16_swap(__float_as_uint(w), __float_as_uint(w), false, false);   // [w0 w0 w2 w2], [w1 w1 w3 w3]
+    const float u = fmaxf(__uint_as_float(q[0]), __uint_as_float(q[1]));                                  // [A A B B]
+    auto t = __builtin_amdgcn_permlane32_swap(__float_as_uint(u), __float_as_uint(u), false, false);   // [A A A A], [B B B B]
+    a = __uint_as_float(t[0]);
+    b = __uint_as_float(t[1]);
+}
+
+__device__ __forceinline__ float max8(const f32x4v a, const f32x4v b) {
+    return fmaxf(fmaxf(fmaxf(a[0], a[1]), fmaxf(a[2], a[3])), fmaxf(fmaxf(b[0], b[1]), fmaxf(b[2], b[3])));
+}
+
+// The softmax reference of a query is not its running maximum but a fixed integer m_ref >= max(block 0) - 1, and it enters the
+// score product as the INITIAL VALUE of the MFMA accumulator (C = -m_ref): the probabilities are exp2 of the accumulator, with
+// no maximum, no cross-lane exchange, no subtraction and no rescaling of O in the loop.  A guard on the block's probability sum
+// (> 2^60: the scores have risen 60 binades above the reference) sends the wave through a slow path that raises the
+// reference by an integer (exact power-of-two rescale).  fp32 MFMA and VALU instructions share the SIMD's issue slot on this
+// chip, so every VALU instruction removed from the loop is time saved.
+// two dropout decisions from one pair hash: p0 / p1 are kept or zeroed, their keep bits are shifted into acc
+__device__ __forceinline__ void keep2(uint32_t h, uint32_t t16, float& p0, float& p1, uint32_t& acc) {
+    asm("v_cmp_ge_u32_sdwa vcc, %3, %4 src0_sel:WORD_0 src1_sel:DWORD\n\t"
+        "v_cndmask_b32_e32 %0, 0, %0, vcc\n\t"
+        "v_addc_co_u32_e32 %2, vcc, %2, %2, vcc\n\t"
+        "v_cmp_ge_u32_sdwa vcc, %3, %4 src0_sel:WORD_1 src1_sel:DWORD\n\t"
+        "v_cndmask_b32_e32 %1, 0, %1, vcc\n\t"
+        "v_addc_co_u32_e32 %2, vcc, %2, %2, vcc"
+        : "+v"(p0), "+v"(p1), "+v"(acc) : "v"(h), "v"(t16) : "vcc");
+}
+
 template <bool TRAIN, bool RAGGED>
 __global__ __launch_bounds__(256)
 void k_attention(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ Vt,
-                 float* __restrict__ out, float* __restrict__ lse, int L, int Lv, int H, uint32_t seed, uint32_t thresh,
-                 float inv_keep, float* __restrict__ part) {
-    // grid.x = L/128 query blocks (4 waves x 32 queries), grid.y = B*H, grid.z = key slices (inference at small batch:
-    // 256 workgroups cannot fill 256 CUs x 4 SIMDs; each slice then leaves un-normalised partials for k_attn_combine)
+                   float* __restrict__ out, float* __restrict__ lse, int L, int Lv, int H, uint32_t seed, uint32_t thresh,
+                   float inv_keep, float* __restrict__ part, uint16_t* __restrict__ keep) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = lane & 15, g = lane >> 4;
     const int bh = blockIdx.y;
@@ -167,34 +175,29 @@ void k_attention(const float* __restrict__ Q, const float* __restrict__ K, const
     const float* Kh = K + (size_t)bh * L * DH;
     const float* Vh = Vt + (size_t)bh * DH * L;
     const uint32_t hkey = site_key(seed, (uint32_t)bh);
-    const uint32_t t16 = thresh >> 16;                 // p * 2^16: the 16-bit threshold of the pair hash
+    uint32_t t16v = thresh >> 16;                 // p * 2^16: the 16-bit threshold of the pair hash, in a vector register
+    asm("" : "+v"(t16v));
+    uint16_t* keep_out = TRAIN ? keep + ((size_t)bh * (L / KB) + (q0 >> 5)) * (L / KB) * 64 + lane : nullptr;   // [bh][query tile][key block][lane]
 
-    f32x4v qf[2], o[2];
-    float m[2], lsum[2];
+    f32x4v qf[2], o[2], nm[2];                      // nm: -m_ref in all four registers (the accumulator's initial value)
+    float mref[2], lsum[2];
 #pragma unroll
     for (int qc = 0; qc < 2; ++qc) {
         qf[qc] = *reinterpret_cast<const f32x4v*>(Qh + (size_t)(q0 + 16 * qc + c) * DH + 4 * g);
         o[qc] = f32x4v{0.f, 0.f, 0.f, 0.f};
-        m[qc] = -INFINITY; lsum[qc] = 0.f;
+        lsum[qc] = 0.f;
     }
-    const int nblk = RAGGED ? (Lv + KB - 1) / KB : L / KB;               // key blocks that hold at least one real key
-    const int kb0 = nblk * blockIdx.z / gridDim.z;
-    f32x4v kn[2], vn[2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-        kn[kt] = *reinterpret_cast<const f32x4v*>(Kh + (size_t)(kb0 * KB + 16 * kt + c) * DH + 4 * g);
-        vn[kt] = *reinterpret_cast<const f32x4v*>(Vh + (size_t)c * L + kb0 * KB + 16 * kt + 4 * g);
-    }
-    const int nkb = nblk * (blockIdx.z + 1) / gridDim.z;                  // this slice: key blocks [kb0, nkb)
-    for (int kblk = kb0; kblk < nkb; ++kblk) {
-        const f32x4v kf[2] = {kn[0], kn[1]}, vf[2] = {vn[0], vn[1]};
-        const int nx = kblk + 1 < nkb ? kblk + 1 : kblk;                 // prefetch (clamped on the last block)
+    const int nblk = RAGGED ? (Lv + KB - 1) / KB : L / KB;
+    const int kb0 = nblk * blockIdx.z / gridDim.z, nkb = nblk * (blockIdx.z + 1) / gridDim.z;
+
+    auto loadKV = [&](int blk, f32x4v k[2], f32x4v v[2]) {
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-            kn[kt] = *reinterpret_cast<const f32x4v*>(Kh + (size_t)(nx * KB + 16 * kt + c) * DH + 4 * g);
-            vn[kt] = *reinterpret_cast<const f32x4v*>(Vh + (size_t)c * L + nx * KB + 16 * kt + 4 * g);
+            k[kt] = *reinterpret_cast<const f32x4v*>(Kh + (size_t)(blk * KB + 16 * kt + c) * DH + 4 * g);
+            v[kt] = *reinterpret_cast<const f32x4v*>(Vh + (size_t)c * L + blk * KB + 16 * kt + 4 * g);
         }
-        f32x4v s[2][2];                                                  // [kt][qc], log2 units (Q carries scale*log2 e)
+    };
+    auto raw_scores = [&](const f32x4v k[2], f32x4v s[2][2], int kblk) {      // C = 0, padded keys -> -inf
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -204,49 +207,130 @@ void k_attention(const float* __restrict__ Q, const float* __restrict__ K, const
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int qc = 0; qc < 2; ++qc) s[kt][qc] = MFMA16(kf[kt][t], qf[qc][t], s[kt][qc]);
-        if (RAGGED && (kblk + 1) * KB > Lv) {                            // the one partial block (wave-uniform branch)
+                for (int qc = 0; qc < 2; ++qc) s[kt][qc] = MFMA16(k[kt][t], qf[qc][t], s[kt][qc]);
+        if (RAGGED && (kblk + 1) * KB > Lv) {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
                     if (kblk * KB + 16 * kt + 4 * g + r >= Lv) { s[kt][0][r] = -INFINITY; s[kt][1][r] = -INFINITY; }
         }
+    };
+    auto block_max = [&](const f32x4v s[2][2], float mx[2]) {                 // per query, over the 32 keys of the block
+        mx[0] = max8(s[0][0], s[1][0]);
+        mx[1] = max8(s[0][1], s[1][1]);
+        quad_max2(mx[0], mx[1]);
+    };
+    // dropout: keeps / zeroes the 16 probabilities of this lane and leaves their keep bits (decision d = 8 qc + 4 kt + r in bit
+    // 15 - d) in the block's mask halfword, which the two backward kernels read instead of hashing again
+    auto drop = [&](f32x4v s[2][2], int kblk) {
+        uint32_t acc = 0;
 #pragma unroll
         for (int qc = 0; qc < 2; ++qc) {
-            float mloc = fmaxf(fmaxf(fmaxf(s[0][qc][0], s[0][qc][1]), fmaxf(s[0][qc][2], s[0][qc][3])),
-                               fmaxf(fmaxf(s[1][qc][0], s[1][qc][1]), fmaxf(s[1][qc][2], s[1][qc][3])));
-            mloc = quad_max(mloc);
-            const float mnew = fmaxf(m[qc], mloc);
-            const float alpha = fast_exp2(m[qc] - mnew);
-            m[qc] = mnew;
-            float psum = 0.f;
+            const uint32_t base = (uint32_t)(q0 + 16 * qc + c) * (uint32_t)L + (uint32_t)(kblk * KB + 4 * g);
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) { s[kt][qc][r] = fast_exp2(s[kt][qc][r] - mnew); psum += s[kt][qc][r]; }
-            lsum[qc] = lsum[qc] * alpha + psum;                           // this lane's 8 keys; the quad is summed at the end
-            if (TRAIN && thresh) {
-                const uint32_t base = (uint32_t)(q0 + 16 * qc + c) * (uint32_t)L + (uint32_t)(kblk * KB + 4 * g);
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; r += 2) {                  // base is even: (r, r + 1) share a hash
-                        const uint32_t h = pair_hash(base + 16 * kt + r, hkey);
-                        if ((h & 0xffffU) < t16) s[kt][qc][r] = 0.f;
-                        if ((h >> 16) < t16) s[kt][qc][r + 1] = 0.f;
-                    }
-            }
-            o[qc] *= alpha;
+                for (int r = 0; r < 4; r += 2) {
+                    float p0 = s[kt][qc][r], p1 = s[kt][qc][r + 1];
+                    keep2(pair_hash(base + 16 * kt + r, hkey), t16v, p0, p1, acc);
+                    s[kt][qc][r] = p0; s[kt][qc][r + 1] = p1;
+                }
         }
+        keep_out[(size_t)kblk * 64] = (uint16_t)acc;
+    };
+    auto pv = [&](const f32x4v s[2][2], const f32x4v v[2]) {
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int qc = 0; qc < 2; ++qc) o[qc] = MFMA16(vf[kt][r], s[kt][qc][r], o[qc]);
+                for (int qc = 0; qc < 2; ++qc) o[qc] = MFMA16(v[kt][r], s[kt][qc][r], o[qc]);
+    };
+    // fast block; `ok` loses a lane's bit when the block's scores sit 60 binades above the reference (the wave then repeats its
+    // whole key range in the slow loop below: nothing of the fast pass is kept)
+    uint64_t ok = ~0ull;
+    auto fast_block = [&](const f32x4v k[2], const f32x4v v[2], int kblk) {
+        f32x4v s[2][2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int qc = 0; qc < 2; ++qc) s[kt][qc] = MFMA16(k[kt][0], qf[qc][0], nm[qc]);
+#pragma unroll
+        for (int t = 1; t < 4; ++t)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int qc = 0; qc < 2; ++qc) s[kt][qc] = MFMA16(k[kt][t], qf[qc][t], s[kt][qc]);
+        if (RAGGED && (kblk + 1) * KB > Lv) {
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kblk * KB + 16 * kt + 4 * g + r >= Lv) { s[kt][0][r] = -INFINITY; s[kt][1][r] = -INFINITY; }
+        }
+        float psum[2] = {0.f, 0.f};
+#pragma unroll
+        for (int qc = 0; qc < 2; ++qc)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { s[kt][qc][r] = fast_exp2(s[kt][qc][r]); psum[qc] += s[kt][qc][r]; }
+        ok &= __builtin_amdgcn_ballot_w64(psum[0] + psum[1] < 0x1p60f);
+        lsum[0] += psum[0]; lsum[1] += psum[1];
+        if (TRAIN && thresh) drop(s, kblk);
+        pv(s, v);
+    };
+
+    f32x4v kA[2], vA[2], kB[2], vB[2];
+    loadKV(kb0, kA, vA);
+    {   // reference from the first block of this slice (it holds at least one real key)
+        f32x4v sr[2][2];
+        float mx[2];
+        raw_scores(kA, sr, kb0);
+        block_max(sr, mx);
+#pragma unroll
+        for (int qc = 0; qc < 2; ++qc) { mref[qc] = ceilf(mx[qc]); nm[qc] = f32x4v{-mref[qc], -mref[qc], -mref[qc], -mref[qc]}; }
     }
-    if (gridDim.z > 1) {          // partials of this key slice: o (un-normalised) [z][bh][L][16], then m and l [z][bh][L]
+    int kblk = kb0;
+    for (; kblk + 1 < nkb; kblk += 2) {                   // branch-free body: two blocks on ping-pong registers
+        loadKV(kblk + 1, kB, vB);
+        __builtin_amdgcn_sched_barrier(0);               // the loads of the next block are issued BEFORE this block's work
+        fast_block(kA, vA, kblk);
+        loadKV(kblk + 2 < nkb ? kblk + 2 : kblk, kA, vA);
+        __builtin_amdgcn_sched_barrier(0);
+        fast_block(kB, vB, kblk + 1);
+    }
+    if (kblk < nkb) fast_block(kA, vA, kblk);
+    if (__builtin_expect(ok != ~0ull, 0)) {
+        // the whole key range again with a running maximum (the textbook online softmax): only reached when scores rise by more
+        // than 60 binades along the key axis
+#pragma unroll
+        for (int qc = 0; qc < 2; ++qc) { o[qc] = f32x4v{0.f, 0.f, 0.f, 0.f}; lsum[qc] = 0.f; mref[qc] = -INFINITY; }
+        for (kblk = kb0; kblk < nkb; ++kblk) {
+            f32x4v k[2], v[2], s[2][2];
+            float mx[2];
+            loadKV(kblk, k, v);
+            raw_scores(k, s, kblk);
+            block_max(s, mx);
+#pragma unroll
+            for (int qc = 0; qc < 2; ++qc) {
+                const float mnew = fmaxf(mref[qc], mx[qc]);
+                const float alpha = fast_exp2(mref[qc] - mnew);
+                mref[qc] = mnew;
+                float psum = 0.f;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { s[kt][qc][r] = fast_exp2(s[kt][qc][r] - mnew); psum += s[kt][qc][r]; }
+                lsum[qc] = lsum[qc] * alpha + psum;
+                o[qc] *= alpha;
+            }
+            if (TRAIN && thresh) drop(s, kblk);
+            pv(s, v);
+        }
+    }
+    if (gridDim.z > 1) {
         const size_t rows = (size_t)gridDim.y * L;
         float* po = part + (size_t)blockIdx.z * rows * (DH + 2);
 #pragma unroll
@@ -254,7 +338,7 @@ void k_attention(const float* __restrict__ Q, const float* __restrict__ K, const
             const size_t row = (size_t)bh * L + q0 + 16 * qc + c;
             const float ltot = quad_sum(lsum[qc]);
             *reinterpret_cast<f32x4v*>(po + row * DH + 4 * g) = o[qc];
-            if (g == 0) { po[rows * DH + row] = m[qc]; po[rows * (DH + 1) + row] = ltot; }
+            if (g == 0) { po[rows * DH + row] = mref[qc]; po[rows * (DH + 1) + row] = ltot; }
         }
         return;
     }
@@ -264,10 +348,11 @@ void k_attention(const float* __restrict__ Q, const float* __restrict__ K, const
     for (int qc = 0; qc < 2; ++qc) {
         const float ltot = quad_sum(lsum[qc]);
         const float inv = TRAIN ? inv_keep / ltot : 1.0f / ltot;
-        if (TRAIN && g == 0) lse[(size_t)bh * L + q0 + 16 * qc + c] = m[qc] + log2f(ltot);
+        if (TRAIN && g == 0) lse[(size_t)bh * L + q0 + 16 * qc + c] = mref[qc] + log2f(ltot);
         *reinterpret_cast<f32x4v*>(out + ((size_t)b * L + q0 + 16 * qc + c) * Dm + hd * DH + 4 * g) = o[qc] * inv;
     }
 }
+
 
 // merges the key slices: out = sum_z o_z 2^(m_z - M) / sum_z l_z 2^(m_z - M), M = max_z m_z; one thread per (row, d quad)
 __global__ void k_attn_combine(const float* __restrict__ part, float* __restrict__ out, int nz, int64_t BH, int L, int H) {
@@ -298,13 +383,45 @@ __global__ void k_attn_combine(const float* __restrict__ part, float* __restrict
 // Two kernels, no atomics: k_attn_bwd_dq owns 32 queries per wave and streams the keys; k_attn_bwd_dkv owns 32 keys
 // per wave and streams the queries.  Same register trick as the forward: a [16x16] tile of dS (or Pd) sits in the
 // accumulator layout and is fed back as the B operand of the next product, whose A operand is a 16-byte load of the
-// transposed tensor ([16][L]).
-template <bool RAGGED>
+// transposed tensor ([16][L]).  Neither kernel hashes: the dropout decisions are the keep bits the forward stored.
+// dout, out [T, D], lse [BH][L] -> dOh [BH][L][16], dOt [BH][16][L], nD [BH][L] = -keep * sum_d dO * O, nlse = -lse: the two
+// per-query constants enter the backward products as the INITIAL VALUES of their accumulators (S' = S - lse, dP' = dP - keep D)
+__global__ void k_dout_prep(const float* __restrict__ dout, const float* __restrict__ out, const float* __restrict__ lse,
+                              float* __restrict__ dOh, float* __restrict__ dOt, float* __restrict__ nD, float* __restrict__ nlse,
+                              float keep, int B, int L, int H) {
+    const int64_t total = (int64_t)B * L * H;
+    const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+    const int D = H * DH;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gs) {
+        const int64_t l = idx % L, bh = idx / L;
+        const int64_t b = bh / H, h = bh % H;
+        const float* g = dout + (b * L + l) * D + h * DH;
+        const float* o = out + (b * L + l) * D + h * DH;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 gv = *reinterpret_cast<const f32x4*>(g + 4 * i);
+            const f32x4 ov = *reinterpret_cast<const f32x4*>(o + 4 * i);
+            *reinterpret_cast<f32x4*>(dOh + (bh * L + l) * DH + 4 * i) = gv;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc = fmaf(gv[e], ov[e], acc);
+                dOt[(bh * DH + 4 * i + e) * L + l] = gv[e];
+            }
+        }
+        nD[bh * L + l] = -keep * acc;
+        nlse[bh * L + l] = -lse[bh * L + l];
+    }
+}
+
+// dS / inv_keep = P o (kept ? dP - keep D : -keep D): the accumulator of dP starts at -keep D, a dropped element takes that
+// start value back, and 1 / keep is applied once to the finished dQ
+template <bool RAGGED, bool DROP>
 __global__ __launch_bounds__(256)
 void k_attn_bwd_dq(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
-                   const float* __restrict__ Kt, const float* __restrict__ dOh, const float* __restrict__ lse,
-                   const float* __restrict__ Drow, float* __restrict__ dqkv, int L, int Lv, int H, uint32_t seed,
-                   uint32_t thresh, float inv_keep) {
+                     const float* __restrict__ Kt, const float* __restrict__ dOh, const float* __restrict__ nlse,
+                     const float* __restrict__ nD, float* __restrict__ dqkv, int L, int Lv, int H,
+                     const uint16_t* __restrict__ keep, float inv_keep) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = lane & 15, g = lane >> 4;
     const int bh = blockIdx.y;
@@ -313,52 +430,48 @@ void k_attn_bwd_dq(const float* __restrict__ Q, const float* __restrict__ K, con
     const float* Kh = K + hb;
     const float* Vh = V + hb;
     const float* Kth = Kt + hb;
-    const uint32_t hkey = site_key(seed, (uint32_t)bh);
-    const uint32_t t16 = thresh >> 16;                 // p * 2^16: the 16-bit threshold of the pair hash
+    // keep bits of this wave's 32 queries, as the forward left them: one halfword per lane and key block (same lane layout)
+    const uint16_t* kp = keep + ((size_t)bh * (L / KB) + (q0 >> 5)) * (L / KB) * 64 + lane;
 
-    f32x4v qf[2], gf[2], dq[2];
-    float lse_q[2], d_q[2];
+    f32x4v qf[2], gf[2], dq[2], nl[2], nd[2];
 #pragma unroll
     for (int qc = 0; qc < 2; ++qc) {
         const size_t row = (size_t)(q0 + 16 * qc + c);
         qf[qc] = *reinterpret_cast<const f32x4v*>(Q + hb + row * DH + 4 * g);
         gf[qc] = *reinterpret_cast<const f32x4v*>(dOh + hb + row * DH + 4 * g);
-        lse_q[qc] = lse[(size_t)bh * L + row];
-        d_q[qc] = Drow[(size_t)bh * L + row];
+        const float a = nlse[(size_t)bh * L + row], b = nD[(size_t)bh * L + row];
+        nl[qc] = f32x4v{a, a, a, a};
+        nd[qc] = f32x4v{b, b, b, b};
         dq[qc] = f32x4v{0.f, 0.f, 0.f, 0.f};
     }
-    f32x4v kn[2], vn[2], tn[2];
-#pragma unroll
-    for (int kt = 0; kt < 2; ++kt) {
-        kn[kt] = *reinterpret_cast<const f32x4v*>(Kh + (size_t)(16 * kt + c) * DH + 4 * g);
-        vn[kt] = *reinterpret_cast<const f32x4v*>(Vh + (size_t)(16 * kt + c) * DH + 4 * g);
-        tn[kt] = *reinterpret_cast<const f32x4v*>(Kth + (size_t)c * L + 16 * kt + 4 * g);
-    }
-    const int nkb = RAGGED ? (Lv + KB - 1) / KB : L / KB;
-    for (int kblk = 0; kblk < nkb; ++kblk) {
-        const f32x4v kf[2] = {kn[0], kn[1]}, vf[2] = {vn[0], vn[1]}, tf[2] = {tn[0], tn[1]};
-        const int nx = kblk + 1 < nkb ? kblk + 1 : kblk;
+    auto load = [&](int blk, f32x4v k[2], f32x4v v[2], f32x4v t[2], uint32_t& w) {
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt) {
-            kn[kt] = *reinterpret_cast<const f32x4v*>(Kh + (size_t)(nx * KB + 16 * kt + c) * DH + 4 * g);
-            vn[kt] = *reinterpret_cast<const f32x4v*>(Vh + (size_t)(nx * KB + 16 * kt + c) * DH + 4 * g);
-            tn[kt] = *reinterpret_cast<const f32x4v*>(Kth + (size_t)c * L + nx * KB + 16 * kt + 4 * g);
+            k[kt] = *reinterpret_cast<const f32x4v*>(Kh + (size_t)(blk * KB + 16 * kt + c) * DH + 4 * g);
+            v[kt] = *reinterpret_cast<const f32x4v*>(Vh + (size_t)(blk * KB + 16 * kt + c) * DH + 4 * g);
+            t[kt] = *reinterpret_cast<const f32x4v*>(Kth + (size_t)c * L + blk * KB + 16 * kt + 4 * g);
         }
+        if (DROP) w = kp[(size_t)blk * 64];
+    };
+    auto block = [&](const f32x4v kf[2], const f32x4v vf[2], const f32x4v tf[2], uint32_t w, int kblk) {
         f32x4v s[2][2], dp[2][2];
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int qc = 0; qc < 2; ++qc) { s[kt][qc] = f32x4v{0.f, 0.f, 0.f, 0.f}; dp[kt][qc] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+            for (int qc = 0; qc < 2; ++qc) {
+                s[kt][qc] = MFMA16(kf[kt][0], qf[qc][0], nl[qc]);            // S^T[key][query] - lse
+                dp[kt][qc] = MFMA16(vf[kt][0], gf[qc][0], nd[qc]);           // dPd^T[key][query] - keep D
+            }
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 1; t < 4; ++t)
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int qc = 0; qc < 2; ++qc) {
-                    s[kt][qc] = MFMA16(kf[kt][t], qf[qc][t], s[kt][qc]);        // S^T[key][query]
-                    dp[kt][qc] = MFMA16(vf[kt][t], gf[qc][t], dp[kt][qc]);      // dPd^T[key][query]
+                    s[kt][qc] = MFMA16(kf[kt][t], qf[qc][t], s[kt][qc]);
+                    dp[kt][qc] = MFMA16(vf[kt][t], gf[qc][t], dp[kt][qc]);
                 }
-        if (RAGGED && (kblk + 1) * KB > Lv) {                            // padded keys: P = exp2(-inf) = 0, so dS = 0
+        if (RAGGED && (kblk + 1) * KB > Lv) {
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -367,27 +480,16 @@ void k_attn_bwd_dq(const float* __restrict__ Q, const float* __restrict__ K, con
         }
 #pragma unroll
         for (int qc = 0; qc < 2; ++qc) {
-            const uint32_t base = (uint32_t)(q0 + 16 * qc + c) * (uint32_t)L + (uint32_t)(kblk * KB + 4 * g);
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) dp[kt][qc][r] *= inv_keep;
-            if (thresh) {
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int r = 0; r < 4; r += 2) {                  // base is even: (r, r + 1) share a hash
-                        const uint32_t h = pair_hash(base + 16 * kt + r, hkey);
-                        if ((h & 0xffffU) < t16) dp[kt][qc][r] = 0.f;
-                        if ((h >> 16) < t16) dp[kt][qc][r + 1] = 0.f;
-                    }
-            }
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = fast_exp2(s[kt][qc][r] - lse_q[qc]);
-                    s[kt][qc][r] = p * (dp[kt][qc][r] - d_q[qc]);                // dS
+                    float a = dp[kt][qc][r];
+                    if (DROP) {
+                        const uint32_t km = (uint32_t)__builtin_amdgcn_sbfe((int)w, 15 - (8 * qc + 4 * kt + r), 1);   // all ones = kept
+                        a = __uint_as_float((km & __float_as_uint(a)) | (~km & __float_as_uint(nd[qc][0])));
+                    }
+                    s[kt][qc][r] = fast_exp2(s[kt][qc][r]) * a;
                 }
         }
 #pragma unroll
@@ -395,21 +497,36 @@ void k_attn_bwd_dq(const float* __restrict__ Q, const float* __restrict__ K, con
 #pragma unroll
             for (int r = 0; r < 4; ++r)
 #pragma unroll
-                for (int qc = 0; qc < 2; ++qc) dq[qc] = MFMA16(tf[kt][r], s[kt][qc][r], dq[qc]);   // dQ^T[d][query]
+                for (int qc = 0; qc < 2; ++qc) dq[qc] = MFMA16(tf[kt][r], s[kt][qc][r], dq[qc]);
+    };
+    const int nkb = RAGGED ? (Lv + KB - 1) / KB : L / KB;
+    f32x4v kA[2], vA[2], tA[2], kB[2], vB[2], tB[2];
+    uint32_t wA = 0, wB = 0;
+    load(0, kA, vA, tA, wA);
+    int kblk = 0;
+    for (; kblk + 1 < nkb; kblk += 2) {                   // branch-free body: two blocks on ping-pong registers
+        load(kblk + 1, kB, vB, tB, wB);
+        __builtin_amdgcn_sched_barrier(0);               // the loads of the next block are issued BEFORE this block's work
+        block(kA, vA, tA, wA, kblk);
+        load(kblk + 2 < nkb ? kblk + 2 : kblk, kA, vA, tA, wA);
+        __builtin_amdgcn_sched_barrier(0);
+        block(kB, vB, tB, wB, kblk + 1);
     }
+    if (kblk < nkb) block(kA, vA, tA, wA, kblk);
     const int Dm = H * DH;
     const int b = bh / H, hd = bh % H;
+    const float sc = 0.25f * inv_keep;
 #pragma unroll
     for (int qc = 0; qc < 2; ++qc)
-        *reinterpret_cast<f32x4v*>(dqkv + ((size_t)b * L + q0 + 16 * qc + c) * 3 * Dm + hd * DH + 4 * g) = dq[qc] * 0.25f;
+        *reinterpret_cast<f32x4v*>(dqkv + ((size_t)b * L + q0 + 16 * qc + c) * 3 * Dm + hd * DH + 4 * g) = dq[qc] * sc;
 }
 
-template <bool RAGGED>
+template <bool RAGGED, bool DROP>
 __global__ __launch_bounds__(256)
 void k_attn_bwd_dkv(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
-                    const float* __restrict__ Qt, const float* __restrict__ dOh, const float* __restrict__ dOt,
-                    const float* __restrict__ lse, const float* __restrict__ Drow, float* __restrict__ dqkv, int L, int Lv,
-                    int H, uint32_t seed, uint32_t thresh, float inv_keep) {
+                      const float* __restrict__ Qt, const float* __restrict__ dOh, const float* __restrict__ dOt,
+                      const float* __restrict__ nlse, const float* __restrict__ nD, float* __restrict__ dqkv, int L, int Lv,
+                      int H, const uint16_t* __restrict__ keep, float inv_keep) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = lane & 15, g = lane >> 4;
     const int bh = blockIdx.y;
@@ -419,10 +536,13 @@ void k_attn_bwd_dkv(const float* __restrict__ Q, const float* __restrict__ K, co
     const float* Gh = dOh + hb;
     const float* Qth = Qt + hb;
     const float* Gth = dOt + hb;
-    const float* lse_h = lse + (size_t)bh * L;
-    const float* d_h = Drow + (size_t)bh * L;
-    const uint32_t hkey = site_key(seed, (uint32_t)bh);
-    const uint32_t t16 = thresh >> 16;                 // p * 2^16: the 16-bit threshold of the pair hash
+    const float* nl_h = nlse + (size_t)bh * L;
+    const float* nd_h = nD + (size_t)bh * L;
+    // keep bits: the forward wave of query block qb left, for key block kb, one halfword per lane (c_q + 16 g_k) with decision
+    // (qc, kt, r) in bit 15 - (8 qc + 4 kt + r), key = 16 kt + 4 g_k + r.  This lane (key c, query rows 4g + r') needs, for its key
+    // 16 kc + c, the halfwords of forward lanes 16 (c >> 2) + 4g + r', r' = 0..3: eight consecutive bytes
+    const uint16_t* kp = keep + ((size_t)bh * (L / KB) * (L / KB) + (k0 >> 5)) * 64 + 16 * (c >> 2) + 4 * g;
+    const uint32_t ksh = 3 - (c & 3);              // after this shift the bit of (qt, kc) sits at 12 - 8 qt - 4 kc of every halfword
 
     f32x4v kf[2], vf[2], dv[2], dk[2];
 #pragma unroll
@@ -432,71 +552,54 @@ void k_attn_bwd_dkv(const float* __restrict__ Q, const float* __restrict__ K, co
         dv[kc] = f32x4v{0.f, 0.f, 0.f, 0.f};
         dk[kc] = f32x4v{0.f, 0.f, 0.f, 0.f};
     }
-    f32x4v qn[2], gn[2], qtn[2], gtn[2];
+    struct QB { f32x4v q[2], gq[2], qt[2], gt[2], nl[2], nd[2]; };
+    auto load = [&](int blk, QB& x) {
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
-        qn[qt] = *reinterpret_cast<const f32x4v*>(Qh + (size_t)(16 * qt + c) * DH + 4 * g);
-        gn[qt] = *reinterpret_cast<const f32x4v*>(Gh + (size_t)(16 * qt + c) * DH + 4 * g);
-        qtn[qt] = *reinterpret_cast<const f32x4v*>(Qth + (size_t)c * L + 16 * qt + 4 * g);
-        gtn[qt] = *reinterpret_cast<const f32x4v*>(Gth + (size_t)c * L + 16 * qt + 4 * g);
-    }
-    // RAGGED: a padded query row has dO = 0 and Drow = 0 (nothing downstream reads its output), so it adds nothing to dK / dV
-    // and its blocks are skipped; a padded KEY column of this wave's tile gets P = 0 through a -inf score
-    const int nqb = RAGGED ? (Lv + KB - 1) / KB : L / KB;
+        for (int qt = 0; qt < 2; ++qt) {
+            x.q[qt] = *reinterpret_cast<const f32x4v*>(Qh + (size_t)(blk * KB + 16 * qt + c) * DH + 4 * g);
+            x.gq[qt] = *reinterpret_cast<const f32x4v*>(Gh + (size_t)(blk * KB + 16 * qt + c) * DH + 4 * g);
+            x.qt[qt] = *reinterpret_cast<const f32x4v*>(Qth + (size_t)c * L + blk * KB + 16 * qt + 4 * g);
+            x.gt[qt] = *reinterpret_cast<const f32x4v*>(Gth + (size_t)c * L + blk * KB + 16 * qt + 4 * g);
+            x.nl[qt] = *reinterpret_cast<const f32x4v*>(nl_h + blk * KB + 16 * qt + 4 * g);      // per query row 16 qt + 4g + r
+            x.nd[qt] = *reinterpret_cast<const f32x4v*>(nd_h + blk * KB + 16 * qt + 4 * g);
+        }
+    };
     const bool kdead[2] = {RAGGED && k0 + c >= Lv, RAGGED && k0 + 16 + c >= Lv};
-    for (int qblk = 0; qblk < nqb; ++qblk) {
-        const f32x4v qf[2] = {qn[0], qn[1]}, gf[2] = {gn[0], gn[1]}, qtf[2] = {qtn[0], qtn[1]}, gtf[2] = {gtn[0], gtn[1]};
-        f32x4v ls[2], dr[2];                                             // per query row 16 qt + 4g + r
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            ls[qt] = *reinterpret_cast<const f32x4v*>(lse_h + qblk * KB + 16 * qt + 4 * g);
-            dr[qt] = *reinterpret_cast<const f32x4v*>(d_h + qblk * KB + 16 * qt + 4 * g);
-        }
-        const int nx = qblk + 1 < nqb ? qblk + 1 : qblk;
-#pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            qn[qt] = *reinterpret_cast<const f32x4v*>(Qh + (size_t)(nx * KB + 16 * qt + c) * DH + 4 * g);
-            gn[qt] = *reinterpret_cast<const f32x4v*>(Gh + (size_t)(nx * KB + 16 * qt + c) * DH + 4 * g);
-            qtn[qt] = *reinterpret_cast<const f32x4v*>(Qth + (size_t)c * L + nx * KB + 16 * qt + 4 * g);
-            gtn[qt] = *reinterpret_cast<const f32x4v*>(Gth + (size_t)c * L + nx * KB + 16 * qt + 4 * g);
-        }
+    auto loadw = [&](int blk) -> uint2 { return *reinterpret_cast<const uint2*>(kp + (size_t)blk * (L / KB) * 64); };
+    auto block = [&](const QB& x, const uint2 w, int qblk) {
         f32x4v s[2][2], dp[2][2];                                        // [qt][kc]: rows = queries, columns = keys
+        const uint32_t wsh[2] = {DROP ? w.x >> ksh : 0u, DROP ? w.y >> ksh : 0u};
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
-            for (int kc = 0; kc < 2; ++kc) { s[qt][kc] = f32x4v{0.f, 0.f, 0.f, 0.f}; dp[qt][kc] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+            for (int kc = 0; kc < 2; ++kc) {
+                s[qt][kc] = MFMA16(x.q[qt][0], kf[kc][0], x.nl[qt]);         // S[query][key] - lse[query]
+                dp[qt][kc] = MFMA16(x.gq[qt][0], vf[kc][0], x.nd[qt]);       // dPd[query][key] - keep D[query]
+            }
 #pragma unroll
-        for (int t = 0; t < 4; ++t)
+        for (int t = 1; t < 4; ++t)
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
                 for (int kc = 0; kc < 2; ++kc) {
-                    s[qt][kc] = MFMA16(qf[qt][t], kf[kc][t], s[qt][kc]);        // S[query][key]
-                    dp[qt][kc] = MFMA16(gf[qt][t], vf[kc][t], dp[qt][kc]);      // dPd[query][key]
+                    s[qt][kc] = MFMA16(x.q[qt][t], kf[kc][t], s[qt][kc]);
+                    dp[qt][kc] = MFMA16(x.gq[qt][t], vf[kc][t], dp[qt][kc]);
                 }
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
             for (int kc = 0; kc < 2; ++kc) {
-                // Here a lane holds four QUERIES of one key, so the pair hash (keys 2j, 2j+1 of a query) is shared with the
-                // neighbouring lane c ^ 1, not inside the lane: the even lane hashes queries r = 0, 1, the odd lane r = 2, 3,
-                // and they swap (one DPP move each): two hashes per lane for four elements here too.
-                uint32_t hq[4] = {0xffffffffU, 0xffffffffU, 0xffffffffU, 0xffffffffU};
-                if (thresh) {
-                    const int odd = c & 1;
-                    const uint32_t ih0 = (uint32_t)(qblk * KB + 16 * qt + 4 * g + 2 * odd) * (uint32_t)(L >> 1) +
-                                         (uint32_t)((k0 + 16 * kc + c) >> 1);      // idx >> 1 = query * (L / 2) + key / 2
-                    const uint32_t ha = mix32(ih0 ^ hkey), hb = mix32((ih0 + (uint32_t)(L >> 1)) ^ hkey);
-                    const uint32_t pa = (uint32_t)__shfl_xor((int)ha, 1, 64), pb = (uint32_t)__shfl_xor((int)hb, 1, 64);
-                    hq[0] = odd ? pa : ha; hq[1] = odd ? pb : hb; hq[2] = odd ? ha : pa; hq[3] = odd ? hb : pb;
-                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float p = (RAGGED && kdead[kc]) ? 0.f : fast_exp2(s[qt][kc][r] - ls[qt][r]);
-                    float pd = p, gd = dp[qt][kc][r] * inv_keep;
-                    if (thresh && __builtin_amdgcn_ubfe(hq[r], 16U * (c & 1), 16U) < t16) { pd = 0.f; gd = 0.f; }
-                    s[qt][kc][r] = p * (gd - dr[qt][r]);       // dS
-                    dp[qt][kc][r] = pd;                         // Pd (the 1/keep factor is applied once at the end)
+                    const float p = (RAGGED && kdead[kc]) ? 0.f : fast_exp2(s[qt][kc][r]);
+                    float a = dp[qt][kc][r], pd = p;
+                    if (DROP) {
+                        const uint32_t km = (uint32_t)__builtin_amdgcn_sbfe((int)wsh[r >> 1], 16 * (r & 1) + 12 - 8 * qt - 4 * kc, 1);
+                        a = __uint_as_float((km & __float_as_uint(a)) | (~km & __float_as_uint(x.nd[qt][r])));
+                        pd = __uint_as_float(km & __float_as_uint(p));
+                    }
+                    s[qt][kc][r] = p * a;                                   // dS / inv_keep
+                    dp[qt][kc][r] = pd;                                     // Pd * keep
                 }
             }
 #pragma unroll
@@ -505,17 +608,37 @@ void k_attn_bwd_dkv(const float* __restrict__ Q, const float* __restrict__ K, co
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int kc = 0; kc < 2; ++kc) {
-                    dv[kc] = MFMA16(gtf[qt][r], dp[qt][kc][r], dv[kc]);          // dV^T[d][key]
-                    dk[kc] = MFMA16(qtf[qt][r], s[qt][kc][r], dk[kc]);           // dK^T[d][key]
+                    dv[kc] = MFMA16(x.gt[qt][r], dp[qt][kc][r], dv[kc]);          // dV^T[d][key]
+                    dk[kc] = MFMA16(x.qt[qt][r], s[qt][kc][r], dk[kc]);           // dK^T[d][key]
                 }
+    };
+    const int nqb = RAGGED ? (Lv + KB - 1) / KB : L / KB;
+    QB A, Bq;
+    load(0, A);
+    // the keep bits are cold in every cache (each 128-byte line is read once, by one wave) and vector loads retire in order:
+    // they are fetched two iterations (four blocks) ahead so that no operand load ever queues behind one of them
+    uint2 wA = {0u, 0u}, wB = {0u, 0u}, wA2 = {0u, 0u}, wB2 = {0u, 0u}, wA3 = {0u, 0u}, wB3 = {0u, 0u};
+    auto clampq = [&](int b) { return b < nqb ? b : nqb - 1; };
+    if (DROP) { wA = loadw(0); wB = loadw(clampq(1)); wA2 = loadw(clampq(2)); wB2 = loadw(clampq(3)); }
+    int qblk = 0;
+    for (; qblk + 1 < nqb; qblk += 2) {
+        load(qblk + 1, Bq);
+        if (DROP) { wA3 = loadw(clampq(qblk + 4)); wB3 = loadw(clampq(qblk + 5)); }
+        __builtin_amdgcn_sched_barrier(0);
+        block(A, wA, qblk);
+        load(qblk + 2 < nqb ? qblk + 2 : qblk, A);
+        __builtin_amdgcn_sched_barrier(0);
+        block(Bq, wB, qblk + 1);
+        wA = wA2; wB = wB2; wA2 = wA3; wB2 = wB3;
     }
+    if (qblk < nqb) block(A, wA, qblk);
     const int Dm = H * DH;
     const int b = bh / H, hd = bh % H;
-    const float ln2 = 0.69314718055994530942f;            // Q carries scale * log2 e
+    const float ln2 = 0.69314718055994530942f;
 #pragma unroll
     for (int kc = 0; kc < 2; ++kc) {
         float* dst = dqkv + ((size_t)b * L + k0 + 16 * kc + c) * 3 * Dm + hd * DH + 4 * g;
-        *reinterpret_cast<f32x4v*>(dst + Dm) = dk[kc] * ln2;
+        *reinterpret_cast<f32x4v*>(dst + Dm) = dk[kc] * (ln2 * inv_keep);
         *reinterpret_cast<f32x4v*>(dst + 2 * Dm) = dv[kc] * inv_keep;
     }
 }
@@ -528,6 +651,31 @@ __global__ void k_attn_dropout_mask(float* __restrict__ mask, int64_t BH, int L,
         const int64_t bh = i / ((int64_t)L * L);
         const uint32_t idx = (uint32_t)(i - bh * (int64_t)L * L);
         mask[i] = pair_dropped(idx, site_key(seed, (uint32_t)bh), thresh >> 16) ? 0.f : 1.f;
+    }
+}
+
+// The keep bits exactly as k_attention<true> stores them ([bh][query tile of 32][key block of 32][lane] halfwords, decision
+// d = 8 qc + 4 kt + r of lane (c, g) - query 16 qc + c, key 16 kt + 4 g + r - in bit 15 - d): for a backward call whose forward
+// workspace was reused in between, and for the test that pins the forward's stores to the formula.  One wave per halfword line.
+__global__ __launch_bounds__(256)
+void k_attn_keep_bits(uint16_t* __restrict__ keep, int64_t lines, int L, uint32_t seed, uint32_t thresh) {
+    const int lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+    const int nb = L / KB;
+    const uint32_t t16 = thresh >> 16;
+    for (int64_t line = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); line < lines; line += (int64_t)gridDim.x * 4) {
+        const int kb = (int)(line % nb), qw = (int)((line / nb) % nb);
+        const uint32_t hkey = site_key(seed, (uint32_t)(line / ((int64_t)nb * nb)));
+        uint32_t acc = 0;
+#pragma unroll
+        for (int qc = 0; qc < 2; ++qc)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const uint32_t idx = (uint32_t)(qw * 32 + 16 * qc + c) * (uint32_t)L + (uint32_t)(kb * KB + 16 * kt + 4 * g + r);
+                    acc = (acc << 1) | (pair_dropped(idx, hkey, t16) ? 0u : 1u);
+                }
+        keep[line * 64 + lane] = (uint16_t)acc;
     }
 }
 
@@ -670,10 +818,10 @@ extern "C" int be_attention_f32(const float* qkv, float* out, float* workspace, 
     float* part = workspace + 3 * n;
     if (l_valid == L)
         hipLaunchKernelGGL((k_attention<false, false>), dim3(L / 128, B * H, nz), dim3(256), 0, s, Q, K, Vt, out, (float*)nullptr,
-                           L, L, H, 0u, 0u, 1.0f, part);
+                           L, L, H, 0u, 0u, 1.0f, part, (uint16_t*)nullptr);
     else
         hipLaunchKernelGGL((k_attention<false, true>), dim3(L / 128, B * H, nz), dim3(256), 0, s, Q, K, Vt, out, (float*)nullptr,
-                           L, l_valid, H, 0u, 0u, 1.0f, part);
+                           L, l_valid, H, 0u, 0u, 1.0f, part, (uint16_t*)nullptr);
     if (nz > 1) {
         const int64_t total = (int64_t)B * H * L * 4;
         hipLaunchKernelGGL(k_attn_combine, dim3((unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256)), dim3(256), 0, s,
@@ -683,11 +831,14 @@ extern "C" int be_attention_f32(const float* qkv, float* out, float* workspace, 
 }
 
 namespace {
-struct TrainWs { float *Q, *K, *V, *Qt, *Kt, *Vt, *dOh, *dOt, *Drow; };
+// nD = -keep * rowsum(dO o O) and nlse = -lse (the accumulator start values of the backward), keep = the dropout keep bits
+struct TrainWs { float *Q, *K, *V, *Qt, *Kt, *Vt, *dOh, *dOt, *nD, *nlse; uint16_t* keep; };
 TrainWs train_ws(float* w, int B, int L, int H) {
-    const size_t n = (size_t)B * H * L * DH;
-    return {w, w + n, w + 2 * n, w + 3 * n, w + 4 * n, w + 5 * n, w + 6 * n, w + 7 * n, w + 8 * n};
+    const size_t n = (size_t)B * H * L * DH, r = (size_t)B * H * L;
+    return {w, w + n, w + 2 * n, w + 3 * n, w + 4 * n, w + 5 * n, w + 6 * n, w + 7 * n, w + 8 * n, w + 8 * n + r,
+            reinterpret_cast<uint16_t*>(w + 8 * n + 2 * r)};
 }
+size_t keep_lines(int B, int L, int H) { return (size_t)B * H * (L / KB) * (L / KB); }      // 64 halfwords each
 int attn_args_ok(const char* who, int B, int L, int H, float p, int l_valid = -1) {
     BE_REQUIRE(B > 0 && H > 0 && L > 0 && L % 128 == 0 && L <= 65536, "%s: L must be a multiple of 128, <= 65536 (got %d)", who, L);
     BE_REQUIRE(l_valid == -1 || (l_valid > L - 128 && l_valid <= L), "%s: l_valid %d outside (L - 128, L] for L = %d", who, l_valid, L);
@@ -697,7 +848,7 @@ int attn_args_ok(const char* who, int B, int L, int H, float p, int l_valid = -1
 }  // namespace
 
 extern "C" size_t be_attention_train_workspace_floats(int B, int L, int H) {
-    return (size_t)8 * B * H * L * DH + (size_t)B * H * L;
+    return (size_t)8 * B * H * L * DH + (size_t)2 * B * H * L + keep_lines(B, L, H) * 32;      // 64 halfwords = 32 floats per line
 }
 
 extern "C" int be_attention_train_fwd_f32(const float* qkv, float* out, float* lse, float* workspace, int B, int L, int l_valid,
@@ -712,10 +863,10 @@ extern "C" int be_attention_train_fwd_f32(const float* qkv, float* out, float* l
                        0.25f * 1.44269504088896340736f);
     if (l_valid == L)
         hipLaunchKernelGGL((k_attention<true, false>), dim3(L / 128, B * H), dim3(256), 0, s, w.Q, w.K, w.Vt, out, lse, L, L, H, seed,
-                           drop_threshold(dropout_p), 1.0f / (1.0f - dropout_p), (float*)nullptr);
+                           drop_threshold(dropout_p), 1.0f / (1.0f - dropout_p), (float*)nullptr, w.keep);
     else
         hipLaunchKernelGGL((k_attention<true, true>), dim3(L / 128, B * H), dim3(256), 0, s, w.Q, w.K, w.Vt, out, lse, L, l_valid, H,
-                           seed, drop_threshold(dropout_p), 1.0f / (1.0f - dropout_p), (float*)nullptr);
+                           seed, drop_threshold(dropout_p), 1.0f / (1.0f - dropout_p), (float*)nullptr, w.keep);
     return be::check_launch("be_attention_train_fwd_f32");
 }
 
@@ -729,24 +880,29 @@ extern "C" int be_attention_bwd_f32(const float* qkv, const float* out, const fl
     hipStream_t s = be::as_stream(stream);
     const TrainWs w = train_ws(workspace, B, L, H);
     int64_t g = ((int64_t)B * H * L + 255) / 256; if (g > 8192) g = 8192;
-    if (!operands_ready)          // the workspace of this layer's forward call was reused in between: split q/k/v again
-        hipLaunchKernelGGL(k_qkv_split_train, dim3((unsigned)g), dim3(256), 0, s, qkv, w.Q, w.K, w.V, w.Qt, w.Kt, w.Vt, B, L,
-                           H, 0.25f * 1.44269504088896340736f);
-    int64_t g2 = g;
-    hipLaunchKernelGGL(k_dout_prep, dim3((unsigned)g2), dim3(256), 0, s, dout, out, w.dOh, w.dOt, w.Drow, B, L, H);
     const uint32_t th = drop_threshold(dropout_p);
     const float ik = 1.0f / (1.0f - dropout_p);
-    if (l_valid == L) {
-        hipLaunchKernelGGL(k_attn_bwd_dq<false>, dim3(L / 128, B * H), dim3(256), 0, s, w.Q, w.K, w.V, w.Kt, w.dOh, lse, w.Drow, dqkv,
-                           L, L, H, seed, th, ik);
-        hipLaunchKernelGGL(k_attn_bwd_dkv<false>, dim3(L / 128, B * H), dim3(256), 0, s, w.Q, w.K, w.V, w.Qt, w.dOh, w.dOt, lse,
-                           w.Drow, dqkv, L, L, H, seed, th, ik);
-    } else {
-        hipLaunchKernelGGL(k_attn_bwd_dq<true>, dim3(L / 128, B * H), dim3(256), 0, s, w.Q, w.K, w.V, w.Kt, w.dOh, lse, w.Drow, dqkv,
-                           L, l_valid, H, seed, th, ik);
-        hipLaunchKernelGGL(k_attn_bwd_dkv<true>, dim3(L / 128, B * H), dim3(256), 0, s, w.Q, w.K, w.V, w.Qt, w.dOh, w.dOt, lse,
-                           w.Drow, dqkv, L, l_valid, H, seed, th, ik);
+    if (!operands_ready) {        // the workspace of this layer's forward call was reused in between: split q/k/v again, and
+        //                           write the keep bits the forward left there again
+        hipLaunchKernelGGL(k_qkv_split_train, dim3((unsigned)g), dim3(256), 0, s, qkv, w.Q, w.K, w.V, w.Qt, w.Kt, w.Vt, B, L,
+                           H, 0.25f * 1.44269504088896340736f);
+        if (th) {
+            const int64_t lines = (int64_t)keep_lines(B, L, H);
+            hipLaunchKernelGGL(k_attn_keep_bits, dim3((unsigned)((lines + 3) / 4 > 16384 ? 16384 : (lines + 3) / 4)), dim3(256), 0, s,
+                               w.keep, lines, L, seed, th);
+        }
     }
+    hipLaunchKernelGGL(k_dout_prep, dim3((unsigned)g), dim3(256), 0, s, dout, out, lse, w.dOh, w.dOt, w.nD, w.nlse, 1.0f - dropout_p,
+                       B, L, H);
+    const dim3 grid(L / 128, B * H);
+#define BE_ATTN_BWD(RAG, DROP, LV)                                                                                              \
+    hipLaunchKernelGGL((k_attn_bwd_dq<RAG, DROP>), grid, dim3(256), 0, s, w.Q, w.K, w.V, w.Kt, w.dOh, w.nlse, w.nD, dqkv, L, LV, \
+                       H, w.keep, ik);                                                                                          \
+    hipLaunchKernelGGL((k_attn_bwd_dkv<RAG, DROP>), grid, dim3(256), 0, s, w.Q, w.K, w.V, w.Qt, w.dOh, w.dOt, w.nlse, w.nD,      \
+                       dqkv, L, LV, H, w.keep, ik)
+    if (l_valid == L) { if (th) { BE_ATTN_BWD(false, true, L); } else { BE_ATTN_BWD(false, false, L); } }
+    else { if (th) { BE_ATTN_BWD(true, true, l_valid); } else { BE_ATTN_BWD(true, false, l_valid); } }
+#undef BE_ATTN_BWD
     return be::check_launch("be_attention_bwd_f32");
 }
 
@@ -758,6 +914,19 @@ extern "C" int be_attention_dropout_mask_f32(float* mask, int B, int L, int H, f
     hipLaunchKernelGGL(k_attn_dropout_mask, dim3((unsigned)g), dim3(256), 0, be::as_stream(stream), mask, (int64_t)B * H, L,
                        seed, drop_threshold(dropout_p));
     return be::check_launch("be_attention_dropout_mask_f32");
+}
+
+extern "C" size_t be_attention_train_keep_offset_floats(int B, int L, int H) {
+    return (size_t)8 * B * H * L * DH + (size_t)2 * B * H * L;
+}
+
+extern "C" int be_attention_keep_bits_u16(uint16_t* keep, int B, int L, int H, float dropout_p, uint32_t seed, void* stream) {
+    BE_REQUIRE(keep, "be_attention_keep_bits_u16: null pointer");
+    if (int rc = attn_args_ok("be_attention_keep_bits_u16", B, L, H, dropout_p)) return rc;
+    const int64_t lines = (int64_t)keep_lines(B, L, H);
+    hipLaunchKernelGGL(k_attn_keep_bits, dim3((unsigned)((lines + 3) / 4 > 16384 ? 16384 : (lines + 3) / 4)), dim3(256), 0,
+                       be::as_stream(stream), keep, lines, L, seed, drop_threshold(dropout_p));
+    return be::check_launch("be_attention_keep_bits_u16");
 }
 
 extern "C" int be_dropout_f32(const float* x, const float* gate, float* y, int64_t n, float dropout_p, uint32_t seed,

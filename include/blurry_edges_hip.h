@@ -425,20 +425,26 @@ int be_add_pe_f32(float* x, const float* pe, int64_t batches, int64_t per_batch,
  * kept iff hash(i, seed, site) >= p * 2^32, so the backward kernels re-derive the masks and nothing is stored.
  * ------------------------------------------------------------------------------------------------- */
 /* Attention forward for training: out as be_attention_f32 with dropout on the probabilities (site = batch*H + head,
- * element = query*L + key), lse [B*H, L] = log2-sum-exp of each score row (saved for the backward). */
+ * element = query*L + key), lse [B*H, L] = log2-sum-exp of each score row (saved for the backward).  The workspace keeps, for
+ * the backward call of the same layer, the split q / k / v and one keep bit per probability (B*H*L*L/8 bytes, from float
+ * offset be_attention_train_keep_offset_floats on: [B*H][L/32 query tiles][L/32 key blocks][64 lanes] halfwords). */
 size_t be_attention_train_workspace_floats(int B, int L, int H);
 int be_attention_train_fwd_f32(const float* qkv, float* out, float* lse, float* workspace, int B, int L, int l_valid, int H,
                                float dropout_p, uint32_t seed, void* stream);
 /* Attention backward: dout [B*L, H*16] -> dqkv [B*L, 3*H*16]; probabilities are recomputed from qkv and lse
- * (no [L,L] tensor is ever stored); deterministic (no atomics).  Same workspace size as the forward.
+ * (no [L,L] float tensor is ever stored); deterministic (no atomics).  Same workspace size as the forward.
  * operands_ready != 0: `workspace` is the buffer the forward call of this layer used and nothing wrote to it since
- * (its split q/k/v are reused); 0: they are split again from qkv.  l_valid as in be_attention_f32: rows >= l_valid of
+ * (its split q/k/v and keep bits are reused); 0: they are produced again from qkv and the seed.  l_valid as in be_attention_f32: rows >= l_valid of
  * dout must be zero (they are when the caller slices the padded output), and dqkv comes out zero there. */
 int be_attention_bwd_f32(const float* qkv, const float* out, const float* lse, const float* dout, float* dqkv,
                          float* workspace, int operands_ready, int B, int L, int l_valid, int H, float dropout_p, uint32_t seed,
                          void* stream);
 /* The keep mask the two functions above apply, [B*H, L, L] in {0,1} (test hook; small L only). */
 int be_attention_dropout_mask_f32(float* mask, int B, int L, int H, float dropout_p, uint32_t seed, void* stream);
+/* The same decisions in the packed layout the forward leaves in its workspace (B*H*L*L/16 halfwords), from the formula:
+ * what be_attention_bwd_f32 regenerates when operands_ready == 0, and what the tests compare the forward's stores with. */
+size_t be_attention_train_keep_offset_floats(int B, int L, int H);
+int be_attention_keep_bits_u16(uint16_t* keep, int B, int L, int H, float dropout_p, uint32_t seed, void* stream);
 /* y = dropout(x) = x * keep / (1-p); with gate != NULL additionally zero where gate <= 0, which makes it the
  * backward of dropout(relu(.)) given the ReLU output.  y may alias x.  n < 2^32. */
 int be_dropout_f32(const float* x, const float* gate, float* y, int64_t n, float dropout_p, uint32_t seed, uint32_t site,

@@ -359,6 +359,73 @@ def test_attention_train_forward_backward_vs_fp64_autograd(p):
         from be_hip import native
         inf, _ = native.attention(qkv, B, L, H)
         assert torch.equal(inf, out)
+    else:
+        # the keep bits the forward left in its workspace (what the backward kernels read) are the formula's decisions, and they
+        # are the mask of the test hook in another layout: lane (c, g) of tile (qw, kb), bit 15 - (8 qc + 4 kt + r) <-> query
+        # 32 qw + 16 qc + c, key 32 kb + 16 kt + 4 g + r
+        out2, lse2, ws2 = tg.attention_train_fwd(qkv, B, L, H, p, seed)
+        stored = tg.workspace_keep_bits(ws2, B, L, H)
+        assert torch.equal(stored, tg.attention_keep_bits(B, L, H, p, seed, DEV))
+        bits = (stored.int() & 0xffff).cpu().numpy().astype(np.uint32)            # [BH, qw, kb, lane]
+        m = mask.view(B * H, L, L).cpu().numpy()
+        lane = np.arange(64)
+        c, g = lane & 15, lane >> 4
+        for qc in range(2):
+            for kt in range(2):
+                for r in range(4):
+                    got = (bits >> (15 - (8 * qc + 4 * kt + r))) & 1                   # [BH, qw, kb, lane]
+                    qi = 32 * np.arange(L // 32)[:, None, None] + 16 * qc + c[None, None, :]
+                    ki = 32 * np.arange(L // 32)[None, :, None] + 16 * kt + 4 * g[None, None, :] + r
+                    assert np.array_equal(got, m[:, qi, ki].astype(np.uint32))
+
+
+def test_attention_kernels_are_run_to_run_bit_identical():
+    """Twenty runs of the inference kernel (one pair: four key slices + combine; batch 8: one slice) and of the training forward /
+    backward give the same bits (no atomics, no timing-dependent register reads)."""
+    from be_hip import native, train_global_stage as tg
+    L, H = 4096, 8
+    for B in (1, 4):
+        qkv = torch.from_numpy(synth.hash_normal(6, f"attn_det_{B}", (B * L, 3 * H * 16)).astype(np.float32) * 1.5).to(DEV)
+        dout = torch.from_numpy(synth.hash_normal(7, f"attn_det_do_{B}", (B * L, H * 16)).astype(np.float32)).to(DEV)
+        first = None
+        for _ in range(20):
+            inf, _ = native.attention(qkv, B, L, H)
+            out, lse, ws = tg.attention_train_fwd(qkv, B, L, H, 0.1, 11)
+            dqkv, _ = tg.attention_bwd(qkv, out, lse, dout, B, L, H, 0.1, 11, ws, operands_ready=True)
+            cur = (inf.clone(), out.clone(), lse.clone(), dqkv.clone())
+            if first is None:
+                first = cur
+            else:
+                assert all(torch.equal(a, b) for a, b in zip(first, cur))
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_attention_scores_far_above_the_first_block_take_the_running_maximum_path(p):
+    """The forward's softmax reference is fixed from the first key block; keys whose scores sit more than 60 binades above it send
+    the wave through the textbook running-maximum loop.  Both paths against the float64 reference, inference and training."""
+    from be_hip import native, train_global_stage as tg
+    from conftest import relmax
+    B, L, H, seed = 1, 256, 8, 99
+    x = synth.hash_normal(5, "attn_qkv_big", (B * L, 3 * H * 16)).astype(np.float32) * 1.5
+    x[160:, 128:256] *= 60.0                                     # the keys of tokens 160.. are sixty times longer
+    x[40:80, 128:256] *= 0.01                                    # ... and some are tiny
+    qkv = torch.from_numpy(x).to(DEV)
+    s = (qkv.double()[:, :128].view(B, L, H, 16).permute(0, 2, 1, 3) @
+         qkv.double()[:, 128:256].view(B, L, H, 16).permute(0, 2, 3, 1)) / 4.0 / np.log(2.0)
+    rise = s[..., 160:].amax(-1) - s[..., :32].amax(-1)
+    assert float((rise > 60).float().mean()) > 0.5              # most rows do leave the fast path
+    mask = tg.attention_dropout_mask(B, L, H, p, seed, DEV).double() if p > 0 else None
+    ref = _attn_ref(qkv.double(), B, L, H, p, mask)
+    out, lse, ws = tg.attention_train_fwd(qkv, B, L, H, p, seed)
+    # scores of magnitude ~500 (log2 units) carry an fp32 rounding error of ~3e-5 each, whatever the softmax does with them:
+    # measured 1.4e-5 on the outputs
+    assert torch.isfinite(out).all() and relmax(out.cpu(), ref.cpu()) <= 5e-5
+    assert relmax(lse.cpu(), (torch.logsumexp(s * np.log(2.0), dim=-1) / np.log(2.0)).view(B * H, L).cpu()) <= 2e-6
+    if p == 0:
+        inf, _ = native.attention(qkv, B, L, H)
+        assert torch.equal(inf, out)
+    else:
+        assert torch.equal(tg.workspace_keep_bits(ws, B, L, H), tg.attention_keep_bits(B, L, H, p, seed, DEV))
 
 
 @pytest.mark.parametrize("p", [0.0, 0.1])

@@ -22,7 +22,7 @@ def timed(f):
 
 t_inf, _ = timed(lambda: native.attention(qkv, B, L, H))
 t_fwd, (out, lse, ws) = timed(lambda: tg.attention_train_fwd(qkv, B, L, H, p, 7))
-t_bwd, _ = timed(lambda: tg.attention_bwd(qkv, out, lse, dout, B, L, H, p, 7, ws))
+t_bwd, _ = timed(lambda: tg.attention_bwd(qkv, out, lse, dout, B, L, H, p, 7, ws, operands_ready=True))   # as the training step calls it
 fl = 4.0 * L * L * 16 * B * H
 print(f"B={B}: inference {t_inf:.3f} ms ({fl / t_inf / 1e9:.1f} TF alg)  train fwd {t_fwd:.3f} ms ({fl / t_fwd / 1e9:.1f} TF)  "
       f"bwd {t_bwd:.3f} ms ({2.5 * fl / t_bwd / 1e9:.1f} TF alg)")
