@@ -14,7 +14,8 @@ with the input already resident in HBM.  Prints ONE JSON line (rank 0).
                  `frac` = ALGORITHMIC FLOPs (the reference's direct-convolution count) / duration / peak - it exceeds 1
                  because layers 1-3 run as Winograd F(3x3,3x3) (100 multiplies where the direct form has 324);
                  `executed_frac` = the FLOPs the matrix pipe really issued / duration / peak, the utilisation figure
-  extra_configs  configs[2] (local training step as a hipGraph), configs[3] (147x147 and 587x587 image pairs end to end),
+  extra_configs  configs[2] (local training step as a hipGraph), configs[3] (147x147 and 587x587 image pairs end to end), the global-stage
+                 training step at batch 8,
                  each with its own clock and dominant kernel
   dp             the data-parallel training step (configs[4]): at N > 1 K steps of be_hip.train_local.train_step(world=N)
                  with the five-bucket RCCL gradient all-reduce overlapped with the backward; at N = 1 the same code, world 1
@@ -211,6 +212,39 @@ def leg_image_pairs(dev, native, peak):
                         cnn_patch_pairs_per_s=round((npos if size == 147 else 36 * 4096) / ms * 1e3, 1),
                         dominant_kernel=prof))
     return out
+
+
+def leg_global_training(dev, steps=12):
+    """configs[4], global half on one GPU: global_training.py:207-213 at batch 8 (147 x 147 pairs): GlobalStage in train mode
+    (dropout 0.1) on the HIP attention / LayerNorm / linear kernels, fused GlobalLoss forward + backward, clip 1.0, AdamW.  Synthetic
+    scenes, features from the HIP local pass, portable-generator LocalStage weights, Xavier-initialised GlobalStage."""
+    import models, utils
+    from be_hip import dp, synth, train_global
+    B = 8
+    args = utils.get_args("global_train", argv=[])
+    args.batch_size = B
+    local = models.LocalStage().to(dev)
+    local.load_state_dict({k: torch.from_numpy(np.asarray(v)).to(dev) for k, v in synth.local_stage_state_dict().items()})
+    local.eval()
+    helper, dcal = utils.PostProcessGlobalBase(args, dev), utils.DepthEtas(args, dev)
+    data = train_global.make_dataset(B, dev, local, helper)
+    torch.manual_seed(1898)
+    model = models.GlobalStage(in_parameter_size=args.input_size, out_parameter_size=args.output_size, device=dev).to(dev)
+    for p in model.parameters():
+        if p.dim() > 1:
+            torch.nn.init.xavier_normal_(p)
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=dp.fused_adamw())
+    gamma = train_global.GammaSchedule(args).final()
+    batch = {k: torch.stack([d[k] for d in data]) for k in ("pm", "img_gt", "bndry_dist", "deri", "bndry_depth")}
+    model.train()
+    losses = []
+
+    def step():
+        losses.append(train_global.train_step(model, helper, dcal, opt, batch, gamma))
+    ms = timed(step, steps, warmup=2)                      # the warm-up steps grow the allocator by the per-layer workspaces
+    return dict(config="configs[4], global half on one GPU: global_training.py step, batch 8 (GlobalStage train mode with dropout 0.1 "
+                       "+ fused GlobalLoss + bwd + clip 1.0 + AdamW), eager launches", ms_per_step=round(ms, 3),
+                images_per_s=round(B / ms * 1e3, 1), steps=steps, first_loss=float(losses[0]), last_loss=float(losses[-1]))
 
 
 def leg_dp(dev, native, dist, rank, world, steps):
@@ -468,7 +502,8 @@ def main():
     if not args.no_extra:
         if rank == 0:
             extra = []
-            for leg in (lambda: [leg_local_training(dev, native, peak)], lambda: leg_image_pairs(dev, native, peak)):
+            for leg in (lambda: [leg_local_training(dev, native, peak)], lambda: leg_image_pairs(dev, native, peak),
+                        lambda: [leg_global_training(dev)]):
                 try:
                     extra.extend(leg())
                 except Exception as e:                    # a broken side leg must not take the headline number with it

@@ -1,4 +1,4 @@
-// GlobalLoss forward + analytic backward in one launch, one wavefront per patch position (gfx950).
+// GlobalLoss forward + analytic backward in one launch, one workgroup of seven wavefronts per patch position (gfx950).
 //
 // Replaces GlobalLoss.get_patches + get_loss (global_training.py:69-139) and the autograd graph under them.
 // The reference detaches the folded global image / boundary before the consistency terms (:94,:100,:106), so once
@@ -10,14 +10,17 @@
 //   depth              : ((depth_map - bndry_depth) mask)^2, normalised by the GLOBAL mask count: the kernel
 //                        returns numerator, count and the un-normalised gradient separately; the host combines.
 // Nothing is unfolded: the "patches" of the image-sized tensors are gathered on read at (stride*i + r, stride*j + c).
-// Geometry in fp64 (be_wedge_d.h); one colour set shared by the two apertures (882-row ridge system).
+// Geometry in fp64 (be_wedge_d.h): the signed distances and the gradient chain through them, because a distance error is
+// amplified by 1 / eta (down to 1e-4).  The transcendental functions of the per-pixel work run in fp32 ON fp64-accurate arguments
+// (z = d / (sqrt2 eta) is formed in fp64 and rounded once): erf and exp(-z^2) then carry 1e-7 relative error, which nothing amplifies.
+// One colour set shared by the two apertures (882-row ridge system).
 #include "be_common.h"
 #include "be_wedge_d.h"
 
 namespace {
 
 using namespace be_d;
-constexpr int NPIX = BE_NPIX, R = BE_R, PASSES = 7, WAVES = 4, Q = 19, NQ = Q * Q;
+constexpr int NPIX = BE_NPIX, R = BE_R, Q = 19, NQ = Q * Q;
 
 struct GLArgs {
     const float* est;        // [B,P,12] raw GlobalStage output
@@ -56,165 +59,209 @@ __device__ __forceinline__ real depth_and_grad(const be_depth_consts& c, real e1
     return z;
 }
 
-__global__ __launch_bounds__(64 * WAVES)
+// One WORKGROUP of 448 threads (7 waves) per patch position, one pixel per thread (441 live).  The first version gave a patch to
+// one wave, seven pixels per lane with every per-pixel quantity of all seven kept in registers across the phases: 512 VGPRs, 310
+// of them spilled, one wave per SIMD waiting on its own scratch traffic (3.5 ms per batch of 8 images).  Here a thread's state is
+// two fp64 distances, four blur indicators and six colour adjoints; the sums over the patch go through LDS.
+constexpr int NT = 448, NWV = NT / 64;
+
+struct PatchScalars {            // computed once per patch (wave 0 / thread 0), read by everyone from LDS: what is uniform over the
+    GeomD g;                     // patch does not occupy registers in 448 threads
+    real eta[4], irad[4], deta[4], idelta;
+    real z1, z2, dz1a, dz1b, dz2a, dz2b;
+    float Cc[3][3], inv[3][3], V[3][3], S[3][3];
+};
+
+// sum over the workgroup of n floats per thread; every thread gets the totals.  red: [NWV][n] floats of LDS.
+template <int N>
+__device__ __forceinline__ void block_sum(float (&v)[N], float* red, int lane, int wv) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = be::wave_sum(v[k]);
+    __syncthreads();                                         // the previous use of red is over
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) red[wv * N + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        float t = red[k];
+#pragma unroll
+        for (int w = 1; w < NWV; ++w) t += red[w * N + k];
+        v[k] = t;
+    }
+}
+template <int N>
+__device__ __forceinline__ void block_sum_d(real (&v)[N], real* red, int lane, int wv) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) v[k] = wave_sum_d(v[k]);
+    __syncthreads();
+    if (lane == 0) {
+#pragma unroll
+        for (int k = 0; k < N; ++k) red[wv * N + k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        real t = red[k];
+#pragma unroll
+        for (int w = 1; w < NWV; ++w) t += red[w * N + k];
+        v[k] = t;
+    }
+}
+
+__global__ __launch_bounds__(NT)
 void k_global_loss(be_render_opts o, GLArgs a) {
     __shared__ float lin[R];
-    __shared__ float sPatch[WAVES][3][NPIX];
-    __shared__ float sDx[WAVES][3][NQ];
-    __shared__ float sDy[WAVES][3][NQ];
-    if (threadIdx.x < R) lin[threadIdx.x] = o.lin[threadIdx.x];
-    __syncthreads();
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t total = (int64_t)a.B * a.P;
-    const int64_t gp_raw = (int64_t)blockIdx.x * WAVES + wv;
-    const bool active = gp_raw < total;
-    const int64_t gp = active ? gp_raw : total - 1;
+    __shared__ float sPatch[3][NPIX];
+    __shared__ float sDx[3][NQ];
+    __shared__ float sDy[3][NQ];
+    __shared__ PatchScalars sc;
+    __shared__ real red_d[NWV * 14];
+    float* red = reinterpret_cast<float*>(red_d);             // the float sums use the same scratch (never at the same time)
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid < R) lin[tid] = o.lin[tid];
+    const int64_t gp = blockIdx.x;
     const int b = (int)(gp / a.P), p = (int)(gp % a.P);
     const int pi = p / a.wp, pj = p % a.wp;
     const int y0 = a.stride * pi, x0 = a.stride * pj;
     const size_t HW = (size_t)a.H * a.W, HWd = (size_t)(a.H - 2) * (a.W - 2);
 
-    // ---- parameters (global_training.py:141-145) and their chain factors
-    const float* e = a.est + gp * 12;
-    real v[8];
+    // ---- parameters (global_training.py:141-145) and their chain factors: wave 0, once per patch
+    if (wv == 0) {
+        const float* e = a.est + gp * 12;
+        real v[8];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) v[k] = 3.0 * (real)e[k];
+        for (int k = 0; k < 4; ++k) v[k] = 3.0 * (real)e[k];
 #pragma unroll
-    for (int k = 4; k < 8; ++k) v[k] = ((real)e[k] + 1.0) * 3.14159265358979323846;
-    const GeomD g = make_geom_dv(v);
-    real eta[4], rad[4], deta[4];                               // d eta / d est
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const real pk = (real)e[8 + k] + 0.5;
-        eta[k] = pow(10.0, 2.0 * erf(pk) - 2.0);
-        rad[k] = (real)be::kRoot2 * eta[k];
-        deta[k] = eta[k] * 2.302585092994046 * 4.0 * (real)kInvSqrtPi * exp(-pk * pk);
+        for (int k = 4; k < 8; ++k) v[k] = ((real)e[k] + 1.0) * 3.14159265358979323846;
+        const GeomD g0 = make_geom_dv(v);
+        if (lane == 0) sc.g = g0;
+        if (lane < 4) {
+            const real pk = (real)e[8 + lane] + 0.5;
+            const real eta = pow(10.0, 2.0 * erf(pk) - 2.0);
+            sc.eta[lane] = eta;
+            sc.irad[lane] = 1.0 / ((real)be::kRoot2 * eta);
+            sc.deta[lane] = eta * 2.302585092994046 * 4.0 * (real)kInvSqrtPi * exp(-pk * pk);
+        }
+        if (lane == 4) sc.idelta = 1.0 / (real)o.delta_sq;
     }
+    __syncthreads();
+    const real irad[4] = {sc.irad[0], sc.irad[1], sc.irad[2], sc.irad[3]};
+
+    const int pix = tid;
+    const bool live = pix < NPIX;
+    const int pc = live ? pix : 0;
+    const int row = pc / R, col = pc - row * R;
+    const size_t at = (size_t)(y0 + row) * a.W + x0 + col;
 
     // ---- pass 1: distances, indicators of both blur sets, normal equations over the 882 rows
-    real d1s[PASSES], d2s[PASSES];
-    float h[2][2][PASSES];                                      // [set][wedge][pass]
-    float gs[6] = {0, 0, 0, 0, 0, 0}, bs[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    real d1, d2;
+    {
+        const GeomD g = sc.g;
+        d1 = wedge_dist_d(lin[col], lin[row], g.x0, g.y0, g.s11, g.c11, g.s12, g.c12, g.sg1, false, o.w);
+        d2 = wedge_dist_d(lin[col], lin[row], g.x1, g.y1, g.s21, g.c21, g.s22, g.c22, g.sg2, true, o.w);
+    }
+    float h[2][2], y[2][3], u[2][3];
+    float nb[15] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};        // gs[6], bs[9]
 #pragma unroll
-    for (int it = 0; it < PASSES; ++it) {
-        const int pix = it * 64 + lane;
-        const bool live = pix < NPIX;
-        const int pc = live ? pix : 0;
-        const int row = pc / R, col = pc - row * R;
-        const real d1 = wedge_dist_d(lin[col], lin[row], g.x0, g.y0, g.s11, g.c11, g.s12, g.c12, g.sg1, false, o.w);
-        const real d2 = wedge_dist_d(lin[col], lin[row], g.x1, g.y1, g.s21, g.c21, g.s22, g.c22, g.sg2, true, o.w);
-        d1s[it] = d1; d2s[it] = d2;
+    for (int s = 0; s < 2; ++s) {
+        const float h1 = 0.5f * (1.0f + erff((float)(d1 * irad[2 * s]))), h2 = 0.5f * (1.0f + erff((float)(d2 * irad[2 * s + 1])));
+        h[s][0] = h1; h[s][1] = h2;
+        u[s][0] = live ? (1.0f - h1) * (1.0f - h2) : 0.f; u[s][1] = live ? h1 * (1.0f - h2) : 0.f; u[s][2] = live ? h2 : 0.f;
+        const float* src = a.img_fit + ((size_t)(b * 2 + s) * HW + at) * 3;
+        y[s][0] = live ? src[0] : 0.f; y[s][1] = live ? src[1] : 0.f; y[s][2] = live ? src[2] : 0.f;
+        const float u0 = u[s][0], u1 = u[s][1], u2 = u[s][2];
+        nb[0] = fmaf(u0, u0, nb[0]); nb[1] = fmaf(u0, u1, nb[1]); nb[2] = fmaf(u0, u2, nb[2]);
+        nb[3] = fmaf(u1, u1, nb[3]); nb[4] = fmaf(u1, u2, nb[4]); nb[5] = fmaf(u2, u2, nb[5]);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const float h1 = (float)(0.5 * (1.0 + erf(d1 / rad[2 * s]))), h2 = (float)(0.5 * (1.0 + erf(d2 / rad[2 * s + 1])));
-            h[s][0][it] = h1; h[s][1][it] = h2;
-            const float u0 = live ? (1.0f - h1) * (1.0f - h2) : 0.f, u1 = live ? h1 * (1.0f - h2) : 0.f, u2 = live ? h2 : 0.f;
-            const float* src = a.img_fit + (((size_t)(b * 2 + s) * a.H + y0 + row) * a.W + x0 + col) * 3;
-            const float yr = live ? src[0] : 0.f, yg = live ? src[1] : 0.f, yb = live ? src[2] : 0.f;
-            gs[0] = fmaf(u0, u0, gs[0]); gs[1] = fmaf(u0, u1, gs[1]); gs[2] = fmaf(u0, u2, gs[2]);
-            gs[3] = fmaf(u1, u1, gs[3]); gs[4] = fmaf(u1, u2, gs[4]); gs[5] = fmaf(u2, u2, gs[5]);
-            bs[0] = fmaf(u0, yr, bs[0]); bs[1] = fmaf(u0, yg, bs[1]); bs[2] = fmaf(u0, yb, bs[2]);
-            bs[3] = fmaf(u1, yr, bs[3]); bs[4] = fmaf(u1, yg, bs[4]); bs[5] = fmaf(u1, yb, bs[5]);
-            bs[6] = fmaf(u2, yr, bs[6]); bs[7] = fmaf(u2, yg, bs[7]); bs[8] = fmaf(u2, yb, bs[8]);
+        for (int c = 0; c < 3; ++c) {
+            nb[6 + c] = fmaf(u0, y[s][c], nb[6 + c]); nb[9 + c] = fmaf(u1, y[s][c], nb[9 + c]); nb[12 + c] = fmaf(u2, y[s][c], nb[12 + c]);
         }
     }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) gs[k] = be::wave_sum(gs[k]);
-#pragma unroll
-    for (int k = 0; k < 9; ++k) bs[k] = be::wave_sum(bs[k]);
-    const double A00 = (double)gs[0] + o.lambda_ridge, A01 = gs[1], A02 = gs[2], A11 = (double)gs[3] + o.lambda_ridge,
-                 A12 = gs[4], A22 = (double)gs[5] + o.lambda_ridge;
-    double inv[3][3];
-    {
+    block_sum(nb, red, lane, wv);
+    if (tid == 0) {
+        const float* gs = nb;
+        const float* bs = nb + 6;
+        const double A00 = (double)gs[0] + o.lambda_ridge, A01 = gs[1], A02 = gs[2], A11 = (double)gs[3] + o.lambda_ridge,
+                     A12 = gs[4], A22 = (double)gs[5] + o.lambda_ridge;
         const double C00 = A11 * A22 - A12 * A12, C01 = A02 * A12 - A01 * A22, C02 = A01 * A12 - A02 * A11;
         const double C11 = A00 * A22 - A02 * A02, C12 = A01 * A02 - A00 * A12, C22 = A00 * A11 - A01 * A01;
         const double idet = 1.0 / (A00 * C00 + A01 * C01 + A02 * C02);
-        inv[0][0] = C00 * idet; inv[0][1] = inv[1][0] = C01 * idet; inv[0][2] = inv[2][0] = C02 * idet;
-        inv[1][1] = C11 * idet; inv[1][2] = inv[2][1] = C12 * idet; inv[2][2] = C22 * idet;
+        const double iv[3][3] = {{C00 * idet, C01 * idet, C02 * idet}, {C01 * idet, C11 * idet, C12 * idet}, {C02 * idet, C12 * idet, C22 * idet}};
+#pragma unroll
+        for (int c = 0; c < 3; ++c)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                sc.Cc[c][k] = (float)(iv[k][0] * bs[c] + iv[k][1] * bs[3 + c] + iv[k][2] * bs[6 + c]);
+                sc.inv[c][k] = (float)iv[c][k];
+            }
+        // depth of the two wedges and its derivative w.r.t. the four etas
+        real a_, b_;
+        sc.z1 = depth_and_grad(a.dc, sc.eta[0], sc.eta[2], a_, b_); sc.dz1a = a_; sc.dz1b = b_;
+        sc.z2 = depth_and_grad(a.dc, sc.eta[1], sc.eta[3], a_, b_); sc.dz2a = a_; sc.dz2b = b_;
     }
-    float Cc[3][3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-#pragma unroll
-        for (int k = 0; k < 3; ++k)
-            Cc[c][k] = (float)(inv[k][0] * bs[c] + inv[k][1] * bs[3 + c] + inv[k][2] * bs[6 + c]);
+    __syncthreads();
 
     // ---- pass 2 (per blur set): composite -> colour terms; Sobel terms and their adjoint gathered back
-    float gP[2][PASSES][3];
-    float T1 = 0, T2 = 0, T4 = 0, T5 = 0;
+    float gP[2][3];
+    float T[7] = {0, 0, 0, 0, 0, 0, 0};                          // T1 T2 T4 T5 | T3 T6 | T7 ; MS separately
     for (int s = 0; s < 2; ++s) {
         const float* gt = a.img_gt + ((size_t)(b * 2 + s) * HW) * 3;
         const float* Gs = a.G + (size_t)(b * 2 + s) * 3 * HW;
 #pragma unroll
-        for (int it = 0; it < PASSES; ++it) {
-            const int pix = it * 64 + lane;
-            const bool live = pix < NPIX;
-            const int pc = live ? pix : 0;
-            const int row = pc / R, col = pc - row * R;
-            const size_t at = (size_t)(y0 + row) * a.W + x0 + col;
-            const float h1 = h[s][0][it], h2 = h[s][1][it];
-            const float u0 = (1.0f - h1) * (1.0f - h2), u1 = h1 * (1.0f - h2), u2 = h2;
+        for (int c = 0; c < 3; ++c) {
+            const float val = u[s][0] * sc.Cc[c][0] + u[s][1] * sc.Cc[c][1] + u[s][2] * sc.Cc[c][2];
+            float r1 = 0.f, r2 = 0.f;
+            if (live) {
+                sPatch[c][pix] = val;
+                r1 = val - gt[at * 3 + c];
+                r2 = val - Gs[c * HW + at];
+            }
+            T[0] = fmaf(r1, r1, T[0]); T[1] = fmaf(r2, r2, T[1]);
+            gP[s][c] = 2.0f * (r1 * a.wc + r2 * a.wcc);
+        }
+        __syncthreads();
+        if (tid < NQ) {
+            const int q = tid;
+            const int qy = q / Q, qx = q - qy * Q;
+            const size_t atd = (size_t)(y0 + qy) * (a.W - 2) + x0 + qx;
+            const float* dr = a.deri + ((size_t)(b * 2 + s) * HWd) * 3;
+            const float* Gds = a.Gd + (size_t)(b * 2 + s) * 3 * HWd;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float val = u0 * Cc[c][0] + u1 * Cc[c][1] + u2 * Cc[c][2];
-                float r1 = 0.f, r2 = 0.f;
-                if (live) {
-                    sPatch[wv][c][pix] = val;
-                    r1 = val - gt[at * 3 + c];
-                    r2 = val - Gs[c * HW + at];
-                }
-                T1 = fmaf(r1, r1, T1); T2 = fmaf(r2, r2, T2);
-                gP[s][it][c] = 2.0f * (r1 * a.wc + r2 * a.wcc);
+                const float* Pp = sPatch[c] + qy * R + qx;
+                const float p00 = Pp[0], p01 = Pp[1], p02 = Pp[2], p10 = Pp[R], p12 = Pp[R + 2], p20 = Pp[2 * R],
+                            p21 = Pp[2 * R + 1], p22 = Pp[2 * R + 2];
+                const float gx = (p02 - p00) + 2.0f * (p12 - p10) + (p22 - p20);
+                const float gy = (p00 - p20) + 2.0f * (p01 - p21) + (p02 - p22);
+                const float sm = sqrtf(gx * gx + gy * gy + 1e-8f);
+                const float t4 = sm - dr[atd * 3 + c], t5 = sm - Gds[c * HWd + atd];
+                T[2] = fmaf(t4, t4, T[2]); T[3] = fmaf(t5, t5, T[3]);
+                const float k = 2.0f * (t4 * a.ws + t5 * a.wsc) / sm;
+                sDx[c][q] = k * gx;
+                sDy[c][q] = k * gy;
             }
         }
         __syncthreads();
-        const float* dr = a.deri + ((size_t)(b * 2 + s) * HWd) * 3;
-        const float* Gds = a.Gd + (size_t)(b * 2 + s) * 3 * HWd;
-        for (int q0 = 0; q0 < NQ; q0 += 64) {
-            const int q = q0 + lane;
-            if (q < NQ) {
-                const int qy = q / Q, qx = q - qy * Q;
-                const size_t atd = (size_t)(y0 + qy) * (a.W - 2) + x0 + qx;
+        if (live) {
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    const float* Pp = sPatch[wv][c] + qy * R + qx;
-                    const float p00 = Pp[0], p01 = Pp[1], p02 = Pp[2], p10 = Pp[R], p12 = Pp[R + 2], p20 = Pp[2 * R],
-                                p21 = Pp[2 * R + 1], p22 = Pp[2 * R + 2];
-                    const float gx = (p02 - p00) + 2.0f * (p12 - p10) + (p22 - p20);
-                    const float gy = (p00 - p20) + 2.0f * (p01 - p21) + (p02 - p22);
-                    const float sm = sqrtf(gx * gx + gy * gy + 1e-8f);
-                    const float t4 = sm - dr[atd * 3 + c], t5 = sm - Gds[c * HWd + atd];
-                    T4 = fmaf(t4, t4, T4); T5 = fmaf(t5, t5, T5);
-                    const float k = 2.0f * (t4 * a.ws + t5 * a.wsc) / sm;
-                    sDx[wv][c][q] = k * gx;
-                    sDy[wv][c][q] = k * gy;
-                }
-            }
-        }
-        __syncthreads();
+            for (int c = 0; c < 3; ++c) {
+                float acc = 0.f;
 #pragma unroll
-        for (int it = 0; it < PASSES; ++it) {
-            const int pix = it * 64 + lane;
-            if (pix < NPIX) {
-                const int row = pix / R, col = pix - row * R;
+                for (int dy = 0; dy < 3; ++dy) {
+                    const int qy = row - dy;
+                    if (qy < 0 || qy >= Q) continue;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) {
-                    float acc = 0.f;
-#pragma unroll
-                    for (int dy = 0; dy < 3; ++dy) {
-                        const int qy = row - dy;
-                        if (qy < 0 || qy >= Q) continue;
-#pragma unroll
-                        for (int dx = 0; dx < 3; ++dx) {
-                            const int qx = col - dx;
-                            if (qx < 0 || qx >= Q) continue;
-                            const float kx = (dx == 0 ? -1.f : (dx == 2 ? 1.f : 0.f)) * (dy == 1 ? 2.f : 1.f);
-                            const float ky = (dy == 0 ? 1.f : (dy == 2 ? -1.f : 0.f)) * (dx == 1 ? 2.f : 1.f);
-                            acc += kx * sDx[wv][c][qy * Q + qx] + ky * sDy[wv][c][qy * Q + qx];
-                        }
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int qx = col - dx;
+                        if (qx < 0 || qx >= Q) continue;
+                        const float kx = (dx == 0 ? -1.f : (dx == 2 ? 1.f : 0.f)) * (dy == 1 ? 2.f : 1.f);
+                        const float ky = (dy == 0 ? 1.f : (dy == 2 ? -1.f : 0.f)) * (dx == 1 ? 2.f : 1.f);
+                        acc += kx * sDx[c][qy * Q + qx] + ky * sDy[c][qy * Q + qx];
                     }
-                    gP[s][it][c] += acc;
                 }
+                gP[s][c] += acc;
             }
         }
         __syncthreads();                                        // LDS is reused by the second blur set
@@ -225,121 +272,103 @@ void k_global_loss(be_render_opts o, GLArgs a) {
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
-        for (int it = 0; it < PASSES; ++it) {
-            const bool live = it * 64 + lane < NPIX;
-            const float h1 = h[s][0][it], h2 = h[s][1][it];
-            const float u[3] = {live ? (1.0f - h1) * (1.0f - h2) : 0.f, live ? h1 * (1.0f - h2) : 0.f, live ? h2 : 0.f};
+        for (int c = 0; c < 3; ++c)
 #pragma unroll
-            for (int c = 0; c < 3; ++c)
+            for (int k = 0; k < 3; ++k) dC[c * 3 + k] = fmaf(gP[s][c], u[s][k], dC[c * 3 + k]);      // u is 0 on dead threads
+    block_sum(dC, red, lane, wv);
+    if (tid == 0) {
+        float V[3][3];
 #pragma unroll
-                for (int k = 0; k < 3; ++k) dC[c * 3 + k] = fmaf(gP[s][it][c], u[k], dC[c * 3 + k]);
-        }
+        for (int c = 0; c < 3; ++c)
 #pragma unroll
-    for (int k = 0; k < 9; ++k) dC[k] = be::wave_sum(dC[k]);
-    float V[3][3], S[3][3];
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
+            for (int k = 0; k < 3; ++k) {
+                V[c][k] = sc.inv[k][0] * dC[c * 3] + sc.inv[k][1] * dC[c * 3 + 1] + sc.inv[k][2] * dC[c * 3 + 2];
+                sc.V[c][k] = V[c][k];
+            }
 #pragma unroll
         for (int k = 0; k < 3; ++k)
-            V[c][k] = (float)(inv[k][0] * dC[c * 3] + inv[k][1] * dC[c * 3 + 1] + inv[k][2] * dC[c * 3 + 2]);
 #pragma unroll
-    for (int k = 0; k < 3; ++k)
+            for (int j = 0; j < 3; ++j) {
+                float dkj = 0.f, djk = 0.f;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            float dkj = 0.f, djk = 0.f;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) { dkj -= V[c][k] * Cc[c][j]; djk -= V[c][j] * Cc[c][k]; }
-            S[k][j] = dkj + djk;
-        }
-
-    // ---- depth of the two wedges and its derivative w.r.t. the four etas
-    real dz1a, dz1b, dz2a, dz2b;
-    const real z1 = depth_and_grad(a.dc, eta[0], eta[2], dz1a, dz1b);
-    const real z2 = depth_and_grad(a.dc, eta[1], eta[3], dz2a, dz2b);
+                for (int c = 0; c < 3; ++c) { dkj -= V[c][k] * sc.Cc[c][j]; djk -= V[c][j] * sc.Cc[c][k]; }
+                sc.S[k][j] = dkj + djk;
+            }
+    }
+    __syncthreads();
 
     // ---- pass 3: per-pixel adjoints down to the twelve parameters
-    real gx0 = 0, gy0 = 0, gt1 = 0, gf1 = 0, gx1 = 0, gy1 = 0, gt2 = 0, gf2 = 0, gr[4] = {0, 0, 0, 0};
-    real gz1 = 0, gz2 = 0;
-    float T3 = 0, T6 = 0, T7 = 0, MS = 0;
+    real acc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // gx0 gy0 gt1 gf1 gx1 gy1 gt2 gf2 | gr[4] | gz1 gz2
+    float MS = 0.f;
+    if (live) {
+        const real px = lin[col], py = lin[row];
+        const real idelta = sc.idelta;
+        real gd1 = 0, gd2 = 0;
 #pragma unroll
-    for (int it = 0; it < PASSES; ++it) {
-        const int pix = it * 64 + lane;
-        if (pix < NPIX) {
-            const int row = pix / R, col = pix - row * R;
-            const real px = lin[col], py = lin[row];
-            const real d1 = d1s[it], d2 = d2s[it];
-            const size_t at = (size_t)(y0 + row) * a.W + x0 + col;
-            real gd1 = 0, gd2 = 0;
+        for (int s = 0; s < 2; ++s) {
+            const float h1 = h[s][0], h2 = h[s][1];
+            float du[3];
 #pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const float h1 = h[s][0][it], h2 = h[s][1][it];
-                const float u[3] = {(1.0f - h1) * (1.0f - h2), h1 * (1.0f - h2), h2};
-                const float* src = a.img_fit + ((size_t)(b * 2 + s) * HW + at) * 3;
-                const float y[3] = {src[0], src[1], src[2]};
-                float du[3];
+            for (int k = 0; k < 3; ++k) {
+                float t = 0.f;
 #pragma unroll
-                for (int k = 0; k < 3; ++k) {
-                    float acc = 0.f;
+                for (int c = 0; c < 3; ++c) t += gP[s][c] * sc.Cc[c][k] + sc.V[c][k] * y[s][c];
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) acc += gP[s][it][c] * Cc[c][k] + V[c][k] * y[c];
-#pragma unroll
-                    for (int j = 0; j < 3; ++j) acc += S[k][j] * u[j];
-                    du[k] = acc;
-                }
-                const real dh1 = (du[1] - du[0]) * (1.0f - h2);
-                const real dh2 = -du[0] * (1.0f - h1) - du[1] * h1 + du[2];
-                const real ra = rad[2 * s], rb = rad[2 * s + 1];
-                const real za = d1 / ra, zb = d2 / rb;
-                const real ea = exp(-za * za) * (real)kInvSqrtPi, eb = exp(-zb * zb) * (real)kInvSqrtPi;
-                gd1 += dh1 * ea / ra; gd2 += dh2 * eb / rb;
-                gr[2 * s] -= dh1 * ea * d1 / (ra * ra);
-                gr[2 * s + 1] -= dh2 * eb * d2 / (rb * rb);
+                for (int j = 0; j < 3; ++j) t += sc.S[k][j] * u[s][j];
+                du[k] = t;
             }
-            // boundary terms (:99-103, :121-125)
-            const real a1 = fabs(d1), a2 = fabs(d2);
-            const real db = d2 >= 0.0 ? d2 : (a1 < a2 ? a1 : a2);
-            const real Bv = exp(-(db * db) / (real)o.delta_sq);
-            const size_t atb = (size_t)b * HW + at;
-            const real r3 = Bv - (real)a.Gb[atb];
-            const real lb = log2((real)a.bdist[atb] + 1.0);
-            T3 += (float)(r3 * r3); T6 += (float)((lb * Bv) * (lb * Bv));
-            const real gB = 2.0 * r3 * a.wbc + 2.0 * lb * lb * Bv * a.wbl;
-            const real gdb = gB * Bv * (-2.0 * db / (real)o.delta_sq);
-            if (d2 >= 0.0) gd2 += gdb;
-            else if (a1 < a2) gd1 += gdb * (d1 > 0. ? 1. : (d1 < 0. ? -1. : 0.));
-            else gd2 += gdb * (d2 > 0. ? 1. : (d2 < 0. ? -1. : 0.));
-            // depth term (:127-133): mask as blurry_edges / global_training :83-85
-            const bool m1 = exp(-(d1 * d1) / (real)o.delta_sq) > 0.5, m2 = exp(-(d2 * d2) / (real)o.delta_sq) > 0.5;
-            const int mk = (m2 || d2 >= 0.0) ? (m2 ? 2 : 0) : (m1 ? 1 : 0);
-            const real bdp = a.bdepth[atb];
-            if (bdp != 0.0 && mk != 0) {
-                const real diff = (mk == 1 ? z1 : z2) - bdp;
-                T7 += (float)(diff * diff); MS += 1.0f;
-                if (mk == 1) gz1 += 2.0 * diff; else gz2 += 2.0 * diff;
-            }
-            wedge_backward(px, py, g.x0, g.y0, g.s11, g.c11, g.s12, g.c12, g.sg1, false, o.w, gd1, gx0, gy0, gt1, gf1);
-            wedge_backward(px, py, g.x1, g.y1, g.s21, g.c21, g.s22, g.c22, g.sg2, true, o.w, gd2, gx1, gy1, gt2, gf2);
+            const real dh1 = (du[1] - du[0]) * (1.0f - h2);
+            const real dh2 = -du[0] * (1.0f - h1) - du[1] * h1 + du[2];
+            const real ia = irad[2 * s], ib = irad[2 * s + 1];
+            const real za = d1 * ia, zb = d2 * ib;
+            const float zaf = (float)za, zbf = (float)zb;
+            const real ea = (real)(__expf(-zaf * zaf) * kInvSqrtPi), eb = (real)(__expf(-zbf * zbf) * kInvSqrtPi);
+            gd1 += dh1 * ea * ia; gd2 += dh2 * eb * ib;
+            acc[8 + 2 * s] -= dh1 * ea * za * ia;
+            acc[8 + 2 * s + 1] -= dh2 * eb * zb * ib;
         }
+        // boundary terms (:99-103, :121-125)
+        const real a1 = fabs(d1), a2 = fabs(d2);
+        const real db = d2 >= 0.0 ? d2 : (a1 < a2 ? a1 : a2);
+        const real Bv = (real)__expf(-(float)(db * db * idelta));
+        const size_t atb = (size_t)b * HW + at;
+        const real r3 = Bv - (real)a.Gb[atb];
+        const real lb = (real)__log2f(a.bdist[atb] + 1.0f);
+        T[4] += (float)(r3 * r3); T[5] += (float)((lb * Bv) * (lb * Bv));
+        const real gB = 2.0 * r3 * a.wbc + 2.0 * lb * lb * Bv * a.wbl;
+        const real gdb = gB * Bv * (-2.0 * db * idelta);
+        if (d2 >= 0.0) gd2 += gdb;
+        else if (a1 < a2) gd1 += gdb * (d1 > 0. ? 1. : (d1 < 0. ? -1. : 0.));
+        else gd2 += gdb * (d2 > 0. ? 1. : (d2 < 0. ? -1. : 0.));
+        // depth term (:127-133): mask as blurry_edges / global_training :83-85
+        const bool m1 = d1 * d1 * idelta < 0.69314718055994530942, m2 = d2 * d2 * idelta < 0.69314718055994530942;   // exp(-d^2 / delta^2) > 0.5
+        const int mk = (m2 || d2 >= 0.0) ? (m2 ? 2 : 0) : (m1 ? 1 : 0);
+        const real bdp = a.bdepth[atb];
+        if (bdp != 0.0 && mk != 0) {
+            const real diff = (mk == 1 ? sc.z1 : sc.z2) - bdp;
+            T[6] += (float)(diff * diff); MS += 1.0f;
+            if (mk == 1) acc[12] += 2.0 * diff; else acc[13] += 2.0 * diff;
+        }
+        const GeomD g = sc.g;
+        wedge_backward(px, py, g.x0, g.y0, g.s11, g.c11, g.s12, g.c12, g.sg1, false, o.w, gd1, acc[0], acc[1], acc[2], acc[3]);
+        wedge_backward(px, py, g.x1, g.y1, g.s21, g.c21, g.s22, g.c22, g.sg2, true, o.w, gd2, acc[4], acc[5], acc[6], acc[7]);
     }
-    gx0 = wave_sum_d(gx0); gy0 = wave_sum_d(gy0); gx1 = wave_sum_d(gx1); gy1 = wave_sum_d(gy1);
-    gt1 = wave_sum_d(gt1); gf1 = wave_sum_d(gf1); gt2 = wave_sum_d(gt2); gf2 = wave_sum_d(gf2);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) gr[k] = wave_sum_d(gr[k]);
-    gz1 = wave_sum_d(gz1); gz2 = wave_sum_d(gz2);
-    T1 = be::wave_sum(T1); T2 = be::wave_sum(T2); T3 = be::wave_sum(T3); T4 = be::wave_sum(T4);
-    T5 = be::wave_sum(T5); T6 = be::wave_sum(T6); T7 = be::wave_sum(T7); MS = be::wave_sum(MS);
-    if (lane == 0 && active) {
+    block_sum_d(acc, red_d, lane, wv);
+    float Tm[8] = {T[0], T[1], T[4], T[2], T[3], T[5], T[6], MS};       // the order of the partial record: T1 T2 T3 T4 T5 T6 T7 MS
+    block_sum(Tm, red, lane, wv);
+    if (tid == 0) {
         float* pt = a.partial + gp * 8;
-        pt[0] = T1; pt[1] = T2; pt[2] = T3; pt[3] = T4; pt[4] = T5; pt[5] = T6; pt[6] = T7; pt[7] = MS;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) pt[k] = Tm[k];
         float* go = a.grad + gp * 12;
         const real pi_ = 3.14159265358979323846;
-        go[0] = (float)(3.0 * gx0); go[1] = (float)(3.0 * gy0); go[2] = (float)(3.0 * gx1); go[3] = (float)(3.0 * gy1);
-        go[4] = (float)(pi_ * gt1); go[5] = (float)(pi_ * gf1); go[6] = (float)(pi_ * gt2); go[7] = (float)(pi_ * gf2);
+        go[0] = (float)(3.0 * acc[0]); go[1] = (float)(3.0 * acc[1]); go[2] = (float)(3.0 * acc[4]); go[3] = (float)(3.0 * acc[5]);
+        go[4] = (float)(pi_ * acc[2]); go[5] = (float)(pi_ * acc[3]); go[6] = (float)(pi_ * acc[6]); go[7] = (float)(pi_ * acc[7]);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) go[8 + k] = (float)(gr[k] * (real)be::kRoot2 * deta[k]);
+        for (int k = 0; k < 4; ++k) go[8 + k] = (float)(acc[8 + k] * (real)be::kRoot2 * sc.deta[k]);
         float* gd = a.gdepth + gp * 4;                          // depth1 <- (eta0, eta2), depth2 <- (eta1, eta3)
-        gd[0] = (float)(gz1 * dz1a * deta[0]); gd[2] = (float)(gz1 * dz1b * deta[2]);
-        gd[1] = (float)(gz2 * dz2a * deta[1]); gd[3] = (float)(gz2 * dz2b * deta[3]);
+        gd[0] = (float)(acc[12] * sc.dz1a * sc.deta[0]); gd[2] = (float)(acc[12] * sc.dz1b * sc.deta[2]);
+        gd[1] = (float)(acc[13] * sc.dz2a * sc.deta[1]); gd[3] = (float)(acc[13] * sc.dz2b * sc.deta[3]);
     }
 }
 
@@ -362,7 +391,6 @@ extern "C" int be_global_loss_f32(const be_render_opts* o, const be_depth_consts
     a.wc = (float)(gamma6[0] / n1); a.wcc = (float)(gamma6[1] / n1); a.wbc = (float)(gamma6[2] / n3);
     a.ws = (float)(gamma6[3] / n4); a.wsc = (float)(gamma6[4] / n4); a.wbl = (float)(gamma6[5] / n3);
     a.B = B; a.P = P; a.hp = hp; a.wp = wp; a.H = H; a.W = W; a.stride = stride;
-    const int64_t blocks = ((int64_t)B * P + WAVES - 1) / WAVES;
-    hipLaunchKernelGGL(k_global_loss, dim3((unsigned)blocks), dim3(64 * WAVES), 0, be::as_stream(stream), *o, a);
+    hipLaunchKernelGGL(k_global_loss, dim3((unsigned)((int64_t)B * P)), dim3(NT), 0, be::as_stream(stream), *o, a);
     return be::check_launch("be_global_loss_f32");
 }
