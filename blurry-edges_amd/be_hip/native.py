@@ -99,7 +99,8 @@ _SIGNATURES = {
     "be_datagen_crop_f64": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64] + [C.c_int] * 4 + [_P, _P]),
     "be_attention_train_workspace_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "be_attention_train_fwd_f32": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint32, _P]),
-    "be_attention_bwd_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint32, _P]),
+    "be_attention_bwd_scratch_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
+    "be_attention_bwd_f32": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint32, _P]),
     "be_attention_dropout_mask_f32": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint32, _P]),
     "be_attention_train_keep_offset_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "be_attention_keep_bits_u16": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_float, C.c_uint32, _P]),

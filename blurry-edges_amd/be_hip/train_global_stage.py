@@ -76,9 +76,24 @@ def attention_bwd(qkv, out, lse, dout, B, L, H, p, seed, ws=None, operands_ready
         ws, operands_ready = _new(need, dev), False
     dqkv = torch.empty_like(qkv)
     check(lib().be_attention_bwd_f32(dptr(qkv, "qkv"), dptr(out), dptr(lse), dptr(dout.contiguous(), "dout"), dptr(dqkv),
-                                     dptr(ws), int(bool(operands_ready)), B, L, L if l_valid is None else int(l_valid), H, float(p),
-                                     int(seed) & 0xffffffff, stream_ptr(dev)), "be_attention_bwd_f32")
+                                     dptr(ws), dptr(_bwd_scratch(B, L, H, dev)), int(bool(operands_ready)), B, L,
+                                     L if l_valid is None else int(l_valid), H, float(p), int(seed) & 0xffffffff, stream_ptr(dev)),
+          "be_attention_bwd_f32")
     return dqkv, ws
+
+
+_SCRATCH = {}
+
+
+def _bwd_scratch(B, L, H, dev):
+    """The partial-dQ buffer of the attention backward (537 MB at batch 8): its contents mean nothing between calls, so ONE
+    buffer per device serves every layer and step (calls on one stream are ordered)."""
+    need = lib().be_attention_bwd_scratch_floats(B, L, H)
+    key = (dev.type, dev.index)
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() < need:
+        buf = _SCRATCH[key] = _new(need, dev)
+    return buf
 
 
 def attention_dropout_mask(B, L, H, p, seed, dev):

@@ -380,10 +380,7 @@ __global__ void k_attn_combine(const float* __restrict__ part, float* __restrict
 // ---- attention backward -------------------------------------------------------------------------------------
 // With P = softmax(S), Pd = dropout(P), O = Pd V:   dV = Pd^T dO,  dPd = dO V^T,  dS = P o (dropout'(dPd) - Drow),
 // Drow_i = sum_d dO_id O_id,  dQ = scale dS K,  dK = scale dS^T Q.   P is recomputed from the saved log2-sum-exp.
-// Two kernels, no atomics: k_attn_bwd_dq owns 32 queries per wave and streams the keys; k_attn_bwd_dkv owns 32 keys
-// per wave and streams the queries.  Same register trick as the forward: a [16x16] tile of dS (or Pd) sits in the
-// accumulator layout and is fed back as the B operand of the next product, whose A operand is a 16-byte load of the
-// transposed tensor ([16][L]).  Neither kernel hashes: the dropout decisions are the keep bits the forward stored.
+// P is recomputed from the saved log2-sum-exp; no [L,L] float tensor is stored; deterministic (fixed summation orders, no atomics).
 // dout, out [T, D], lse [BH][L] -> dOh [BH][L][16], dOt [BH][16][L], nD [BH][L] = -keep * sum_d dO * O, nlse = -lse: the two
 // per-query constants enter the backward products as the INITIAL VALUES of their accumulators (S' = S - lse, dP' = dP - keep D)
 __global__ void k_dout_prep(const float* __restrict__ dout, const float* __restrict__ out, const float* __restrict__ lse,
@@ -414,123 +411,26 @@ __global__ void k_dout_prep(const float* __restrict__ dout, const float* __restr
     }
 }
 
-// dS / inv_keep = P o (kept ? dP - keep D : -keep D): the accumulator of dP starts at -keep D, a dropped element takes that
-// start value back, and 1 / keep is applied once to the finished dQ
+// ---- experiment: ONE backward kernel (S and dP computed once: 80 MFMAs per 32 x 32 tile instead of 48 + 64) ---------------------
+// dK/dV layout (a wave owns 32 keys, streams the queries); the dS tile is transposed through LDS for the extra product
+// dQ^T[d][q] += K^T[d][key] dS^T[key][q]; the per-wave dQ partials of a query block are summed over the 8 waves of the workgroup
+// in LDS and written as one partial per workgroup (256 keys) - fixed order, no atomics - for a small finishing kernel.
+constexpr int FW = 4;
+
 template <bool RAGGED, bool DROP>
-__global__ __launch_bounds__(256)
-void k_attn_bwd_dq(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
-                     const float* __restrict__ Kt, const float* __restrict__ dOh, const float* __restrict__ nlse,
-                     const float* __restrict__ nD, float* __restrict__ dqkv, int L, int Lv, int H,
-                     const uint16_t* __restrict__ keep, float inv_keep) {
+__global__ __launch_bounds__(64 * FW)
+void k_attn_bwd_fused(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+                      const float* __restrict__ Qt, const float* __restrict__ Kt, const float* __restrict__ dOh,
+                      const float* __restrict__ dOt, const float* __restrict__ nlse, const float* __restrict__ nD,
+                      float* __restrict__ dqkv, float* __restrict__ dqpart, int L, int Lv, int H,
+                      const uint16_t* __restrict__ keep, float inv_keep) {
+    __shared__ __attribute__((aligned(16))) float sT[FW][2][2][320];        // [wave][qt][kc][key c][16 queries + 4 pad]: rows of 20 floats
+    //                                                                           keep the transposed 4-byte reads of a half-wave on 32 different banks
+    __shared__ __attribute__((aligned(16))) float sQ[2][FW][512];           // [buffer][wave][query 32][d 16]
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int c = lane & 15, g = lane >> 4;
     const int bh = blockIdx.y;
-    const int q0 = (blockIdx.x * 4 + wave) * 32;
-    const size_t hb = (size_t)bh * L * DH;
-    const float* Kh = K + hb;
-    const float* Vh = V + hb;
-    const float* Kth = Kt + hb;
-    // keep bits of this wave's 32 queries, as the forward left them: one halfword per lane and key block (same lane layout)
-    const uint16_t* kp = keep + ((size_t)bh * (L / KB) + (q0 >> 5)) * (L / KB) * 64 + lane;
-
-    f32x4v qf[2], gf[2], dq[2], nl[2], nd[2];
-#pragma unroll
-    for (int qc = 0; qc < 2; ++qc) {
-        const size_t row = (size_t)(q0 + 16 * qc + c);
-        qf[qc] = *reinterpret_cast<const f32x4v*>(Q + hb + row * DH + 4 * g);
-        gf[qc] = *reinterpret_cast<const f32x4v*>(dOh + hb + row * DH + 4 * g);
-        const float a = nlse[(size_t)bh * L + row], b = nD[(size_t)bh * L + row];
-        nl[qc] = f32x4v{a, a, a, a};
-        nd[qc] = f32x4v{b, b, b, b};
-        dq[qc] = f32x4v{0.f, 0.f, 0.f, 0.f};
-    }
-    auto load = [&](int blk, f32x4v k[2], f32x4v v[2], f32x4v t[2], uint32_t& w) {
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
-            k[kt] = *reinterpret_cast<const f32x4v*>(Kh + (size_t)(blk * KB + 16 * kt + c) * DH + 4 * g);
-            v[kt] = *reinterpret_cast<const f32x4v*>(Vh + (size_t)(blk * KB + 16 * kt + c) * DH + 4 * g);
-            t[kt] = *reinterpret_cast<const f32x4v*>(Kth + (size_t)c * L + blk * KB + 16 * kt + 4 * g);
-        }
-        if (DROP) w = kp[(size_t)blk * 64];
-    };
-    auto block = [&](const f32x4v kf[2], const f32x4v vf[2], const f32x4v tf[2], uint32_t w, int kblk) {
-        f32x4v s[2][2], dp[2][2];
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int qc = 0; qc < 2; ++qc) {
-                s[kt][qc] = MFMA16(kf[kt][0], qf[qc][0], nl[qc]);            // S^T[key][query] - lse
-                dp[kt][qc] = MFMA16(vf[kt][0], gf[qc][0], nd[qc]);           // dPd^T[key][query] - keep D
-            }
-#pragma unroll
-        for (int t = 1; t < 4; ++t)
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int qc = 0; qc < 2; ++qc) {
-                    s[kt][qc] = MFMA16(kf[kt][t], qf[qc][t], s[kt][qc]);
-                    dp[kt][qc] = MFMA16(vf[kt][t], gf[qc][t], dp[kt][qc]);
-                }
-        if (RAGGED && (kblk + 1) * KB > Lv) {
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r)
-                    if (kblk * KB + 16 * kt + 4 * g + r >= Lv) { s[kt][0][r] = -INFINITY; s[kt][1][r] = -INFINITY; }
-        }
-#pragma unroll
-        for (int qc = 0; qc < 2; ++qc) {
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    float a = dp[kt][qc][r];
-                    if (DROP) {
-                        const uint32_t km = (uint32_t)__builtin_amdgcn_sbfe((int)w, 15 - (8 * qc + 4 * kt + r), 1);   // all ones = kept
-                        a = __uint_as_float((km & __float_as_uint(a)) | (~km & __float_as_uint(nd[qc][0])));
-                    }
-                    s[kt][qc][r] = fast_exp2(s[kt][qc][r]) * a;
-                }
-        }
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int qc = 0; qc < 2; ++qc) dq[qc] = MFMA16(tf[kt][r], s[kt][qc][r], dq[qc]);
-    };
-    const int nkb = RAGGED ? (Lv + KB - 1) / KB : L / KB;
-    f32x4v kA[2], vA[2], tA[2], kB[2], vB[2], tB[2];
-    uint32_t wA = 0, wB = 0;
-    load(0, kA, vA, tA, wA);
-    int kblk = 0;
-    for (; kblk + 1 < nkb; kblk += 2) {                   // branch-free body: two blocks on ping-pong registers
-        load(kblk + 1, kB, vB, tB, wB);
-        __builtin_amdgcn_sched_barrier(0);               // the loads of the next block are issued BEFORE this block's work
-        block(kA, vA, tA, wA, kblk);
-        load(kblk + 2 < nkb ? kblk + 2 : kblk, kA, vA, tA, wA);
-        __builtin_amdgcn_sched_barrier(0);
-        block(kB, vB, tB, wB, kblk + 1);
-    }
-    if (kblk < nkb) block(kA, vA, tA, wA, kblk);
-    const int Dm = H * DH;
-    const int b = bh / H, hd = bh % H;
-    const float sc = 0.25f * inv_keep;
-#pragma unroll
-    for (int qc = 0; qc < 2; ++qc)
-        *reinterpret_cast<f32x4v*>(dqkv + ((size_t)b * L + q0 + 16 * qc + c) * 3 * Dm + hd * DH + 4 * g) = dq[qc] * sc;
-}
-
-template <bool RAGGED, bool DROP>
-__global__ __launch_bounds__(256)
-void k_attn_bwd_dkv(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
-                      const float* __restrict__ Qt, const float* __restrict__ dOh, const float* __restrict__ dOt,
-                      const float* __restrict__ nlse, const float* __restrict__ nD, float* __restrict__ dqkv, int L, int Lv,
-                      int H, const uint16_t* __restrict__ keep, float inv_keep) {
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int c = lane & 15, g = lane >> 4;
-    const int bh = blockIdx.y;
-    const int k0 = (blockIdx.x * 4 + wave) * 32;
+    const int k0 = (blockIdx.x * FW + wave) * 32;
     const size_t hb = (size_t)bh * L * DH;
     const float* Qh = Q + hb;
     const float* Gh = dOh + hb;
@@ -538,17 +438,15 @@ void k_attn_bwd_dkv(const float* __restrict__ Q, const float* __restrict__ K, co
     const float* Gth = dOt + hb;
     const float* nl_h = nlse + (size_t)bh * L;
     const float* nd_h = nD + (size_t)bh * L;
-    // keep bits: the forward wave of query block qb left, for key block kb, one halfword per lane (c_q + 16 g_k) with decision
-    // (qc, kt, r) in bit 15 - (8 qc + 4 kt + r), key = 16 kt + 4 g_k + r.  This lane (key c, query rows 4g + r') needs, for its key
-    // 16 kc + c, the halfwords of forward lanes 16 (c >> 2) + 4g + r', r' = 0..3: eight consecutive bytes
     const uint16_t* kp = keep + ((size_t)bh * (L / KB) * (L / KB) + (k0 >> 5)) * 64 + 16 * (c >> 2) + 4 * g;
-    const uint32_t ksh = 3 - (c & 3);              // after this shift the bit of (qt, kc) sits at 12 - 8 qt - 4 kc of every halfword
+    const uint32_t ksh = 3 - (c & 3);
 
-    f32x4v kf[2], vf[2], dv[2], dk[2];
+    f32x4v kf[2], vf[2], tf[2], dv[2], dk[2];
 #pragma unroll
     for (int kc = 0; kc < 2; ++kc) {
         kf[kc] = *reinterpret_cast<const f32x4v*>(K + hb + (size_t)(k0 + 16 * kc + c) * DH + 4 * g);
         vf[kc] = *reinterpret_cast<const f32x4v*>(V + hb + (size_t)(k0 + 16 * kc + c) * DH + 4 * g);
+        tf[kc] = *reinterpret_cast<const f32x4v*>(Kt + hb + (size_t)c * L + k0 + 16 * kc + 4 * g);      // K^T[d = c][key 16 kc + 4g + r]
         dv[kc] = f32x4v{0.f, 0.f, 0.f, 0.f};
         dk[kc] = f32x4v{0.f, 0.f, 0.f, 0.f};
     }
@@ -560,21 +458,31 @@ void k_attn_bwd_dkv(const float* __restrict__ Q, const float* __restrict__ K, co
             x.gq[qt] = *reinterpret_cast<const f32x4v*>(Gh + (size_t)(blk * KB + 16 * qt + c) * DH + 4 * g);
             x.qt[qt] = *reinterpret_cast<const f32x4v*>(Qth + (size_t)c * L + blk * KB + 16 * qt + 4 * g);
             x.gt[qt] = *reinterpret_cast<const f32x4v*>(Gth + (size_t)c * L + blk * KB + 16 * qt + 4 * g);
-            x.nl[qt] = *reinterpret_cast<const f32x4v*>(nl_h + blk * KB + 16 * qt + 4 * g);      // per query row 16 qt + 4g + r
+            x.nl[qt] = *reinterpret_cast<const f32x4v*>(nl_h + blk * KB + 16 * qt + 4 * g);
             x.nd[qt] = *reinterpret_cast<const f32x4v*>(nd_h + blk * KB + 16 * qt + 4 * g);
         }
     };
     const bool kdead[2] = {RAGGED && k0 + c >= Lv, RAGGED && k0 + 16 + c >= Lv};
     auto loadw = [&](int blk) -> uint2 { return *reinterpret_cast<const uint2*>(kp + (size_t)blk * (L / KB) * 64); };
+    float* part = dqpart + ((size_t)blockIdx.x * gridDim.y + bh) * L * DH;           // this workgroup's partial dQ [L][16]
+    auto reduce = [&](int qb) {       // sum of the waves' partials of query block qb, element e = query * 16 + d
+#pragma unroll
+        for (int e = threadIdx.x; e < 512; e += 64 * FW) {
+            float t = sQ[qb & 1][0][e];
+#pragma unroll
+            for (int w2 = 1; w2 < FW; ++w2) t += sQ[qb & 1][w2][e];
+            part[(size_t)qb * 512 + e] = t;
+        }
+    };
     auto block = [&](const QB& x, const uint2 w, int qblk) {
-        f32x4v s[2][2], dp[2][2];                                        // [qt][kc]: rows = queries, columns = keys
+        f32x4v s[2][2], dp[2][2];
         const uint32_t wsh[2] = {DROP ? w.x >> ksh : 0u, DROP ? w.y >> ksh : 0u};
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
             for (int kc = 0; kc < 2; ++kc) {
-                s[qt][kc] = MFMA16(x.q[qt][0], kf[kc][0], x.nl[qt]);         // S[query][key] - lse[query]
-                dp[qt][kc] = MFMA16(x.gq[qt][0], vf[kc][0], x.nd[qt]);       // dPd[query][key] - keep D[query]
+                s[qt][kc] = MFMA16(x.q[qt][0], kf[kc][0], x.nl[qt]);
+                dp[qt][kc] = MFMA16(x.gq[qt][0], vf[kc][0], x.nd[qt]);
             }
 #pragma unroll
         for (int t = 1; t < 4; ++t)
@@ -585,6 +493,9 @@ void k_attn_bwd_dkv(const float* __restrict__ Q, const float* __restrict__ K, co
                     s[qt][kc] = MFMA16(x.q[qt][t], kf[kc][t], s[qt][kc]);
                     dp[qt][kc] = MFMA16(x.gq[qt][t], vf[kc][t], dp[qt][kc]);
                 }
+        // the partial dQ of the PREVIOUS query block: every wave has stored its share by now and has 32 MFMAs in flight behind
+        // it, so the barrier costs the skew between the waves, not a drained pipe
+        if (qblk > 0) { __syncthreads(); reduce(qblk - 1); }
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
@@ -598,9 +509,11 @@ void k_attn_bwd_dkv(const float* __restrict__ Q, const float* __restrict__ K, co
                         a = __uint_as_float((km & __float_as_uint(a)) | (~km & __float_as_uint(x.nd[qt][r])));
                         pd = __uint_as_float(km & __float_as_uint(p));
                     }
-                    s[qt][kc][r] = p * a;                                   // dS / inv_keep
-                    dp[qt][kc][r] = pd;                                     // Pd * keep
+                    s[qt][kc][r] = p * a;
+                    dp[qt][kc][r] = pd;
                 }
+                // dS tile [queries 4g + r][key c] -> LDS as [key c][query 4g .. 4g + 3]
+                *reinterpret_cast<f32x4v*>(&sT[wave][qt][kc][c * 20 + 4 * g]) = s[qt][kc];
             }
 #pragma unroll
         for (int qt = 0; qt < 2; ++qt)
@@ -608,15 +521,24 @@ void k_attn_bwd_dkv(const float* __restrict__ Q, const float* __restrict__ K, co
             for (int r = 0; r < 4; ++r)
 #pragma unroll
                 for (int kc = 0; kc < 2; ++kc) {
-                    dv[kc] = MFMA16(x.gt[qt][r], dp[qt][kc][r], dv[kc]);          // dV^T[d][key]
-                    dk[kc] = MFMA16(x.qt[qt][r], s[qt][kc][r], dk[kc]);           // dK^T[d][key]
+                    dv[kc] = MFMA16(x.gt[qt][r], dp[qt][kc][r], dv[kc]);
+                    dk[kc] = MFMA16(x.qt[qt][r], s[qt][kc][r], dk[kc]);
                 }
+        // dQ^T[d][query 16 qt + c] += K^T[d][key] dS^T[key][query]: the B operand of k-step (kc, r) is dS[query c][key 16 kc + 4g + r]
+        float* xq = &sQ[qblk & 1][wave][0];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            f32x4v dq = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dq = MFMA16(tf[kc][r], sT[wave][qt][kc][(4 * g + r) * 20 + c], dq);
+            *reinterpret_cast<f32x4v*>(xq + (16 * qt + c) * 16 + 4 * g) = dq;       // [query][d 4g .. 4g + 3]
+        }
     };
     const int nqb = RAGGED ? (Lv + KB - 1) / KB : L / KB;
     QB A, Bq;
     load(0, A);
-    // the keep bits are cold in every cache (each 128-byte line is read once, by one wave) and vector loads retire in order:
-    // they are fetched two iterations (four blocks) ahead so that no operand load ever queues behind one of them
     uint2 wA = {0u, 0u}, wB = {0u, 0u}, wA2 = {0u, 0u}, wB2 = {0u, 0u}, wA3 = {0u, 0u}, wB3 = {0u, 0u};
     auto clampq = [&](int b) { return b < nqb ? b : nqb - 1; };
     if (DROP) { wA = loadw(0); wB = loadw(clampq(1)); wA2 = loadw(clampq(2)); wB2 = loadw(clampq(3)); }
@@ -632,6 +554,8 @@ void k_attn_bwd_dkv(const float* __restrict__ Q, const float* __restrict__ K, co
         wA = wA2; wB = wB2; wA2 = wA3; wB2 = wB3;
     }
     if (qblk < nqb) block(A, wA, qblk);
+    __syncthreads();
+    reduce(nqb - 1);
     const int Dm = H * DH;
     const int b = bh / H, hd = bh % H;
     const float ln2 = 0.69314718055994530942f;
@@ -640,6 +564,23 @@ void k_attn_bwd_dkv(const float* __restrict__ Q, const float* __restrict__ K, co
         float* dst = dqkv + ((size_t)b * L + k0 + 16 * kc + c) * 3 * Dm + hd * DH + 4 * g;
         *reinterpret_cast<f32x4v*>(dst + Dm) = dk[kc] * (ln2 * inv_keep);
         *reinterpret_cast<f32x4v*>(dst + 2 * Dm) = dv[kc] * inv_keep;
+    }
+}
+
+// dQ = scale * sum over the key groups of the partials; rows of query blocks no workgroup visited (padding) are zero
+__global__ void k_attn_dq_finish(const float* __restrict__ part, float* __restrict__ dqkv, int ngroups, int BH, int L, int H,
+                                 int rows_done, float scale) {
+    const int64_t total = (int64_t)BH * L * 4;
+    const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gs) {
+        const int dq4 = (int)(idx & 3);
+        const int64_t row = idx >> 2;
+        const int64_t bh = row / L, l = row % L;
+        f32x4v acc = {0.f, 0.f, 0.f, 0.f};
+        if (l < rows_done)
+            for (int gq = 0; gq < ngroups; ++gq) acc += *reinterpret_cast<const f32x4v*>(part + (((size_t)gq * BH + bh) * L + l) * DH + 4 * dq4);
+        const int64_t b = bh / H, hd = bh % H;
+        *reinterpret_cast<f32x4v*>(dqkv + ((size_t)b * L + l) * 3 * H * DH + hd * DH + 4 * dq4) = acc * scale;
     }
 }
 
@@ -870,12 +811,16 @@ extern "C" int be_attention_train_fwd_f32(const float* qkv, float* out, float* l
     return be::check_launch("be_attention_train_fwd_f32");
 }
 
+extern "C" size_t be_attention_bwd_scratch_floats(int B, int L, int H) {
+    return (size_t)(L / (KB * FW)) * B * H * L * DH;              // one partial dQ per workgroup of FW x 32 keys
+}
+
 extern "C" int be_attention_bwd_f32(const float* qkv, const float* out, const float* lse, const float* dout, float* dqkv,
-                                    float* workspace, int operands_ready, int B, int L, int l_valid, int H, float dropout_p,
-                                    uint32_t seed, void* stream) {
-    BE_REQUIRE(qkv && out && lse && dout && dqkv && workspace, "be_attention_bwd_f32: null pointer");
+                                    float* workspace, float* scratch, int operands_ready, int B, int L, int l_valid, int H,
+                                    float dropout_p, uint32_t seed, void* stream) {
+    BE_REQUIRE(qkv && out && lse && dout && dqkv && workspace && scratch, "be_attention_bwd_f32: null pointer");
     if (int rc = attn_args_ok("be_attention_bwd_f32", B, L, H, dropout_p, l_valid)) return rc;
-    BE_REQUIRE(be::aligned16(qkv) && be::aligned16(dqkv) && be::aligned16(workspace) && be::aligned16(lse),
+    BE_REQUIRE(be::aligned16(qkv) && be::aligned16(dqkv) && be::aligned16(workspace) && be::aligned16(lse) && be::aligned16(scratch),
                "be_attention_bwd_f32: 16-byte alignment");
     hipStream_t s = be::as_stream(stream);
     const TrainWs w = train_ws(workspace, B, L, H);
@@ -894,15 +839,16 @@ extern "C" int be_attention_bwd_f32(const float* qkv, const float* out, const fl
     }
     hipLaunchKernelGGL(k_dout_prep, dim3((unsigned)g), dim3(256), 0, s, dout, out, lse, w.dOh, w.dOt, w.nD, w.nlse, 1.0f - dropout_p,
                        B, L, H);
-    const dim3 grid(L / 128, B * H);
-#define BE_ATTN_BWD(RAG, DROP, LV)                                                                                              \
-    hipLaunchKernelGGL((k_attn_bwd_dq<RAG, DROP>), grid, dim3(256), 0, s, w.Q, w.K, w.V, w.Kt, w.dOh, w.nlse, w.nD, dqkv, L, LV, \
-                       H, w.keep, ik);                                                                                          \
-    hipLaunchKernelGGL((k_attn_bwd_dkv<RAG, DROP>), grid, dim3(256), 0, s, w.Q, w.K, w.V, w.Qt, w.dOh, w.dOt, w.nlse, w.nD,      \
-                       dqkv, L, LV, H, w.keep, ik)
+    const dim3 grid(L / (KB * FW), B * H);
+#define BE_ATTN_BWD(RAG, DROP, LV)                                                                                             \
+    hipLaunchKernelGGL((k_attn_bwd_fused<RAG, DROP>), grid, dim3(64 * FW), 0, s, w.Q, w.K, w.V, w.Qt, w.Kt, w.dOh, w.dOt, w.nlse, \
+                       w.nD, dqkv, scratch, L, LV, H, w.keep, ik)
     if (l_valid == L) { if (th) { BE_ATTN_BWD(false, true, L); } else { BE_ATTN_BWD(false, false, L); } }
     else { if (th) { BE_ATTN_BWD(true, true, l_valid); } else { BE_ATTN_BWD(true, false, l_valid); } }
 #undef BE_ATTN_BWD
+    const int rows_done = ((l_valid + KB - 1) / KB) * KB;            // query blocks the kernel visited; the padding rows get zeros
+    hipLaunchKernelGGL(k_attn_dq_finish, dim3(4096), dim3(256), 0, s, scratch, dqkv, L / (KB * FW), B * H, L, H,
+                       rows_done < L ? rows_done : L, 0.25f * ik);
     return be::check_launch("be_attention_bwd_f32");
 }
 

@@ -432,13 +432,16 @@ size_t be_attention_train_workspace_floats(int B, int L, int H);
 int be_attention_train_fwd_f32(const float* qkv, float* out, float* lse, float* workspace, int B, int L, int l_valid, int H,
                                float dropout_p, uint32_t seed, void* stream);
 /* Attention backward: dout [B*L, H*16] -> dqkv [B*L, 3*H*16]; probabilities are recomputed from qkv and lse
- * (no [L,L] float tensor is ever stored); deterministic (no atomics).  Same workspace size as the forward.
+ * (no [L,L] float tensor is ever stored); deterministic (no atomics).  Same workspace size as the forward; `scratch`
+ * (be_attention_bwd_scratch_floats floats, contents irrelevant before and after the call: one buffer can serve every layer)
+ * receives the partial dQ sums of the key groups.
  * operands_ready != 0: `workspace` is the buffer the forward call of this layer used and nothing wrote to it since
  * (its split q/k/v and keep bits are reused); 0: they are produced again from qkv and the seed.  l_valid as in be_attention_f32: rows >= l_valid of
  * dout must be zero (they are when the caller slices the padded output), and dqkv comes out zero there. */
+size_t be_attention_bwd_scratch_floats(int B, int L, int H);
 int be_attention_bwd_f32(const float* qkv, const float* out, const float* lse, const float* dout, float* dqkv,
-                         float* workspace, int operands_ready, int B, int L, int l_valid, int H, float dropout_p, uint32_t seed,
-                         void* stream);
+                         float* workspace, float* scratch, int operands_ready, int B, int L, int l_valid, int H, float dropout_p,
+                         uint32_t seed, void* stream);
 /* The keep mask the two functions above apply, [B*H, L, L] in {0,1} (test hook; small L only). */
 int be_attention_dropout_mask_f32(float* mask, int B, int L, int H, float dropout_p, uint32_t seed, void* stream);
 /* The same decisions in the packed layout the forward leaves in its workspace (B*H*L*L/16 halfwords), from the formula:

@@ -54,18 +54,30 @@ int main(int argc, char** argv) {
         const uint32_t th = drop_threshold(p);
         const float ik = 1.0f / (1.0f - p);
         if (be_attention_train_fwd_f32(qkv, out, lse, ws, B, L, L, H, p, 7u, nullptr)) { printf("fwd failed\n"); return 1; }
-        if (be_attention_bwd_f32(qkv, out, lse, dout, dqkv, ws, 1, B, L, L, H, p, 7u, nullptr)) { printf("bwd failed\n"); return 1; }
+        {
+            float* sc0;
+            CK(hipMalloc(&sc0, be_attention_bwd_scratch_floats(B, L, H) * 4));
+            if (be_attention_bwd_f32(qkv, out, lse, dout, dqkv, ws, sc0, 1, B, L, L, H, p, 7u, nullptr)) { printf("bwd failed\n"); return 1; }
+            CK(hipDeviceSynchronize());
+            CK(hipFree(sc0));
+        }
         CK(hipDeviceSynchronize());
         const TrainWs w = train_ws(ws, B, L, H);
         char nm[64];
         snprintf(nm, sizeof nm, "k_attention<train> p=%.1f", p);
         tk(nm, fl, [&] { hipLaunchKernelGGL((k_attention<true, false>), grid, blk, 0, 0, w.Q, w.K, w.Vt, out, lse, L, L, H, 7u, th, ik, (float*)nullptr, w.keep); });
-        snprintf(nm, sizeof nm, "k_attn_bwd_dq p=%.1f", p);
-        if (th) tk(nm, 1.5 * fl, [&] { hipLaunchKernelGGL((k_attn_bwd_dq<false, true>), grid, blk, 0, 0, w.Q, w.K, w.V, w.Kt, w.dOh, w.nlse, w.nD, dqkv, L, L, H, w.keep, ik); });
-        else tk(nm, 1.5 * fl, [&] { hipLaunchKernelGGL((k_attn_bwd_dq<false, false>), grid, blk, 0, 0, w.Q, w.K, w.V, w.Kt, w.dOh, w.nlse, w.nD, dqkv, L, L, H, w.keep, ik); });
-        snprintf(nm, sizeof nm, "k_attn_bwd_dkv p=%.1f", p);
-        if (th) tk(nm, 2.0 * fl, [&] { hipLaunchKernelGGL((k_attn_bwd_dkv<false, true>), grid, blk, 0, 0, w.Q, w.K, w.V, w.Qt, w.dOh, w.dOt, w.nlse, w.nD, dqkv, L, L, H, w.keep, ik); });
-        else tk(nm, 2.0 * fl, [&] { hipLaunchKernelGGL((k_attn_bwd_dkv<false, false>), grid, blk, 0, 0, w.Q, w.K, w.V, w.Qt, w.dOh, w.dOt, w.nlse, w.nD, dqkv, L, L, H, w.keep, ik); });
+        {
+            float* part;
+            CK(hipMalloc(&part, be_attention_bwd_scratch_floats(B, L, H) * 4));
+            const int ngroups = L / (KB * FW);
+            const dim3 gridf(ngroups, B * H), blkf(64 * FW);
+            snprintf(nm, sizeof nm, "k_attn_bwd_fused p=%.1f", p);
+            if (th) tk(nm, 2.5 * fl, [&] { hipLaunchKernelGGL((k_attn_bwd_fused<false, true>), gridf, blkf, 0, 0, w.Q, w.K, w.V, w.Qt, w.Kt, w.dOh, w.dOt, w.nlse, w.nD, dqkv, part, L, L, H, w.keep, ik); });
+            else tk(nm, 2.5 * fl, [&] { hipLaunchKernelGGL((k_attn_bwd_fused<false, false>), gridf, blkf, 0, 0, w.Q, w.K, w.V, w.Qt, w.Kt, w.dOh, w.dOt, w.nlse, w.nD, dqkv, part, L, L, H, w.keep, ik); });
+            snprintf(nm, sizeof nm, "k_attn_dq_finish p=%.1f", p);
+            tk(nm, 0.0, [&] { hipLaunchKernelGGL(k_attn_dq_finish, dim3(4096), dim3(256), 0, 0, part, dqkv, ngroups, B * H, L, H, L, 0.25f * ik); });
+            CK(hipFree(part));
+        }
     }
     return 0;
 }
