@@ -242,4 +242,5 @@ def test_bench_two_rank_rehearsal_on_one_gpu(tmp_path):
     dp = d["dp"]
     assert dp["world"] == 2 and dp["global_batch"] == 128 and dp["allreduce_bytes"] == 4 * 7254122 and dp["allreduce_buckets"] == 5
     assert dp["dp_step_ms"] > 0 and dp["allreduce_ms"] > 0 and dp["segmented_graph_step_ms"] > 0 and "error" not in dp
-    assert d["roofline"]["executed_frac"] > 0.5 and len(d["extra_configs"]) == 3
+    assert d["roofline"]["executed_frac"] > 0.5 and len(d["extra_configs"]) == 4 and all("error" not in e for e in d["extra_configs"])
+    assert d["extra_configs"][3]["images_per_s"] > 0                       # the global-stage training step
