@@ -117,6 +117,7 @@ _SIGNATURES = {
     "be_render_full_f32": (C.c_int, [C.POINTER(RenderOpts), C.POINTER(DepthConsts), C.c_float, C.c_int, _P,
                                      C.POINTER(PatchView), _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
     "be_fold_records_f32": (C.c_int, [C.POINTER(RenderOpts), _P] + [C.c_int] * 6 + [_P] * 6 + [_P]),
+    "be_fold_records_batch_f32": (C.c_int, [C.POINTER(RenderOpts), _P] + [C.c_int] * 7 + [_P] * 6 + [_P]),
     "be_unfold_patches_f32": (C.c_int, [_P, _P] + [C.c_int] * 5 + [_P]),
     "be_local_features_f32": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
     "be_global_denorm_f32": (C.c_int, [_P, _P, C.c_int64, _P]),
@@ -573,6 +574,20 @@ def fold_records(opts, records, hp, wp, H, W, stride=2, densify_w=False, want=FO
     check(lib().be_fold_records_f32(C.byref(opts), dptr(records, "records"), hp, wp, H, W, stride, int(bool(densify_w)),
                                     g("image"), g("shpd"), g("refoc"), g("bndry"), g("depth"), g("conf"),
                                     stream_ptr(dev)), "be_fold_records_f32")
+    return out
+
+
+def fold_records_batch(opts, records, hp, wp, H, W, stride=2, densify_w=False, want=FOLD_MAPS):
+    """records [B, hp*wp, 32] -> the maps of fold_records with a leading batch dimension, one launch."""
+    if records.dim() != 3 or tuple(records.shape[1:]) != (hp * wp, RECORD_FLOATS):
+        raise RuntimeError(f"fold_records_batch: records must be [B,{hp * wp},{RECORD_FLOATS}], got {tuple(records.shape)}")
+    dev, B = records.device, records.shape[0]
+    shapes = dict(image=(B, 2, 3, H, W), shpd=(B, 3, H, W), refoc=(B, 3, H, W), bndry=(B, H, W), depth=(B, H, W), conf=(B, H, W))
+    out = {k: torch.empty(shapes[k], dtype=torch.float32, device=dev) for k in want}
+    g = lambda k: dptr(out.get(k))
+    check(lib().be_fold_records_batch_f32(C.byref(opts), dptr(records, "records"), B, hp, wp, H, W, stride, int(bool(densify_w)),
+                                          g("image"), g("shpd"), g("refoc"), g("bndry"), g("depth"), g("conf"),
+                                          stream_ptr(dev)), "be_fold_records_batch_f32")
     return out
 
 

@@ -173,6 +173,7 @@ struct FoldArgs {
     float* bndry;            // [H,W] or null
     float* depth;            // [H,W] or null
     float* conf;             // [H,W] or null
+    int64_t rec_stride;      // batched form (grid.z = image): floats between the records / maps of consecutive images
 };
 
 __global__ __launch_bounds__(256)
@@ -183,6 +184,16 @@ void k_fold_records(be_render_opts o, FoldArgs a) {
     const int x = blockIdx.x * 16 + (threadIdx.x & 15);
     const int y = blockIdx.y * 16 + (threadIdx.x >> 4);
     if (x >= a.W || y >= a.H) return;
+    if (blockIdx.z) {                                           // image blockIdx.z of a batch
+        const size_t b = blockIdx.z, hw = (size_t)a.H * a.W;
+        a.records += b * a.rec_stride;
+        if (a.image) a.image += b * 6 * hw;
+        if (a.shpd) a.shpd += b * 3 * hw;
+        if (a.refoc) a.refoc += b * 3 * hw;
+        if (a.bndry) a.bndry += b * hw;
+        if (a.depth) a.depth += b * hw;
+        if (a.conf) a.conf += b * hw;
+    }
     // patches covering (y,x): stride*i <= y <= stride*i + 20
     const int s = a.stride;
     int i_lo = (y - (R - 1) + s - 1) / s; if (y - (R - 1) < 0) i_lo = 0;
@@ -326,9 +337,21 @@ extern "C" int be_fold_records_f32(const be_render_opts* o, const float* records
     BE_REQUIRE(hp > 0 && wp > 0 && H > 0 && W > 0 && stride > 0, "be_fold_records_f32: bad sizes");
     BE_REQUIRE(stride * (hp - 1) + R <= H && stride * (wp - 1) + R <= W, "be_fold_records_f32: patch grid exceeds the image");
     BE_REQUIRE(be::aligned16(records), "be_fold_records_f32: records must be 16-byte aligned");
-    FoldArgs a{records, hp, wp, H, W, stride, densify_w, image, shpd, refoc, bndry, depth, conf};
+    FoldArgs a{records, hp, wp, H, W, stride, densify_w, image, shpd, refoc, bndry, depth, conf, 0};
     hipLaunchKernelGGL(k_fold_records, dim3((W + 15) / 16, (H + 15) / 16), dim3(256), 0, be::as_stream(stream), *o, a);
     return be::check_launch("be_fold_records_f32");
+}
+
+extern "C" int be_fold_records_batch_f32(const be_render_opts* o, const float* records, int B, int hp, int wp, int H, int W,
+                                         int stride, int densify_w, float* image, float* shpd, float* refoc, float* bndry,
+                                         float* depth, float* conf, void* stream) {
+    BE_REQUIRE(o && records, "be_fold_records_batch_f32: null pointer");
+    BE_REQUIRE(B > 0 && B <= 65535 && hp > 0 && wp > 0 && H > 0 && W > 0 && stride > 0, "be_fold_records_batch_f32: bad sizes");
+    BE_REQUIRE(stride * (hp - 1) + R <= H && stride * (wp - 1) + R <= W, "be_fold_records_batch_f32: patch grid exceeds the image");
+    BE_REQUIRE(be::aligned16(records), "be_fold_records_batch_f32: records must be 16-byte aligned");
+    FoldArgs a{records, hp, wp, H, W, stride, densify_w, image, shpd, refoc, bndry, depth, conf, (int64_t)hp * wp * REC};
+    hipLaunchKernelGGL(k_fold_records, dim3((W + 15) / 16, (H + 15) / 16, B), dim3(256), 0, be::as_stream(stream), *o, a);
+    return be::check_launch("be_fold_records_batch_f32");
 }
 
 extern "C" int be_unfold_patches_f32(const float* img, float* out, int B, int C, int H, int W, int stride, void* stream) {

@@ -209,13 +209,10 @@ class _GlobalLossFn(torch.autograd.Function):
         opts = helper.render_opts(False)
         img_fit, img_gt = img_fit.contiguous(), img_gt.contiguous()
         # the CURRENT folded image / boundary (the reference detaches them before the consistency terms)
-        G = torch.empty(B, 2, 3, H, W, dtype=torch.float32, device=e.device)
-        Gb = torch.empty(B, H, W, dtype=torch.float32, device=e.device)
-        for b in range(B):
-            rec, _ = native.render_full(opts, dcal.consts, 0.0, False, native.global_denorm(e[b]),
-                                        native.view_image_pair_nhwc(img_fit[b], st))
-            m = native.fold_records(opts, rec, hp, wp, H, W, st, False, want=("image", "bndry"))
-            G[b], Gb[b] = m["image"], m["bndry"]
+        recs = torch.stack([native.render_full(opts, dcal.consts, 0.0, False, native.global_denorm(e[b]),
+                                               native.view_image_pair_nhwc(img_fit[b], st))[0] for b in range(B)])
+        m = native.fold_records_batch(opts, recs, hp, wp, H, W, st, False, want=("image", "bndry"))     # one launch for the batch
+        G, Gb = m["image"], m["bndry"]
         Gd = helper.get_image_derivative(G.view(B * 2, 3, H, W)).view(B, 2, 3, H - 2, W - 2)
         g6 = [gam[k] for k in ("color", "color_cons", "bndry_cons", "smthns", "smthns_cons", "bndry_loc")]
         partial, grad, gdep = native.global_loss(opts, dcal.consts, e, img_fit, img_gt, G, Gd, Gb, bndry_dist.contiguous(),

@@ -142,6 +142,11 @@ int be_render_full_f32(const be_render_opts* opts_host, const be_depth_consts* c
 int be_fold_records_f32(const be_render_opts* opts_host, const float* records, int hp, int wp, int H, int W,
                         int stride, int densify_w, float* image, float* shpd, float* refoc, float* bndry,
                         float* depth, float* conf, void* stream);
+/* The same for B images in one launch (records [B][hp*wp][32], every map with a leading batch dimension): a 147 x 147 image is
+ * 100 workgroups, a batch fills the chip (GlobalLoss folds the current image and boundary map of every image of a batch). */
+int be_fold_records_batch_f32(const be_render_opts* o, const float* records, int B, int hp, int wp, int H, int W, int stride,
+                              int densify_w, float* image, float* shpd, float* refoc, float* bndry, float* depth, float* conf,
+                              void* stream);
 
 /* nn.Unfold(21, stride) in the order blurry_edges_test.py:120-121 consumes it:
  * img [B,C,H,W] -> out [B, Hp*Wp, C, 21, 21], patch (i,j) = rows stride*i.., cols stride*j.., index i*Wp+j. */
