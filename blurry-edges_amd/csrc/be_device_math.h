@@ -67,4 +67,50 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
+// The same sum with register-to-register lane exchanges only (no ds_bpermute: a butterfly step through the LDS crossbar costs an
+// LDS instruction and its latency): v_permlane32_swap / v_permlane16_swap for the partners 32 and 16 lanes away, DPP for the
+// four steps inside a row of 16 (rotate by 8 = xor 8, half-row mirror = xor 7, quad permutes xor 2 and xor 1: the four masks span
+// the row).  Fixed order -> bitwise reproducible; NOT the order of wave_sum, so the two differ in the last bits.
+__device__ __forceinline__ float wave_sum_dpp(float v) {
+    {
+        auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    {
+        auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x128, 0xf, 0xf, false));      // row_ror:8
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x141, 0xf, 0xf, false));      // row_half_mirror
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x4e, 0xf, 0xf, false));       // quad_perm [2,3,0,1]
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0xb1, 0xf, 0xf, false));       // quad_perm [1,0,3,2]
+    return v;
+}
+
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+    auto halves = [](double x, uint32_t& lo, uint32_t& hi) { const uint64_t b = __double_as_longlong(x); lo = (uint32_t)b; hi = (uint32_t)(b >> 32); };
+    auto join = [](uint32_t lo, uint32_t hi) { return __longlong_as_double((long long)(((uint64_t)hi << 32) | lo)); };
+    uint32_t lo, hi;
+    {
+        halves(v, lo, hi);
+        auto a = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+        auto b = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+        v = join(a[0], b[0]) + join(a[1], b[1]);
+    }
+    {
+        halves(v, lo, hi);
+        auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+        auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+        v = join(a[0], b[0]) + join(a[1], b[1]);
+    }
+#define BE_DPP_STEP_D(CTRL)                                                                                          \
+    {                                                                                                                \
+        halves(v, lo, hi);                                                                                           \
+        v += join(__builtin_amdgcn_update_dpp(0u, lo, CTRL, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(0u, hi, CTRL, 0xf, 0xf, false)); \
+    }
+    BE_DPP_STEP_D(0x128) BE_DPP_STEP_D(0x141) BE_DPP_STEP_D(0x4e) BE_DPP_STEP_D(0xb1)
+#undef BE_DPP_STEP_D
+    return v;
+}
+
 }  // namespace be

@@ -69,15 +69,15 @@ struct PatchScalars {            // computed once per patch (wave 0 / thread 0),
     GeomD g;                     // patch does not occupy registers in 448 threads
     real eta[4], irad[4], deta[4], idelta;
     real z1, z2, dz1a, dz1b, dz2a, dz2b;
-    float Cc[3][3], inv[3][3], V[3][3], S[3][3];
 };
+struct SolveScalars { float Cc[3][3], inv[3][3], V[3][3], S[3][3]; };
 
 // sum over the workgroup of n floats per thread; every thread gets the totals.  red: [NWV][n] floats of LDS.
+// (each call site owns its `red`: no barrier is needed to protect an earlier use)
 template <int N>
 __device__ __forceinline__ void block_sum(float (&v)[N], float* red, int lane, int wv) {
 #pragma unroll
-    for (int k = 0; k < N; ++k) v[k] = be::wave_sum(v[k]);
-    __syncthreads();                                         // the previous use of red is over
+    for (int k = 0; k < N; ++k) v[k] = be::wave_sum_dpp(v[k]);
     if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < N; ++k) red[wv * N + k] = v[k];
@@ -94,8 +94,7 @@ __device__ __forceinline__ void block_sum(float (&v)[N], float* red, int lane, i
 template <int N>
 __device__ __forceinline__ void block_sum_d(real (&v)[N], real* red, int lane, int wv) {
 #pragma unroll
-    for (int k = 0; k < N; ++k) v[k] = wave_sum_d(v[k]);
-    __syncthreads();
+    for (int k = 0; k < N; ++k) v[k] = be::wave_sum_dpp(v[k]);
     if (lane == 0) {
 #pragma unroll
         for (int k = 0; k < N; ++k) red[wv * N + k] = v[k];
@@ -110,15 +109,16 @@ __device__ __forceinline__ void block_sum_d(real (&v)[N], real* red, int lane, i
     }
 }
 
-__global__ __launch_bounds__(NT)
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))       // 128 registers: two workgroups of 7 waves per CU
 void k_global_loss(be_render_opts o, GLArgs a) {
     __shared__ float lin[R];
-    __shared__ float sPatch[3][NPIX];
-    __shared__ float sDx[3][NQ];
-    __shared__ float sDy[3][NQ];
+    __shared__ float sPatch[2][3][NPIX];                       // both blur sets at once: no barrier between the sets
+    __shared__ float sDx[2][3][NQ];
+    __shared__ float sDy[2][3][NQ];
     __shared__ PatchScalars sc;
-    __shared__ real red_d[NWV * 14];
-    float* red = reinterpret_cast<float*>(red_d);             // the float sums use the same scratch (never at the same time)
+    __shared__ SolveScalars sv[NWV];                           // every wave keeps its own copy of the 3x3 solve: no block barrier for it
+    __shared__ float red_nb[NWV * 15], red_dc[NWV * 9];
+    __shared__ real red_d[NWV * 22];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     if (tid < R) lin[tid] = o.lin[tid];
     const int64_t gp = blockIdx.x;
@@ -127,24 +127,32 @@ void k_global_loss(be_render_opts o, GLArgs a) {
     const int y0 = a.stride * pi, x0 = a.stride * pj;
     const size_t HW = (size_t)a.H * a.W, HWd = (size_t)(a.H - 2) * (a.W - 2);
 
-    // ---- parameters (global_training.py:141-145) and their chain factors: wave 0, once per patch
-    if (wv == 0) {
+    // ---- parameters (global_training.py:141-145) and their chain factors, once per patch.  The fp64 sin / cos / pow / erf / exp
+    // are a few hundred instructions each: one lane per value, on two waves (the eight trigonometric values on wave 0, the four
+    // eta chains on wave 1), not eight values one after the other on every lane while six waves wait.
+    {
         const float* e = a.est + gp * 12;
-        real v[8];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = 3.0 * (real)e[k];
-#pragma unroll
-        for (int k = 4; k < 8; ++k) v[k] = ((real)e[k] + 1.0) * 3.14159265358979323846;
-        const GeomD g0 = make_geom_dv(v);
-        if (lane == 0) sc.g = g0;
-        if (lane < 4) {
+        if (wv == 0 && lane < 8) {
+            const int w2 = (lane >> 1) & 1;                          // wedge 0 / 1
+            const real th = wrap_2pi_d(((real)e[4 + 2 * w2] + 1.0) * 3.14159265358979323846);
+            const real ph = wrap_2pi_d(((real)e[5 + 2 * w2] + 1.0) * 3.14159265358979323846);
+            const real ang = (lane & 1) ? th + ph : th;              // lane: 0 t1, 1 t1+f1, 2 t2, 3 t2+f2; +4: cosine
+            const real val = lane < 4 ? sin(ang) : cos(ang);
+            real* gsc = lane < 4 ? (lane == 0 ? &sc.g.s11 : lane == 1 ? &sc.g.s12 : lane == 2 ? &sc.g.s21 : &sc.g.s22)
+                                 : (lane == 4 ? &sc.g.c11 : lane == 5 ? &sc.g.c12 : lane == 6 ? &sc.g.c21 : &sc.g.c22);
+            *gsc = val;
+            if (lane == 1) sc.g.sg1 = ph < 3.14159265358979323846 ? 1.0 : -1.0;
+            if (lane == 3) sc.g.sg2 = ph < 3.14159265358979323846 ? 1.0 : -1.0;
+            if (lane == 0) { sc.g.x0 = 3.0 * (real)e[0]; sc.g.y0 = 3.0 * (real)e[1]; sc.g.x1 = 3.0 * (real)e[2]; sc.g.y1 = 3.0 * (real)e[3]; }
+        }
+        if (wv == 1 && lane < 4) {
             const real pk = (real)e[8 + lane] + 0.5;
             const real eta = pow(10.0, 2.0 * erf(pk) - 2.0);
             sc.eta[lane] = eta;
             sc.irad[lane] = 1.0 / ((real)be::kRoot2 * eta);
             sc.deta[lane] = eta * 2.302585092994046 * 4.0 * (real)kInvSqrtPi * exp(-pk * pk);
         }
-        if (lane == 4) sc.idelta = 1.0 / (real)o.delta_sq;
+        if (wv == 1 && lane == 4) sc.idelta = 1.0 / (real)o.delta_sq;
     }
     __syncthreads();
     const real irad[4] = {sc.irad[0], sc.irad[1], sc.irad[2], sc.irad[3]};
@@ -179,8 +187,9 @@ void k_global_loss(be_render_opts o, GLArgs a) {
             nb[6 + c] = fmaf(u0, y[s][c], nb[6 + c]); nb[9 + c] = fmaf(u1, y[s][c], nb[9 + c]); nb[12 + c] = fmaf(u2, y[s][c], nb[12 + c]);
         }
     }
-    block_sum(nb, red, lane, wv);
-    if (tid == 0) {
+    block_sum(nb, red_nb, lane, wv);
+    SolveScalars& my = sv[wv];                                   // this wave's copy (LDS operations of a wave are ordered)
+    if (lane == 0) {
         const float* gs = nb;
         const float* bs = nb + 6;
         const double A00 = (double)gs[0] + o.lambda_ridge, A01 = gs[1], A02 = gs[2], A11 = (double)gs[3] + o.lambda_ridge,
@@ -193,44 +202,49 @@ void k_global_loss(be_render_opts o, GLArgs a) {
         for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                sc.Cc[c][k] = (float)(iv[k][0] * bs[c] + iv[k][1] * bs[3 + c] + iv[k][2] * bs[6 + c]);
-                sc.inv[c][k] = (float)iv[c][k];
+                my.Cc[c][k] = (float)(iv[k][0] * bs[c] + iv[k][1] * bs[3 + c] + iv[k][2] * bs[6 + c]);
+                my.inv[c][k] = (float)iv[c][k];
             }
-        // depth of the two wedges and its derivative w.r.t. the four etas
-        real a_, b_;
+    }
+    if (tid == 64) {                                             // depth of the two wedges and its derivative w.r.t. the four etas
+        real a_, b_;                                             // (first read in pass 3, two barriers later)
         sc.z1 = depth_and_grad(a.dc, sc.eta[0], sc.eta[2], a_, b_); sc.dz1a = a_; sc.dz1b = b_;
         sc.z2 = depth_and_grad(a.dc, sc.eta[1], sc.eta[3], a_, b_); sc.dz2a = a_; sc.dz2b = b_;
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
 
-    // ---- pass 2 (per blur set): composite -> colour terms; Sobel terms and their adjoint gathered back
+    // ---- pass 2 (both blur sets): composite -> colour terms; Sobel terms and their adjoint gathered back
     float gP[2][3];
     float T[7] = {0, 0, 0, 0, 0, 0, 0};                          // T1 T2 T4 T5 | T3 T6 | T7 ; MS separately
+#pragma unroll
     for (int s = 0; s < 2; ++s) {
         const float* gt = a.img_gt + ((size_t)(b * 2 + s) * HW) * 3;
         const float* Gs = a.G + (size_t)(b * 2 + s) * 3 * HW;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float val = u[s][0] * sc.Cc[c][0] + u[s][1] * sc.Cc[c][1] + u[s][2] * sc.Cc[c][2];
+            const float val = u[s][0] * my.Cc[c][0] + u[s][1] * my.Cc[c][1] + u[s][2] * my.Cc[c][2];
             float r1 = 0.f, r2 = 0.f;
             if (live) {
-                sPatch[c][pix] = val;
+                sPatch[s][c][pix] = val;
                 r1 = val - gt[at * 3 + c];
                 r2 = val - Gs[c * HW + at];
             }
             T[0] = fmaf(r1, r1, T[0]); T[1] = fmaf(r2, r2, T[1]);
             gP[s][c] = 2.0f * (r1 * a.wc + r2 * a.wcc);
         }
-        __syncthreads();
-        if (tid < NQ) {
-            const int q = tid;
-            const int qy = q / Q, qx = q - qy * Q;
-            const size_t atd = (size_t)(y0 + qy) * (a.W - 2) + x0 + qx;
+    }
+    __syncthreads();
+    if (tid < NQ) {
+        const int q = tid;
+        const int qy = q / Q, qx = q - qy * Q;
+        const size_t atd = (size_t)(y0 + qy) * (a.W - 2) + x0 + qx;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
             const float* dr = a.deri + ((size_t)(b * 2 + s) * HWd) * 3;
             const float* Gds = a.Gd + (size_t)(b * 2 + s) * 3 * HWd;
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const float* Pp = sPatch[c] + qy * R + qx;
+                const float* Pp = sPatch[s][c] + qy * R + qx;
                 const float p00 = Pp[0], p01 = Pp[1], p02 = Pp[2], p10 = Pp[R], p12 = Pp[R + 2], p20 = Pp[2 * R],
                             p21 = Pp[2 * R + 1], p22 = Pp[2 * R + 2];
                 const float gx = (p02 - p00) + 2.0f * (p12 - p10) + (p22 - p20);
@@ -239,12 +253,15 @@ void k_global_loss(be_render_opts o, GLArgs a) {
                 const float t4 = sm - dr[atd * 3 + c], t5 = sm - Gds[c * HWd + atd];
                 T[2] = fmaf(t4, t4, T[2]); T[3] = fmaf(t5, t5, T[3]);
                 const float k = 2.0f * (t4 * a.ws + t5 * a.wsc) / sm;
-                sDx[c][q] = k * gx;
-                sDy[c][q] = k * gy;
+                sDx[s][c][q] = k * gx;
+                sDy[s][c][q] = k * gy;
             }
         }
-        __syncthreads();
-        if (live) {
+    }
+    __syncthreads();
+    if (live) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 float acc = 0.f;
@@ -258,13 +275,11 @@ void k_global_loss(be_render_opts o, GLArgs a) {
                         if (qx < 0 || qx >= Q) continue;
                         const float kx = (dx == 0 ? -1.f : (dx == 2 ? 1.f : 0.f)) * (dy == 1 ? 2.f : 1.f);
                         const float ky = (dy == 0 ? 1.f : (dy == 2 ? -1.f : 0.f)) * (dx == 1 ? 2.f : 1.f);
-                        acc += kx * sDx[c][qy * Q + qx] + ky * sDy[c][qy * Q + qx];
+                        acc += kx * sDx[s][c][qy * Q + qx] + ky * sDy[s][c][qy * Q + qx];
                     }
                 }
                 gP[s][c] += acc;
             }
-        }
-        __syncthreads();                                        // LDS is reused by the second blur set
     }
 
     // ---- adjoint of the shared colour solve
@@ -275,15 +290,15 @@ void k_global_loss(be_render_opts o, GLArgs a) {
         for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int k = 0; k < 3; ++k) dC[c * 3 + k] = fmaf(gP[s][c], u[s][k], dC[c * 3 + k]);      // u is 0 on dead threads
-    block_sum(dC, red, lane, wv);
-    if (tid == 0) {
+    block_sum(dC, red_dc, lane, wv);
+    if (lane == 0) {
         float V[3][3];
 #pragma unroll
         for (int c = 0; c < 3; ++c)
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
-                V[c][k] = sc.inv[k][0] * dC[c * 3] + sc.inv[k][1] * dC[c * 3 + 1] + sc.inv[k][2] * dC[c * 3 + 2];
-                sc.V[c][k] = V[c][k];
+                V[c][k] = my.inv[k][0] * dC[c * 3] + my.inv[k][1] * dC[c * 3 + 1] + my.inv[k][2] * dC[c * 3 + 2];
+                my.V[c][k] = V[c][k];
             }
 #pragma unroll
         for (int k = 0; k < 3; ++k)
@@ -291,11 +306,11 @@ void k_global_loss(be_render_opts o, GLArgs a) {
             for (int j = 0; j < 3; ++j) {
                 float dkj = 0.f, djk = 0.f;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) { dkj -= V[c][k] * sc.Cc[c][j]; djk -= V[c][j] * sc.Cc[c][k]; }
-                sc.S[k][j] = dkj + djk;
+                for (int c = 0; c < 3; ++c) { dkj -= V[c][k] * my.Cc[c][j]; djk -= V[c][j] * my.Cc[c][k]; }
+                my.S[k][j] = dkj + djk;
             }
     }
-    __syncthreads();
+    __builtin_amdgcn_wave_barrier();
 
     // ---- pass 3: per-pixel adjoints down to the twelve parameters
     real acc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};   // gx0 gy0 gt1 gf1 gx1 gy1 gt2 gf2 | gr[4] | gz1 gz2
@@ -312,9 +327,9 @@ void k_global_loss(be_render_opts o, GLArgs a) {
             for (int k = 0; k < 3; ++k) {
                 float t = 0.f;
 #pragma unroll
-                for (int c = 0; c < 3; ++c) t += gP[s][c] * sc.Cc[c][k] + sc.V[c][k] * y[s][c];
+                for (int c = 0; c < 3; ++c) t += gP[s][c] * my.Cc[c][k] + my.V[c][k] * y[s][c];
 #pragma unroll
-                for (int j = 0; j < 3; ++j) t += sc.S[k][j] * u[s][j];
+                for (int j = 0; j < 3; ++j) t += my.S[k][j] * u[s][j];
                 du[k] = t;
             }
             const real dh1 = (du[1] - du[0]) * (1.0f - h2);
@@ -353,13 +368,17 @@ void k_global_loss(be_render_opts o, GLArgs a) {
         wedge_backward(px, py, g.x0, g.y0, g.s11, g.c11, g.s12, g.c12, g.sg1, false, o.w, gd1, acc[0], acc[1], acc[2], acc[3]);
         wedge_backward(px, py, g.x1, g.y1, g.s21, g.c21, g.s22, g.c22, g.sg2, true, o.w, gd2, acc[4], acc[5], acc[6], acc[7]);
     }
-    block_sum_d(acc, red_d, lane, wv);
-    float Tm[8] = {T[0], T[1], T[4], T[2], T[3], T[5], T[6], MS};       // the order of the partial record: T1 T2 T3 T4 T5 T6 T7 MS
-    block_sum(Tm, red, lane, wv);
+    real fin[22];                                                // the 14 parameter adjoints and the 8 term sums: one reduction
+#pragma unroll
+    for (int k = 0; k < 14; ++k) fin[k] = acc[k];
+    fin[14] = T[0]; fin[15] = T[1]; fin[16] = T[4]; fin[17] = T[2]; fin[18] = T[3]; fin[19] = T[5]; fin[20] = T[6]; fin[21] = MS;
+    block_sum_d(fin, red_d, lane, wv);                           // (order of the partial record: T1 T2 T3 T4 T5 T6 T7 MS)
+#pragma unroll
+    for (int k = 0; k < 14; ++k) acc[k] = fin[k];
     if (tid == 0) {
         float* pt = a.partial + gp * 8;
 #pragma unroll
-        for (int k = 0; k < 8; ++k) pt[k] = Tm[k];
+        for (int k = 0; k < 8; ++k) pt[k] = (float)fin[14 + k];
         float* go = a.grad + gp * 12;
         const real pi_ = 3.14159265358979323846;
         go[0] = (float)(3.0 * acc[0]); go[1] = (float)(3.0 * acc[1]); go[2] = (float)(3.0 * acc[4]); go[3] = (float)(3.0 * acc[5]);
