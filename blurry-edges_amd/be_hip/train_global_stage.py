@@ -6,8 +6,9 @@ seed, p, nhead, eps, *params)` is a torch.autograd.Function whose backward retur
 the reference's layout (nn.TransformerEncoderLayer, post-norm, ReLU; models/global_stage.py:28-32), so AdamW /
 clip_grad_norm_ / a gradient all-reduce work on it unchanged.  torch allocates buffers and supplies the stream.
 
-Dropout masks are counter-based (hash of element index, seed and site number), re-derived in the backward; the
-[L,L] attention probabilities are never stored (recomputed from the saved log-sum-exp).  Dropout sites per layer i:
+Dropout masks are counter-based (hash of element index, seed and site number): the elementwise sites re-derive them in the
+backward, the attention forward leaves one keep BIT per probability in the layer's workspace for its backward; the [L,L]
+attention probabilities themselves are never stored (recomputed from the saved log-sum-exp).  Dropout sites per layer i:
   16 i + 0  attention probabilities (one sub-site per batch*head inside the kernel)
   16 i + 1  dropout1 (self-attention branch before norm1)
   16 i + 2  dropout  (after the FFN ReLU)
