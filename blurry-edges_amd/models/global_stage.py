@@ -96,6 +96,15 @@ class GlobalStage(nn.Module):
                                       "dim_feedforward a multiple of 32, one dropout probability (models/global_stage.py:23-32)")
 
     # ------------------------------------------------------------------ inference on the HIP library
+    def invalidate_packed(self):
+        """Drop the cached weight pack: for a caller that changes the parameters where `Tensor._version` does not see it (a
+        replayed hipGraph that contains the optimizer step; cf. LocalStage.invalidate_packed)."""
+        self._pk_key = None
+
+    def train(self, mode: bool = True):
+        self._pk_key = None                      # a train -> eval switch never meets a pack made before the training
+        return super().train(mode)
+
     def _packed(self):
         """Linear weights in the implicit-GEMM layout, re-packed when a parameter changes."""
         from be_hip import native
