@@ -57,6 +57,73 @@ def _wgrad_lin(x, dy, w_shape):
     return _wgrad(x.view(t, 1, 1, x.shape[1]), dy.view(t, 1, 1, dy.shape[1]), tuple(w_shape), 1)
 
 
+class _Packs:
+    """Packed weights of every linear of one training step - forward form and data-gradient form - written by ONE launch
+    (be_conv_pack_jobs_f32) at the top of the forward (71 single pack launches per step before); buffers and the device job table
+    are built once per parameter set.  Keys are positions in the parameter list t."""
+    cache = {}
+
+    def __init__(self, t, cin):
+        dev = t[0].device
+        nl = (len(t) - 6) // PER_LAYER
+        self.pad = (-cin) % 32
+        d = t[0].shape[0]
+        self.w_in = torch.zeros(d, cin + self.pad, dtype=torch.float32, device=dev)       # in-projection with zero input columns
+        cout = t[-2].shape[0]
+        self.cp = (cout + 31) // 32 * 32
+        self.wg = torch.zeros(self.cp, t[-2].shape[1], dtype=torch.float32, device=dev)   # generator with zero output rows (dgrad / wgrad)
+        self.fwd, self.dg, jobs = {}, {}, []
+
+        def add(key, w, b, want_dgrad, w_dgrad=None):
+            co, ci = w.shape
+            pw, pb = _new(lib().be_conv_packed_floats(co, ci, 1), dev), _new((co + 31) // 32 * 32, dev)
+            self.fwd[key] = (pw, pb, co)
+            jobs.append(native.PackJob(dptr(w), dptr(b), None, None, None, None, dptr(pw), dptr(pb), 0.0, co, ci, 1, 0, 0))
+            if want_dgrad:
+                wd = w if w_dgrad is None else w_dgrad
+                co2, ci2 = wd.shape
+                dw, db = _new(lib().be_conv_dgrad_packed_floats(co2, ci2, 1), dev), _new((ci2 + 31) // 32 * 32, dev)
+                self.dg[key] = (dw, db, ci2)
+                jobs.append(native.PackJob(dptr(wd), None, None, None, None, None, dptr(dw), dptr(db), 0.0, co2, ci2, 1, 0, 1))
+        add(0, self.w_in, t[1], False)
+        for i in range(nl):
+            base = 2 + PER_LAYER * i
+            for k in (0, 2, 4, 6):
+                add(base + k, t[base + k], t[base + k + 1], True)
+        add(len(t) - 2, t[-2], t[-1], True, w_dgrad=self.wg)
+        arr = (native.PackJob * len(jobs))(*jobs)
+        self.njobs = len(jobs)
+        self.table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
+        self.keep = list(t)
+
+    @classmethod
+    def get(cls, t, cin):
+        key = tuple(v.data_ptr() for v in t) + (cin,)
+        p = cls.cache.get(key)
+        if p is None:
+            for v in t:
+                if not v.is_contiguous():
+                    raise RuntimeError("GlobalStage training: parameters must be contiguous")
+            cls.cache.clear()                                           # one model at a time keeps its buffers
+            p = cls.cache[key] = cls(t, cin)
+        return p
+
+    def pack(self, t, cin):
+        self.w_in[:, :cin].copy_(t[0])
+        self.wg[:t[-2].shape[0]].copy_(t[-2])
+        dev = self.table.device
+        check(lib().be_conv_pack_jobs_f32(dptr(self.table, "job table", (torch.uint8,)), self.njobs, stream_ptr(dev)),
+              "be_conv_pack_jobs_f32")
+
+    def lin(self, key, x, act=0):
+        pw, pb, co = self.fwd[key]
+        return native.linear(x, pw, pb, co, act=act)
+
+    def dgrad(self, key, dy, residual=None):
+        dw, db, ci = self.dg[key]
+        return native.linear(dy, dw, db, ci, residual=residual)
+
+
 def attention_train_fwd(qkv, B, L, H, p, seed, ws=None, l_valid=None):
     dev = qkv.device
     need = lib().be_attention_train_workspace_floats(B, L, H)
@@ -157,31 +224,33 @@ def forward_train(src, pe, seed, p, H, eps, t, l_valid=None):
     T = B * L
     dev = src.device
     nl = (len(t) - 6) // PER_LAYER
-    pad = (-cin) % 32
+    packs = _Packs.get(t, cin)
+    packs.pack(t, cin)                                         # every linear, both forms, one launch
+    pad = packs.pad
     x0 = src.reshape(T, cin).to(torch.float32)
     if pad:
         x0 = torch.cat([x0, x0.new_zeros(T, pad)], dim=1)
     x0 = x0.contiguous()
-    w_in = torch.cat([t[0], t[0].new_zeros(t[0].shape[0], pad)], dim=1) if pad else t[0]
-    h = _linear(x0, w_in, t[1])
+    h = packs.lin(0, x0)
     native.add_pe_(h, pe[:L].contiguous(), B)
-    S = dict(x0=x0, layers=[], shape=(B, L, cin), l_valid=l_valid)
+    S = dict(x0=x0, layers=[], shape=(B, L, cin), l_valid=l_valid, packs=packs)
     for i in range(nl):
-        wqkv, bqkv, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2 = t[2 + PER_LAYER * i:2 + PER_LAYER * (i + 1)]
-        qkv = _linear(h, wqkv, bqkv)
+        base = 2 + PER_LAYER * i
+        wqkv, bqkv, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2 = t[base:base + PER_LAYER]
+        qkv = packs.lin(base, h)
         a, lse, ws = attention_train_fwd(qkv, B, L, H, p, seed + 16 * i, l_valid=l_valid)   # one workspace per layer: the split q/k/v
                                                                               # (6 x 16 B per token and head) are reused by the backward
-        sa = _linear(a, wo, bo)
+        sa = packs.lin(base + 2, a)
         v1, h1 = add_layernorm_train(sa, h, g1, be1, eps, p, seed, 16 * i + 1)
-        f = _linear(h1, w1, b1, act=2)
+        f = packs.lin(base + 4, h1, act=2)
         fd = dropout(f, p, seed, 16 * i + 2) if p > 0 else f
-        y2 = _linear(fd, w2, b2)
+        y2 = packs.lin(base + 6, fd)
         v2, h2 = add_layernorm_train(y2, h1, g2, be2, eps, p, seed, 16 * i + 3)
         S["layers"].append((h, qkv, a, lse, v1, h1, f, v2, ws))
         h = h2
     gN, bN, wg, bg = t[-4:]
     vN, hN = add_layernorm_train(h, None, gN, bN, eps, 0.0, seed, 0)
-    out = _linear(hN, wg, bg)
+    out = packs.lin(len(t) - 2, hN)
     S.update(vN=vN, hN=hN)
     return out.view(B, L, -1), S
 
@@ -195,16 +264,15 @@ def backward_train(dout, seed, p, H, eps, t, S):
     grads = [None] * len(t)
     gN, bN, wg, bg = t[-4:]
     cout = wg.shape[0]
-    # generator: pad the 12 output columns to 32 so that the MFMA dgrad / wgrad paths take it
-    cp = (cout + 31) // 32 * 32
+    # generator: the 12 output columns padded to 32 so that the MFMA dgrad / wgrad paths take it
+    packs = S["packs"]
+    cp = packs.cp
     dy = dout.reshape(T, cout).to(torch.float32)
     dyp = torch.zeros(T, cp, dtype=torch.float32, device=dev)
     dyp[:, :cout] = dy
-    wgp = torch.zeros(cp, wg.shape[1], dtype=torch.float32, device=dev)
-    wgp[:cout] = wg
-    grads[-2] = _wgrad_lin(S["hN"], dyp, wgp.shape)[:cout].contiguous()
+    grads[-2] = _wgrad_lin(S["hN"], dyp, packs.wg.shape)[:cout].contiguous()
     grads[-1] = _col_sum(dyp)[:cout].contiguous()
-    d_hN = _dgrad_lin(dyp, wgp)
+    d_hN = packs.dgrad(len(t) - 2, dyp)
     dh, _, grads[-4], grads[-3] = layernorm_bwd(d_hN, S["vN"], gN, eps, 0.0, seed, 0, want_dx=False)
     for i in reversed(range(nl)):
         base = 2 + PER_LAYER * i
@@ -214,19 +282,19 @@ def backward_train(dout, seed, p, H, eps, t, S):
         fd = dropout(f, p, seed, 16 * i + 2) if p > 0 else f
         grads[base + 6] = _wgrad_lin(fd, dy2, w2.shape)
         grads[base + 7] = _col_sum(dy2)
-        dfd = _dgrad_lin(dy2, w2)
+        dfd = packs.dgrad(base + 6, dy2)
         df = dropout(dfd, p, seed, 16 * i + 2, gate=f)                    # dropout' and relu' in one pass
         grads[base + 4] = _wgrad_lin(h1, df, w1.shape)
         grads[base + 5] = _col_sum(df)
-        dh1 = _dgrad_lin(df, w1, residual=dv2)
+        dh1 = packs.dgrad(base + 4, df, residual=dv2)
         dv1, dsa, grads[base + 8], grads[base + 9] = layernorm_bwd(dh1, v1, g1, eps, p, seed, 16 * i + 1)
         grads[base + 2] = _wgrad_lin(a, dsa, wo.shape)
         grads[base + 3] = _col_sum(dsa)
-        da = _dgrad_lin(dsa, wo)
+        da = packs.dgrad(base + 2, dsa)
         dqkv, _ = attention_bwd(qkv, a, lse, da, B, L, H, p, seed + 16 * i, ws, operands_ready=True, l_valid=S["l_valid"])
         grads[base] = _wgrad_lin(h_in, dqkv, wqkv.shape)
         grads[base + 1] = _col_sum(dqkv)
-        dh = _dgrad_lin(dqkv, wqkv, residual=dv1)
+        dh = packs.dgrad(base, dqkv, residual=dv1)
     x0 = S["x0"]
     grads[0] = _wgrad_lin(x0, dh, (t[0].shape[0], x0.shape[1]))[:, :cin].contiguous()
     grads[1] = _col_sum(dh)
