@@ -505,8 +505,10 @@ void k_attn_bwd_fused(const float* __restrict__ Q, const float* __restrict__ K, 
                     const float p = (RAGGED && kdead[kc]) ? 0.f : fast_exp2(s[qt][kc][r]);
                     float a = dp[qt][kc][r], pd = p;
                     if (DROP) {
-                        const uint32_t km = (uint32_t)__builtin_amdgcn_sbfe((int)wsh[r >> 1], 16 * (r & 1) + 12 - 8 * qt - 4 * kc, 1);
-                        a = __uint_as_float((km & __float_as_uint(a)) | (~km & __float_as_uint(x.nd[qt][r])));
+                        uint32_t km = (uint32_t)__builtin_amdgcn_sbfe((int)wsh[r >> 1], 16 * (r & 1) + 12 - 8 * qt - 4 * kc, 1);
+                        asm("" : "+v"(km));       // opaque: the compiler otherwise turns the two bit-selects into v_cmp + 2 v_cndmask
+                        const uint32_t ndb = __float_as_uint(x.nd[qt][r]);
+                        a = __uint_as_float(ndb ^ (km & (__float_as_uint(a) ^ ndb)));                                  // v_bfi_b32
                         pd = __uint_as_float(km & __float_as_uint(p));
                     }
                     s[qt][kc][r] = p * a;
