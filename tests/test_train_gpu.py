@@ -317,11 +317,14 @@ def test_global_training_loop_runs_and_descends():
 
 # ---- GlobalStage training kernels: attention / LayerNorm / dropout forward + backward --------------------
 
-def _attn_ref(qkv, B, L, H, p, mask):
-    """float64 autograd reference of be_attention_train_fwd_f32 with the kernel's own keep mask."""
+def _attn_ref(qkv, B, L, H, p, mask, l_valid=None):
+    """float64 autograd reference of be_attention_train_fwd_f32 with the kernel's own keep mask (keys >= l_valid masked)."""
     D = H * 16
     q, k, v = [t.view(B, L, H, 16).permute(0, 2, 1, 3) for t in qkv.split(D, dim=-1)]
-    pr = torch.softmax(q @ k.transpose(-1, -2) / 4.0, dim=-1)
+    sc = q @ k.transpose(-1, -2) / 4.0
+    if l_valid is not None:
+        sc = sc.masked_fill(torch.arange(L, device=sc.device)[None, None, None, :] >= l_valid, float("-inf"))
+    pr = torch.softmax(sc, dim=-1)
     if mask is not None:
         pr = pr * mask.view(B, H, L, L) / (1.0 - p)
     return (pr @ v).permute(0, 2, 1, 3).reshape(B * L, D)
@@ -377,6 +380,34 @@ def test_attention_train_forward_backward_vs_fp64_autograd(p):
                     qi = 32 * np.arange(L // 32)[:, None, None] + 16 * qc + c[None, None, :]
                     ki = 32 * np.arange(L // 32)[None, :, None] + 16 * kt + 4 * g[None, None, :] + r
                     assert np.array_equal(got, m[:, qi, ki].astype(np.uint32))
+
+
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_attention_padded_sequence_forward_backward_vs_fp64_autograd(p):
+    """l_valid < L (the host padded the sequence to 128-token tiles): padded keys carry no probability, with and without dropout;
+    forward and the three gradients on the real rows against float64 autograd; the gradient rows of the padding are zero."""
+    from be_hip import native, train_global_stage as tg
+    from conftest import relmax
+    B, L, lv, H, seed = 2, 256, 200, 8, 77
+    qkv = torch.from_numpy(synth.hash_normal(8, "attn_qkv_pad", (B * L, 3 * H * 16)).astype(np.float32) * 1.5).to(DEV)
+    dout = torch.from_numpy(synth.hash_normal(9, "attn_dout_pad", (B * L, H * 16)).astype(np.float32)).to(DEV)
+    real = (torch.arange(B * L, device=DEV) % L) < lv
+    dout = dout * real[:, None]                                        # the caller slices the padded output away: zero upstream gradient
+    out, lse, ws = tg.attention_train_fwd(qkv, B, L, H, p, seed, l_valid=lv)
+    dqkv, _ = tg.attention_bwd(qkv, out, lse, dout, B, L, H, p, seed, ws, operands_ready=True, l_valid=lv)
+    regen, _ = tg.attention_bwd(qkv, out, lse, dout, B, L, H, p, seed, ws, operands_ready=False, l_valid=lv)
+    assert torch.equal(dqkv, regen)                                     # keep bits stored by the forward == regenerated from the formula
+    mask = tg.attention_dropout_mask(B, L, H, p, seed, DEV).double() if p > 0 else None
+    q64 = qkv.double().requires_grad_(True)
+    ref = _attn_ref(q64, B, L, H, p, mask, l_valid=lv)
+    (ref * dout.double()).sum().backward()
+    assert relmax(out[real].cpu(), ref.detach()[real].cpu()) <= 2e-6
+    g = q64.grad
+    assert relmax(dqkv[real].cpu(), g[real].cpu()) <= 5e-6
+    assert float(dqkv[~real].abs().max()) == 0.0 and float(g[~real].abs().max()) == 0.0
+    if p == 0:
+        inf, _ = native.attention(qkv, B, L, H, l_valid=lv)
+        assert torch.equal(inf[real], out[real])
 
 
 def test_attention_kernels_are_run_to_run_bit_identical():
