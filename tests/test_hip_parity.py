@@ -584,6 +584,11 @@ def test_entry_points_reject_bad_arguments_before_launching(native):
         n.attention(z[:200], 1, 200, 8)                                   # L not a multiple of 128
     with pytest.raises(RuntimeError, match="dropout probability"):
         tg.attention_train_fwd(z, 1, 256, 8, 1.5, 0)
+    with pytest.raises(RuntimeError, match="null pointer"):                # the backward needs its partial-dQ scratch
+        ws = torch.zeros(int(n.lib().be_attention_train_workspace_floats(1, 256, 8)), device=DEV)
+        n.check(n.lib().be_attention_bwd_f32(n.dptr(z), n.dptr(torch.zeros(256, 128, device=DEV)), n.dptr(torch.zeros(8, 256, device=DEV)),
+                                             n.dptr(torch.zeros(256, 128, device=DEV)), n.dptr(torch.zeros(256, 384, device=DEV)),
+                                             n.dptr(ws), None, 0, 1, 256, 256, 8, 0.0, 0, None), "be_attention_bwd_f32")
     with pytest.raises(RuntimeError, match="D must be 128"):
         tg.add_layernorm_train(torch.zeros(4, 64, device=DEV), None, torch.ones(64, device=DEV), torch.zeros(64, device=DEV), 1e-5, 0.0, 0, 0)
     with pytest.raises(RuntimeError, match="unsupported"):
