@@ -839,7 +839,8 @@ extern "C" int be_conv_pack_f32(const float* w, const float* b, const float* g, 
     BE_REQUIRE(cout > 0 && cin > 0, "be_conv_pack_f32: bad channel counts");
     BE_REQUIRE((g == nullptr) == (beta == nullptr) && (g == nullptr) == (mean == nullptr) &&
                (g == nullptr) == (var == nullptr), "be_conv_pack_f32: BatchNorm tensors must be all set or all null");
-    if (ksize == 7) BE_REQUIRE(cin <= 4, "be_conv_pack_f32: the 7x7 row-gather mode takes cin <= 4 (got %d)", cin);
+    // (the fourth channel of the NHWC4 staging is padding: the large-batch kernel does not even issue its products)
+    if (ksize == 7) BE_REQUIRE(cin <= 3, "be_conv_pack_f32: the 7x7 row-gather mode takes cin <= 3 (got %d)", cin);
     else BE_REQUIRE((ksize == 1 || ksize == 3) && cin % BK == 0,
                     "be_conv_pack_f32: ksize %d / cin %d unsupported (ksize 1|3 with cin %% 32 == 0, or 7)", ksize, cin);
     BE_REQUIRE(chw_hw == 0 || (ksize == 1 && cin % chw_hw == 0), "be_conv_pack_f32: bad layout_chw_hw");

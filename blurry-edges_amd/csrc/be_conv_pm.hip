@@ -175,7 +175,9 @@ void k_conv_pm(PmArgs a) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+                        // ROW8 (conv1): a quad is one pixel's four channels and the fourth is zero in the staging AND in the
+                        // packed weights - that product adds exactly 0, so it is not issued (K 224 -> 168 executed columns)
+                        if (MODE != PM_ROW8) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
                     }
             }
         }
@@ -253,7 +255,8 @@ int launch_pm(const PmArgs& a, hipStream_t s, int kernel_id) {
             }
         chunks *= (double)a.groups * a.n_tiles;
         be::ProfileScope prof(s, kernel_id, 2.0 * M * (k_real + k2) * a.Cout,
-                              4.0 * (M * (cin_real + k2) + (k_real + k2) * a.Cout + M * a.Cout), chunks * 2.0 * BM * BN * 16);
+                              4.0 * (M * (cin_real + k2) + (k_real + k2) * a.Cout + M * a.Cout),
+                              chunks * 2.0 * BM * BN * (MODE == PM_ROW8 ? 12 : 16));
         hipLaunchKernelGGL((k_conv_pm<MT, NT, MODE>), dim3(grid), dim3(256), lds, s, a);
     }
     return be::check_launch("be_conv_nhwc_f32(pixel-major)");

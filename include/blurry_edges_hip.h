@@ -253,7 +253,8 @@ int be_local_stage_forward_view_f32(const float* packed, const be_patch_view* vi
 typedef struct be_conv_desc {
     int n, h, w;          /* batch, spatial size (stride 1, "same" padding)      */
     int cin, cout;        /* cin % 32 == 0 (conv1: cin = 4, NHWC4 input)         */
-    int ksize;            /* 1, 3, or 7 (7: the conv1 row-gather mode, cin = 4)  */
+    int ksize;            /* 1, 3, or 7 (7: the conv1 row-gather mode: cin = 4 = the staging's channels, of which the fourth is
+                           * zero padding - weights are packed from cin <= 3)  */
     int act;
 } be_conv_desc;
 size_t be_conv_packed_floats(int cout, int cin, int ksize);
