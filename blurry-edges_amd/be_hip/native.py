@@ -725,3 +725,23 @@ def conv_nhwc_fused2(x, x2, pw, pb, cout, ksize, act):
     check(lib().be_conv_nhwc_fused2_f32(C.byref(d), dptr(x, "x"), dptr(x2, "x2"), x2.shape[-1], dptr(pw), dptr(pb), dptr(y),
                                         cout, stream_ptr(x.device)), "be_conv_nhwc_fused2_f32")
     return y
+
+
+def graph_node_counts(graph) -> dict:
+    """Node census of a captured torch.cuda.CUDAGraph built with keep_graph=True: {'nodes': all, 'kernels': kernel nodes,
+    'memcpy': .., 'memset': ..} read with hipGraphGetNodes / hipGraphNodeGetType (measurement plumbing: the launch count of a
+    replayed training step is not visible from the host otherwise)."""
+    hip = C.CDLL("libamdhip64.so")
+    raw = C.c_void_p(graph.raw_cuda_graph())
+    n = C.c_size_t(0)
+    if hip.hipGraphGetNodes(raw, None, C.byref(n)) != 0:
+        raise RuntimeError("hipGraphGetNodes failed")
+    nodes = (C.c_void_p * max(1, n.value))()
+    if hip.hipGraphGetNodes(raw, nodes, C.byref(n)) != 0:
+        raise RuntimeError("hipGraphGetNodes failed")
+    kinds = {}
+    for i in range(n.value):
+        t = C.c_int(-1)
+        hip.hipGraphNodeGetType(C.c_void_p(nodes[i]), C.byref(t))
+        kinds[t.value] = kinds.get(t.value, 0) + 1
+    return dict(nodes=n.value, kernels=kinds.get(0, 0), memcpy=kinds.get(1, 0), memset=kinds.get(2, 0))

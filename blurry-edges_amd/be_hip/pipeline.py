@@ -97,9 +97,17 @@ class DepthPipeline:
         return out
 
     @torch.no_grad()
-    def run_big(self, img, block=147, n_margin=10, rank=0, world=1, group=None):
+    def run_big(self, img, block=147, n_margin=10, rank=0, world=1, group=None, dedup=True):
         """rank / world: this process handles the blocks shard.my_blocks gives it; the record grid is completed with one
-        all-reduce (shard.assemble_records) and every rank folds the full image.  world = 1: no communication."""
+        all-reduce (shard.assemble_records) and every rank folds the full image.  world = 1: no communication.
+
+        dedup=True (default): the reference calls the CNN once per 147x147 block (blurry_edges_test_big.py:142-165): 36 x 8192 =
+        294 912 patches for the 2 x 284 x 284 = 161 312 DISTINCT windows of a 587x587 pair (neighbouring blocks share their 20
+        margin rows / columns of patches).  LocalStage, pass A and the feature glue are per-patch and position-independent bit for
+        bit, so here they run ONCE over the whole patch grid and every block gathers its 64x64 rows of `pm` from it: same
+        numbers, 45 % fewer patches.  With world > 1 the local pass is sharded by rows of the patch grid (shard.row_range) and the
+        feature grid is completed by one all-reduce before the blocks - which GlobalStage's attention keeps whole - are dealt out.
+        dedup=False: the reference's schedule, one local pass per block."""
         from . import shard
         img = img.contiguous()
         _, _, H, W = img.shape
@@ -110,9 +118,23 @@ class DepthPipeline:
         big = torch.zeros(HP * WP, native.RECORD_FLOATS, dtype=torch.float32, device=img.device).view(HP, WP, -1)
         wins = self.big_windows(H, W, block, n_margin, s, R)
         mine = shard.my_blocks(len(wins), rank, world)
-        # local stage block by block (8192 patches each = one CNN sub-batch), then GlobalStage on groups of blocks in one
-        # batch (attention at batch 1 leaves three quarters of the SIMD slots empty), then pass B per block
-        feats = [self.local_pass(img, wins[k][0])[3] for k in mine]
+        if dedup:
+            r0, r1 = shard.row_range(HP, rank, world)
+            if world > 1:
+                grid = torch.zeros(HP, WP, 38, dtype=torch.float32, device=img.device)
+                if r1 > r0:
+                    grid[r0:r1] = self.local_pass(img, (r0 * s, 0, (r1 - r0 - 1) * s + R, W))[3].view(r1 - r0, WP, 38)
+                grid = shard.assemble_records(grid, group)                          # x + 0 is exact: rows are owned once
+            else:
+                grid = self.local_pass(img)[3].view(HP, WP, 38)
+            # a block whose pixel window starts at (top, left) owns the patch rows top/s .. top/s + hp - 1 of the big grid
+            feats = [grid[wins[k][0][0] // s:wins[k][0][0] // s + hp, wins[k][0][1] // s:wins[k][0][1] // s + hp].reshape(hp * hp, 38)
+                     for k in mine]
+        else:
+            # local stage block by block (8192 patches each = one CNN sub-batch)
+            feats = [self.local_pass(img, wins[k][0])[3] for k in mine]
+        # GlobalStage on groups of blocks in one batch (attention at batch 1 leaves three quarters of the SIMD slots empty),
+        # then pass B per block
         est = []
         for g0 in range(0, len(mine), 12):
             y = self.globl(torch.stack(feats[g0:g0 + 12]))                          # [g,4096,12]

@@ -54,6 +54,12 @@ def my_blocks(n_blocks: int, rank: int, world: int):
     return [k for k in range(n_blocks) if block_owner(k, world) == rank]
 
 
+def row_range(n_rows: int, rank: int, world: int):
+    """Contiguous [start, stop) of the patch-grid rows whose LOCAL pass (CNN + pass A + feature glue: per patch, no coupling)
+    `rank` computes for the de-duplicated big-image path; sizes differ by at most one row."""
+    return pair_range(n_rows, rank, world)
+
+
 def assemble_records(big_local: torch.Tensor, group=None) -> torch.Tensor:
     """big_local [HP,WP,32]: the record grid with this rank's kept block windows filled and zeros elsewhere.
     The kept windows of the 36 blocks tile the grid exactly once (golden g8), so ONE sum all-reduce (10.3 MB for

@@ -70,10 +70,12 @@ class GraphedStep:
     between replays (they are kernel arguments baked into the capture), so a new epoch value means a new capture - cheap
     next to an epoch, and done lazily.  The optimizer must have been built with capturable=True."""
 
-    def __init__(self, model, helper, opt, flat=None, world=1):
+    def __init__(self, model, helper, opt, flat=None, world=1, keep_graph=False):
+        """keep_graph: keep the hipGraph itself next to its executable (native.graph_node_counts reads the launch count)."""
         self.model, self.helper, self.opt, self.flat, self.world = model, helper, opt, flat, world
         self.key = self.graph = self.static = self.loss = None
         self.warm = False
+        self.keep_graph = keep_graph
 
     def __call__(self, batch, beta_b, beta_s):
         if not self.warm:                               # the very first step runs eagerly: it creates the optimizer state
@@ -85,7 +87,7 @@ class GraphedStep:
         if key != self.key:
             self.static = {k: v.clone() for k, v in batch.items()}
             torch.cuda.synchronize()
-            self.graph = torch.cuda.CUDAGraph()
+            self.graph = torch.cuda.CUDAGraph(keep_graph=True) if self.keep_graph else torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):          # records the step; nothing executes yet
                 self.loss = train_step(self.model, self.helper, self.opt, self.static, beta_b, beta_s, self.flat, self.world)
             self.key = key
@@ -172,6 +174,8 @@ class SegmentedGraphStep:
                 h.wait()                                 # the compute stream waits for the collectives (the division is captured)
             self.sync.handles, self.sync.flat = [], None
         self.graphs[5].replay()
+        # the replay moved weights and BatchNorm statistics on the device; no tensor version changed (as in GraphedStep)
+        self.model.invalidate_packed()
         return self.loss.clone()
 
     def _capture(self, batch, beta_b, beta_s):
@@ -236,30 +240,25 @@ def main(argv=None):
     sched.final()
     model.train()
     losses = []
-    if a.graph:
-        # ~150 short launches per step at batch 64: replaying one captured hipGraph removes the host launch cost.
-        # Static input buffers; every kernel of the step runs on the capture stream (the library takes the stream
-        # from torch and never allocates or synchronises).
-        static = {k: v[:a.batch].clone() for k, v in data.items()}
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(3):
-                train_step(model, helper, opt, static, sched.beta_b, sched.beta_s, flat, world, sync=sync)
-        torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            static_loss = train_step(model, helper, opt, static, sched.beta_b, sched.beta_s, flat, world, sync=sync)
+    step_fn = None
+    if a.graph and world > 1:
+        # a collective cannot be captured into a hipGraph on this stack: the data-parallel step is six graph segments with the
+        # bucket all-reduces issued between them (one whole-step capture here would hang or fail at capture)
+        opt = torch.optim.AdamW(model.parameters(), lr=a.lr, capturable=True, fused=dp.fused_adamw())
+        step_fn = SegmentedGraphStep(model, helper, opt, sync, world=world)
+    elif a.graph:
+        # ~130 short launches per step at batch 64: replaying one captured hipGraph removes the host launch cost
+        step_fn = GraphedStep(model, helper, opt)
+    if step_fn is not None:                                     # eager first step(s) + the capture stay outside the clock
+        for _ in range(3):
+            step_fn({k: v[:a.batch] for k, v in data.items()}, sched.beta_b, sched.beta_s)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for it in range(a.steps):
         lo = (it * a.batch) % (a.patches - a.batch + 1)
         batch = {k: v[lo:lo + a.batch] for k, v in data.items()}
-        if a.graph:
-            for k in static:
-                static[k].copy_(batch[k])
-            graph.replay()
-            losses.append(static_loss.clone())
+        if step_fn is not None:
+            losses.append(step_fn(batch, sched.beta_b, sched.beta_s))
         else:
             losses.append(train_step(model, helper, opt, batch, sched.beta_b, sched.beta_s, flat, world, sync=sync))
     torch.cuda.synchronize()

@@ -110,13 +110,9 @@ def local_train(args, quiet=False, graph=True):
         for epoch in range(args.epoch_num):
             beta.step()
             model.train()
-            nb = len(tr) // args.batch_size
-            for i, (img_ny, img_gt, bndry_dist, deri) in enumerate(tr.batches(args.batch_size, shuffle=True, drop_last=True,
-                                                                             generator=sampler)):
-                if i >= nb - nb % world:
-                    break                                     # every rank takes the same number of steps (collectives pair up)
-                if i % world != rank:
-                    continue
+            # every rank takes the same number of steps (collectives pair up) and gathers only its own batches
+            for img_ny, img_gt, bndry_dist, deri in tr.batches(args.batch_size, shuffle=True, drop_last=True, generator=sampler,
+                                                               rank=rank, world=world):
                 b = dict(img_ny=img_ny, img_gt=img_gt, bndry_dist=bndry_dist, deri=deri)
                 if gstep is not None:
                     gstep(b, beta.beta_b, beta.beta_s)
@@ -203,6 +199,9 @@ def global_train(args, quiet=False):
         dp.broadcast_parameters(model, src=0)
         for p_ in model.parameters():
             p_.grad = None
+        # every rank seeds torch identically (same shuffle, same initial weights); the dropout masks must NOT be identical across
+        # the replicas of one global batch, so each rank salts the seed GlobalStage draws per step
+        model.dropout_seed_salt = (rank * 0x9E3779B1) & 0x7FFFFFFF
     opt = torch.optim.AdamW(model.parameters(), lr=args.learning_rate, fused=dp.fused_adamw())
     helper = utils.PostProcessGlobalBase(args, dev)
     dcal = utils.DepthEtas(args, dev)
@@ -216,13 +215,8 @@ def global_train(args, quiet=False):
         for epoch in range(args.epoch_num):
             g = gamma.step()
             model.train()
-            nb = len(tr) // args.batch_size
-            for i, (param, _, img_gt, bndry_dist, deri, bndry_depth) in enumerate(tr.batches(args.batch_size, shuffle=True,
-                                                                                           drop_last=True, generator=sampler)):
-                if i >= nb - nb % world:
-                    break
-                if i % world != rank:
-                    continue
+            for param, _, img_gt, bndry_dist, deri, bndry_depth in tr.batches(args.batch_size, shuffle=True, drop_last=True,
+                                                                             generator=sampler, rank=rank, world=world):
                 train_step(model, helper, dcal, opt, dict(pm=feats(param), img_gt=img_gt, bndry_dist=bndry_dist, deri=deri,
                                                           bndry_depth=bndry_depth), g, flat=flat, world=world)
             model.eval()

@@ -49,14 +49,20 @@ class ShapeDataset(Dataset):
         return out[0] if len(out) == 1 else tuple(out)
 
     # ---- extension (not in the reference): whole batches gathered on the device --------------------------------------
-    def batches(self, batch_size, shuffle=False, drop_last=True, generator=None):
+    def batches(self, batch_size, shuffle=False, drop_last=True, generator=None, rank=0, world=1):
         """Yields what DataLoader(self, batch_size, shuffle, drop_last) would collate (same tuple order, same division by
         alpha), but with the arrays resident on `device` and one gather per batch instead of one host-to-device copy per
         sample and tensor: at batch 64 the per-sample path costs more than the training step itself."""
         if getattr(self, "_resident", None) is None:
             self._resident = {a: getattr(self, a).to(self.device) for a in tuple(_ORDER[self.mode]) + ("alpha",)}
         r = self._resident
-        for idx in _batches(self, batch_size, shuffle, drop_last, generator):
+        # data parallel (world > 1): every rank draws the SAME permutation and materialises only its own batches - batch i goes
+        # to rank i % world, and the batches past the last full round of `world` are dropped so that all ranks take equally many
+        # steps (each step ends in a collective)
+        index_lists = list(_batches(self, batch_size, shuffle, drop_last, generator))
+        if world > 1:
+            index_lists = index_lists[:len(index_lists) - len(index_lists) % world][rank::world]
+        for idx in index_lists:
             idx = idx.to(self.device)
             al = r["alpha"][idx]
             out = []

@@ -81,10 +81,14 @@ class GlobalStage(nn.Module):
             # torch's CPU generator, so torch.manual_seed makes a run repeatable
             from be_hip.train_global_stage import GlobalStageTrainFn, parameter_list
             lyr = self.encoder.layers[0]
-            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+            seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) ^ int(self.dropout_seed_salt)
             out = GlobalStageTrainFn.apply(src, self.positional_encoding.pe[0], seed, lyr.dropout.p, lyr.self_attn.num_heads,
                                            lyr.norm1.eps, L, *parameter_list(self))
         return out if Lp == L else out[:, :L]
+
+    # xor-ed into the per-step dropout seed: a data-parallel run gives every rank its own salt (be_hip.workflow.global_train),
+    # otherwise identically seeded replicas would all drop the same elements of their share of the global batch
+    dropout_seed_salt = 0
 
     def _require_hip_shapes(self):
         lyr = self.encoder.layers[0]

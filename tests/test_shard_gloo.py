@@ -105,3 +105,57 @@ def test_two_rank_big_image_block_sharding_assembles_the_full_record_grid():
     for k, (_, (vs, ve, hs, he), (Vs, Hs)) in enumerate(DepthPipeline.big_windows(587, 587)):
         ref[Vs:Vs + ve - vs, Hs:Hs + he - hs] = _fake_block_records(k)[vs:ve, hs:he]
     assert np.array_equal(got, ref.numpy())
+
+
+def _fake_feature_grid(rows=284, cols=284):
+    """stands in for the local pass of every patch position: a function of the GLOBAL patch position only"""
+    i = torch.arange(rows, dtype=torch.float32).view(-1, 1, 1)
+    j = torch.arange(cols, dtype=torch.float32).view(1, -1, 1)
+    c = torch.arange(38, dtype=torch.float32).view(1, 1, -1)
+    return torch.sin(0.37 * i + 0.11 * j * j + c) + i / 7 - j / 3
+
+
+def _row_worker(rank, world, port, q):
+    for p in (ROOT, PKG):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import torch.distributed as dist
+    from be_hip import shard
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    r0, r1 = shard.row_range(284, rank, world)
+    grid = torch.zeros(284, 284, 38)
+    grid[r0:r1] = _fake_feature_grid()[r0:r1]              # this rank's rows of the de-duplicated local pass
+    grid = shard.assemble_records(grid)
+    if rank == 0:
+        q.put(grid.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_row_sharded_local_pass_of_the_big_image_and_the_block_gather():
+    """run_big(dedup=True): the local pass runs once per DISTINCT patch position, sharded by rows of the 284 x 284 patch grid;
+    one sum all-reduce completes the feature grid; block k then reads its 64 x 64 rows at (top / 2, left / 2).  The rows are
+    owned exactly once and every block window lies inside the grid on the global patch lattice."""
+    from be_hip import shard
+    from be_hip.pipeline import DepthPipeline
+    for world in (1, 2, 3, 8):
+        spans = [shard.row_range(284, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == 284 and all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_row_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = torch.from_numpy(q.get(timeout=120))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    full = _fake_feature_grid()
+    assert torch.equal(got, full)
+    for (top, left, bh, bw), _, _ in DepthPipeline.big_windows(587, 587):
+        assert top % 2 == 0 and left % 2 == 0 and top // 2 + 64 <= 284 and left // 2 + 64 <= 284
+        blk = got[top // 2:top // 2 + 64, left // 2:left // 2 + 64]
+        # the block's own patch (i, j) is the window at pixel (top + 2 i, left + 2 j) = global patch (top / 2 + i, left / 2 + j)
+        assert torch.equal(blk, _fake_feature_grid()[top // 2:top // 2 + 64, left // 2:left // 2 + 64])
