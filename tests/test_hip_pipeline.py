@@ -284,6 +284,23 @@ def test_big_image_tiler_and_fold_587(env):
     assert relmax(maps["image"].cpu()[:, :, 220:279], fi[:, :, 220:279]) <= 1e-4
 
 
+def test_big_image_deduplicated_local_pass_is_bit_identical_to_the_block_schedule(env):
+    """run_big(dedup=True) runs LocalStage + pass A + the feature glue once per DISTINCT 21x21 window of the 587x587 pair
+    (161 312 patches) and every block gathers its rows; the reference's schedule (blurry_edges_test_big.py:142-165, dedup=False)
+    runs them once per block (294 912 patches).  Per-patch kernels, position-independent bit for bit: all maps must be EQUAL,
+    on one stream and on the two-stream schedule."""
+    pipe = _pipeline(env)
+    imgs, _ = synth.synthetic_image_pair(587, 587, nshape=14)
+    img = T(imgs).to(DEV)
+    ref = pipe.run_big(img, dedup=False)
+    for streams in (1, 2):
+        pipe.local.streams = streams
+        got = pipe.run_big(img)
+        for k in ("image", "shpd", "refoc", "bndry", "depth", "conf", "depth_map"):
+            assert torch.equal(got[k], ref[k]), (k, streams)
+    pipe.local.streams = 2
+
+
 def test_big_image_path_matches_the_reference_run_g17(env):
     """Golden g17: the reference's own big-image depth_estimator (blurry_edges_test_big.py:113-215; its PostProcess in float64,
     stub networks with fixed outputs per block) on one 587 x 587 pair.  run_big with the same stub outputs must reproduce its
@@ -309,7 +326,9 @@ def test_big_image_path_matches_the_reference_run_g17(env):
 
     pipe = DepthPipeline(FixedLocal(), FixedGlobal(), env["helper"], env["dcal"])
     imgs, _ = synth.synthetic_image_pair(587, 587, nshape=14)
-    maps = pipe.run_big(T(imgs).to(DEV))
+    # the stub local module returns fixed outputs PER BLOCK (as the golden's stub did), so this run takes the reference's own
+    # schedule, one local pass per block; the de-duplicated default is pinned to it bit for bit by the test below
+    maps = pipe.run_big(T(imgs).to(DEV), dedup=False)
     assert pipe.local.k == 36 and pipe.globl.k == 36
     got = {k: maps[k].double().cpu() for k in ("image", "shpd", "refoc", "bndry", "conf", "depth_map")}
     for k in ("image", "shpd", "refoc", "bndry"):                       # fp32 kernels against the fp64 reference helper
