@@ -164,7 +164,8 @@ def leg_local_training(dev, native, peak, steps=60):
     model = models.LocalStage().to(dev)
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)).to(dev) for k, v in synth.local_stage_state_dict().items()})
     helper = utils.PostProcessLocalBase(args, dev)
-    opt = torch.optim.AdamW(model.parameters(), lr=args.learning_rate, capturable=True, fused=dp.fused_adamw())
+    from be_hip.optim import ClipAdamW
+    opt = ClipAdamW(model.parameters(), lr=args.learning_rate)
     data = {k: torch.from_numpy(v).to(dev) for k, v in synth.synthetic_training_patches(B * 8, seed=1869).items()}
     model.train()
     gstep = train_local.GraphedStep(model, helper, opt, keep_graph=True)
@@ -271,7 +272,8 @@ def leg_dp(dev, native, dist, rank, world, steps):
     model = models.LocalStage().to(dev)
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)).to(dev) for k, v in synth.local_stage_state_dict().items()})
     helper = utils.PostProcessLocalBase(args, dev)
-    opt = torch.optim.AdamW(model.parameters(), lr=args.learning_rate, fused=dp.fused_adamw())
+    from be_hip.optim import ClipAdamW
+    opt = ClipAdamW(model.parameters(), lr=args.learning_rate)
     data = {k: torch.from_numpy(v).to(dev) for k, v in synth.synthetic_training_patches(B * 8, seed=1869 + rank).items()}
     model.train()
     own_group = False
@@ -340,8 +342,7 @@ def leg_dp(dev, native, dist, rank, world, steps):
     if sync is not None:
         # the same step as six hipGraph segments with the RCCL calls between them (train_local.SegmentedGraphStep): what
         # `be_hip.workflow local_train` runs under torchrun.  Last, because it is the newest code on the RCCL path.
-        opt2 = torch.optim.AdamW(model.parameters(), lr=args.learning_rate, capturable=True, fused=dp.fused_adamw())
-        seg = train_local.SegmentedGraphStep(model, helper, opt2, sync, world=world)
+        seg = train_local.SegmentedGraphStep(model, helper, opt, sync, world=world)
 
         def seg_step():
             lo = (it[0] % 8) * B

@@ -27,6 +27,11 @@ class PackJob(C.Structure):
                 ("dgrad", C.c_int)]
 
 
+class AdamEntry(C.Structure):
+    """be_adam_entry: one workgroup's slice of a parameter for be_clip_adamw_f32."""
+    _fields_ = [("p", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("goff", C.c_int64), ("n", C.c_int)]
+
+
 class DepthConsts(C.Structure):
     _fields_ = [(n, C.c_float) for n in
                 ("s", "numerator", "den_const", "k", "k2", "intercept", "sin_w", "cos_w", "sin_m", "cos_m")]
@@ -133,6 +138,14 @@ _SIGNATURES = {
     "be_conv_dgrad_packed_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "be_conv_pack_dgrad_f32": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "be_linear_small_bwd_f32": (C.c_int, [_P] * 6 + [C.c_int] * 3 + [_P]),
+    "be_adam_chunk": (C.c_int, []),
+    "be_clip_adamw_f32": (C.c_int, [_P, C.c_int, _P, C.c_int64, _P, C.c_int] + [C.c_float] * 7 + [_P, _P, C.c_int, _P]),
+    "be_local_loss_finish_f32": (C.c_int, [_P, C.c_int, C.c_float, C.c_float, _P, _P]),
+    "be_train_unit_fwd_f32": (C.c_int, [_P] * 7 + [C.c_float, C.c_float] + [_P] * 7 + [C.c_int, _P, C.c_size_t, _P]),
+    "be_train_unit_bwd_f32": (C.c_int, [_P] * 11 + [C.c_int] + [_P] * 8 + [C.c_size_t, _P]),
+    "be_linear_small_fwd_f32": (C.c_int, [_P] * 4 + [C.c_int] * 3 + [_P]),
+    "be_maxpool_nhwc_fwd_idx_f32": (C.c_int, [_P, _P, _P] + [C.c_int] * 7 + [_P]),
+    "be_maxpool_nhwc_bwd_idx_f32": (C.c_int, [_P, _P, _P] + [C.c_int] * 7 + [_P]),
     "be_params2dists_f32": (C.c_int, [C.POINTER(RenderOpts), _P, _P, C.c_int64, _P]),
     "be_dists2indicators_f32": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
     "be_inverse3x3_f32": (C.c_int, [_P, _P, C.c_int64, _P]),
@@ -637,6 +650,14 @@ def local_loss(opts, est, img_fit, gt, bdist, deri, beta_bndry, beta_smooth, wan
 
 
 # ---------------------------------------------------------------------------------------------- GlobalStage pieces
+
+def local_loss_finish(partial, beta_bndry, beta_smooth):
+    """partial [B,3] of local_loss -> the scalar loss (0-dim tensor): S0/(441 B) + beta_b S1/(441 B) + beta_s S2/(361 B)."""
+    out = torch.empty(1, dtype=torch.float32, device=partial.device)
+    check(lib().be_local_loss_finish_f32(dptr(partial, "partial"), partial.shape[0], float(beta_bndry), float(beta_smooth), dptr(out),
+                                         stream_ptr(partial.device)), "be_local_loss_finish_f32")
+    return out[0]
+
 
 def linear(x2d, pw, pb, cout, act=0, residual=None):
     """x2d [T, Cin] (Cin % 32 == 0) -> [T, cout] on the implicit-GEMM kernel (a Linear is a 1x1 conv on a 1x1 image)."""

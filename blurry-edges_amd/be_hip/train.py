@@ -46,7 +46,8 @@ class _Packs:
 
     def __init__(self, t):
         dev = t[0].device
-        units = [(6 * i, CONVS[i][1], CONVS[i][2], CONVS[i][3], 0) for i in range(13)] + [(78, 1024, 2304, 1, 9), (84, 10, 1024, 1, 0)]
+        # (fc.4 runs from the raw parameters, forward and backward: no pack)
+        units = [(6 * i, CONVS[i][1], CONVS[i][2], CONVS[i][3], 0) for i in range(13)] + [(78, 1024, 2304, 1, 9)]
         self.fwd, self.dg, self.keep = {}, {}, [v for v in t]
         jobs = []
         for wi, cout, cin, ks, chw in units:
@@ -56,7 +57,7 @@ class _Packs:
             self.fwd[wi] = (pw, pb)
             jobs.append(native.PackJob(dptr(t[wi]), dptr(t[wi + 1]), None, None, None, None, dptr(pw), dptr(pb), 0.0,
                                        cout, cin_k, ks, chw, 0))
-            if ks != 7 and wi != 84:                                    # conv1 needs no input gradient; fc.4 has its own kernel
+            if ks != 7:                                                 # conv1 needs no input gradient
                 nd = lib().be_conv_dgrad_packed_floats(cout, cin, ks)
                 dw, db = _new(nd, dev), _new((cin + 31) // 32 * 32, dev)
                 self.dg[wi] = (dw, db)
@@ -148,6 +149,62 @@ def _pool_bwd(x, dout, k, stride, pad):
     return dx
 
 
+def _pool_fwd_idx(x, k, stride, pad):
+    """max-pool that also records the winning window element per output value (one byte): (y, (idx, input shape))"""
+    n, h, w, c = x.shape
+    oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
+    y = torch.empty(n, oh, ow, c, dtype=torch.float32, device=x.device)
+    idx = torch.empty(n, oh, ow, c, dtype=torch.uint8, device=x.device)
+    check(lib().be_maxpool_nhwc_fwd_idx_f32(dptr(x), dptr(y), dptr(idx, "idx", (torch.uint8,)), n, h, w, c, k, stride, pad,
+                                            stream_ptr(x.device)), "be_maxpool_nhwc_fwd_idx_f32")
+    return y, (idx, (n, h, w, c))
+
+
+def _pool_bwd_idx(saved, dout, k, stride, pad):
+    idx, (n, h, w, c) = saved
+    dx = torch.empty(n, h, w, c, dtype=torch.float32, device=dout.device)
+    check(lib().be_maxpool_nhwc_bwd_idx_f32(dptr(idx, "idx", (torch.uint8,)), dptr(dout), dptr(dx), n, h, w, c, k, stride, pad,
+                                            stream_ptr(dout.device)), "be_maxpool_nhwc_bwd_idx_f32")
+    return dx
+
+
+def _unit_fwd(xin, packs, wi, cout, ks, gamma, beta, rm, rv, res, act):
+    """conv / linear + BatchNorm (batch statistics, running statistics updated in place) [+ res] [+ Smish]: three launches
+    (be_train_unit_fwd_f32).  Returns (out, (y, mean, invstd, s_in)) - what the backward needs."""
+    n, h, w, cin = xin.shape
+    dev = xin.device
+    pw, pb = packs.fwd[wi]
+    y = torch.empty(n, h, w, cout, dtype=torch.float32, device=dev)
+    out = torch.empty_like(y)
+    s_in = torch.empty_like(y) if act else None
+    mean, invstd = _new(cout, dev), _new(cout, dev)
+    sc = _Scratch.get(dev)
+    d = native.ConvDesc(n, h, w, cin, cout, ks, 0)
+    check(lib().be_train_unit_fwd_f32(C.byref(d), dptr(xin), dptr(pw), dptr(pb), dptr(gamma), dptr(beta), dptr(res), BN_EPS,
+                                      BN_MOMENTUM, dptr(rm), dptr(rv), dptr(y), dptr(mean), dptr(invstd), dptr(s_in), dptr(out),
+                                      int(act), dptr(sc), sc.numel() * 4, stream_ptr(dev)), "be_train_unit_fwd_f32")
+    return out, (y, mean, invstd, s_in)
+
+
+def _unit_bwd(xin, dout, saved, gamma, dg_pack, dx_add, ks, chw_hw, dgamma, dbeta, dw, db):
+    """backward of _unit_fwd in five launches (be_train_unit_bwd_f32): -> (ds, dx); dx is None when dg_pack is None, and
+    includes dx_add (the other branch of a residual block) when given."""
+    y, mean, invstd, s_in = saved
+    n, h, w, cin = xin.shape
+    cout = y.shape[-1]
+    dev = xin.device
+    ds, dy = torch.empty_like(y), torch.empty_like(y)
+    dx = torch.empty(n, h, w, cin, dtype=torch.float32, device=dev) if dg_pack is not None else None
+    pw, pb = dg_pack if dg_pack is not None else (None, None)
+    sc = _Scratch.get(dev)
+    d = native.ConvDesc(n, h, w, cin, cout, ks, 0)
+    check(lib().be_train_unit_bwd_f32(C.byref(d), dptr(xin), dptr(dout), dptr(s_in), dptr(y), dptr(mean), dptr(invstd), dptr(gamma),
+                                      dptr(pw), dptr(pb), dptr(dx_add), int(chw_hw), dptr(ds), dptr(dy), dptr(dgamma), dptr(dbeta),
+                                      dptr(dw), dptr(db), dptr(dx), dptr(sc), sc.numel() * 4, stream_ptr(dev)),
+          "be_train_unit_bwd_f32")
+    return ds, dx
+
+
 def forward_train(x, t):
     """x [N,3,21,21]; t = the 86 tensors (native.local_stage_pack order).  Returns (logits [N,10], saved)."""
     n = x.shape[0]
@@ -158,15 +215,13 @@ def forward_train(x, t):
     def unit(name, i, xin, res=None, act=True):
         _, cout, cin, ks = CONVS[i]
         w, b, g, be_, rm, rv = t[6 * i:6 * i + 6]
-        y = _conv_fwd(xin, packs, 6 * i, cout, ks)
-        out, saved = _bn_fwd(y, g, be_, rm, rv, res, act)
+        out, saved = _unit_fwd(xin, packs, 6 * i, cout, ks, g, be_, rm, rv, res, act)
         S[name] = (xin, saved)
         return out
 
     x4 = native.nchw3_to_nhwc4(x)
     a1 = unit("conv1", 0, x4)
-    p1 = native.maxpool_nhwc(a1, 3, 2, 1)
-    S["pool1"] = a1
+    p1, S["pool1"] = _pool_fwd_idx(a1, 3, 2, 1)
 
     def block(tag, base, xin):
         tt = unit(tag + ".conv1", base, xin)
@@ -174,20 +229,19 @@ def forward_train(x, t):
         return unit(tag + ".conv2", base + 1, tt, res=d)
 
     l0 = block("layer0", 1, p1)
-    p2 = native.maxpool_nhwc(l0, 3, 2, 1)
-    S["pool2"] = l0
+    p2, S["pool2"] = _pool_fwd_idx(l0, 3, 2, 1)
     l1 = block("layer1", 4, p2)
     l2 = block("layer2", 7, l1)
     l3 = block("layer3", 10, l2)
-    p3 = native.maxpool_nhwc(l3, 2, 2, 0)
-    S["pool3"] = l3
+    p3, S["pool3"] = _pool_fwd_idx(l3, 2, 2, 0)
     f_in = p3.reshape(n, 1, 1, 2304)
     w1, b1, g1, be1, rm1, rv1, w4, b4 = t[78:86]
-    y1 = _conv_fwd(f_in, packs, 78, 1024, 1)
-    f1, saved1 = _bn_fwd(y1, g1, be1, rm1, rv1, None, True)
+    f1, saved1 = _unit_fwd(f_in, packs, 78, 1024, 1, g1, be1, rm1, rv1, None, True)
     S["fc1"] = (f_in, saved1)
-    pw4, pb4 = packs.fwd[84]
-    out = native.conv_nhwc(f1, pw4, pb4, 10, 1, act=0).reshape(n, 10)
+    # fc.4 (1024 -> 10) from the raw parameters: one wave per output element
+    out = _new((n, 10), x.device)
+    check(lib().be_linear_small_fwd_f32(dptr(f1), dptr(w4), dptr(b4), dptr(out), n, 1024, 10, stream_ptr(x.device)),
+          "be_linear_small_fwd_f32")
     S["fc4"] = f1
     return out, S
 
@@ -229,6 +283,7 @@ def backward_train(dlogits, t, S):
         if hook is not None:
             hook(flat, *buckets[k])
     w1, b1, g1, be1, rm1, rv1, w4, b4 = t[78:86]
+    packs = S["packs"]
     # fc.4
     f1 = S["fc4"].reshape(n, 1024)
     dx = _new((n, 1024), dev)
@@ -236,30 +291,22 @@ def backward_train(dlogits, t, S):
                                         dptr(grads[85]), n, 1024, 10, stream_ptr(dev)), "be_linear_small_bwd_f32")
     # fc.1 + BN1d + Smish
     f_in, saved1 = S["fc1"]
-    ds, dy, _, _ = _bn_bwd(dx.reshape(n, 1, 1, 1024), saved1, g1, grads[80], grads[81])
-    _wgrad(f_in, dy, tuple(w1.shape), 1, chw_hw=9, out=grads[78])
-    _col_sum(dy, out=grads[79])
+    _, d = _unit_bwd(f_in, dx.reshape(n, 1, 1, 1024), saved1, g1, packs.dg[78], None, 1, 9, grads[80], grads[81], grads[78], grads[79])
     done(0)                                                            # fc.1 / fc.2 / fc.4: the tail of the buffer
-    packs = S["packs"]
-    d = _dgrad(dy, packs, 78, 2304, 1).reshape(n, 3, 3, 256)
-    d = _pool_bwd(S["pool3"], d, 2, 2, 0)
+    d = _pool_bwd_idx(S["pool3"], d.reshape(n, 3, 3, 256), 2, 2, 0)
 
-    def unit_bwd(name, i, dout, need_dx=True):
-        """dout = gradient w.r.t. the unit's OUTPUT (after Smish if any).  Returns (ds, dx)."""
+    def unit_bwd(name, i, dout, need_dx=True, dx_add=None):
+        """dout = gradient w.r.t. the unit's OUTPUT (after Smish if any).  Returns (ds, dx [+ dx_add])."""
         _, cout, cin, ks = CONVS[i]
-        w, b, g = t[6 * i], t[6 * i + 1], t[6 * i + 2]
         xin, saved = S[name]
-        ds_, dy_, _, _ = _bn_bwd(dout, saved, g, grads[6 * i + 2], grads[6 * i + 3])
-        _wgrad(xin, dy_, tuple(w.shape), ks, out=grads[6 * i])
-        _col_sum(dy_, out=grads[6 * i + 1])
-        dxi = _dgrad(dy_, packs, 6 * i, cin, ks) if need_dx else None
-        return ds_, dxi
+        return _unit_bwd(xin, dout, saved, t[6 * i + 2], packs.dg[6 * i] if need_dx else None, dx_add, ks, 0,
+                         grads[6 * i + 2], grads[6 * i + 3], grads[6 * i], grads[6 * i + 1])
 
     def block_bwd(tag, base, dout):
         ds_, dt = unit_bwd(tag + ".conv2", base + 1, dout)            # ds_ = dout * smish'(.) = grad of the residual too
         _, dx_ds = unit_bwd(tag + ".ds", base + 2, ds_)
-        _, dx_c1 = unit_bwd(tag + ".conv1", base, dt)
-        return dx_c1 + dx_ds                                           # elementwise add: torch op on GPU buffers
+        _, dx_in = unit_bwd(tag + ".conv1", base, dt, dx_add=dx_ds)   # both branches' input gradients, summed in the last kernel
+        return dx_in
 
     d = block_bwd("layer3", 10, d)
     done(1)
@@ -267,9 +314,9 @@ def backward_train(dlogits, t, S):
     done(2)
     d = block_bwd("layer1", 4, d)
     done(3)
-    d = _pool_bwd(S["pool2"], d, 3, 2, 1)
+    d = _pool_bwd_idx(S["pool2"], d, 3, 2, 1)
     d = block_bwd("layer0", 1, d)
-    d = _pool_bwd(S["pool1"], d, 3, 2, 1)
+    d = _pool_bwd_idx(S["pool1"], d, 3, 2, 1)
     unit_bwd("conv1", 0, d, need_dx=False)
     done(4)                                                            # conv1 + layer0: the head of the buffer
     return grads

@@ -57,10 +57,13 @@ def train_step(model, helper, opt, batch, beta_b, beta_s, flat=None, world=1, cl
         loss.backward()
         if flat is not None and world > 1:
             dp.allreduce_mean_(dp.grads_as_flat(list(model.parameters()), flat), world)      # zero-copy when the backward wrote one buffer
-    norm = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=clip, norm_type=2)
+    if hasattr(opt, "clip_and_step"):    # be_hip.optim.ClipAdamW: norm + clip + AdamW over the flat gradient buffer, three launches
+        norm = opt.clip_and_step(clip)
+    else:
+        norm = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=clip, norm_type=2)
+        opt.step()
     if stats is not None:
         stats["grad_norm"] = norm
-    opt.step()
     return loss.detach()
 
 
@@ -133,8 +136,7 @@ class SegmentedGraphStep:
         partial, grad_est, _ = native.local_loss(self.helper.render_opts(False), logits, batch["img_gt"].contiguous(),
                                                  batch["img_gt"].contiguous(), batch["bndry_dist"].contiguous(),
                                                  batch["deri"].contiguous(), beta_b, beta_s, want_grad=True)
-        sm = partial.sum(dim=0)
-        loss = sm[0] / (b * 441) + beta_b * sm[1] / (b * 441) + beta_s * sm[2] / (b * 361)      # utils._LocalLossFn.forward
+        loss = native.local_loss_finish(partial, beta_b, beta_s)                                 # utils._LocalLossFn.forward
         train.set_grad_hook(hook)
         try:
             grads = train.backward_train(grad_est, t, S)
@@ -144,10 +146,16 @@ class SegmentedGraphStep:
             p.grad = grads[i]
         return loss
 
+    def _clip_step(self):
+        if hasattr(self.opt, "clip_and_step"):
+            self.opt.clip_and_step(self.clip)
+        else:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=self.clip, norm_type=2)
+            self.opt.step()
+
     def _tail(self):
         flat = self.sync.finish() if self.sync is not None else None
-        torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=self.clip, norm_type=2)
-        self.opt.step()
+        self._clip_step()
         return flat
 
     def __call__(self, batch, beta_b, beta_s):
@@ -203,8 +211,7 @@ class SegmentedGraphStep:
             flat = seen[0][0]
             if self.sync is not None and (self.world > 1 or self.sync.always):
                 flat.div_(self.world)                    # GradSync.finish's division, captured
-            torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=self.clip, norm_type=2)
-            self.opt.step()
+            self._clip_step()
             graphs[5].capture_end()
         torch.cuda.current_stream().wait_stream(self.stream)
         self.graphs, self.flat, self.ranges = graphs, flat, [(lo, hi) for _, lo, hi in seen]
@@ -230,7 +237,8 @@ def main(argv=None):
     model = models.LocalStage().to(dev)
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)).to(dev) for k, v in synth.local_stage_state_dict().items()})
     helper = utils.PostProcessLocalBase(args, dev)
-    opt = torch.optim.AdamW(model.parameters(), lr=a.lr, capturable=a.graph, fused=dp.fused_adamw())
+    from .optim import ClipAdamW
+    opt = ClipAdamW(model.parameters(), lr=a.lr)            # clip + AdamW over the flat gradient buffer (three launches)
     flat = None
     sync = dp.GradSync(world) if world > 1 else None       # five buckets, each all-reduced while the backward goes on
     if world > 1:
@@ -244,7 +252,6 @@ def main(argv=None):
     if a.graph and world > 1:
         # a collective cannot be captured into a hipGraph on this stack: the data-parallel step is six graph segments with the
         # bucket all-reduces issued between them (one whole-step capture here would hang or fail at capture)
-        opt = torch.optim.AdamW(model.parameters(), lr=a.lr, capturable=True, fused=dp.fused_adamw())
         step_fn = SegmentedGraphStep(model, helper, opt, sync, world=world)
     elif a.graph:
         # ~130 short launches per step at batch 64: replaying one captured hipGraph removes the host launch cost

@@ -91,7 +91,8 @@ def local_train(args, quiet=False, graph=True):
     sync = dp.GradSync(world) if world > 1 else None
     if world > 1:
         dp.broadcast_parameters(model, src=0)
-    opt = torch.optim.AdamW(model.parameters(), lr=args.learning_rate, capturable=graph, fused=dp.fused_adamw())
+    from .optim import ClipAdamW
+    opt = ClipAdamW(model.parameters(), lr=args.learning_rate)   # AdamW defaults of local_training.py:86, fused with the clipping
     helper = utils.PostProcessLocalBase(args, dev)
     if not graph:
         gstep = None

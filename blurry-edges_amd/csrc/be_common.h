@@ -76,6 +76,12 @@ bool wino_fused_ok(int64_t n, int cin, int cout);
 int wino_fused(const float* V, const float* packed_w, const float* packed_bias, const float* residual, int act, float* y,
                float* Vout, int64_t n, int cin, int cout, int mode, void* stream);
 
+// be_conv.hip: convolution / linear of a training unit (small M).  With scratch the K loop may be split: then the S raw slices
+// are LEFT in scratch as [S][M][ldp] (S > 1 reported, nothing written to y, bias / res not applied) for the caller's kernel to sum;
+// S == 1: y = conv + bias (+ res).
+int conv_train(const be_conv_desc* d, const float* x, const float* pw, const float* pb, const float* res, float* y, int ldy,
+               void* scratch, size_t scratch_bytes, int* S_out, int* ldp_out, void* stream);
+
 #define BE_REQUIRE(cond, ...) do { if (!(cond)) return be::fail(BE_EINVAL, __VA_ARGS__); } while (0)
 
 }  // namespace be

@@ -969,8 +969,12 @@ __global__ void k_splitk_reduce(const float* __restrict__ partial, int S, int64_
     }
 }
 
+// defer (training units): when the K loop was split the S raw slices stay in scratch [S][M][ldp] and NO reduce kernel is launched -
+// the caller's own kernel sums them (with the bias) while it does its other work on the tile; S = 1: y = conv + bias as always
+struct SplitOut { int S, ldp; };
 static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2, int cin2, const float* pw, const float* pb,
-                         const float* res, float* y, int ldy, void* stream, void* scratch = nullptr, size_t scratch_bytes = 0);
+                         const float* res, float* y, int ldy, void* stream, void* scratch = nullptr, size_t scratch_bytes = 0,
+                         SplitOut* defer = nullptr);
 
 extern "C" int be_conv_nhwc_f32(const be_conv_desc* d, const float* x, const float* pw, const float* pb,
                                 const float* res, float* y, int ldy, void* stream) {
@@ -1001,8 +1005,16 @@ extern "C" int be_conv_nhwc_splitk_f32(const be_conv_desc* d, const float* x, co
     return conv_dispatch(d, x, nullptr, 0, pw, pb, res, y, ldy, stream, scratch, scratch_bytes);
 }
 
+int be::conv_train(const be_conv_desc* d, const float* x, const float* pw, const float* pb, const float* res, float* y, int ldy,
+                   void* scratch, size_t scratch_bytes, int* S_out, int* ldp_out, void* stream) {
+    SplitOut so{1, 0};
+    const int rc = conv_dispatch(d, x, nullptr, 0, pw, pb, res, y, ldy, stream, scratch, scratch_bytes, &so);
+    *S_out = so.S; *ldp_out = so.ldp;
+    return rc;
+}
+
 static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2, int cin2, const float* pw, const float* pb,
-                         const float* res, float* y, int ldy, void* stream, void* scratch, size_t scratch_bytes) {
+                         const float* res, float* y, int ldy, void* stream, void* scratch, size_t scratch_bytes, SplitOut* defer) {
     BE_REQUIRE(d && x && pw && y, "be_conv_nhwc_f32: null pointer");
     BE_REQUIRE(d->n > 0 && d->h > 0 && d->w > 0 && d->cout > 0, "be_conv_nhwc_f32: empty shape");
     BE_REQUIRE(d->h < 32768 && d->w < 32768, "be_conv_nhwc_f32: image too large");
@@ -1061,6 +1073,7 @@ static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2,
                 const int rc = t64 ? launch_conv<2, 2, 1, 1, MODE_TAPS, 16, 0>(a, s, BE_KERNEL_CONV_SMALL)
                                    : launch_conv<4, 1, 1, 1, MODE_TAPS, 16, 0>(a, s, BE_KERNEL_CONV_SMALL);
                 if (rc) return rc;
+                if (defer) { defer->S = S; defer->ldp = cp; return BE_OK; }
                 const int64_t total = M * d->cout;
                 hipLaunchKernelGGL(k_splitk_reduce, dim3(grid_cap(total, 256)), dim3(256), 0, s, a.partial, S, M, d->cout, cp,
                                    pb, res, d->act, y, ldy);

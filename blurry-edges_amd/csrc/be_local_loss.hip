@@ -279,3 +279,19 @@ extern "C" int be_local_loss_f32(const be_render_opts* o, const float* est, cons
     hipLaunchKernelGGL(k_local_loss, dim3((unsigned)blocks), dim3(64 * WAVES), 0, be::as_stream(stream), *o, a);
     return be::check_launch("be_local_loss_f32");
 }
+
+namespace {
+__global__ void k_local_loss_finish(const float* __restrict__ partial, int B, float beta_b, float beta_s, float* __restrict__ out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    for (int i = 0; i < B; ++i) { s0 += partial[3 * i]; s1 += partial[3 * i + 1]; s2 += partial[3 * i + 2]; }
+    const double n1 = (double)B * NPIX, n2 = (double)B * NQ;
+    out[0] = (float)(s0 / n1 + (double)beta_b * s1 / n1 + (double)beta_s * s2 / n2);
+}
+}  // namespace
+
+extern "C" int be_local_loss_finish_f32(const float* partial, int B, float beta_bndry, float beta_smooth, float* loss_out, void* stream) {
+    BE_REQUIRE(partial && loss_out && B > 0, "be_local_loss_finish_f32: bad arguments");
+    hipLaunchKernelGGL(k_local_loss_finish, dim3(1), dim3(64), 0, be::as_stream(stream), partial, B, beta_bndry, beta_smooth, loss_out);
+    return be::check_launch("be_local_loss_finish_f32");
+}

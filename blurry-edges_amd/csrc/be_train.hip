@@ -355,6 +355,462 @@ __global__ void k_linear_small_bwd(const float* __restrict__ x, const float* __r
     }
 }
 
+
+// =====================================================================================================================
+// Round 3: the training UNIT (conv / linear -> BatchNorm with batch statistics -> [+ residual] -> [Smish]) in few launches.
+// Round 2 ran a unit's forward as conv, k_splitk_reduce, k_col_reduce<0>, k_bn_finalize_fwd, k_bn_apply_fwd and its backward
+// as k_col_reduce<1>, k_bn_finalize_bwd, k_bn_apply_bwd, k_wgrad, k_sum_splits, k_col_sum, k_col_sum_final, conv (dgrad),
+// k_splitk_reduce: at batch 64 every one of these is a 4-9 us launch (232 per step).  Now:
+//   forward   conv | k_bn_stats (sums the split-K slices + bias -> y AND the per-row-block column sums of y, y^2)
+//             | k_bn_fwd_apply (finishes the statistics for its 32 columns in its prologue - <= 32 row-block partials, fixed
+//               order, every workgroup of a column block computes the same bits - then normalises, adds the residual, Smish)
+//   backward  k_bn_bwd_reduce (ds = dout * smish'(s_in), column sums of ds, ds * xhat) | k_bn_bwd_apply (finishes dgamma /
+//             dbeta in its prologue, writes dy and per-workgroup column sums of dy = the bias-gradient partials)
+//             | k_wgrad + data-gradient conv | k_bwd_post (ONE launch: weight-gradient slices -> dW, bias partials -> db, the
+//             data-gradient split-K slices (+ the other branch's dx) -> dx)
+// All reductions keep a fixed order (fp64 partials, no atomics): bitwise reproducible run to run.
+// A workgroup = 32 columns x 32 row lanes; a thread moves float4 (4 columns), a wave touches 8 rows x 128 B.
+// =====================================================================================================================
+constexpr int UC = 32;              // columns per workgroup
+constexpr int UR = 32;              // row lanes per workgroup
+
+// fixed-order sum of the 32 row lanes' fp64 partials for `nv` values per column (nv <= 2), via LDS
+template <int NV>
+__device__ __forceinline__ void block_col_sums(double (&v)[NV][4], double* lds /* [UR][UC][NV] */, double* out, size_t out_stride_c,
+                                               int C, int c_base) {
+    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int k = 0; k < NV; ++k) lds[(ty * UC + tx * 4 + e) * NV + k] = v[k][e];
+    __syncthreads();
+    if (threadIdx.x < UC * NV) {
+        const int col = threadIdx.x / NV, k = threadIdx.x % NV;
+        double t = 0.0;
+        for (int r = 0; r < UR; ++r) t += lds[(r * UC + col) * NV + k];
+        if (c_base + col < C) out[(size_t)(c_base + col) * out_stride_c + k] = t;
+    }
+}
+
+// fixed-order sum of `nrb` row-block partials [nrb][C][NV] for this workgroup's 32 columns -> tot[col][k] (LDS, doubles)
+template <int NV>
+__device__ __forceinline__ void finish_partials(const double* __restrict__ partial, int nrb, int C, int c_base, double* part_lds /* [8][UC][NV] */,
+                                                double* tot /* [UC][NV] */) {
+    const int col = threadIdx.x & 31, pr = threadIdx.x >> 5;        // 8 partial lanes per column
+    double a[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) a[k] = 0.0;
+    if (c_base + col < C)
+        for (int rb = pr; rb < nrb; rb += 8)
+#pragma unroll
+            for (int k = 0; k < NV; ++k) a[k] += partial[((size_t)rb * C + c_base + col) * NV + k];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) part_lds[(pr * UC + col) * NV + k] = a[k];
+    __syncthreads();
+    if (threadIdx.x < UC * NV) {
+        const int c2 = threadIdx.x / NV, k = threadIdx.x % NV;
+        double t = 0.0;
+        for (int r = 0; r < 8; ++r) t += part_lds[(r * UC + c2) * NV + k];
+        tot[c2 * NV + k] = t;
+    }
+    __syncthreads();
+}
+
+struct StatsArgs {
+    const float* partial;   // [S][M][ldp] raw split-K slices, or null (S = 0: y is final already)
+    const float* bias;      // [C] added to the slice sum (S > 0)
+    float* y;               // [M][C]
+    double* stats;          // [nrb][C][2]
+    int S, M, C, ldp, rows_per_block;
+};
+
+__global__ __launch_bounds__(256)
+void k_bn_stats(StatsArgs a) {
+    __shared__ double lds[UR * UC * 2];
+    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+    const int c_base = blockIdx.x * UC, c = c_base + tx * 4;
+    const int r0 = blockIdx.y * a.rows_per_block, r1 = min(a.M, r0 + a.rows_per_block);
+    double v[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    if (c < a.C) {
+        f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
+        if (a.S > 0 && a.bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + c);
+        for (int r = r0 + ty; r < r1; r += UR) {
+            f32x4 t;
+            if (a.S > 0) {
+                // the (<= 8) slices of a row are independent loads: issue them together, then add in slice order
+                f32x4 p[8];
+#pragma unroll
+                for (int s = 0; s < 8; ++s)
+                    if (s < a.S) p[s] = *reinterpret_cast<const f32x4*>(a.partial + ((size_t)s * a.M + r) * a.ldp + c);
+                t = p[0];
+#pragma unroll
+                for (int s = 1; s < 8; ++s) if (s < a.S) t += p[s];
+                t += b4;
+                *reinterpret_cast<f32x4*>(a.y + (size_t)r * a.C + c) = t;
+            } else {
+                t = *reinterpret_cast<const f32x4*>(a.y + (size_t)r * a.C + c);
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[0][e] += t[e]; v[1][e] += (double)t[e] * t[e]; }
+        }
+    }
+    block_col_sums<2>(v, lds, a.stats + (size_t)blockIdx.y * a.C * 2, 2, a.C, c_base);
+}
+
+struct FwdApplyArgs {
+    const float* y; const double* stats; const float* gamma; const float* beta; const float* res;
+    float* run_mean; float* run_var; float* mean; float* invstd; float* s_in; float* out;
+    int nrb, M, C, rows_per_block, act;
+    float eps, momentum;
+};
+
+__global__ __launch_bounds__(256)
+void k_bn_fwd_apply(FwdApplyArgs a) {
+    __shared__ double part[8 * UC * 2];
+    __shared__ double tot[UC * 2];
+    __shared__ float s_mu[UC], s_is[UC];
+    const int c_base = blockIdx.x * UC;
+    finish_partials<2>(a.stats, a.nrb, a.C, c_base, part, tot);
+    if (threadIdx.x < UC && c_base + threadIdx.x < a.C) {
+        const int col = threadIdx.x, c = c_base + col;
+        const double mu = tot[col * 2] / a.M;
+        double var = tot[col * 2 + 1] / a.M - mu * mu;
+        if (var < 0.0) var = 0.0;
+        const float mf = (float)mu, isf = (float)(1.0 / sqrt(var + (double)a.eps));
+        s_mu[col] = mf; s_is[col] = isf;
+        if (blockIdx.y == 0) {                                  // one workgroup per column block publishes the statistics
+            a.mean[c] = mf; a.invstd[c] = isf;
+            if (a.run_mean) {
+                const double unb = a.M > 1 ? var * a.M / (a.M - 1) : var;
+                a.run_mean[c] = (float)((1.0 - a.momentum) * a.run_mean[c] + a.momentum * mu);
+                a.run_var[c] = (float)((1.0 - a.momentum) * a.run_var[c] + a.momentum * unb);
+            }
+        }
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3, c = c_base + tx * 4;
+    if (c >= a.C) return;
+    const f32x4 g = *reinterpret_cast<const f32x4*>(a.gamma + c), b = *reinterpret_cast<const f32x4*>(a.beta + c);
+    f32x4 mu, is;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { mu[e] = s_mu[tx * 4 + e]; is[e] = s_is[tx * 4 + e]; }
+    const int r0 = blockIdx.y * a.rows_per_block, r1 = min(a.M, r0 + a.rows_per_block);
+    for (int r = r0 + ty; r < r1; r += UR) {
+        const size_t at = (size_t)r * a.C + c;
+        const f32x4 yv = *reinterpret_cast<const f32x4*>(a.y + at);
+        f32x4 z;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) z[e] = (yv[e] - mu[e]) * is[e] * g[e] + b[e];
+        if (a.res) z += *reinterpret_cast<const f32x4*>(a.res + at);
+        if (a.s_in) *reinterpret_cast<f32x4*>(a.s_in + at) = z;
+        if (a.act) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) z[e] = be::smish(z[e]);
+        }
+        *reinterpret_cast<f32x4*>(a.out + at) = z;
+    }
+}
+
+struct BwdReduceArgs {
+    const float* dout; const float* s_in; const float* y; const float* mean; const float* invstd;
+    float* ds; double* partial;   // [nrb][C][2]: sum ds, sum ds * xhat
+    int M, C, rows_per_block;
+};
+
+__global__ __launch_bounds__(256)
+void k_bn_bwd_reduce(BwdReduceArgs a) {
+    __shared__ double lds[UR * UC * 2];
+    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+    const int c_base = blockIdx.x * UC, c = c_base + tx * 4;
+    const int r0 = blockIdx.y * a.rows_per_block, r1 = min(a.M, r0 + a.rows_per_block);
+    double v[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    if (c < a.C) {
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + c), is = *reinterpret_cast<const f32x4*>(a.invstd + c);
+        for (int r = r0 + ty; r < r1; r += UR) {
+            const size_t at = (size_t)r * a.C + c;
+            f32x4 d = *reinterpret_cast<const f32x4*>(a.dout + at);
+            if (a.s_in) {
+                const f32x4 si = *reinterpret_cast<const f32x4*>(a.s_in + at);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) d[e] *= smish_grad(si[e]);
+            }
+            *reinterpret_cast<f32x4*>(a.ds + at) = d;
+            const f32x4 yv = *reinterpret_cast<const f32x4*>(a.y + at);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[0][e] += d[e]; v[1][e] += (double)d[e] * ((yv[e] - mu[e]) * is[e]); }
+        }
+    }
+    block_col_sums<2>(v, lds, a.partial + (size_t)blockIdx.y * a.C * 2, 2, a.C, c_base);
+}
+
+struct BwdApplyArgs {
+    const float* ds; const float* y; const float* mean; const float* invstd; const float* gamma; const double* partial;
+    float* dy; float* dgamma; float* dbeta;
+    double* dbpart;           // [gridDim.y][C]: column sums of dy per workgroup (bias-gradient partials)
+    int nrb, M, C, rows_per_block;
+    float inv_m;
+};
+
+__global__ __launch_bounds__(256)
+void k_bn_bwd_apply(BwdApplyArgs a) {
+    __shared__ double part[8 * UC * 2];
+    __shared__ double tot[UC * 2];
+    __shared__ double lds[UR * UC];
+    __shared__ float s_db[UC], s_dg[UC];
+    const int c_base = blockIdx.x * UC;
+    finish_partials<2>(a.partial, a.nrb, a.C, c_base, part, tot);
+    if (threadIdx.x < UC && c_base + threadIdx.x < a.C) {
+        const int col = threadIdx.x;
+        const float db = (float)tot[col * 2], dg = (float)tot[col * 2 + 1];
+        s_db[col] = db; s_dg[col] = dg;
+        if (blockIdx.y == 0) { a.dbeta[c_base + col] = db; a.dgamma[c_base + col] = dg; }
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3, c = c_base + tx * 4;
+    double v[1][4] = {{0, 0, 0, 0}};
+    if (c < a.C) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(a.gamma + c);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + c), is = *reinterpret_cast<const f32x4*>(a.invstd + c);
+        f32x4 db, dg;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { db[e] = s_db[tx * 4 + e]; dg[e] = s_dg[tx * 4 + e]; }
+        const int r0 = blockIdx.y * a.rows_per_block, r1 = min(a.M, r0 + a.rows_per_block);
+        for (int r = r0 + ty; r < r1; r += UR) {
+            const size_t at = (size_t)r * a.C + c;
+            const f32x4 d = *reinterpret_cast<const f32x4*>(a.ds + at), yv = *reinterpret_cast<const f32x4*>(a.y + at);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (yv[e] - mu[e]) * is[e];
+                o[e] = g[e] * is[e] * (d[e] - db[e] * a.inv_m - xh * dg[e] * a.inv_m);
+                v[0][e] += o[e];
+            }
+            *reinterpret_cast<f32x4*>(a.dy + at) = o;
+        }
+    }
+    block_col_sums<1>(v, lds, a.dbpart + (size_t)blockIdx.y * a.C, 1, a.C, c_base);
+}
+
+// ONE launch after a unit's weight-gradient GEMM and data-gradient convolution: workgroups [0, nb_w) sum the weight-gradient
+// slices into dW, [nb_w, nb_w + nb_b) finish the bias gradient, the rest sum the data-gradient split-K slices (+ the other
+// branch's dx of a residual block) into dx.  Fixed order everywhere.
+struct PostArgs {
+    const float* wpart; float* dw; int64_t wsize; int wS; int conv1_map, cout1;   // conv1_map: slices are [cout][7][8 px][4 ch]
+    const double* dbpart; float* db; int nb_rows, C;
+    const float* xpart; const float* xadd; float* dx; int64_t xM; int xC, xldp, xS;
+    int nb_w, nb_b;
+};
+
+__global__ __launch_bounds__(256)
+void k_bwd_post(PostArgs a) {
+    const int b = blockIdx.x;
+    if (b < a.nb_w) {
+        if (a.conv1_map) {                                  // dW[co][ci][kh][kw] <- slice[co][kh][kw][ci] of a 224-column row
+            const int64_t total = (int64_t)a.cout1 * 147;
+            for (int64_t i = (int64_t)b * 256 + threadIdx.x; i < total; i += (int64_t)a.nb_w * 256) {
+                const int co = (int)(i / 147), rr = (int)(i % 147), ci = rr / 49, kh = (rr % 49) / 7, kw = rr % 7;
+                const int64_t src = (int64_t)co * 224 + kh * 32 + kw * 4 + ci;
+                float s = 0.f;
+                for (int k0 = 0; k0 < a.wS; k0 += 8) {      // eight independent loads in flight, added in slice order
+                    float p[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) p[k] = k0 + k < a.wS ? a.wpart[(int64_t)(k0 + k) * a.cout1 * 224 + src] : 0.f;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) if (k0 + k < a.wS) s += p[k];
+                }
+                a.dw[i] = s;
+            }
+            return;
+        }
+        const int64_t n4 = a.wsize >> 2;                    // weight tensors of the convs / linears: multiples of 4 floats
+        for (int64_t i = (int64_t)b * 256 + threadIdx.x; i < n4; i += (int64_t)a.nb_w * 256) {
+            f32x4 s = reinterpret_cast<const f32x4*>(a.wpart)[i];
+            for (int k0 = 1; k0 < a.wS; k0 += 8) {
+                f32x4 p[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k)
+                    if (k0 + k < a.wS) p[k] = reinterpret_cast<const f32x4*>(a.wpart + (int64_t)(k0 + k) * a.wsize)[i];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) if (k0 + k < a.wS) s += p[k];
+            }
+            reinterpret_cast<f32x4*>(a.dw)[i] = s;
+        }
+    } else if (b < a.nb_w + a.nb_b) {
+        // bias gradient: 32 columns per workgroup, 8 lanes per column walk the row-block partials (a single lane walking up
+        // to 128 dependent loads was 20-30 us), combined in lane order
+        __shared__ double red[8 * 32];
+        const int col = threadIdx.x & 31, pr = threadIdx.x >> 5, c = (b - a.nb_w) * 32 + col;
+        double s = 0.0;
+        if (c < a.C)
+            for (int r = pr; r < a.nb_rows; r += 8) s += a.dbpart[(size_t)r * a.C + c];
+        red[pr * 32 + col] = s;
+        __syncthreads();
+        if (threadIdx.x < 32 && c < a.C) {
+            double t = 0.0;
+            for (int r = 0; r < 8; ++r) t += red[r * 32 + col];
+            a.db[c] = (float)t;
+        }
+    } else {
+        const int nb_x = gridDim.x - a.nb_w - a.nb_b, bx = b - a.nb_w - a.nb_b;
+        const int c4n = a.xC >> 2;
+        const int64_t total = a.xM * c4n;
+        for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < total; i += (int64_t)nb_x * 256) {
+            const int64_t m = i / c4n;
+            const int c = (int)(i - m * c4n) * 4;
+            f32x4 p[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k)
+                if (k < a.xS) p[k] = *reinterpret_cast<const f32x4*>(a.xpart + ((int64_t)k * a.xM + m) * a.xldp + c);
+            f32x4 s = p[0];
+#pragma unroll
+            for (int k = 1; k < 8; ++k) if (k < a.xS) s += p[k];
+            if (a.xadd) s += *reinterpret_cast<const f32x4*>(a.xadd + m * a.xC + c);
+            *reinterpret_cast<f32x4*>(a.dx + m * a.xC + c) = s;
+        }
+    }
+}
+
+// conv1's weight gradient on the matrix pipe (round 2: a scalar FMA kernel, 89 + 16 us for 0.53 GFLOP).  Same GEMM as k_wgrad
+// with the 7x7x3 taps laid out as conv1's forward lays them out: column j = kh * 32 + px * 4 + ch of a 224-column row (px = kw,
+// the eighth pixel and the fourth channel are padding), x4 the NHWC4 staging.  A tile = 64 cout x 2 kernel rows; K = pixels.
+struct WgradC1Args { const float* x4; const float* dy; float* partial; int M, H, W, HW, Cout, rows_per_split; };
+
+__global__ __launch_bounds__(256)
+void k_wgrad_conv1_mfma(WgradC1Args a) {
+    constexpr int LD = 68;
+    __shared__ __attribute__((aligned(16))) float As[2][32][LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][32][LD];
+    const int kh0 = blockIdx.y * 2;
+    const int m_begin = blockIdx.z * a.rows_per_split, m_end = min(a.M, m_begin + a.rows_per_split);
+    const int tid = threadIdx.x, q = tid & 15, r0 = tid >> 4;
+    const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int kh = kh0 + (q >> 3), tdy = kh - 3, tdx = (q & 7) - 3;     // this thread's staged pixel of the B tile
+    const bool b_ok = kh < 7 && (q & 7) < 7;
+    const bool a_ok = 4 * q < a.Cout;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    f32x4 a_st[2], b_st[2];
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    auto load = [&](int m0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + r0 + 16 * i;
+            a_st[i] = zero; b_st[i] = zero;
+            if (m < m_end) {
+                if (a_ok) a_st[i] = *reinterpret_cast<const f32x4*>(a.dy + (size_t)m * a.Cout + 4 * q);
+                const int pp = m % a.HW, yy = pp / a.W + tdy, xx = pp % a.W + tdx;
+                if (b_ok && (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W)
+                    b_st[i] = *reinterpret_cast<const f32x4*>(a.x4 + ((int64_t)m + tdy * a.W + tdx) * 4);
+            }
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<f32x4*>(&As[buf][r0 + 16 * i][4 * q]) = a_st[i];
+            *reinterpret_cast<f32x4*>(&Bs[buf][r0 + 16 * i][4 * q]) = b_st[i];
+        }
+    };
+    const int nchunk = (m_end - m_begin + 31) / 32;
+    if (nchunk > 0) { load(m_begin); store(0); }
+    __syncthreads();
+    for (int kc = 0; kc < nchunk; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < nchunk) load(m_begin + 32 * (kc + 1));
+#pragma unroll
+        for (int s = 0; s < 16; ++s)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[buf][2 * s + lh][wm * 32 + li], Bs[buf][2 * s + lh][wn * 32 + li],
+                                                       acc, 0, 0, 0);
+        if (kc + 1 < nchunk) store(buf ^ 1);
+        __syncthreads();
+    }
+    float* out = a.partial + (size_t)blockIdx.z * a.Cout * 224;
+    const int col = kh0 * 32 + wn * 32 + li;                              // column of the 224-wide row
+    if (col < 224) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (co < a.Cout) out[(size_t)co * 224 + col] = acc[r];
+        }
+    }
+}
+
+// last Linear forward (1024 -> 10) of the training step: one wave per output element (round 2 ran it as a 128x32-tile conv:
+// 8 workgroups walking 64 K chunks each, 45 us)
+__global__ __launch_bounds__(256)
+void k_linear_small_fwd(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ y,
+                        int M, int K, int J) {
+    const int o = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (o >= M * J) return;
+    const int m = o / J, j = o % J;
+    float s = 0.f;
+    for (int k = lane * 4; k < K; k += 256) {
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (size_t)m * K + k), wv = *reinterpret_cast<const f32x4*>(w + (size_t)j * K + k);
+        s = fmaf(xv[0], wv[0], s); s = fmaf(xv[1], wv[1], s); s = fmaf(xv[2], wv[2], s); s = fmaf(xv[3], wv[3], s);
+    }
+    s = be::wave_sum(s);
+    if (lane == 0) y[o] = s + b[j];
+}
+
+// max-pool forward that also records WHICH element of the window won (first maximum in scan order, PyTorch's rule), one byte per
+// output value, and the backward that reads those bytes: an input pixel receives the gradient of the (at most four) windows whose
+// recorded winner it is.  Round 2's backward re-scanned every window that contains the pixel (36 loads per value).
+__global__ void k_maxpool_fwd_idx(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ idx, int n, int h,
+                                  int w, int c4, int oh, int ow, int k, int stride, int pad) {
+    const int64_t total = (int64_t)n * oh * ow * c4;
+    const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gs) {
+        const int cq = (int)(i % c4);
+        int64_t t = i / c4;
+        const int ox = (int)(t % ow); t /= ow;
+        const int oy = (int)(t % oh);
+        const int64_t img = t / oh;
+        f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        unsigned wi[4] = {0, 0, 0, 0};
+        for (int dy = 0; dy < k; ++dy) {
+            const int yy = oy * stride - pad + dy;
+            if ((unsigned)yy >= (unsigned)h) continue;
+            for (int dx = 0; dx < k; ++dx) {
+                const int xx = ox * stride - pad + dx;
+                if ((unsigned)xx >= (unsigned)w) continue;
+                const f32x4 v = reinterpret_cast<const f32x4*>(x)[((img * h + yy) * w + xx) * c4 + cq];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (v[e] > m[e]) { m[e] = v[e]; wi[e] = (unsigned)(dy * k + dx); }
+            }
+        }
+        reinterpret_cast<f32x4*>(y)[i] = m;
+        reinterpret_cast<unsigned*>(idx)[i] = wi[0] | (wi[1] << 8) | (wi[2] << 16) | (wi[3] << 24);
+    }
+}
+
+__global__ void k_maxpool_bwd_idx(const unsigned char* __restrict__ idx, const float* __restrict__ dout, float* __restrict__ dx, int n,
+                                  int h, int w, int c4, int oh, int ow, int k, int stride, int pad) {
+    const int64_t total = (int64_t)n * h * w * c4;
+    const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gs) {
+        const int cq = (int)(i % c4);
+        int64_t t = i / c4;
+        const int xx = (int)(t % w); t /= w;
+        const int yy = (int)(t % h);
+        const int64_t img = t / h;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const int oy_lo = max(0, (yy + pad - k + 1 + stride - 1) / stride), oy_hi = min(oh - 1, (yy + pad) / stride);
+        const int ox_lo = max(0, (xx + pad - k + 1 + stride - 1) / stride), ox_hi = min(ow - 1, (xx + pad) / stride);
+        for (int oy = oy_lo; oy <= oy_hi; ++oy)
+            for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+                const int64_t o = ((img * oh + oy) * ow + ox) * c4 + cq;
+                const unsigned me = (unsigned)((yy - (oy * stride - pad)) * k + (xx - (ox * stride - pad)));
+                const unsigned wv = reinterpret_cast<const unsigned*>(idx)[o];
+                const f32x4 d = reinterpret_cast<const f32x4*>(dout)[o];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) if (((wv >> (8 * e)) & 255u) == me) acc[e] += d[e];
+            }
+        reinterpret_cast<f32x4*>(dx)[i] = acc;
+    }
+}
+
 inline unsigned cap_grid(int64_t total, int block, int64_t cap = 4096) {
     int64_t g = (total + block - 1) / block;
     return (unsigned)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -375,7 +831,12 @@ inline int pick_splits(int M, int col_blocks, int max_splits, int target_blocks 
 
 }  // namespace
 
-extern "C" size_t be_train_scratch_bytes(void) { return (size_t)64 * 1024 * 1024; }   // split partials (largest: wgrad)
+// scratch of the training units: [0, 1 MB) BatchNorm row-block partials, [1, 2 MB) bias-gradient partials, [2, 42 MB) split-K
+// slices of the forward / data-gradient convolution, [42, 112 MB) weight-gradient slices (the older single-purpose entry
+// points use the buffer from its start)
+constexpr size_t SCR_STATS = 0, SCR_DBPART = (size_t)1 << 20, SCR_CONV = (size_t)2 << 20, SCR_WGRAD = (size_t)42 << 20,
+                 SCR_TOTAL = (size_t)112 << 20;
+extern "C" size_t be_train_scratch_bytes(void) { return SCR_TOTAL; }
 
 extern "C" int be_bn_train_fwd_f32(const float* y, const float* gamma, const float* beta, const float* res, float eps,
                                    float momentum, float* run_mean, float* run_var, float* mean, float* invstd,
@@ -437,11 +898,31 @@ extern "C" int be_maxpool_nhwc_bwd_f32(const float* x, const float* dout, float*
     return be::check_launch("be_maxpool_nhwc_bwd_f32");
 }
 
+// launches the weight-gradient GEMM; the S slices [S][wsize] land in `partial` (S == 1: `partial` may be dw itself)
+static int wgrad_slices(const float* x, const float* dy, float* partial, size_t partial_bytes, int n, int h, int w, int cin, int cout,
+                        int ksize, int layout_chw_hw, hipStream_t s, int* S_out, int64_t* wsize_out) {
+    const int M = n * h * w;
+    BE_REQUIRE((ksize == 1 || ksize == 3) && cin % 4 == 0 && cout % 4 == 0, "be_conv_wgrad_f32: ksize 1|3, channels %% 4 == 0");
+    BE_REQUIRE(layout_chw_hw == 0 || (ksize == 1 && cin % layout_chw_hw == 0), "be_conv_wgrad_f32: bad layout_chw_hw");
+    BE_REQUIRE(be::aligned16(x) && be::aligned16(dy), "be_conv_wgrad_f32: x / dy must be 16-byte aligned");
+    const int taps = ksize * ksize;
+    const int ct = (cout + 63) / 64, it = (cin + 63) / 64;
+    const int64_t wsize = (int64_t)cout * cin * taps;
+    int S = pick_splits(M, ct * it * taps, 64, 512);       // every split is another full copy of dW to sum
+    while (S > 1 && (size_t)S * wsize * sizeof(float) > partial_bytes) --S;
+    BE_REQUIRE((size_t)S * wsize * sizeof(float) <= partial_bytes, "be_conv_wgrad_f32: scratch too small");
+    int rows = (M + S - 1) / S; rows = (rows + 31) / 32 * 32;
+    S = (M + rows - 1) / rows;
+    WgradArgs a{x, dy, partial, M, h, w, h * w, cin, cout, ksize, rows, layout_chw_hw, it};
+    hipLaunchKernelGGL(k_wgrad, dim3(ct * it, taps, S), dim3(256), 0, s, a);
+    *S_out = S; *wsize_out = wsize;
+    return be::check_launch("be_conv_wgrad_f32");
+}
+
 extern "C" int be_conv_wgrad_f32(const float* x, const float* dy, float* dw, int n, int h, int w, int cin, int cout,
                                  int ksize, int layout_chw_hw, void* scratch, size_t scratch_bytes, void* stream) {
     BE_REQUIRE(x && dy && dw && scratch, "be_conv_wgrad_f32: null pointer");
     BE_REQUIRE(n > 0 && h > 0 && w > 0 && cin > 0 && cout > 0, "be_conv_wgrad_f32: empty");
-    const int M = n * h * w;
     hipStream_t s = be::as_stream(stream);
     if (ksize == 7) {
         BE_REQUIRE(cin == 4, "be_conv_wgrad_f32: ksize 7 takes the NHWC4 input (cin = 4); dW has 3 input channels");
@@ -455,21 +936,160 @@ extern "C" int be_conv_wgrad_f32(const float* x, const float* dy, float* dw, int
                            (int64_t)total, S);
         return be::check_launch("be_conv_wgrad_f32(conv1)");
     }
-    BE_REQUIRE((ksize == 1 || ksize == 3) && cin % 4 == 0 && cout % 4 == 0, "be_conv_wgrad_f32: ksize 1|3, channels %% 4 == 0");
-    BE_REQUIRE(layout_chw_hw == 0 || (ksize == 1 && cin % layout_chw_hw == 0), "be_conv_wgrad_f32: bad layout_chw_hw");
-    BE_REQUIRE(be::aligned16(x) && be::aligned16(dy), "be_conv_wgrad_f32: x / dy must be 16-byte aligned");
-    const int taps = ksize * ksize;
-    const int ct = (cout + 63) / 64, it = (cin + 63) / 64;
-    const int64_t wsize = (int64_t)cout * cin * taps;
-    int S = pick_splits(M, ct * it * taps, 64, 512);       // every split is another full copy of dW to sum
-    while (S > 1 && (size_t)S * wsize * sizeof(float) > scratch_bytes) --S;
-    BE_REQUIRE((size_t)S * wsize * sizeof(float) <= scratch_bytes, "be_conv_wgrad_f32: scratch too small");
-    int rows = (M + S - 1) / S; rows = (rows + 31) / 32 * 32;
-    S = (M + rows - 1) / rows;
-    WgradArgs a{x, dy, static_cast<float*>(scratch), M, h, w, h * w, cin, cout, ksize, rows, layout_chw_hw, it};
-    hipLaunchKernelGGL(k_wgrad, dim3(ct * it, taps, S), dim3(256), 0, s, a);
+    int S = 1; int64_t wsize = 0;
+    const int rc = wgrad_slices(x, dy, static_cast<float*>(scratch), scratch_bytes, n, h, w, cin, cout, ksize, layout_chw_hw, s, &S, &wsize);
+    if (rc) return rc;
     hipLaunchKernelGGL(k_sum_splits, dim3(cap_grid(wsize, 256)), dim3(256), 0, s, static_cast<const float*>(scratch), dw, wsize, S);
     return be::check_launch("be_conv_wgrad_f32");
+}
+
+// ---------------------------------------------------------------------------------------------- training units (round 3)
+namespace {
+struct RowBlocks { int n, rows; };
+inline RowBlocks row_blocks(int M, int want) {             // `want` blocks of a multiple of 32 rows (>= 1 block)
+    if (want < 1) want = 1;
+    int rows = (M + want - 1) / want;
+    rows = (rows + UR - 1) / UR * UR;
+    return RowBlocks{(M + rows - 1) / rows, rows};
+}
+// row blocks of the two reductions (= partials the apply kernels' prologues walk: 512 B each per workgroup): enough workgroups
+// to cover the chip for the narrow matrices (conv1: 2 column blocks over 28 224 rows), few partials for the wide ones
+inline RowBlocks stat_blocks(int M, int C) {
+    const int cb = C / UC, cap = cb >= 8 ? 36 : (cb >= 3 ? 64 : 128);
+    int w = (M + 63) / 64;
+    return row_blocks(M, w > cap ? cap : w);
+}
+inline RowBlocks apply_blocks(int M, int C, int cap) {
+    const int cb = C / UC;
+    int w = (768 + cb - 1) / cb;
+    if (w > cap) w = cap;
+    return row_blocks(M, w);
+}
+}  // namespace
+
+extern "C" int be_train_unit_fwd_f32(const be_conv_desc* d, const float* x, const float* pw, const float* pb, const float* gamma,
+                                     const float* beta, const float* res, float eps, float momentum, float* run_mean,
+                                     float* run_var, float* y, float* mean, float* invstd, float* s_in, float* out, int act,
+                                     void* scratch, size_t scratch_bytes, void* stream) {
+    BE_REQUIRE(d && x && pw && pb && gamma && beta && y && mean && invstd && out && scratch, "be_train_unit_fwd_f32: null pointer");
+    BE_REQUIRE(scratch_bytes >= SCR_TOTAL && be::aligned16(scratch), "be_train_unit_fwd_f32: scratch of be_train_scratch_bytes() bytes required");
+    const int64_t M64 = (int64_t)d->n * d->h * d->w;
+    const int C = d->cout;
+    BE_REQUIRE(M64 > 0 && M64 < ((int64_t)1 << 31) && C > 0 && C % UC == 0 && C <= 1024, "be_train_unit_fwd_f32: cout %% 32 == 0, <= 1024");
+    BE_REQUIRE(be::aligned16(y) && be::aligned16(out) && be::aligned16(gamma) && be::aligned16(beta) && be::aligned16(pb) &&
+               (!res || be::aligned16(res)) && (!s_in || be::aligned16(s_in)), "be_train_unit_fwd_f32: 16-byte alignment");
+    const int M = (int)M64;
+    char* sc = static_cast<char*>(scratch);
+    hipStream_t s = be::as_stream(stream);
+    be_conv_desc dc = *d; dc.act = 0;
+    int S = 1, ldp = 0;
+    int rc = be::conv_train(&dc, x, pw, pb, nullptr, y, C, sc + SCR_CONV, SCR_WGRAD - SCR_CONV, &S, &ldp, stream);
+    if (rc) return rc;
+    const RowBlocks sb = stat_blocks(M, C);
+    StatsArgs sa{S > 1 ? reinterpret_cast<const float*>(sc + SCR_CONV) : nullptr, pb, y, reinterpret_cast<double*>(sc + SCR_STATS),
+                 S > 1 ? S : 0, M, C, ldp, sb.rows};
+    hipLaunchKernelGGL(k_bn_stats, dim3(C / UC, sb.n), dim3(256), 0, s, sa);
+    const RowBlocks ab = apply_blocks(M, C, 256);
+    FwdApplyArgs fa{y, reinterpret_cast<const double*>(sc + SCR_STATS), gamma, beta, res, run_mean, run_var, mean, invstd, s_in, out,
+                    sb.n, M, C, ab.rows, act, eps, momentum};
+    hipLaunchKernelGGL(k_bn_fwd_apply, dim3(C / UC, ab.n), dim3(256), 0, s, fa);
+    return be::check_launch("be_train_unit_fwd_f32");
+}
+
+extern "C" int be_train_unit_bwd_f32(const be_conv_desc* d, const float* x, const float* dout, const float* s_in, const float* y,
+                                     const float* mean, const float* invstd, const float* gamma, const float* dgrad_pw,
+                                     const float* dgrad_pb, const float* dx_add, int layout_chw_hw, float* ds, float* dy,
+                                     float* dgamma, float* dbeta, float* dw, float* db, float* dx, void* scratch,
+                                     size_t scratch_bytes, void* stream) {
+    BE_REQUIRE(d && x && dout && y && mean && invstd && gamma && ds && dy && dgamma && dbeta && dw && db && scratch,
+               "be_train_unit_bwd_f32: null pointer");
+    BE_REQUIRE(scratch_bytes >= SCR_TOTAL && be::aligned16(scratch), "be_train_unit_bwd_f32: scratch of be_train_scratch_bytes() bytes required");
+    BE_REQUIRE((dx != nullptr) == (dgrad_pw != nullptr), "be_train_unit_bwd_f32: dx and the data-gradient pack go together");
+    const int64_t M64 = (int64_t)d->n * d->h * d->w;
+    const int C = d->cout;
+    BE_REQUIRE(M64 > 0 && M64 < ((int64_t)1 << 31) && C > 0 && C % UC == 0 && C <= 1024, "be_train_unit_bwd_f32: cout %% 32 == 0, <= 1024");
+    BE_REQUIRE(be::aligned16(dout) && be::aligned16(y) && be::aligned16(ds) && be::aligned16(dy) && be::aligned16(mean) &&
+               be::aligned16(invstd) && be::aligned16(gamma) && (!s_in || be::aligned16(s_in)) && be::aligned16(dw) &&
+               (!dx || be::aligned16(dx)) && (!dx_add || be::aligned16(dx_add)), "be_train_unit_bwd_f32: 16-byte alignment");
+    const int M = (int)M64;
+    char* sc = static_cast<char*>(scratch);
+    hipStream_t s = be::as_stream(stream);
+    double* part = reinterpret_cast<double*>(sc + SCR_STATS);
+    double* dbpart = reinterpret_cast<double*>(sc + SCR_DBPART);
+    // 1. ds = dout * smish'(s_in); row-block column sums of ds and ds * xhat
+    const RowBlocks sb = stat_blocks(M, C);
+    BwdReduceArgs ra{dout, s_in, y, mean, invstd, ds, part, M, C, sb.rows};
+    hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(C / UC, sb.n), dim3(256), 0, s, ra);
+    // 2. dgamma / dbeta finished in the prologue; dy; column sums of dy per workgroup
+    const RowBlocks ab = apply_blocks(M, C, 128);
+    BwdApplyArgs ba{ds, y, mean, invstd, gamma, part, dy, dgamma, dbeta, dbpart, sb.n, M, C, ab.rows, 1.0f / (float)M};
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(C / UC, ab.n), dim3(256), 0, s, ba);
+    // 3. weight-gradient GEMM (slices stay in scratch)
+    PostArgs pa{};
+    float* wpart = reinterpret_cast<float*>(sc + SCR_WGRAD);
+    if (d->ksize == 7) {
+        BE_REQUIRE(d->cin == 4 && C == 64, "be_train_unit_bwd_f32: ksize 7 is conv1 (NHWC4 staging, 64 outputs)");
+        int rows = (M + 63) / 64; rows = (rows + 31) / 32 * 32;
+        const int S = (M + rows - 1) / rows;
+        BE_REQUIRE((size_t)S * C * 224 * sizeof(float) <= SCR_TOTAL - SCR_WGRAD, "be_train_unit_bwd_f32: scratch too small");
+        WgradC1Args wa{x, dy, wpart, M, d->h, d->w, d->h * d->w, C, rows};
+        hipLaunchKernelGGL(k_wgrad_conv1_mfma, dim3(1, 4, S), dim3(256), 0, s, wa);
+        pa.wpart = wpart; pa.dw = dw; pa.wsize = (int64_t)C * 147; pa.wS = S; pa.conv1_map = 1; pa.cout1 = C;
+        pa.nb_w = (C * 147 + 255) / 256;
+    } else {
+        int S = 1; int64_t wsize = 0;
+        const int rc = wgrad_slices(x, dy, wpart, SCR_TOTAL - SCR_WGRAD, d->n, d->h, d->w, d->cin, C, d->ksize, layout_chw_hw, s, &S, &wsize);
+        if (rc) return rc;
+        pa.wpart = wpart; pa.dw = dw; pa.wsize = wsize; pa.wS = S; pa.conv1_map = 0; pa.cout1 = C;
+        pa.nb_w = (int)cap_grid(wsize / 4, 256, 1024);
+    }
+    pa.dbpart = dbpart; pa.db = db; pa.nb_rows = ab.n; pa.C = C; pa.nb_b = C / 32;
+    // 4. data-gradient convolution through the transposed / mirrored pack (slices stay in scratch when the K loop was split)
+    pa.xS = 0;
+    if (dx) {
+        be_conv_desc dd{d->n, d->h, d->w, C, d->cin, d->ksize, 0};
+        int S = 1, ldp = 0;
+        const int rc = be::conv_train(&dd, dy, dgrad_pw, dgrad_pb, dx_add, dx, d->cin, sc + SCR_CONV, SCR_WGRAD - SCR_CONV, &S, &ldp, stream);
+        if (rc) return rc;
+        if (S > 1) {
+            BE_REQUIRE(d->cin % 4 == 0, "be_train_unit_bwd_f32: cin %% 4 == 0");
+            pa.xpart = reinterpret_cast<const float*>(sc + SCR_CONV); pa.xadd = dx_add; pa.dx = dx; pa.xM = M; pa.xC = d->cin;
+            pa.xldp = ldp; pa.xS = S;
+        }
+    }
+    const int nb_x = pa.xS ? (int)cap_grid((int64_t)M * (d->cin / 4), 256, 2048) : 0;
+    // 5. slices -> dW, partials -> db, slices (+ the other branch) -> dx: one launch
+    hipLaunchKernelGGL(k_bwd_post, dim3(pa.nb_w + pa.nb_b + nb_x), dim3(256), 0, s, pa);
+    return be::check_launch("be_train_unit_bwd_f32");
+}
+
+extern "C" int be_linear_small_fwd_f32(const float* x, const float* w, const float* b, float* y, int M, int K, int J, void* stream) {
+    BE_REQUIRE(x && w && b && y && M > 0 && J > 0 && K > 0 && K % 4 == 0, "be_linear_small_fwd_f32: bad arguments (K %% 4 == 0)");
+    BE_REQUIRE(be::aligned16(x) && be::aligned16(w), "be_linear_small_fwd_f32: x / w must be 16-byte aligned");
+    hipLaunchKernelGGL(k_linear_small_fwd, dim3((M * J + 3) / 4), dim3(256), 0, be::as_stream(stream), x, w, b, y, M, K, J);
+    return be::check_launch("be_linear_small_fwd_f32");
+}
+
+extern "C" int be_maxpool_nhwc_fwd_idx_f32(const float* x, float* y, unsigned char* idx, int n, int h, int w, int c, int k, int stride,
+                                           int pad, void* stream) {
+    BE_REQUIRE(x && y && idx && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0 && k >= 1 && k <= 15, "be_maxpool_nhwc_fwd_idx_f32: bad arguments");
+    BE_REQUIRE(be::aligned16(x) && be::aligned16(y) && (reinterpret_cast<uintptr_t>(idx) & 3u) == 0, "be_maxpool_nhwc_fwd_idx_f32: alignment");
+    const int oh = (h + 2 * pad - k) / stride + 1, ow = (w + 2 * pad - k) / stride + 1;
+    const int64_t total = (int64_t)n * oh * ow * (c / 4);
+    hipLaunchKernelGGL(k_maxpool_fwd_idx, dim3(cap_grid(total, 256)), dim3(256), 0, be::as_stream(stream), x, y, idx, n, h, w, c / 4,
+                       oh, ow, k, stride, pad);
+    return be::check_launch("be_maxpool_nhwc_fwd_idx_f32");
+}
+
+extern "C" int be_maxpool_nhwc_bwd_idx_f32(const unsigned char* idx, const float* dout, float* dx, int n, int h, int w, int c, int k,
+                                           int stride, int pad, void* stream) {
+    BE_REQUIRE(idx && dout && dx && n > 0 && h > 0 && w > 0 && c > 0 && c % 4 == 0, "be_maxpool_nhwc_bwd_idx_f32: bad arguments");
+    BE_REQUIRE(be::aligned16(dout) && be::aligned16(dx) && (reinterpret_cast<uintptr_t>(idx) & 3u) == 0, "be_maxpool_nhwc_bwd_idx_f32: alignment");
+    const int oh = (h + 2 * pad - k) / stride + 1, ow = (w + 2 * pad - k) / stride + 1;
+    const int64_t total = (int64_t)n * h * w * (c / 4);
+    hipLaunchKernelGGL(k_maxpool_bwd_idx, dim3(cap_grid(total, 256)), dim3(256), 0, be::as_stream(stream), idx, dout, dx, n, h, w,
+                       c / 4, oh, ow, k, stride, pad);
+    return be::check_launch("be_maxpool_nhwc_bwd_idx_f32");
 }
 
 extern "C" int be_linear_small_bwd_f32(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,

@@ -182,8 +182,7 @@ class _LocalLossFn(torch.autograd.Function):
                                              gt.contiguous(), bdist.contiguous(), deri.contiguous(), beta_b, beta_s,
                                              want_grad=True)
         ctx.save_for_backward(grad)
-        s = partial.sum(dim=0)                                  # three scalars; deterministic reduction
-        return s[0] / (b * 441) + beta_b * s[1] / (b * 441) + beta_s * s[2] / (b * 361)
+        return native.local_loss_finish(partial, beta_b, beta_s)     # the three sums (fp64, patch order) and the weights: one launch
 
     @staticmethod
     def backward(ctx, g):

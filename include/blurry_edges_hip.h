@@ -389,6 +389,59 @@ int be_conv_pack_dgrad_f32(const float* weight_oihw, int cout, int cin, int ksiz
 int be_linear_small_bwd_f32(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db, int M,
                             int K, int J, void* stream);
 
+/* One training UNIT of LocalStage = nn.Conv2d / nn.Linear -> nn.BatchNorm (batch statistics) [-> + residual] [-> Smish]
+ * (models/local_stage.py:11-17, 20-28, 44-50 in train mode; the forward half of local_training.py:103) in three launches:
+ * the convolution (desc->act is ignored; its K loop may be split), one kernel that sums the split-K slices with the bias
+ * into y [M,cout] and forms the per-row-block column sums of y and y^2, and one that finishes the batch statistics in its
+ * prologue (fixed order), updates run_mean / run_var (momentum, unbiased variance; may be NULL), stores mean / invstd [cout]
+ * and writes out = act((y-mean)*invstd*gamma + beta (+res)); s_in (may be NULL) keeps the Smish input for the backward.
+ * packed_w / packed_bias: be_conv_pack_f32 WITHOUT BatchNorm (the conv bias alone).  cout %% 32 == 0, cout <= 1024.
+ * scratch: be_train_scratch_bytes() bytes. */
+int be_train_unit_fwd_f32(const be_conv_desc* desc_host, const float* x, const float* packed_w, const float* packed_bias,
+                          const float* gamma, const float* beta, const float* res, float eps, float momentum, float* run_mean,
+                          float* run_var, float* y, float* mean, float* invstd, float* s_in, float* out, int act,
+                          void* scratch, size_t scratch_bytes, void* stream);
+/* Backward of that unit (the autograd graph under loss.backward(), local_training.py:106) in five launches: ds = dout *
+ * smish'(s_in) (s_in NULL: ds = dout; ds is also the residual's gradient) with its column sums; dgamma / dbeta and
+ * dy = gamma*invstd*(ds - dbeta/M - xhat*dgamma/M) with the column sums of dy; the weight-gradient GEMM over x (desc = the
+ * FORWARD shape; ksize 7: x is the NHWC4 staging and dw is [cout][3][7][7]; layout_chw_hw as in be_conv_pack_f32); the
+ * data-gradient convolution through dgrad_packed_w / dgrad_packed_bias (be_conv_pack_dgrad_f32; both NULL with dx NULL when
+ * no input gradient is wanted); and one kernel that sums the weight-gradient slices into dw (reference layout), the bias
+ * gradient into db and the data-gradient slices (+ dx_add [M,cin] if not NULL: the other branch of a residual block) into dx. */
+int be_train_unit_bwd_f32(const be_conv_desc* desc_host, const float* x, const float* dout, const float* s_in, const float* y,
+                          const float* mean, const float* invstd, const float* gamma, const float* dgrad_packed_w,
+                          const float* dgrad_packed_bias, const float* dx_add, int layout_chw_hw, float* ds, float* dy,
+                          float* dgamma, float* dbeta, float* dw, float* db, float* dx, void* scratch, size_t scratch_bytes,
+                          void* stream);
+/* Last Linear forward (K -> J, J small; models/local_stage.py:50): y [M,J] = x [M,K] w [J,K]^T + b, raw parameter layout. */
+int be_linear_small_fwd_f32(const float* x, const float* w, const float* b, float* y, int M, int K, int J, void* stream);
+/* nn.MaxPool2d forward on NHWC that also records the winning window element (dy*k + dx of the FIRST maximum, one byte per
+ * output value; idx 4-byte aligned, c %% 4 == 0), and the backward that routes dout through those bytes. */
+int be_maxpool_nhwc_fwd_idx_f32(const float* x, float* y, unsigned char* idx, int n, int h, int w, int c, int k, int stride,
+                                int pad, void* stream);
+int be_maxpool_nhwc_bwd_idx_f32(const unsigned char* idx, const float* dout, float* dx, int n, int h, int w, int c, int k,
+                                int stride, int pad, void* stream);
+
+/* Tail of a training step (local_training.py:107-108): torch.nn.utils.clip_grad_norm_(max_norm, 2) + torch.optim.AdamW.step()
+ * for parameters whose gradients are slices of ONE flat buffer (what the LocalStage backward writes), in three launches: squared-
+ * norm partials (fp64), the update, the step counter.  table (device): one entry per workgroup, at most be_adam_chunk() elements
+ * each: parameter / exp_avg / exp_avg_sq pointers, offset of the slice in grad_flat, count.  grad_scale multiplies the gradient
+ * first (1/world after a summing all-reduce).  max_norm <= 0: no clipping.  step_device: float scalar = steps taken so far
+ * (incremented here); grad_norm_out (may be NULL): the norm before clipping.  write_back: store the scaled + clipped gradient
+ * back (clip_grad_norm_ modifies .grad in place).  partial: npartial_cap >= ceil(n_flat / be_adam_chunk()) doubles. */
+typedef struct be_adam_entry {
+    float *p, *m, *v;
+    int64_t goff;
+    int n;
+} be_adam_entry;
+int be_adam_chunk(void);
+int be_clip_adamw_f32(const be_adam_entry* table_device, int nentries, float* grad_flat, int64_t n_flat, double* partial,
+                      int npartial_cap, float max_norm, float grad_scale, float lr, float beta1, float beta2, float eps,
+                      float weight_decay, float* step_device, float* grad_norm_out, int write_back, void* stream);
+/* Final reduction of be_local_loss_f32's per-patch partials [B,3] into the scalar of LocalLoss.forward (local_training.py:47-52):
+ * loss = S0/(441 B) + beta_bndry S1/(441 B) + beta_smooth S2/(361 B), sums in fp64 in patch order. */
+int be_local_loss_finish_f32(const float* partial, int B, float beta_bndry, float beta_smooth, float* loss_out, void* stream);
+
 /* eval_depth (utils/metrics.py:3-20) on the device: pred, gt [B,H,W]; a pixel counts when mask_src > 0 (the scripts pass
  * the estimated depth map itself, blurry_edges_test.py:148); crop pixels dropped on every side; out5 (device, float64) =
  * delta1, delta2, delta3, RMSE in cm, AbsRel in cm, summed jointly over the batch as the reference does. */

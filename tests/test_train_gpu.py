@@ -242,7 +242,7 @@ def test_pack_job_table_equals_the_single_pack_calls():
     packs = train._Packs.get(t)
     packs.pack()
     torch.cuda.synchronize()
-    assert packs.njobs == 28
+    assert packs.njobs == 27        # 14 forward packs (fc.4 runs from the raw parameters) + 13 data-gradient packs
     for wi, (pw, pb) in packs.fwd.items():
         chw = 9 if wi == 78 else 0
         rw, rb = native.conv_pack(t[wi], t[wi + 1], bn=None, chw_hw=chw)
@@ -650,3 +650,110 @@ def test_global_loss_with_an_empty_depth_mask_is_nan_like_the_reference_unless_a
                           empty_mask="zero")
     b.backward()
     assert torch.isfinite(b) and torch.isfinite(est.grad).all()
+
+
+def test_clip_adamw_matches_clip_grad_norm_and_torch_adamw():
+    """be_hip.optim.ClipAdamW (three launches over the flat gradient buffer) against the tail of local_training.py:107-108 done
+    with the stock pieces - torch.nn.utils.clip_grad_norm_(max_norm=1) + torch.optim.AdamW.step() - over six steps whose gradient
+    norms lie on both sides of the clipping threshold.  Norm to 1e-6, clipped gradients to 1e-6, parameters to a few spacings."""
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a GPU")
+    import models
+    from be_hip.optim import ClipAdamW
+    torch.manual_seed(3)
+    ma, mb = models.LocalStage().to(DEV), models.LocalStage().to(DEV)
+    mb.load_state_dict(ma.state_dict())
+    pa, pb = list(ma.parameters()), list(mb.parameters())
+    oa = ClipAdamW(pa, lr=1e-3)
+    ob = torch.optim.AdamW(pb, lr=1e-3)
+    n = sum(p.numel() for p in pa)
+    for it, scale in enumerate((3e-3, 1e-5, 5e-4, 2e-2, 3.7e-4, 1e-6)):          # total norms ~ 8, 0.03, 1.3, 54, 1.0, 0.003
+        flat = torch.randn(n, device=DEV) * scale
+        off = 0
+        for a, b in zip(pa, pb):
+            a.grad = flat[off:off + a.numel()].view_as(a)
+            b.grad = flat[off:off + a.numel()].view_as(a).clone()
+            off += a.numel()
+        norm_b = torch.nn.utils.clip_grad_norm_(pb, max_norm=1.0, norm_type=2)
+        ob.step()
+        norm_a = oa.clip_and_step(1.0)
+        assert abs(float(norm_a) - float(norm_b)) <= 1e-6 * float(norm_b), (it, float(norm_a), float(norm_b))
+        worst = 0.0
+        for a, b in zip(pa, pb):
+            assert float((a.grad - b.grad).norm() / b.grad.norm().clamp_min(1e-30)) <= 1e-6        # the clipped gradient, written back
+            d = (a.detach().double() - b.detach().double()).abs()
+            tol = torch.from_numpy(np.spacing(np.abs(b.detach().cpu().numpy()).astype(np.float32))).double().to(DEV) + 1e-10
+            worst = max(worst, float((d / tol).max()))
+        assert worst <= 4.0, (it, worst)                                            # spacings of the updated fp32 parameter
+    assert float(oa.state[pa[0]]["step"]) == 6.0
+    sd = oa.state_dict()                                                            # the usual optimizer surface still works
+    assert len(sd["state"]) == len(pa) and sd["param_groups"][0]["lr"] == 1e-3
+    # gradients that are not one flat buffer are refused, not silently handled
+    pa[3].grad = pa[3].grad.clone()
+    with pytest.raises(RuntimeError):
+        oa.clip_and_step(1.0)
+
+
+def test_training_unit_matches_the_single_purpose_kernels():
+    """be_train_unit_fwd_f32 / be_train_unit_bwd_f32 (round 3: a unit's forward in 3 launches, its backward in 5) against the
+    layer-level entry points they replace in the step (conv, be_bn_train_fwd/bwd_f32, be_conv_wgrad_f32, be_col_sum_f32, the
+    data-gradient conv): same arithmetic per element, reductions in a different fixed order - equal to rounding.  Shapes: a
+    6x6 3x3 unit with split K, a 1x1 downsample (no Smish, no split), conv1 (7x7 row mode, MFMA weight gradient)."""
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a GPU")
+    from be_hip import native, train
+    from be_hip.native import check, dptr, lib, stream_ptr
+    import ctypes as C
+    g = torch.Generator(device="cpu").manual_seed(11)
+    rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
+    for (n, hw, cin, cout, ks, act, with_res) in ((64, 6, 256, 384, 3, True, True), (64, 6, 96, 256, 1, False, False),
+                                                  (64, 21, 3, 64, 7, True, False)):
+        w = (torch.randn(cout, cin, ks, ks, generator=g) * (1.0 / (cin * ks * ks) ** 0.5)).to(DEV)
+        b = (torch.randn(cout, generator=g) * 0.1).to(DEV)
+        gamma, beta = (1 + 0.1 * torch.randn(cout, generator=g)).to(DEV), (0.1 * torch.randn(cout, generator=g)).to(DEV)
+        if ks == 7:
+            x = native.nchw3_to_nhwc4(torch.rand(n, 3, hw, hw, generator=g).to(DEV))
+        else:
+            x = torch.randn(n, hw, hw, cin, generator=g).to(DEV)
+        res = torch.randn(n, hw, hw, cout, generator=g).to(DEV) if with_res else None
+        dout = torch.randn(n, hw, hw, cout, generator=g).to(DEV)
+        pw, pb = native.conv_pack(w, b, bn=None)
+        class P:                                                # the two packs a unit needs
+            fwd = {0: (pw, pb)}
+            dg = {}
+        if ks != 7:
+            nd = lib().be_conv_dgrad_packed_floats(cout, cin, ks)
+            dw_, db_ = train._new(nd, DEV), train._new((cin + 31) // 32 * 32, DEV)
+            check(lib().be_conv_pack_dgrad_f32(dptr(w), cout, cin, ks, 0, dptr(dw_), dptr(db_), stream_ptr(DEV)), "pack dgrad")
+            P.dg[0] = (dw_, db_)
+        rm_a, rv_a = torch.zeros(cout, device=DEV), torch.ones(cout, device=DEV)
+        rm_b, rv_b = rm_a.clone(), rv_a.clone()
+        # ---- round-2 chain
+        y_ref = train._conv_fwd(x, P, 0, cout, ks)
+        out_ref, saved_ref = train._bn_fwd(y_ref, gamma, beta, rm_b, rv_b, res, act)
+        ds_ref, dy_ref, dgam_ref, dbet_ref = train._bn_bwd(dout, saved_ref, gamma)
+        dw_ref = train._wgrad(x, dy_ref, (cout, 3 if ks == 7 else cin, ks, ks), ks)
+        db_ref = train._col_sum(dy_ref)
+        dx_ref = train._dgrad(dy_ref, P, 0, cin, ks) if ks != 7 else None
+        # ---- the unit
+        out, saved = train._unit_fwd(x, P, 0, cout, ks, gamma, beta, rm_a, rv_a, res, act)
+        dgam, dbet, dwt, dbt = (torch.empty(cout, device=DEV), torch.empty(cout, device=DEV), torch.empty_like(dw_ref), torch.empty(cout, device=DEV))
+        add = torch.randn(n, hw, hw, cin, generator=g).to(DEV) if ks == 3 else None
+        ds, dx = train._unit_bwd(x, dout, saved, gamma, P.dg.get(0), add, ks, 0, dgam, dbet, dwt, dbt)
+        torch.cuda.synchronize()
+        assert rel(saved[0], y_ref) <= 1e-6 and rel(out, out_ref) <= 1e-6, (ks, rel(out, out_ref))
+        assert rel(saved[1], saved_ref[1]) <= 1e-6 and rel(saved[2], saved_ref[2]) <= 1e-6
+        assert rel(rm_a, rm_b) <= 1e-6 and rel(rv_a, rv_b) <= 1e-6
+        assert rel(ds, ds_ref) <= 1e-6 and rel(dgam, dgam_ref) <= 1e-5 and rel(dbet, dbet_ref) <= 1e-5
+        assert rel(dwt, dw_ref) <= 2e-5, (ks, rel(dwt, dw_ref))
+        assert float((dbt - db_ref).abs().max()) <= 1e-5 * float(dy_ref.abs().max()) * n      # both are rounding noise around 0
+        if dx_ref is not None:
+            assert rel(dx, dx_ref + add if add is not None else dx_ref) <= 1e-5
+    # max-pool with recorded winners against the re-scanning backward: identical
+    for (hw, c, k, s_, p_) in ((21, 64, 3, 2, 1), (11, 96, 3, 2, 1), (6, 256, 2, 2, 0)):
+        x = torch.randn(8, hw, hw, c, generator=g).to(DEV)
+        x[0, :4, :4] = 1.0                                       # ties: the FIRST maximum in scan order wins
+        y, saved = train._pool_fwd_idx(x, k, s_, p_)
+        assert torch.equal(y, native.maxpool_nhwc(x, k, s_, p_))
+        d = torch.randn_like(y)
+        assert torch.equal(train._pool_bwd_idx(saved, d, k, s_, p_), train._pool_bwd(x, d, k, s_, p_))
