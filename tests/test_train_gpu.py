@@ -674,17 +674,21 @@ def test_clip_adamw_matches_clip_grad_norm_and_torch_adamw():
             a.grad = flat[off:off + a.numel()].view_as(a)
             b.grad = flat[off:off + a.numel()].view_as(a).clone()
             off += a.numel()
+        before = [b.detach().clone() for b in pb]
         norm_b = torch.nn.utils.clip_grad_norm_(pb, max_norm=1.0, norm_type=2)
         ob.step()
         norm_a = oa.clip_and_step(1.0)
         assert abs(float(norm_a) - float(norm_b)) <= 1e-6 * float(norm_b), (it, float(norm_a), float(norm_b))
         worst = 0.0
-        for a, b in zip(pa, pb):
+        for a, b, b0 in zip(pa, pb, before):
             assert float((a.grad - b.grad).norm() / b.grad.norm().clamp_min(1e-30)) <= 1e-6        # the clipped gradient, written back
             d = (a.detach().double() - b.detach().double()).abs()
-            tol = torch.from_numpy(np.spacing(np.abs(b.detach().cpu().numpy()).astype(np.float32))).double().to(DEV) + 1e-10
+            # yardstick: one spacing of the updated fp32 parameter + the fp32 rounding of the step itself (a parameter that
+            # starts at 0 - a BatchNorm beta - IS its first step: m / (sqrt(v) + eps) rounded in two different operation orders)
+            tol = torch.from_numpy(np.spacing(np.abs(b.detach().cpu().numpy()).astype(np.float32))).double().to(DEV) \
+                + 5e-7 * (b.detach().double() - b0.double()).abs() + 1e-12
             worst = max(worst, float((d / tol).max()))
-        assert worst <= 4.0, (it, worst)                                            # spacings of the updated fp32 parameter
+        assert worst <= 2.0, (it, worst)
     assert float(oa.state[pa[0]]["step"]) == 6.0
     sd = oa.state_dict()                                                            # the usual optimizer surface still works
     assert len(sd["state"]) == len(pa) and sd["param_groups"][0]["lr"] == 1e-3
