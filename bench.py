@@ -18,7 +18,7 @@ with the input already resident in HBM.  Prints ONE JSON line (rank 0).
                  training step at batch 8,
                  each with its own clock and dominant kernel
   dp             the data-parallel training step (configs[4]): at N > 1 K steps of be_hip.train_local.train_step(world=N)
-                 with the five-bucket RCCL gradient all-reduce overlapped with the backward; at N = 1 the same code, world 1
+                 with the bucketed RCCL gradient all-reduce (four buckets) overlapped with the backward; at N = 1 the same code, world 1
   cpu_baseline   the oracle on the host cores, 1024 pairs x 3 runs, median (rank 0, N = 1 only)
 
 Multi-GPU: patch pairs are independent, so every rank runs its own shard of 4096 pairs with NO data-path
@@ -262,7 +262,7 @@ def leg_global_training(dev, steps=12):
 
 
 def leg_dp(dev, native, dist, rank, world, steps):
-    """configs[4], local half: `steps` data-parallel training steps, per-GPU batch 64, gradients averaged by the five-bucket
+    """configs[4], local half: `steps` data-parallel training steps, per-GPU batch 64, gradients averaged by the bucketed
     all-reduce that overlaps the backward (be_hip.dp.GradSync over RCCL); plus the same step without the exchange and the
     exchange alone, so that the exposed communication can be read off.  world = 1 runs the identical code without a group."""
     import models, utils
@@ -318,14 +318,14 @@ def leg_dp(dev, native, dist, rank, world, steps):
         return t / n * 1e3
     ms = clock(step, steps)
     res = dict(config="configs[4] (LocalStage half): data-parallel local training, per-GPU batch 64, eager launches, "
-                      "five gradient buckets all-reduced on a side stream while the backward runs",
+                      "gradient buckets (fc | layer3 | layer2 | layer1 + layer0 + conv1) all-reduced on a side stream while the backward runs",
                world=world, global_batch=B * world, steps=steps, dp_step_ms=round(ms, 4),
                patches_per_s=round(B * world / ms * 1e3, 1), allreduce_bytes=4 * sum(p.numel() for p in model.parameters()),
-               allreduce_buckets=5 if sync is not None else 0)
+               allreduce_buckets=len(sync.groups) if sync is not None else 0)
     if world > 1:
         res["compute_only_step_ms"] = round(clock(lambda: step(False), steps), 4)
         flat = torch.zeros(res["allreduce_bytes"] // 4, dtype=torch.float32, device=dev)
-        ranges = dp.bucket_ranges([v.numel() for v in model._tensor_list()])
+        ranges = dp.bucket_ranges([v.numel() for v in model._tensor_list()], sync.groups)
 
         def exchange():
             for lo, hi in ranges:
@@ -335,6 +335,18 @@ def leg_dp(dev, native, dist, rank, world, steps):
         res["exposed_comm_ms"] = round(res["dp_step_ms"] - res["compute_only_step_ms"], 4)
         res["allreduce_busbw_GBps"] = round(2 * (world - 1) / world * res["allreduce_bytes"] / (res["allreduce_ms"] * 1e-3) / 1e9, 1)
         dp.broadcast_bn_stats(model, src=0)
+    if sync is not None:
+        # per bucket: bytes and the time from "slice final on the compute stream" to "its collective complete" (events), over a few
+        # steps with GradSync's timing switched on - what attributes exposed_comm_ms (the last bucket's time is the exposed part)
+        sync.timing = True
+        per = None
+        for _ in range(5):
+            step()
+            bt = sync.bucket_times()
+            per = bt if per is None else [(b, m0 + m1) for (b, m0), (_, m1) in zip(per, bt)]
+        sync.timing = False
+        if per:
+            res["buckets"] = [dict(bytes=b, issue_to_complete_ms=round(m / 5, 4)) for b, m in per]
     if own_group:
         res["rccl_one_rank_group"] = True
         res["compute_only_step_ms"] = round(clock(lambda: step(False), steps), 4)

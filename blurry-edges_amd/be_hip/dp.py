@@ -2,10 +2,12 @@
 
 The only collective of the training path: an all-reduce (sum, then / world) of the flat fp32
 gradient buffer (7 254 122 elements = 29.0 MB) before clip_grad_norm_ and the optimizer step.  The HIP backward writes
-the gradients of one layer group after another into consecutive slices of that buffer (fc first, conv1 last), so the
-exchange runs as FIVE buckets (`bucket_ranges`: fc 9.5 MB, layer3 6.3, layer2 9.2, layer1 3.3, conv1 + layer0 0.6), each
-launched on a side stream the moment its slice is final (`GradSync`): the collective of a bucket overlaps the backward of
-the layers in front of it, and only the last, smallest bucket is exposed.  With RCCL over xGMI (7 point-to-point links x
+the gradients of one layer group after another into consecutive slices of that buffer (fc first, conv1 last) and reports five
+completion points (`GRAD_POINTS`: fc 9.5 MB, layer3 6.3, layer2 9.2, layer1 3.3, conv1 + layer0 0.6).  The exchange runs as
+BUCKETS made of consecutive points (`DEFAULT_GROUPS`: four buckets - the 0.6 MB head rides with layer1's 3.3 MB, because the
+last bucket is the only one whose collective is exposed and a 0.6 MB ring is latency-bound; `GradSync(groups=...)` takes any
+other split, e.g. `GRAD_POINTS` itself for round 2's five), each launched on a side stream the moment its slice is final
+(`GradSync`): the collective of a bucket overlaps the backward of the layers in front of it.  With RCCL over xGMI (7 point-to-point links x
 ~153 GB/s per GPU) buckets of several MB keep every link busy; BatchNorm statistics stay per replica during training (the
 reference's batch-64 semantics); `broadcast_parameters` aligns the replicas at the start and `broadcast_bn_stats` hands
 rank 0's running statistics to everyone before a checkpoint is written."""
@@ -92,10 +94,31 @@ def grads_as_flat(params, fallback: torch.Tensor | None = None):
 
 
 # ------------------------------------------------------------------------------- overlapped, bucketed gradient exchange
-def bucket_ranges(numels, groups=((78, 86), (60, 78), (42, 60), (24, 42), (0, 24)), trainable=None):
+# tensor-index ranges (native.local_stage_pack order, 86 tensors) whose gradients are final at the backward's five completion
+# points, in completion order: fc.1/fc.2/fc.4, layer3, layer2, layer1, conv1 + layer0
+GRAD_POINTS = ((78, 86), (60, 78), (42, 60), (24, 42), (0, 24))
+# buckets = unions of consecutive completion points.  Round 3 default: the head (0.6 MB) is merged into layer1's bucket.
+DEFAULT_GROUPS = ((78, 86), (60, 78), (42, 60), (0, 42))
+
+
+def check_groups(groups):
+    """groups must tile [0, 86) from the tail, each a union of consecutive completion points; returns them as a tuple."""
+    groups = tuple((int(a), int(b)) for a, b in groups)
+    cuts = {a for a, _ in GRAD_POINTS} | {86}
+    hi = 86
+    for a, b in groups:
+        if b != hi or a >= b or a not in cuts:
+            raise ValueError(f"gradient buckets must be consecutive unions of {GRAD_POINTS} from the tail, got {groups}")
+        hi = a
+    if hi != 0:
+        raise ValueError(f"gradient buckets must cover every tensor, got {groups}")
+    return groups
+
+
+def bucket_ranges(numels, groups=DEFAULT_GROUPS, trainable=None):
     """[(lo, hi)] float offsets into the flat gradient buffer, in the order the LocalStage backward completes them.
-    numels: element count of each of the 86 tensors (native.local_stage_pack order); groups: tensor-index ranges
-    (fc.1/fc.2/fc.4, layer3, layer2, layer1, conv1 + layer0); trainable: be_hip.train.TRAINABLE."""
+    numels: element count of each of the 86 tensors (native.local_stage_pack order); groups: tensor-index ranges (see
+    DEFAULT_GROUPS / GRAD_POINTS); trainable: be_hip.train.TRAINABLE."""
     if trainable is None:
         from .train import TRAINABLE as trainable
     off, start = 0, {}
@@ -110,21 +133,28 @@ def bucket_ranges(numels, groups=((78, 86), (60, 78), (42, 60), (24, 42), (0, 24
 class GradSync:
     """All-reduce of the flat gradient buffer in buckets that start while the backward is still running.
 
-        sync = GradSync(world)                       # once
-        train.set_grad_hook(sync.bucket_ready)       # the backward calls it with (flat, lo, hi) as each slice becomes final
-        loss.backward(); sync.finish()               # all buckets reduced and divided by world; .grad views are the means
+        sync = GradSync(world)                                    # once; groups= picks the bucket boundaries
+        train.set_grad_hook(sync.bucket_ready, sync.groups)       # the backward calls it with (flat, lo, hi) as each bucket becomes final
+        loss.backward(); sync.finish()                            # all buckets reduced and divided by world; .grad views are the means
 
     GPU tensors + RCCL ("nccl"): every bucket is issued under a side stream that waits for an event recorded on the compute
     stream right behind the kernels that wrote the slice; finish() makes the compute stream wait for the collectives.
     gloo (CPU rehearsal, tests): the same calls, synchronous; GPU tensors are staged through the host because gloo has no
-    device transport on this build."""
+    device transport on this build.
+    timing=True (RCCL path): each bucket also records when its slice became final (compute stream) and when its collective
+    completed (side stream); `bucket_times()` then gives, per bucket, bytes and issue -> complete milliseconds of the last step -
+    what a first multi-GPU run needs to attribute `exposed_comm_ms` (a bucket's time includes waiting for the bucket before it:
+    the collectives of one step are serialised on the side stream)."""
 
-    def __init__(self, world, group=None, always=False):
+    def __init__(self, world, group=None, always=False, groups=DEFAULT_GROUPS, timing=False):
         """always: run the exchange even for world == 1 (a one-rank group: the sum is the identity) - how the RCCL path is
         exercised on a single GPU (tests, bench.py at N = 1)."""
         self.world, self.group, self.always = world, group, always
+        self.groups = check_groups(groups)
+        self.timing = timing
         self.handles, self.flat, self.side = [], None, None
         self.bytes = 0
+        self._events, self._timed_side = [], False
 
     def bucket_ready(self, flat, lo, hi):
         if (self.world == 1 and not self.always) or hi <= lo:
@@ -136,11 +166,19 @@ class GradSync:
         if piece.is_cuda and dist.get_backend(self.group) == "nccl":
             if self.side is None:
                 self.side = torch.cuda.Stream(device=flat.device)
-            ev = torch.cuda.Event()
+            ev = torch.cuda.Event(enable_timing=self.timing)
             ev.record()                                               # behind the last kernel that wrote flat[lo:hi]
             with torch.cuda.stream(self.side):
                 self.side.wait_event(ev)
-                self.handles.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                h = dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                if self.timing:
+                    h.wait()                                          # the SIDE stream waits for the collective ...
+                    done = torch.cuda.Event(enable_timing=True)
+                    done.record()                                     # ... so this event is its completion
+                    self._events.append((piece.numel() * 4, ev, done))
+                    self._timed_side = True
+                else:
+                    self.handles.append(h)
         elif piece.is_cuda:
             host = piece.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
@@ -148,15 +186,32 @@ class GradSync:
         else:
             self.handles.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
-    def finish(self):
-        """-> the averaged flat buffer (None if nothing was exchanged)."""
+    def wait(self):
+        """The current (compute) stream waits for every collective issued so far; nothing is divided."""
         for h in self.handles:
             h.wait()                                                  # nccl: the current stream waits for the collective
         self.handles = []
+        if self._timed_side:
+            torch.cuda.current_stream().wait_stream(self.side)
+            self._timed_side = False
+
+    def finish(self):
+        """-> the averaged flat buffer (None if nothing was exchanged)."""
+        self.wait()
         flat, self.flat = self.flat, None
         if flat is not None and self.world > 1:
             flat.div_(self.world)
         return flat
+
+    def bucket_times(self):
+        """[(bytes, ms from 'slice final' to 'collective complete')] of the buckets issued since the last call (timing=True;
+        synchronises on the completion events)."""
+        out = []
+        for nbytes, a, b in self._events:
+            b.synchronize()
+            out.append((nbytes, a.elapsed_time(b)))
+        self._events = []
+        return out
 
 
 def broadcast_parameters(model, src=0, group=None):

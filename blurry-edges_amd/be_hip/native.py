@@ -139,7 +139,7 @@ _SIGNATURES = {
     "be_conv_pack_dgrad_f32": (C.c_int, [_P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "be_linear_small_bwd_f32": (C.c_int, [_P] * 6 + [C.c_int] * 3 + [_P]),
     "be_adam_chunk": (C.c_int, []),
-    "be_clip_adamw_f32": (C.c_int, [_P, C.c_int, _P, C.c_int64, _P, C.c_int] + [C.c_float] * 7 + [_P, _P, C.c_int, _P]),
+    "be_clip_adamw_f32": (C.c_int, [_P, C.c_int, _P, C.c_int64, _P, C.c_int, C.c_float, C.c_float] + [C.c_double] * 5 + [_P, _P, C.c_int, _P]),
     "be_local_loss_finish_f32": (C.c_int, [_P, C.c_int, C.c_float, C.c_float, _P, _P]),
     "be_train_unit_fwd_f32": (C.c_int, [_P] * 7 + [C.c_float, C.c_float] + [_P] * 7 + [C.c_int, _P, C.c_size_t, _P]),
     "be_train_unit_bwd_f32": (C.c_int, [_P] * 11 + [C.c_int] + [_P] * 8 + [C.c_size_t, _P]),

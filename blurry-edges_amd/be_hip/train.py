@@ -252,14 +252,17 @@ TRAINABLE = [6 * i + j for i in range(13) for j in range(4)] + [78, 79, 80, 81, 
 
 
 _GRAD_HOOK = None
+_GRAD_GROUPS = None
 
 
-def set_grad_hook(fn):
-    """fn(flat, lo, hi) is called by backward_train each time a layer group's slice flat[lo:hi] of the gradient buffer is
-    final (all kernels that write it are enqueued on the current stream): fc, layer3, layer2, layer1, conv1 + layer0, in that
-    order.  be_hip.dp.GradSync.bucket_ready starts that bucket's all-reduce there.  None removes the hook."""
-    global _GRAD_HOOK
+def set_grad_hook(fn, groups=None):
+    """fn(flat, lo, hi) is called by backward_train each time a gradient BUCKET's slice flat[lo:hi] of the gradient buffer is
+    final (all kernels that write it are enqueued on the current stream).  groups: the buckets as tensor-index ranges, unions of
+    the backward's completion points fc, layer3, layer2, layer1, conv1 + layer0 (be_hip.dp.GRAD_POINTS; default
+    be_hip.dp.DEFAULT_GROUPS).  be_hip.dp.GradSync.bucket_ready starts that bucket's all-reduce there.  None removes the hook."""
+    global _GRAD_HOOK, _GRAD_GROUPS
     _GRAD_HOOK = fn
+    _GRAD_GROUPS = groups if fn is not None else None
 
 
 def backward_train(dlogits, t, S):
@@ -276,12 +279,15 @@ def backward_train(dlogits, t, S):
         off += t[i].numel()
     hook = _GRAD_HOOK
     if hook is not None:
-        from .dp import bucket_ranges
-        buckets = bucket_ranges([v.numel() for v in t])
+        from .dp import DEFAULT_GROUPS, GRAD_POINTS, bucket_ranges, check_groups
+        groups = check_groups(_GRAD_GROUPS if _GRAD_GROUPS is not None else DEFAULT_GROUPS)
+        ranges = bucket_ranges([v.numel() for v in t], groups)
+        # completion point k closes the bucket whose first tensor is the point's first tensor
+        closes = {GRAD_POINTS.index(next(p for p in GRAD_POINTS if p[0] == a)): r for (a, _), r in zip(groups, ranges)}
 
     def done(k):
-        if hook is not None:
-            hook(flat, *buckets[k])
+        if hook is not None and k in closes:
+            hook(flat, *closes[k])
     w1, b1, g1, be1, rm1, rv1, w4, b4 = t[78:86]
     packs = S["packs"]
     # fc.4

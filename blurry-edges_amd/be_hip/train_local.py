@@ -37,8 +37,8 @@ class BetaSchedule:
 
 def train_step(model, helper, opt, batch, beta_b, beta_s, flat=None, world=1, clip=1.0, stats=None, sync=None):
     """One iteration of local_training.py:103-108.  batch: dict of GPU tensors (dataset layouts).
-    world > 1: the gradients are averaged over the ranks before clipping.  sync = a be_hip.dp.GradSync: five buckets, each
-    all-reduced on a side stream as soon as the backward has finished its slice (overlap); without one, `flat` selects
+    world > 1: the gradients are averaged over the ranks before clipping.  sync = a be_hip.dp.GradSync: its buckets are each
+    all-reduced on a side stream as soon as the backward has finished their slice (overlap); without one, `flat` selects
     the older path - one bucketed all-reduce after the whole backward.
     stats: optional dict that receives `grad_norm` (the total norm clip_grad_norm_ measured, a device scalar)."""
     import utils
@@ -47,7 +47,7 @@ def train_step(model, helper, opt, batch, beta_b, beta_s, flat=None, world=1, cl
     opt.zero_grad(set_to_none=True)      # backward then SETS .grad (no fill, no accumulate launch per parameter)
     loss = utils.local_loss(helper, est, batch["img_gt"], batch["img_gt"], batch["bndry_dist"], batch["deri"], beta_b, beta_s)
     if sync is not None and (world > 1 or sync.always):
-        train.set_grad_hook(sync.bucket_ready)
+        train.set_grad_hook(sync.bucket_ready, sync.groups)
         try:
             loss.backward()
         finally:
@@ -104,7 +104,7 @@ class GraphedStep:
 
 
 class SegmentedGraphStep:
-    """The data-parallel training step as SIX hipGraph segments with the gradient buckets' all-reduces issued between them.
+    """The data-parallel training step as hipGraph segments (buckets + 1) with the gradient buckets' all-reduces issued between them.
 
     The eager data-parallel step is bound by its ~232 host launches (3.3 ms against 2.6 ms for the single-GPU hipGraph step), and a
     collective cannot be captured into a graph on this stack.  So the step is cut where the backward finishes a gradient bucket
@@ -137,7 +137,7 @@ class SegmentedGraphStep:
                                                  batch["img_gt"].contiguous(), batch["bndry_dist"].contiguous(),
                                                  batch["deri"].contiguous(), beta_b, beta_s, want_grad=True)
         loss = native.local_loss_finish(partial, beta_b, beta_s)                                 # utils._LocalLossFn.forward
-        train.set_grad_hook(hook)
+        train.set_grad_hook(hook, self.sync.groups if self.sync is not None else None)
         try:
             grads = train.backward_train(grad_est, t, S)
         finally:
@@ -172,16 +172,15 @@ class SegmentedGraphStep:
         else:
             for k in self.static:
                 self.static[k].copy_(batch[k])
-        cur = torch.cuda.current_stream()
-        for k in range(5):
+        nb = len(self.graphs) - 1
+        for k in range(nb):
             self.graphs[k].replay()
             if self.sync is not None:
                 self.sync.bucket_ready(self.flat, *self.ranges[k])       # event behind segment k, all-reduce on the side stream
         if self.sync is not None:
-            for h in self.sync.handles:
-                h.wait()                                 # the compute stream waits for the collectives (the division is captured)
-            self.sync.handles, self.sync.flat = [], None
-        self.graphs[5].replay()
+            self.sync.wait()                             # the compute stream waits for the collectives (the division is captured)
+            self.sync.flat = None
+        self.graphs[nb].replay()
         # the replay moved weights and BatchNorm statistics on the device; no tensor version changed (as in GraphedStep)
         self.model.invalidate_packed()
         return self.loss.clone()
@@ -189,7 +188,9 @@ class SegmentedGraphStep:
     def _capture(self, batch, beta_b, beta_s):
         self.static = {k: v.clone() for k, v in batch.items()}
         torch.cuda.synchronize()
-        graphs = [torch.cuda.CUDAGraph() for _ in range(6)]
+        from .dp import DEFAULT_GROUPS
+        nb = len(self.sync.groups if self.sync is not None else DEFAULT_GROUPS)
+        graphs = [torch.cuda.CUDAGraph() for _ in range(nb + 1)]
         pool = torch.cuda.graph_pool_handle()            # ONE memory pool: tensors made in one segment live on into the next
         seen = []
         state = dict(k=0)
@@ -207,12 +208,12 @@ class SegmentedGraphStep:
             # and only this thread's calls are policed
             graphs[0].capture_begin(pool=pool, capture_error_mode="thread_local")
             self.loss = self._step(self.static, beta_b, beta_s, hook)
-            assert state["k"] == 5, "the backward did not report its five gradient buckets"
+            assert state["k"] == nb, f"the backward reported {state['k']} gradient buckets, {nb} expected"
             flat = seen[0][0]
             if self.sync is not None and (self.world > 1 or self.sync.always):
                 flat.div_(self.world)                    # GradSync.finish's division, captured
             self._clip_step()
-            graphs[5].capture_end()
+            graphs[nb].capture_end()
         torch.cuda.current_stream().wait_stream(self.stream)
         self.graphs, self.flat, self.ranges = graphs, flat, [(lo, hi) for _, lo, hi in seen]
 
@@ -240,7 +241,7 @@ def main(argv=None):
     from .optim import ClipAdamW
     opt = ClipAdamW(model.parameters(), lr=a.lr)            # clip + AdamW over the flat gradient buffer (three launches)
     flat = None
-    sync = dp.GradSync(world) if world > 1 else None       # five buckets, each all-reduced while the backward goes on
+    sync = dp.GradSync(world) if world > 1 else None       # four buckets, each all-reduced while the backward goes on
     if world > 1:
         dp.broadcast_parameters(model, src=0)               # replicas start from rank 0's weights and statistics
     data = {k: torch.from_numpy(v).to(dev) for k, v in synth.synthetic_training_patches(a.patches, seed=1869 + rank).items()}

@@ -14,14 +14,18 @@ extern "C" const char* be_last_error(void) { return be::last_error_buf(); }
 // ------------------------------------------------------------------------------------------------ profiling
 namespace {
 struct Rec { hipEvent_t a, b; int kernel_id; double flops, bytes, flops_exec; };
-struct Prof { Rec* recs = nullptr; int cap = 0, n = 0; bool on = false; } g_prof;
+// n is claimed with an atomic increment: two host threads launching with the hooks enabled get distinct slots (enable / read are
+// single-threaded by contract: they belong to the measuring harness)
+struct Prof { Rec* recs = nullptr; int cap = 0; std::atomic<int> n{0}; bool on = false; } g_prof;
 }  // namespace
 
 namespace be {
 ProfileScope::ProfileScope(hipStream_t s, int kernel_id, double flops, double bytes, double flops_executed)
     : s_(s), slot_(-1) {
-    if (!g_prof.on || g_prof.n >= g_prof.cap) return;
-    slot_ = g_prof.n++;
+    if (!g_prof.on) return;
+    const int slot = g_prof.n.fetch_add(1, std::memory_order_relaxed);
+    if (slot >= g_prof.cap) { g_prof.n.fetch_sub(1, std::memory_order_relaxed); return; }
+    slot_ = slot;
     Rec& r = g_prof.recs[slot_];
     r.kernel_id = kernel_id; r.flops = flops; r.bytes = bytes; r.flops_exec = flops_executed;
     (void)hipEventRecord(r.a, s_);
@@ -34,7 +38,7 @@ ProfileScope::~ProfileScope() {
 extern "C" int be_profile_enable(int max_launches) {
     for (int i = 0; i < g_prof.cap; ++i) { (void)hipEventDestroy(g_prof.recs[i].a); (void)hipEventDestroy(g_prof.recs[i].b); }
     delete[] g_prof.recs;
-    g_prof = Prof();
+    g_prof.recs = nullptr; g_prof.cap = 0; g_prof.n.store(0); g_prof.on = false;
     if (max_launches <= 0) return BE_OK;
     g_prof.recs = new Rec[max_launches];
     for (int i = 0; i < max_launches; ++i) {
@@ -46,10 +50,11 @@ extern "C" int be_profile_enable(int max_launches) {
     return BE_OK;
 }
 
-extern "C" int be_profile_reset(void) { g_prof.n = 0; return BE_OK; }
+extern "C" int be_profile_reset(void) { g_prof.n.store(0); return BE_OK; }
 
 extern "C" int be_profile_read(int* kernel_id, double* flops, double* bytes, double* flops_executed, float* ms, int cap) {
-    const int n = g_prof.n < cap ? g_prof.n : cap;
+    const int have = g_prof.n.load();
+    const int n = have < cap ? have : cap;
     for (int i = 0; i < n; ++i) {
         Rec& r = g_prof.recs[i];
         if (hipEventSynchronize(r.b) != hipSuccess) return be::fail(BE_ELAUNCH, "be_profile_read: event sync failed");

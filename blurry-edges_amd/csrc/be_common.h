@@ -1,6 +1,7 @@
 // Shared host-side helpers of libblurry_edges_hip (error reporting, launch checks).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include "../../include/blurry_edges_hip.h"
@@ -31,6 +32,29 @@ inline int current_device() {
     int d = 0;
     if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) d = 0;
     return d;
+}
+
+// First-call caches shared by host threads (ADVICE / VERDICT r2: the plain `static bool attr_set[]` arrays were written without
+// synchronisation).  One atomic per device: two threads racing on their first call both set the (idempotent) function attribute
+// and both publish the flag with release semantics; later calls are one acquire load.
+struct DeviceFlags { std::atomic<int> v[kMaxDevices]; };
+inline int ensure_dynamic_lds(const void* kernel, size_t lds_bytes, DeviceFlags& flags) {
+    const int dev = current_device();          // the attribute is per device
+    if (flags.v[dev].load(std::memory_order_acquire)) return BE_OK;
+    hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+    if (e != hipSuccess) return fail(BE_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    flags.v[dev].store(1, std::memory_order_release);
+    return BE_OK;
+}
+// CU count of the current device (256 on MI355X), cached per device
+inline int device_cu_count() {
+    static DeviceFlags cus{};
+    const int dev = current_device();
+    int c = cus.v[dev].load(std::memory_order_acquire);
+    if (c > 0) return c;
+    if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || c <= 0) c = 256;
+    cus.v[dev].store(c, std::memory_order_release);
+    return c;
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }

@@ -573,13 +573,8 @@ void k_conv_b3(ConvArgs a) {
 
 int launch_conv_b3(const ConvArgs& a, hipStream_t s) {
     constexpr size_t lds = 2 * 2 * 3 * 128 * 32;       // 48 KB
-    static bool attr_set[be::kMaxDevices] = {};
-    const int dev_ = be::current_device();          // the attribute is per device
-    if (!attr_set[dev_]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_b3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return be::fail(BE_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set[dev_] = true;
-    }
+    static be::DeviceFlags attr_set{};                      // dynamic-LDS cap raised once per device (thread-safe)
+    if (int rc_ = be::ensure_dynamic_lds(reinterpret_cast<const void*>(&k_conv_b3), lds, attr_set)) return rc_;
     const int per_xcd = a.pixmaj == 1 ? ((a.m_tiles / a.HW + 7) / 8) * a.HW : (a.m_tiles + 7) / 8;
     const unsigned grid = (unsigned)(8 * per_xcd * a.n_tiles);
     {
@@ -596,14 +591,8 @@ int launch_conv(const ConvArgs& a, hipStream_t s, int kernel_id) {
     constexpr int BN = WN * NT * 32;
     constexpr int BM = WM * MT * 32;
     constexpr size_t lds = (size_t)2 * (BM + BN) * (BKT + 4) * sizeof(float);
-    static bool attr_set[be::kMaxDevices] = {};                     // raise the dynamic-LDS cap once per instantiation
-    const int dev_ = be::current_device();          // the attribute is per device
-    if (!attr_set[dev_]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_igemm<WM, WN, MT, NT, MODE, BKT, PRIO>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return be::fail(BE_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set[dev_] = true;
-    }
+    static be::DeviceFlags attr_set{};                      // dynamic-LDS cap raised once per device (thread-safe)
+    if (int rc_ = be::ensure_dynamic_lds(reinterpret_cast<const void*>(&k_conv_igemm<WM, WN, MT, NT, MODE, BKT, PRIO>), lds, attr_set)) return rc_;
     // slots per XCD: flat tiles are dealt round-robin; pixel-major tiles keep a group of images on one XCD
     const int per_xcd = a.pixmaj == 1 ? ((a.m_tiles / a.HW + 7) / 8) * a.HW : (a.m_tiles + 7) / 8;
     const unsigned grid = (unsigned)(8 * per_xcd * a.n_tiles);

@@ -232,14 +232,8 @@ template <int MT, int NT, int MODE>
 int launch_pm(const PmArgs& a, hipStream_t s, int kernel_id) {
     constexpr int BM = 128 * MT, BN = 32 * NT;
     constexpr size_t lds = (size_t)2 * (BM + BN) * 16 * sizeof(float);
-    static bool attr_set[be::kMaxDevices] = {};
-    const int dev_ = be::current_device();          // the attribute is per device
-    if (!attr_set[dev_]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv_pm<MT, NT, MODE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return be::fail(BE_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set[dev_] = true;
-    }
+    static be::DeviceFlags attr_set{};                      // dynamic-LDS cap raised once per device (thread-safe)
+    if (int rc_ = be::ensure_dynamic_lds(reinterpret_cast<const void*>(&k_conv_pm<MT, NT, MODE>), lds, attr_set)) return rc_;
     const unsigned grid = (unsigned)(8 * ((a.groups + 7) / 8) * a.HW * a.n_tiles);
     {   // algorithmic work: 2*M*K*Cout with the REAL K; executed: the chunks the tiles visit x 2*BM*BN*16
         const double M = (double)a.Nimg * a.HW;

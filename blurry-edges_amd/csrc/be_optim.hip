@@ -39,7 +39,9 @@ struct AdamArgs {
     const be_adam_entry* table;      // device: one entry per workgroup
     float* g;                        // flat gradient buffer
     const double* partial; int npartial;
-    float max_norm, lr, beta1, beta2, eps, weight_decay, grad_scale;
+    float max_norm, grad_scale;
+    double lr, beta1, beta2, eps, weight_decay;   // hyper-parameters stay doubles (Python floats) until the last moment, as in torch: 1 - beta2 formed
+                                                  // from the FLOAT 0.999 is off by 1.3e-5 relative
     float* step;                     // device scalar, incremented by workgroup 0 AFTER every workgroup has read it ... see below
     float* grad_norm;                // device scalar out (the norm before clipping), may be null
     int write_back;
@@ -67,22 +69,23 @@ void k_clip_adamw(AdamArgs a) {
         // `step` holds the number of steps taken BEFORE this one; the host-side wrapper bumps it with its own tiny launch
         // after this kernel (a workgroup cannot know when the others have read it)
         const double t = (double)a.step[0] + 1.0;
-        s_bc1 = (float)(1.0 - pow((double)a.beta1, t));
-        s_bc2s = (float)sqrt(1.0 - pow((double)a.beta2, t));
+        s_bc1 = (float)(1.0 - pow(a.beta1, t));
+        s_bc2s = (float)sqrt(1.0 - pow(a.beta2, t));
         if (blockIdx.x == 0 && a.grad_norm) a.grad_norm[0] = total;
     }
     __syncthreads();
     const be_adam_entry e = a.table[blockIdx.x];
     const float coef = s_coef, bc1 = s_bc1, bc2s = s_bc2s;
-    const float step_size = a.lr / bc1, decay = a.lr * a.weight_decay, omb1 = 1.0f - a.beta1, omb2 = 1.0f - a.beta2;
+    const float step_size = (float)(a.lr / (double)bc1), decay = (float)(a.lr * a.weight_decay);
+    const float omb1 = (float)(1.0 - a.beta1), omb2 = (float)(1.0 - a.beta2), b2 = (float)a.beta2, eps = (float)a.eps;
     float* gp = a.g + e.goff;
     auto upd = [&](float& p, float& m, float& v, float& g) {
         g *= coef;
         p -= decay * p;                                       // AdamW: decoupled weight decay
         m = m + omb1 * (g - m);                               // lerp(m, g, 1 - beta1)
-        v = a.beta2 * v + omb2 * g * g;
-        const float denom = sqrtf(v) / bc2s + a.eps;
-        p -= step_size * m / denom;
+        v = b2 * v + omb2 * g * g;
+        const float denom = sqrtf(v) / bc2s + eps;
+        p -= step_size * (m / denom);                          // addcdiv_(exp_avg, denom, value=-step_size)
     };
     const bool vec = ((e.n & 3) == 0) && (((uintptr_t)e.p | (uintptr_t)e.m | (uintptr_t)e.v | (uintptr_t)gp) & 15u) == 0;
     if (vec) {
@@ -115,14 +118,14 @@ __global__ void k_step_inc(float* step) { if (threadIdx.x == 0 && blockIdx.x == 
 extern "C" int be_adam_chunk(void) { return CHUNK; }
 
 extern "C" int be_clip_adamw_f32(const be_adam_entry* table_device, int nentries, float* grad_flat, int64_t n_flat, double* partial,
-                                 int npartial_cap, float max_norm, float grad_scale, float lr, float beta1, float beta2, float eps,
-                                 float weight_decay, float* step_device, float* grad_norm_out, int write_back, void* stream) {
+                                 int npartial_cap, float max_norm, float grad_scale, double lr, double beta1, double beta2, double eps,
+                                 double weight_decay, float* step_device, float* grad_norm_out, int write_back, void* stream) {
     BE_REQUIRE(table_device && grad_flat && partial && step_device && nentries > 0 && n_flat > 0, "be_clip_adamw_f32: bad arguments");
     const int nblk = (int)((n_flat + CHUNK - 1) / CHUNK);
     BE_REQUIRE(nblk <= npartial_cap, "be_clip_adamw_f32: partial buffer too small (%d blocks)", nblk);
     hipStream_t s = be::as_stream(stream);
     hipLaunchKernelGGL(k_grad_sqsum, dim3(nblk), dim3(256), 0, s, grad_flat, n_flat, partial);
-    AdamArgs a{table_device, grad_flat, partial, nblk, max_norm, lr, beta1, beta2, eps, weight_decay, grad_scale, step_device,
+    AdamArgs a{table_device, grad_flat, partial, nblk, max_norm, grad_scale, lr, beta1, beta2, eps, weight_decay, step_device,
                grad_norm_out, write_back};
     hipLaunchKernelGGL(k_clip_adamw, dim3(nentries), dim3(256), 0, s, a);
     hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(64), 0, s, step_device);

@@ -579,20 +579,9 @@ void k_wino_gemm_ws(GemmArgs a, int mgroups) {
 template <int KCH, int KIND = 0>
 int launch_ws(const GemmArgs& g, hipStream_t s, int64_t n, int cin, int cout, int kid = BE_KERNEL_WINO_GEMM) {
     constexpr size_t lds = (size_t)8 * 128 * 16 * sizeof(float);     // 64 KB: eight chunks of the B fill (the A ring uses three)
-    static bool attr_set[be::kMaxDevices] = {};
-    const int dev_ = be::current_device();          // the attribute is per device
-    if (!attr_set[dev_]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino_gemm_ws<KCH, KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return be::fail(BE_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set[dev_] = true;
-    }
-    static int cus_of[be::kMaxDevices] = {};               // CU count, per device
-    if (!cus_of[dev_]) {
-        int c = 0;
-        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev_) != hipSuccess || c <= 0) c = 256;
-        cus_of[dev_] = c;
-    }
-    const int cus = cus_of[dev_];
+    static be::DeviceFlags attr_set{};                      // dynamic-LDS cap raised once per device (thread-safe)
+    if (int rc_ = be::ensure_dynamic_lds(reinterpret_cast<const void*>(&k_wino_gemm_ws<KCH, KIND>), lds, attr_set)) return rc_;
+    const int cus = be::device_cu_count();
     // R rounds of ONE workgroup per CU (the kernel takes the whole register file of a CU).  Workgroup ids go round-robin over the
     // 8 XCDs, so the count that has to fit is per XCD: ceil(units / 8) * n_tiles <= R * (CUs per XCD) - one workgroup too many
     // on an XCD is a whole extra round for everybody.  At least 8 M ranges per problem when there is that much work.
@@ -655,13 +644,8 @@ int wino_gemms(const float* V, const float* packed_w, float* M, int64_t n, int c
     if (wino_large(n, cout)) {
         // large batches: one workgroup per (M tile, N tile) walks the 25 problems back to back
         constexpr size_t lds = (size_t)2 * (128 + 128) * 16 * sizeof(float);
-        static bool attr_set[be::kMaxDevices] = {};
-        const int dev_ = be::current_device();          // the attribute is per device
-        if (!attr_set[dev_]) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino_gemm<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return be::fail(BE_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-            attr_set[dev_] = true;
-        }
+        static be::DeviceFlags attr_set{};                      // dynamic-LDS cap raised once per device (thread-safe)
+        if (int rc_ = be::ensure_dynamic_lds(reinterpret_cast<const void*>(&k_wino_gemm<0>), lds, attr_set)) return rc_;
         // tile-major V [4n][25][cin] and M [4n][25][cout]: problem z = column block z of a row
         GemmArgs g{V, packed_w, M, (int)(4 * n), cin, cout, 25 * cout, 25, (int)((4 * n + 127) / 128), cp / 128,
                    (int64_t)cin, (int64_t)cp * cin, (int64_t)cout, 25 * cin, 128, 0, nullptr, nullptr, 0};
@@ -703,13 +687,8 @@ int be::gemm_rows(const float* x, int64_t M, int K, const float* packed_w, int N
                   float* y, int ldy, void* stream) {
     hipStream_t s = be::as_stream(stream);
     constexpr size_t lds = (size_t)2 * (128 + 128) * 16 * sizeof(float);
-    static bool attr_set[be::kMaxDevices] = {};
-    const int dev_ = be::current_device();          // the attribute is per device
-    if (!attr_set[dev_]) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wino_gemm<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return be::fail(BE_ELAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_set[dev_] = true;
-    }
+    static be::DeviceFlags attr_set{};                      // dynamic-LDS cap raised once per device (thread-safe)
+    if (int rc_ = be::ensure_dynamic_lds(reinterpret_cast<const void*>(&k_wino_gemm<1>), lds, attr_set)) return rc_;
     const int cp = (N + 127) / 128 * 128, n_tiles = cp / 128;
     const int64_t tiles = (M + 127) / 128;
     // short K loops: one workgroup walks nb consecutive row tiles (only when all of them are full), about one round of

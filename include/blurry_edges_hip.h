@@ -436,8 +436,8 @@ typedef struct be_adam_entry {
 } be_adam_entry;
 int be_adam_chunk(void);
 int be_clip_adamw_f32(const be_adam_entry* table_device, int nentries, float* grad_flat, int64_t n_flat, double* partial,
-                      int npartial_cap, float max_norm, float grad_scale, float lr, float beta1, float beta2, float eps,
-                      float weight_decay, float* step_device, float* grad_norm_out, int write_back, void* stream);
+                      int npartial_cap, float max_norm, float grad_scale, double lr, double beta1, double beta2, double eps,
+                      double weight_decay, float* step_device, float* grad_norm_out, int write_back, void* stream);
 /* Final reduction of be_local_loss_f32's per-patch partials [B,3] into the scalar of LocalLoss.forward (local_training.py:47-52):
  * loss = S0/(441 B) + beta_bndry S1/(441 B) + beta_smooth S2/(361 B), sums in fp64 in patch order. */
 int be_local_loss_finish_f32(const float* partial, int B, float beta_bndry, float beta_smooth, float* loss_out, void* stream);

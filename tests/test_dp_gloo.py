@@ -5,6 +5,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.multiprocessing as mp
 
@@ -91,8 +92,8 @@ def test_grads_as_flat_is_zero_copy_for_a_backward_that_writes_one_buffer():
     assert ps[2].grad.data_ptr() == fb[10:].data_ptr()
 
 
-# ------------------------------------------------------------------ the real buffer: 7 254 122 floats in the five buckets
-def _sync_worker(rank, world, port, q):
+# ------------------------------------------------------------------ the real buffer: 7 254 122 floats in its gradient buckets
+def _sync_worker(rank, world, port, q, groups):
     for p in (ROOT, PKG):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -104,10 +105,11 @@ def _sync_worker(rank, world, port, q):
     torch.set_num_threads(2)
     m = models.LocalStage()                                           # module tree only: no HIP call on the CPU
     t = m._tensor_list()
-    ranges = dp.bucket_ranges([v.numel() for v in t])
+    groups = dp.DEFAULT_GROUPS if groups is None else groups
+    ranges = dp.bucket_ranges([v.numel() for v in t], groups)
     n = sum(p.numel() for p in m.parameters())
     flat = torch.from_numpy(synth.f32(synth.hash_normal(100 + rank, "dp_flat", (n,))))
-    sync = dp.GradSync(world)
+    sync = dp.GradSync(world, groups=groups)
     for lo, hi in ranges:                                             # the order the backward completes them: tail first
         sync.bucket_ready(flat, lo, hi)
     out = sync.finish()
@@ -130,15 +132,21 @@ def _sync_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_five_bucket_gradient_sync_on_the_real_local_stage_buffer():
-    """be_hip.dp.GradSync on the 7 254 122-float buffer the LocalStage backward writes, bucket by bucket in completion
-    order (fc, layer3, layer2, layer1, conv1 + layer0), two gloo ranks: every element is the mean, nothing is skipped or
-    reduced twice; parameter / BatchNorm-statistics broadcasts align the replicas."""
-    from be_hip import synth
+@pytest.mark.parametrize("five", [False, True])
+def test_bucketed_gradient_sync_on_the_real_local_stage_buffer(five):
+    """be_hip.dp.GradSync on the 7 254 122-float buffer the LocalStage backward writes, bucket by bucket in completion order, two
+    gloo ranks: every element is the mean, nothing is skipped or reduced twice; parameter / BatchNorm-statistics broadcasts align
+    the replicas.  Default buckets (round 3): fc, layer3, layer2, layer1 + layer0 + conv1 - the 0.6 MB head rides
+    with layer1; `groups=dp.GRAD_POINTS` gives round 2's five; a split that is not made of completion points is refused."""
+    from be_hip import dp, synth
+    with pytest.raises(ValueError):
+        dp.check_groups(((78, 86), (50, 78), (0, 50)))
+    with pytest.raises(ValueError):
+        dp.check_groups(((78, 86), (60, 78)))
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_sync_worker, args=(r, 2, port, q, dp.GRAD_POINTS if five else None)) for r in range(2)]
     for p in procs:
         p.start()
     ranges, sub, total, ok = q.get(timeout=300)
@@ -146,8 +154,11 @@ def test_five_bucket_gradient_sync_on_the_real_local_stage_buffer():
         p.join(timeout=120)
         assert p.exitcode == 0
     n = 7254122
-    assert sorted(ranges) == [(0, 154848), (154848, 992736), (992736, 3306336), (3306336, 4881504), (4881504, n)]
-    assert ranges[0] == (4881504, n) and ranges[-1] == (0, 154848)      # completion order: the tail (fc) first
+    if five:
+        assert sorted(ranges) == [(0, 154848), (154848, 992736), (992736, 3306336), (3306336, 4881504), (4881504, n)]
+        assert ranges[0] == (4881504, n) and ranges[-1] == (0, 154848)      # completion order: the tail (fc) first
+    else:
+        assert ranges == [(4881504, n), (3306336, 4881504), (992736, 3306336), (0, 992736)]
     a = synth.f32(synth.hash_normal(100, "dp_flat", (n,)))
     b = synth.f32(synth.hash_normal(101, "dp_flat", (n,)))
     ref = (a + b) / np.float32(2)

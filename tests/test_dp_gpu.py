@@ -240,7 +240,7 @@ def test_bench_two_rank_rehearsal_on_one_gpu(tmp_path):
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0 and d["cpu_baseline"] is None
     assert d["value"] == pytest.approx(2 * 4096 * 3 / (d["ms_per_step"] * 3e-3), rel=1e-3)          # whole-job aggregate
     dp = d["dp"]
-    assert dp["world"] == 2 and dp["global_batch"] == 128 and dp["allreduce_bytes"] == 4 * 7254122 and dp["allreduce_buckets"] == 5
+    assert dp["world"] == 2 and dp["global_batch"] == 128 and dp["allreduce_bytes"] == 4 * 7254122 and dp["allreduce_buckets"] == 4
     assert dp["dp_step_ms"] > 0 and dp["allreduce_ms"] > 0 and dp["segmented_graph_step_ms"] > 0 and "error" not in dp
     assert d["roofline"]["executed_frac"] > 0.5 and len(d["extra_configs"]) == 4 and all("error" not in e for e in d["extra_configs"])
     assert d["extra_configs"][3]["images_per_s"] > 0                       # the global-stage training step

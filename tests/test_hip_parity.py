@@ -641,3 +641,50 @@ def test_winograd_f33_conv_matches_the_direct_convolution(n, cin, cout):
     assert torch.equal(pair, two)
     plain, _ = native.wino_conv3x3(x, uw, ub, cout)                     # no residual, no activation
     assert relmax(plain.cpu(), (y - res.cpu().double().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)) <= 2e-5
+
+
+_TWO_THREADS = r'''
+import os, sys, threading
+import numpy as np, torch
+sys.path[:0] = [os.environ["BE_ROOT"], os.path.join(os.environ["BE_ROOT"], "blurry-edges_amd")]
+from be_hip import synth
+import models
+dev = "cuda:0"
+sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.local_stage_state_dict().items()}
+ms = []
+for _ in range(2):
+    m = models.LocalStage(); m.load_state_dict(sd); m = m.to(dev).eval(); m.streams = 1
+    ms.append(m)
+# two different batch sizes: the small-batch and the large-batch kernel families, both for the first time in this process
+xs = [torch.from_numpy(synth.uniform_patches(n, name=f"thr{n}")).to(dev) for n in (96, 1024)]
+outs = [None, None]
+go = threading.Barrier(2)
+def run(i):
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st), torch.no_grad():
+        go.wait()                                   # both threads make their FIRST library calls together
+        for rep in range(3):
+            outs[i] = ms[i](xs[i]).clone()
+    st.synchronize()
+ts = [threading.Thread(target=run, args=(i,)) for i in range(2)]
+[t.start() for t in ts]; [t.join() for t in ts]
+torch.cuda.synchronize()
+with torch.no_grad():
+    serial = [ms[i](xs[i]) for i in range(2)]
+torch.cuda.synchronize()
+assert all(torch.equal(a, b) for a, b in zip(outs, serial)), "concurrent result differs from the serial one"
+print("TWO_THREADS_OK")
+'''
+
+
+def test_two_host_threads_on_two_streams_first_calls_race_and_results_are_bit_identical():
+    """VERDICT r2 #6: two Python threads, each with its own stream and its own LocalStage instance, make their first calls into
+    the library at the same moment in a FRESH process (the per-device first-call caches - dynamic-LDS attributes, CU count - are
+    now atomics); ctypes releases the GIL inside the calls, so the launches really interleave.  Results = the serial ones, bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a GPU")
+    import subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ, BE_ROOT=ROOT)
+    r = subprocess.run([sys.executable, "-c", _TWO_THREADS], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "TWO_THREADS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -37,6 +37,46 @@ def test_host_side_argument_checks_fail_before_any_launch():
         native.params2etas(torch.zeros(4))
 
 
+def test_eight_host_threads_in_the_validation_and_sizing_entry_points():
+    """the library is called from several host threads (one per stream).  Eight threads hammer the sizing and
+    validation entry points together: sizes are the single-threaded values, every failing call leaves ITS message in the
+    calling thread's be_last_error (thread-local buffer), nothing crashes.  (No launch: this runs without a GPU.)"""
+    import threading
+    from be_hip import native
+    lib = native.lib()
+    want = dict(packed=lib.be_conv_packed_floats(384, 384, 3), wino=lib.be_wino_packed_floats(384, 384),
+                ws=lib.be_wino_workspace_floats(64, 256, 384), attn=lib.be_attention_workspace_floats(8, 4096, 8),
+                scratch=lib.be_train_scratch_bytes())
+    assert all(v > 0 for v in want.values())
+    errors = []
+    start = threading.Barrier(8)
+
+    def worker(k):
+        try:
+            start.wait()
+            for it in range(300):
+                assert lib.be_conv_packed_floats(384, 384, 3) == want["packed"]
+                assert lib.be_wino_packed_floats(384, 384) == want["wino"]
+                assert lib.be_wino_workspace_floats(64, 256, 384) == want["ws"]
+                assert lib.be_attention_workspace_floats(8, 4096, 8) == want["attn"]
+                assert lib.be_train_scratch_bytes() == want["scratch"]
+                if k % 2:
+                    assert lib.be_params2etas_f32(None, None, -1, None) < 0
+                    assert b"n < 0" in lib.be_last_error()
+                else:
+                    d = native.ConvDesc(1, 6, 6, 48, 64, 3, 0)
+                    assert lib.be_conv_nhwc_f32(d, None, None, None, None, None, 64, None) < 0
+                    assert b"null pointer" in lib.be_last_error()
+        except Exception as e:                                   # pragma: no cover - reported below
+            errors.append(f"thread {k}: {type(e).__name__}: {e}")
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(timeout=120)
+    assert not errors, errors
+
+
 def test_local_stage_state_dict_layout_matches_the_reference():
     import models
     m = models.LocalStage()
