@@ -498,7 +498,8 @@ KERNEL_NAMES = {0: "k_conv_igemm<2,2,2,2,TAPS> (128x128)", 1: "k_conv_igemm<4,1,
                 6: "k_wino_gemm_ws / k_wino_gemm (128x128 tiles, the 25 Winograd transform-domain GEMMs of a layer per launch; weight-stationary form for K = 96 / 256 / 384 and full tiles)",
                 7: "k_wino_gemm as a row GEMM (1x1 convolutions / linears of large batches)",
                 8: "k_wino_in / k_wino_out_in / k_wino_out / k_wino_out_pool2 (Winograd transforms)", 9: "k_maxpool_nhwc",
-                10: "k_render_colors (pass A)", 11: "conv1 input staging"}
+                10: "k_render_colors (pass A)", 11: "conv1 input staging",
+                12: "k_bwd_gemms (a training unit's weight-gradient GEMM + data-gradient convolution in one launch)"}
 HBM_KERNEL_IDS = (8, 9, 10, 11)
 
 

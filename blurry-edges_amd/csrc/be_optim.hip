@@ -76,12 +76,12 @@ void k_clip_adamw(AdamArgs a) {
     __syncthreads();
     const be_adam_entry e = a.table[blockIdx.x];
     const float coef = s_coef, bc1 = s_bc1, bc2s = s_bc2s;
-    const float step_size = (float)(a.lr / (double)bc1), decay = (float)(a.lr * a.weight_decay);
+    const float step_size = (float)(a.lr / (double)bc1), keep = (float)(1.0 - a.lr * a.weight_decay);
     const float omb1 = (float)(1.0 - a.beta1), omb2 = (float)(1.0 - a.beta2), b2 = (float)a.beta2, eps = (float)a.eps;
     float* gp = a.g + e.goff;
     auto upd = [&](float& p, float& m, float& v, float& g) {
         g *= coef;
-        p -= decay * p;                                       // AdamW: decoupled weight decay
+        p *= keep;                                            // AdamW: decoupled weight decay, param.mul_(1 - lr * weight_decay)
         m = m + omb1 * (g - m);                               // lerp(m, g, 1 - beta1)
         v = b2 * v + omb2 * g * g;
         const float denom = sqrtf(v) / bc2s + eps;

@@ -5,8 +5,10 @@
 // bitwise reproducible run to run.
 //
 // Activations are NHWC matrices [M = N*H*W rows][C channels]; a BatchNorm channel is a column.
+#include <cstdlib>
 #include "be_common.h"
 #include "be_device_math.h"
+#include "be_igemm_body.h"
 
 namespace {
 
@@ -208,15 +210,16 @@ struct WgradArgs {
     int M, H, W, HW, Cin, Cout, ks, rows_per_split, chw_hw, cin_tiles;
 };
 
-__global__ __launch_bounds__(256)
-void k_wgrad(WgradArgs a) {
+constexpr int WGRAD64_LDS_FLOATS = 2 * 2 * 32 * 68;
+// body as a device function: bx / by / bz = blockIdx of the stand-alone kernel; smem: WGRAD64_LDS_FLOATS floats
+__device__ __forceinline__ void wgrad64_body(const WgradArgs& a, float* smem, const int bx, const int by, const int bz) {
     constexpr int LD = 68;                               // 64 + 4 floats per LDS row
-    __shared__ __attribute__((aligned(16))) float As[2][32][LD];
-    __shared__ __attribute__((aligned(16))) float Bs[2][32][LD];
-    const int co0 = (blockIdx.x / a.cin_tiles) * 64, ci0 = (blockIdx.x % a.cin_tiles) * 64;
-    const int tap = blockIdx.y, half = a.ks >> 1;
+    float (*As)[32][LD] = reinterpret_cast<float (*)[32][LD]>(smem);
+    float (*Bs)[32][LD] = reinterpret_cast<float (*)[32][LD]>(smem + 2 * 32 * LD);
+    const int co0 = (bx / a.cin_tiles) * 64, ci0 = (bx % a.cin_tiles) * 64;
+    const int tap = by, half = a.ks >> 1;
     const int tdy = tap / a.ks - half, tdx = tap % a.ks - half;
-    const int m_begin = blockIdx.z * a.rows_per_split, m_end = min(a.M, m_begin + a.rows_per_split);
+    const int m_begin = bz * a.rows_per_split, m_end = min(a.M, m_begin + a.rows_per_split);
     const int tid = threadIdx.x;
     const int q = tid & 15, r0 = tid >> 4;               // staging: 16 lanes x 16 B = 64 channels of one pixel row
     const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
@@ -278,7 +281,7 @@ void k_wgrad(WgradArgs a) {
     }
     // D[i = co][j = ci]: lane holds column j = lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int taps = a.ks * a.ks;
-    float* out = a.partial + (size_t)blockIdx.z * a.Cout * a.Cin * taps;
+    float* out = a.partial + (size_t)bz * a.Cout * a.Cin * taps;
     const int ci = ci0 + wn * 32 + li;
     if (ci < a.Cin) {
         const int ci_ref = ci;       // (fc.1: the columns already run in the reference's order, see the gather above)
@@ -287,6 +290,142 @@ void k_wgrad(WgradArgs a) {
             const int co = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
             if (co < a.Cout) out[((size_t)co * a.Cin + ci_ref) * taps + tap] = acc[r];
         }
+    }
+}
+
+__global__ __launch_bounds__(256)
+void k_wgrad(WgradArgs a) {
+    __shared__ __attribute__((aligned(16))) float smem[WGRAD64_LDS_FLOATS];
+    wgrad64_body(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// Round 3: the weight-gradient GEMM for channel counts that are multiples of 128 (layers 1-3: 75 % of the weight-gradient
+// FLOPs).  k_wgrad's 64x64 tile gives a wave ONE 32x32 MFMA tile: two 4-byte LDS reads per MFMA and a tile's operands staged for
+// 16 MFMAs per wave (measured 50-62 TFLOP/s).  Here a workgroup owns 128 cout x 128 cin of one tap and one slice of the pixels,
+// a wave 64 x 64 as 2 x 2 MFMA tiles whose rows / columns INTERLEAVE (lane li holds channels 2 li and 2 li + 1 of its 64), so one
+// ds_read_b64 per operand feeds four MFMAs; K chunks of 16 pixels, register-staged double buffer (33 KB of LDS).  Slices go to
+// scratch as [S][tap][cout][cin] - a lane's two accumulators of a column pair are one 8-byte store, 256 contiguous bytes per half
+// wave - and k_bwd_post transposes to the reference's [cout][cin][kh][kw] while it sums the slices.
+struct Wgrad128Args {
+    const float* x; const float* dy; float* partial;
+    int M, H, W, HW, Cin, Cout, ks, rows_per_split, cin_tiles;
+};
+
+constexpr int WGRAD128_LDS_FLOATS = 2 * 2 * 16 * 132;
+__device__ __forceinline__ void wgrad128_body(const Wgrad128Args& a, float* smem, const int bx, const int by, const int bz) {
+    constexpr int BKW = 16, LD = 132;                      // 128 + 4 floats per LDS row
+    float (*As)[BKW][LD] = reinterpret_cast<float (*)[BKW][LD]>(smem);
+    float (*Bs)[BKW][LD] = reinterpret_cast<float (*)[BKW][LD]>(smem + 2 * BKW * LD);
+    const int co0 = (bx / a.cin_tiles) * 128, ci0 = (bx % a.cin_tiles) * 128;
+    const int tap = by, half = a.ks >> 1;
+    const int tdy = tap / a.ks - half, tdx = tap % a.ks - half;
+    const int m_begin = bz * a.rows_per_split, m_end = min(a.M, m_begin + a.rows_per_split);
+    const int tid = threadIdx.x;
+    const int q = tid & 31, r0 = tid >> 5;                 // staging: 32 lanes x 16 B = the 128 channels of one pixel row; 8 rows per pass
+    const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x4 a_st[2], b_st[2];
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    const int64_t tap_off = (int64_t)(tdy * a.W + tdx) * a.Cin;
+
+    auto load = [&](int m0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = m0 + r0 + 8 * i;
+            a_st[i] = zero; b_st[i] = zero;
+            if (m < m_end) {
+                a_st[i] = *reinterpret_cast<const f32x4*>(a.dy + (size_t)m * a.Cout + co0 + 4 * q);
+                const int pp = m % a.HW, yy = pp / a.W + tdy, xx = pp % a.W + tdx;
+                if ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W)
+                    b_st[i] = *reinterpret_cast<const f32x4*>(a.x + (int64_t)m * a.Cin + tap_off + ci0 + 4 * q);
+            }
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<f32x4*>(&As[buf][r0 + 8 * i][4 * q]) = a_st[i];
+            *reinterpret_cast<f32x4*>(&Bs[buf][r0 + 8 * i][4 * q]) = b_st[i];
+        }
+    };
+    const int nchunk = (m_end - m_begin + BKW - 1) / BKW;
+    if (nchunk > 0) { load(m_begin); store(0); }
+    __syncthreads();
+    for (int kc = 0; kc < nchunk; ++kc) {
+        const int buf = kc & 1;
+        if (kc + 1 < nchunk) load(m_begin + BKW * (kc + 1));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s2 = 0; s2 < BKW / 2; ++s2) {
+            const f32x2 av = *reinterpret_cast<const f32x2*>(&As[buf][2 * s2 + lh][wm * 64 + 2 * li]);
+            const f32x2 bv = *reinterpret_cast<const f32x2*>(&Bs[buf][2 * s2 + lh][wn * 64 + 2 * li]);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[0], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[1], acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv[0], acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv[1], acc[1][1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (kc + 1 < nchunk) store(buf ^ 1);
+        __syncthreads();
+    }
+    // D tile (i, j): row (e&3) + 8*(e>>2) + 4*lh = position ii in the wave's interleaved rows -> co = co0 + wm*64 + 2*ii + i;
+    // column li -> ci = ci0 + wn*64 + 2*li + j: the pair j = 0, 1 is one 8-byte store
+    float* out = a.partial + ((size_t)bz * a.ks * a.ks + tap) * a.Cout * a.Cin;
+    const int ci = ci0 + wn * 64 + 2 * li;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int co = co0 + wm * 64 + 2 * ((e & 3) + 8 * (e >> 2) + 4 * lh) + i;
+            f32x2 v = {acc[i][0][e], acc[i][1][e]};
+            *reinterpret_cast<f32x2*>(out + (size_t)co * a.Cin + ci) = v;
+        }
+}
+
+__global__ __launch_bounds__(256, 2)
+void k_wgrad128(Wgrad128Args a) {
+    __shared__ __attribute__((aligned(16))) float smem[WGRAD128_LDS_FLOATS];
+    wgrad128_body(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// A unit's weight-gradient GEMM and its data-gradient convolution in ONE launch (VERDICT r2 #1a).  Both read dy, neither fills the
+// chip at batch 64 (a 3x3 layer: ~400 weight-gradient workgroups of 20-30 us, ~860 data-gradient workgroups of ~10 us), and a
+// hipGraph replays kernels one after the other: as one grid the two sets of workgroups share the CUs.  Workgroups [0, n_w) take
+// the weight gradient (the long ones first; n_w is a multiple of 8 so that the convolution's XCD-aware tile map - workgroup id mod
+// 8 = XCD - is unchanged), the rest are the convolution's (gx x S).  CV: the convolution's tile variant (be::ConvPrep).
+struct BwdGemmsArgs {
+    be_igemm::ConvArgs ca;
+    Wgrad128Args w128;
+    WgradArgs w64;
+    int wkind;                // 1: k_wgrad128 tiles, 0: k_wgrad tiles
+    int n_w, w_real, wx, wy;  // weight-gradient workgroups: padded count, real count, grid x / y of the stand-alone launch
+    int cgx;                  // convolution: workgroups per K slice
+};
+constexpr int BWD_GEMMS_LDS_FLOATS = WGRAD64_LDS_FLOATS > WGRAD128_LDS_FLOATS ? WGRAD64_LDS_FLOATS : WGRAD128_LDS_FLOATS;   // > the conv's 6400
+
+template <int CV>
+__global__ __launch_bounds__(256, 3)
+void k_bwd_gemms(BwdGemmsArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x;
+    if (b < g.n_w) {
+        if (b >= g.w_real) return;
+        const int bx = b % g.wx, by = (b / g.wx) % g.wy, bz = b / (g.wx * g.wy);
+        if (g.wkind == 1) wgrad128_body(g.w128, smem, bx, by, bz);
+        else wgrad64_body(g.w64, smem, bx, by, bz);
+    } else {
+        const int c = b - g.n_w;
+        if (CV == 0) be_igemm::conv_igemm_body<2, 2, 1, 1, be_igemm::MODE_TAPS, 16, 0>(g.ca, smem, c % g.cgx, c / g.cgx, 0);
+        else be_igemm::conv_igemm_body<4, 1, 1, 1, be_igemm::MODE_TAPS, 16, 0>(g.ca, smem, c % g.cgx, c / g.cgx, 0);
     }
 }
 
@@ -596,6 +735,7 @@ void k_bn_bwd_apply(BwdApplyArgs a) {
 // branch's dx of a residual block) into dx.  Fixed order everywhere.
 struct PostArgs {
     const float* wpart; float* dw; int64_t wsize; int wS; int conv1_map, cout1;   // conv1_map: slices are [cout][7][8 px][4 ch]
+    int wtaps;                // > 0: slices are [S][tap][cout][cin] (k_wgrad128), transposed here
     const double* dbpart; float* db; int nb_rows, C;
     const float* xpart; const float* xadd; float* dx; int64_t xM; int xC, xldp, xS;
     int nb_w, nb_b;
@@ -619,6 +759,32 @@ void k_bwd_post(PostArgs a) {
                     for (int k = 0; k < 8; ++k) if (k0 + k < a.wS) s += p[k];
                 }
                 a.dw[i] = s;
+            }
+            return;
+        }
+        if (a.wtaps) {                                      // k_wgrad128's slices [S][tap][cout*cin] -> dW[cout][cin][tap]
+            // a workgroup sums 256 consecutive (cout, cin) positions for every tap (coalesced reads of each slice plane), parks
+            // the 256 x taps results in LDS and writes them out as ONE contiguous run (the transposed stores straight from
+            // registers were 4-byte pieces 36 bytes apart: 20-30 us per call)
+            __shared__ float tbuf[256 * 9];
+            const int64_t plane = a.wsize / a.wtaps;        // cout * cin
+            for (int64_t i0 = (int64_t)b * 256; i0 < plane; i0 += (int64_t)a.nb_w * 256) {
+                const int64_t i = i0 + threadIdx.x;
+                if (i < plane)
+                    for (int t = 0; t < a.wtaps; ++t) {
+                        float p[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k) p[k] = k < a.wS ? a.wpart[((int64_t)k * a.wtaps + t) * plane + i] : 0.f;
+                        float s = p[0];
+#pragma unroll
+                        for (int k = 1; k < 8; ++k) if (k < a.wS) s += p[k];
+                        for (int k = 8; k < a.wS; ++k) s += a.wpart[((int64_t)k * a.wtaps + t) * plane + i];
+                        tbuf[threadIdx.x * a.wtaps + t] = s;
+                    }
+                __syncthreads();
+                const int64_t n_here = (plane - i0 < 256 ? plane - i0 : 256) * a.wtaps;
+                for (int64_t j = threadIdx.x; j < n_here; j += 256) a.dw[i0 * a.wtaps + j] = tbuf[j];
+                __syncthreads();
             }
             return;
         }
@@ -1024,11 +1190,14 @@ extern "C" int be_train_unit_bwd_f32(const be_conv_desc* d, const float* x, cons
     const RowBlocks ab = apply_blocks(M, C, 128);
     BwdApplyArgs ba{ds, y, mean, invstd, gamma, part, dy, dgamma, dbeta, dbpart, sb.n, M, C, ab.rows, 1.0f / (float)M};
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3(C / UC, ab.n), dim3(256), 0, s, ba);
-    // 3. weight-gradient GEMM (slices stay in scratch)
+    // 3. + 4. the weight-gradient GEMM and the data-gradient convolution (through the transposed / mirrored pack): slices of both
+    //    stay in scratch.  With an input gradient wanted the two run as ONE launch (k_bwd_gemms), else the weight gradient alone.
     PostArgs pa{};
     float* wpart = reinterpret_cast<float*>(sc + SCR_WGRAD);
+    pa.dbpart = dbpart; pa.db = db; pa.nb_rows = ab.n; pa.C = C; pa.nb_b = C / 32;
+    pa.xS = 0;
     if (d->ksize == 7) {
-        BE_REQUIRE(d->cin == 4 && C == 64, "be_train_unit_bwd_f32: ksize 7 is conv1 (NHWC4 staging, 64 outputs)");
+        BE_REQUIRE(d->cin == 4 && C == 64 && !dx, "be_train_unit_bwd_f32: ksize 7 is conv1 (NHWC4 staging, 64 outputs, no input gradient)");
         int rows = (M + 63) / 64; rows = (rows + 31) / 32 * 32;
         const int S = (M + rows - 1) / rows;
         BE_REQUIRE((size_t)S * C * 224 * sizeof(float) <= SCR_TOTAL - SCR_WGRAD, "be_train_unit_bwd_f32: scratch too small");
@@ -1037,24 +1206,88 @@ extern "C" int be_train_unit_bwd_f32(const be_conv_desc* d, const float* x, cons
         pa.wpart = wpart; pa.dw = dw; pa.wsize = (int64_t)C * 147; pa.wS = S; pa.conv1_map = 1; pa.cout1 = C;
         pa.nb_w = (C * 147 + 255) / 256;
     } else {
-        int S = 1; int64_t wsize = 0;
-        const int rc = wgrad_slices(x, dy, wpart, SCR_TOTAL - SCR_WGRAD, d->n, d->h, d->w, d->cin, C, d->ksize, layout_chw_hw, s, &S, &wsize);
-        if (rc) return rc;
-        pa.wpart = wpart; pa.dw = dw; pa.wsize = wsize; pa.wS = S; pa.conv1_map = 0; pa.cout1 = C;
-        pa.nb_w = (int)cap_grid(wsize / 4, 256, 1024);
-    }
-    pa.dbpart = dbpart; pa.db = db; pa.nb_rows = ab.n; pa.C = C; pa.nb_b = C / 32;
-    // 4. data-gradient convolution through the transposed / mirrored pack (slices stay in scratch when the K loop was split)
-    pa.xS = 0;
-    if (dx) {
-        be_conv_desc dd{d->n, d->h, d->w, C, d->cin, d->ksize, 0};
-        int S = 1, ldp = 0;
-        const int rc = be::conv_train(&dd, dy, dgrad_pw, dgrad_pb, dx_add, dx, d->cin, sc + SCR_CONV, SCR_WGRAD - SCR_CONV, &S, &ldp, stream);
-        if (rc) return rc;
-        if (S > 1) {
+        BE_REQUIRE((d->ksize == 1 || d->ksize == 3) && d->cin % 4 == 0 && C % 4 == 0, "be_train_unit_bwd_f32: ksize 1|3, channels %% 4 == 0");
+        BE_REQUIRE(layout_chw_hw == 0 || (d->ksize == 1 && d->cin % layout_chw_hw == 0), "be_train_unit_bwd_f32: bad layout_chw_hw");
+        BE_REQUIRE(be::aligned16(x), "be_train_unit_bwd_f32: x must be 16-byte aligned");
+        const int taps = d->ksize * d->ksize;
+        const int64_t wsize = (int64_t)C * d->cin * taps;
+        BwdGemmsArgs g{};
+        static const bool no128 = getenv("BE_NO_WGRAD128") != nullptr;            // A/B knobs
+        static const bool no_merge = getenv("BE_NO_BWD_MERGE") != nullptr;
+        dim3 wgrid;
+        if (!no128 && layout_chw_hw == 0 && C % 128 == 0 && d->cin % 128 == 0 && M >= 256) {
+            const int tiles = (C / 128) * (d->cin / 128) * taps;
+            // slices: every one is another copy of dW to write and to sum (a 3x3 layer: 2.4-5.3 MB each), so few of them -
+            // ~400 workgroups, at most 8 slices for the 3x3 layers, 24 for the (small) 1x1 ones
+            int S = (400 + tiles - 1) / tiles;
+            const int s_cap = taps == 9 ? 8 : 24;
+            if (S > s_cap) S = s_cap;
+            if (S < 1) S = 1;
+            if (S > M / 64) S = M / 64;
+            while (S > 1 && (size_t)S * wsize * sizeof(float) > SCR_TOTAL - SCR_WGRAD) --S;
+            int rows = (M + S - 1) / S; rows = (rows + 15) / 16 * 16;
+            S = (M + rows - 1) / rows;
+            g.wkind = 1;
+            g.w128 = Wgrad128Args{x, dy, wpart, M, d->h, d->w, d->h * d->w, d->cin, C, d->ksize, rows, d->cin / 128};
+            wgrid = dim3((C / 128) * (d->cin / 128), taps, S);
+            pa.wpart = wpart; pa.dw = dw; pa.wsize = wsize; pa.wS = S; pa.conv1_map = 0; pa.cout1 = C; pa.wtaps = taps;
+            pa.nb_w = (int)cap_grid(wsize / taps, 256, 1024);
+        } else {
+            const int ct = (C + 63) / 64, it = (d->cin + 63) / 64;
+            int S = pick_splits(M, ct * it * taps, 64, 512);       // every split is another full copy of dW to sum
+            while (S > 1 && (size_t)S * wsize * sizeof(float) > SCR_TOTAL - SCR_WGRAD) --S;
+            BE_REQUIRE((size_t)S * wsize * sizeof(float) <= SCR_TOTAL - SCR_WGRAD, "be_train_unit_bwd_f32: scratch too small");
+            int rows = (M + S - 1) / S; rows = (rows + 31) / 32 * 32;
+            S = (M + rows - 1) / rows;
+            g.wkind = 0;
+            g.w64 = WgradArgs{x, dy, wpart, M, d->h, d->w, d->h * d->w, d->cin, C, d->ksize, rows, layout_chw_hw, it};
+            wgrid = dim3(ct * it, taps, S);
+            pa.wpart = wpart; pa.dw = dw; pa.wsize = wsize; pa.wS = S; pa.conv1_map = 0; pa.cout1 = C;
+            pa.nb_w = (int)cap_grid(wsize / 4, 256, 1024);
+        }
+        be::ConvPrep prep;
+        prep.variant = -1;
+        if (dx) {
+            be_conv_desc dd{d->n, d->h, d->w, C, d->cin, d->ksize, 0};
             BE_REQUIRE(d->cin % 4 == 0, "be_train_unit_bwd_f32: cin %% 4 == 0");
-            pa.xpart = reinterpret_cast<const float*>(sc + SCR_CONV); pa.xadd = dx_add; pa.dx = dx; pa.xM = M; pa.xC = d->cin;
-            pa.xldp = ldp; pa.xS = S;
+            if (!no_merge) {
+                const int rc = be::conv_train_prepare(&dd, dy, dgrad_pw, dgrad_pb, dx_add, dx, d->cin, sc + SCR_CONV, SCR_WGRAD - SCR_CONV, &prep);
+                if (rc) return rc;
+            }
+        }
+        if (prep.variant >= 0) {
+            g.ca = prep.args;
+            g.w_real = (int)(wgrid.x * wgrid.y * wgrid.z); g.n_w = (g.w_real + 7) / 8 * 8; g.wx = (int)wgrid.x; g.wy = (int)wgrid.y;
+            g.cgx = (int)prep.gx;
+            const unsigned grid = (unsigned)g.n_w + prep.gx * (unsigned)prep.S;
+            constexpr size_t lds = (size_t)BWD_GEMMS_LDS_FLOATS * sizeof(float);
+            be::ProfileScope prof(s, BE_KERNEL_TRAIN_BWD_GEMMS, prep.flops + 2.0 * M * (double)wsize, 0.0, 0.0);
+            if (prep.variant == 0) {
+                static be::DeviceFlags f0{};
+                if (int rc_ = be::ensure_dynamic_lds(reinterpret_cast<const void*>(&k_bwd_gemms<0>), lds, f0)) return rc_;
+                hipLaunchKernelGGL(k_bwd_gemms<0>, dim3(grid), dim3(256), lds, s, g);
+            } else {
+                static be::DeviceFlags f1{};
+                if (int rc_ = be::ensure_dynamic_lds(reinterpret_cast<const void*>(&k_bwd_gemms<1>), lds, f1)) return rc_;
+                hipLaunchKernelGGL(k_bwd_gemms<1>, dim3(grid), dim3(256), lds, s, g);
+            }
+            if (prep.S > 1) {
+                pa.xpart = reinterpret_cast<const float*>(sc + SCR_CONV); pa.xadd = dx_add; pa.dx = dx; pa.xM = M; pa.xC = d->cin;
+                pa.xldp = prep.ldp; pa.xS = prep.S;
+            }
+        } else {
+            if (g.wkind == 1) hipLaunchKernelGGL(k_wgrad128, wgrid, dim3(256), 0, s, g.w128);
+            else hipLaunchKernelGGL(k_wgrad, wgrid, dim3(256), 0, s, g.w64);
+            if (dx) {
+                be_conv_desc dd{d->n, d->h, d->w, C, d->cin, d->ksize, 0};
+                int S = 1, ldp = 0;
+                const int rc = be::conv_train(&dd, dy, dgrad_pw, dgrad_pb, dx_add, dx, d->cin, sc + SCR_CONV, SCR_WGRAD - SCR_CONV, &S, &ldp, stream);
+                if (rc) return rc;
+                if (S > 1) {
+                    pa.xpart = reinterpret_cast<const float*>(sc + SCR_CONV); pa.xadd = dx_add; pa.dx = dx; pa.xM = M; pa.xC = d->cin;
+                    pa.xldp = ldp; pa.xS = S;
+                }
+            }
         }
     }
     const int nb_x = pa.xS ? (int)cap_grid((int64_t)M * (d->cin / 4), 256, 2048) : 0;

@@ -655,19 +655,24 @@ def test_global_loss_with_an_empty_depth_mask_is_nan_like_the_reference_unless_a
 def test_clip_adamw_matches_clip_grad_norm_and_torch_adamw():
     """be_hip.optim.ClipAdamW (three launches over the flat gradient buffer) against the tail of local_training.py:107-108 done
     with the stock pieces - torch.nn.utils.clip_grad_norm_(max_norm=1) + torch.optim.AdamW.step() - over six steps whose gradient
-    norms lie on both sides of the clipping threshold.  Norm to 1e-6, clipped gradients to 1e-6, parameters to a few spacings."""
+    norms lie on both sides of the clipping threshold.  Teacher-forced: before every step the HIP optimizer takes the stock one's
+    parameters and moments, so nothing compounds.  Norm to 1e-6, clipped gradients to 1e-6, parameters to a yardstick of one
+    spacing of the result + the fp32 rounding of the step + the rounding of the moment where 0.9 m0 + 0.1 g cancels (the two
+    sides clip g with coefficients that differ in the last bit; measured worst 1.6 in units of that yardstick)."""
     if not torch.cuda.is_available():
         pytest.fail("gpu-marked test run without a GPU")
     import models
     from be_hip.optim import ClipAdamW
     torch.manual_seed(3)
+    lr, b1, b2, eps = 1e-3, 0.9, 0.999, 1e-8
     ma, mb = models.LocalStage().to(DEV), models.LocalStage().to(DEV)
     mb.load_state_dict(ma.state_dict())
     pa, pb = list(ma.parameters()), list(mb.parameters())
-    oa = ClipAdamW(pa, lr=1e-3)
-    ob = torch.optim.AdamW(pb, lr=1e-3)
+    oa = ClipAdamW(pa, lr=lr)
+    ob = torch.optim.AdamW(pb, lr=lr)
     n = sum(p.numel() for p in pa)
     for it, scale in enumerate((3e-3, 1e-5, 5e-4, 2e-2, 3.7e-4, 1e-6)):          # total norms ~ 8, 0.03, 1.3, 54, 1.0, 0.003
+        t = it + 1
         flat = torch.randn(n, device=DEV) * scale
         off = 0
         for a, b in zip(pa, pb):
@@ -675,23 +680,31 @@ def test_clip_adamw_matches_clip_grad_norm_and_torch_adamw():
             b.grad = flat[off:off + a.numel()].view_as(a).clone()
             off += a.numel()
         before = [b.detach().clone() for b in pb]
+        m0 = [ob.state[b]["exp_avg"].clone() if it else torch.zeros_like(b) for b in pb]
+        v0 = [ob.state[b]["exp_avg_sq"].clone() if it else torch.zeros_like(b) for b in pb]
+        with torch.no_grad():                                                      # teacher forcing
+            for a, b, m_, v_ in zip(pa, pb, m0, v0):
+                a.copy_(b); oa.state[a]["exp_avg"].copy_(m_); oa.state[a]["exp_avg_sq"].copy_(v_)
+            oa._step.fill_(float(it))
         norm_b = torch.nn.utils.clip_grad_norm_(pb, max_norm=1.0, norm_type=2)
         ob.step()
         norm_a = oa.clip_and_step(1.0)
         assert abs(float(norm_a) - float(norm_b)) <= 1e-6 * float(norm_b), (it, float(norm_a), float(norm_b))
         worst = 0.0
-        for a, b, b0 in zip(pa, pb, before):
+        for a, b, b0, m_, v_ in zip(pa, pb, before, m0, v0):
             assert float((a.grad - b.grad).norm() / b.grad.norm().clamp_min(1e-30)) <= 1e-6        # the clipped gradient, written back
+            g = b.grad.double()
+            v1 = b2 * v_.double() + (1 - b2) * g * g
+            denom = (v1 / (1 - b2 ** t)).sqrt() + eps
+            cancel = lr * (b1 * m_.double().abs() + (1 - b1) * g.abs()) / (1 - b1 ** t) / denom
             d = (a.detach().double() - b.detach().double()).abs()
-            # yardstick: one spacing of the updated fp32 parameter + the fp32 rounding of the step itself (a parameter that
-            # starts at 0 - a BatchNorm beta - IS its first step: m / (sqrt(v) + eps) rounded in two different operation orders)
             tol = torch.from_numpy(np.spacing(np.abs(b.detach().cpu().numpy()).astype(np.float32))).double().to(DEV) \
-                + 5e-7 * (b.detach().double() - b0.double()).abs() + 1e-12
+                + 5e-7 * (b.detach().double() - b0.double()).abs() + 3e-7 * cancel + 1e-12
             worst = max(worst, float((d / tol).max()))
-        assert worst <= 2.0, (it, worst)
+        assert worst <= 3.0, (it, worst)
     assert float(oa.state[pa[0]]["step"]) == 6.0
     sd = oa.state_dict()                                                            # the usual optimizer surface still works
-    assert len(sd["state"]) == len(pa) and sd["param_groups"][0]["lr"] == 1e-3
+    assert len(sd["state"]) == len(pa) and sd["param_groups"][0]["lr"] == lr
     # gradients that are not one flat buffer are refused, not silently handled
     pa[3].grad = pa[3].grad.clone()
     with pytest.raises(RuntimeError):
