@@ -143,6 +143,7 @@ _SIGNATURES = {
     "be_local_loss_finish_f32": (C.c_int, [_P, C.c_int, C.c_float, C.c_float, _P, _P]),
     "be_train_unit_fwd_f32": (C.c_int, [_P] * 7 + [C.c_float, C.c_float] + [_P] * 7 + [C.c_int, _P, C.c_size_t, _P]),
     "be_train_unit_bwd_f32": (C.c_int, [_P] * 11 + [C.c_int] + [_P] * 8 + [C.c_size_t, _P]),
+    "be_linear_param_grads_f32": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
     "be_linear_small_fwd_f32": (C.c_int, [_P] * 4 + [C.c_int] * 3 + [_P]),
     "be_maxpool_nhwc_fwd_idx_f32": (C.c_int, [_P, _P, _P] + [C.c_int] * 7 + [_P]),
     "be_maxpool_nhwc_bwd_idx_f32": (C.c_int, [_P, _P, _P] + [C.c_int] * 7 + [_P]),

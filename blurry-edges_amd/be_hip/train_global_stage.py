@@ -57,6 +57,22 @@ def _wgrad_lin(x, dy, w_shape):
     return _wgrad(x.view(t, 1, 1, x.shape[1]), dy.view(t, 1, 1, dy.shape[1]), tuple(w_shape), 1)
 
 
+def _lin_param_grads(x, dy, w_shape):
+    """(dW, db) of y = x W^T + b.  Channel counts that are multiples of 128 (every linear of an encoder layer): two launches
+    (be_linear_param_grads_f32); otherwise the weight-gradient GEMM and the column sum on their own."""
+    cout, cin = w_shape
+    t = x.shape[0]
+    if cout % 128 == 0 and cin % 128 == 0 and t >= 256:
+        from .train import _Scratch
+        dev = x.device
+        dw, db = _new((cout, cin), dev), _new(cout, dev)
+        sc = _Scratch.get(dev)
+        check(lib().be_linear_param_grads_f32(dptr(x, "x"), dptr(dy.contiguous(), "dy"), dptr(dw), dptr(db), t, cin, cout, dptr(sc),
+                                              sc.numel() * 4, stream_ptr(dev)), "be_linear_param_grads_f32")
+        return dw, db
+    return _wgrad_lin(x, dy, w_shape), _col_sum(dy)
+
+
 class _Packs:
     """Packed weights of every linear of one training step - forward form and data-gradient form - written by ONE launch
     (be_conv_pack_jobs_f32) at the top of the forward (71 single pack launches per step before); buffers and the device job table
@@ -280,20 +296,16 @@ def backward_train(dout, seed, p, H, eps, t, S):
         h_in, qkv, a, lse, v1, h1, f, v2, ws = S["layers"][i]
         dv2, dy2, grads[base + 10], grads[base + 11] = layernorm_bwd(dh, v2, g2, eps, p, seed, 16 * i + 3)
         fd = dropout(f, p, seed, 16 * i + 2) if p > 0 else f
-        grads[base + 6] = _wgrad_lin(fd, dy2, w2.shape)
-        grads[base + 7] = _col_sum(dy2)
+        grads[base + 6], grads[base + 7] = _lin_param_grads(fd, dy2, w2.shape)
         dfd = packs.dgrad(base + 6, dy2)
         df = dropout(dfd, p, seed, 16 * i + 2, gate=f)                    # dropout' and relu' in one pass
-        grads[base + 4] = _wgrad_lin(h1, df, w1.shape)
-        grads[base + 5] = _col_sum(df)
+        grads[base + 4], grads[base + 5] = _lin_param_grads(h1, df, w1.shape)
         dh1 = packs.dgrad(base + 4, df, residual=dv2)
         dv1, dsa, grads[base + 8], grads[base + 9] = layernorm_bwd(dh1, v1, g1, eps, p, seed, 16 * i + 1)
-        grads[base + 2] = _wgrad_lin(a, dsa, wo.shape)
-        grads[base + 3] = _col_sum(dsa)
+        grads[base + 2], grads[base + 3] = _lin_param_grads(a, dsa, wo.shape)
         da = packs.dgrad(base + 2, dsa)
         dqkv, _ = attention_bwd(qkv, a, lse, da, B, L, H, p, seed + 16 * i, ws, operands_ready=True, l_valid=S["l_valid"])
-        grads[base] = _wgrad_lin(h_in, dqkv, wqkv.shape)
-        grads[base + 1] = _col_sum(dqkv)
+        grads[base], grads[base + 1] = _lin_param_grads(h_in, dqkv, wqkv.shape)
         dh = packs.dgrad(base, dqkv, residual=dv1)
     x0 = S["x0"]
     grads[0] = _wgrad_lin(x0, dh, (t[0].shape[0], x0.shape[1]))[:, :cin].contiguous()

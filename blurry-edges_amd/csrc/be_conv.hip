@@ -770,6 +770,12 @@ static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2,
     // Small-M regime (training at batch 64: M = 2304 rows at 6x6): the 128-row tiles give a few dozen workgroups on
     // 256 CUs and one launch lasts as long as ONE workgroup's serial K loop.  Below ~1.5 workgroups per CU switch to
     // 64x64 (or 128x32) tiles: 4x the workgroups, each with a quarter of the work.
+    static const bool no_rows = getenv("BE_NO_GEMM_ROWS") != nullptr;             // A/B knob
+    // linears over many rows with a 128-wide output (GlobalStage at 8 x 4096 tokens: out-projection, second feed-forward linear
+    // and three of the four data gradients): 256 row tiles x ONE column tile is "few tiles" for the rule below, which sent them to
+    // 64x64 tiles (33 us per launch); they are plain row GEMMs for the LDS-DMA kernel (bit-identical, see further down)
+    if (d->ksize == 1 && !x2 && cp == 128 && M >= 16384 && a.nbatch <= 1 && !a.wb3 && !no_rows && d->cin % 16 == 0)
+        return be::gemm_rows(x, M, d->cin, pw, d->cout, pb, res, d->act, y, ldy, stream);
     if (!row8 && (int64_t)a.m_tiles * ((cp + 127) / 128) < 384) {
         const bool t64 = cp % 64 == 0;
         // training units (defer), 3x3 onto 384 channels: 64 x 128 tiles - a wave then owns 32 x 64 (two MFMA tiles per A fragment:
@@ -824,7 +830,6 @@ static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2,
                      : launch_conv<4, 1, 1, 1, MODE_TAPS, 16, 0>(a, s, BE_KERNEL_CONV_SMALL);
     }
     // 1x1 convolutions / linears of large batches are plain row GEMMs: the LDS-DMA kernel of be_wino.hip (bit-identical)
-    static const bool no_rows = getenv("BE_NO_GEMM_ROWS") != nullptr;             // A/B knob
     if (d->ksize == 1 && !x2 && cp % 128 == 0 && M >= 4096 && a.nbatch <= 1 && !a.wb3 && !no_rows && d->cin % 16 == 0)
         return be::gemm_rows(x, M, d->cin, pw, d->cout, pb, res, d->act, y, ldy, stream);
     // large batches of small images, 3x3: the pixel-major LDS-DMA kernel (be_conv_pm.hip; bit-identical)

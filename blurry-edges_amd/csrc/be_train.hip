@@ -773,13 +773,14 @@ void k_bwd_post(PostArgs a) {
                 const int64_t i = i0 + threadIdx.x;
                 if (i < plane)
                     for (int t = 0; t < a.wtaps; ++t) {
-                        float p[8];
+                        float s = 0.f;
+                        for (int k0 = 0; k0 < a.wS; k0 += 8) {          // eight slices in flight, added in slice order
+                            float p[8];
 #pragma unroll
-                        for (int k = 0; k < 8; ++k) p[k] = k < a.wS ? a.wpart[((int64_t)k * a.wtaps + t) * plane + i] : 0.f;
-                        float s = p[0];
+                            for (int k = 0; k < 8; ++k) p[k] = k0 + k < a.wS ? a.wpart[((int64_t)(k0 + k) * a.wtaps + t) * plane + i] : 0.f;
 #pragma unroll
-                        for (int k = 1; k < 8; ++k) if (k < a.wS) s += p[k];
-                        for (int k = 8; k < a.wS; ++k) s += a.wpart[((int64_t)k * a.wtaps + t) * plane + i];
+                            for (int k = 0; k < 8; ++k) if (k0 + k < a.wS) s += p[k];
+                        }
                         tbuf[threadIdx.x * a.wtaps + t] = s;
                     }
                 __syncthreads();
@@ -1299,6 +1300,69 @@ extern "C" int be_train_unit_bwd_f32(const be_conv_desc* d, const float* x, cons
     // 5. slices -> dW, partials -> db, slices (+ the other branch) -> dx: one launch
     hipLaunchKernelGGL(k_bwd_post, dim3(pa.nb_w + pa.nb_b + nb_x), dim3(256), 0, s, pa);
     return be::check_launch("be_train_unit_bwd_f32");
+}
+
+// Parameter gradients of a Linear over many rows (GlobalStage at 8 x 4096 tokens: y = x W^T + b): dW = dy^T x and db = column
+// sums of dy in TWO launches (round 2: k_wgrad, k_sum_splits, k_col_sum, k_col_sum_final).  One grid holds the weight-gradient
+// workgroups (k_wgrad128 tiles over S row slices) and the workgroups that form the column sums of dy per row block; k_bwd_post
+// then sums the slices into dW and the partials into db.
+namespace {
+struct LinGradArgs { Wgrad128Args w; int n_w, wx; const float* dy; double* dbpart; int M, C, rows_per_block, cbx; };
+
+__global__ __launch_bounds__(256, 2)
+void k_lin_grads(LinGradArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int b = blockIdx.x;
+    if (b < g.n_w) { wgrad128_body(g.w, smem, b % g.wx, 0, b / g.wx); return; }
+    const int c = b - g.n_w, bx = c % g.cbx, by = c / g.cbx;
+    const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
+    const int c_base = bx * UC, col = c_base + tx * 4;
+    const int r0 = by * g.rows_per_block, r1 = min(g.M, r0 + g.rows_per_block);
+    double v[1][4] = {{0, 0, 0, 0}};
+    if (col < g.C)
+        for (int r = r0 + ty; r < r1; r += UR) {
+            const f32x4 t = *reinterpret_cast<const f32x4*>(g.dy + (size_t)r * g.C + col);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[0][e] += t[e];
+        }
+    block_col_sums<1>(v, reinterpret_cast<double*>(smem), g.dbpart + (size_t)by * g.C, 1, g.C, c_base);
+}
+}  // namespace
+
+extern "C" int be_linear_param_grads_f32(const float* x, const float* dy, float* dw, float* db, int M, int cin, int cout,
+                                         void* scratch, size_t scratch_bytes, void* stream) {
+    BE_REQUIRE(x && dy && dw && db && scratch && M > 0, "be_linear_param_grads_f32: bad arguments");
+    BE_REQUIRE(cin % 128 == 0 && cout % 128 == 0 && cout <= 1024 && M >= 256, "be_linear_param_grads_f32: cin, cout multiples of 128, M >= 256");
+    BE_REQUIRE(scratch_bytes >= SCR_TOTAL && be::aligned16(scratch) && be::aligned16(x) && be::aligned16(dy) && be::aligned16(dw),
+               "be_linear_param_grads_f32: scratch of be_train_scratch_bytes() bytes, 16-byte aligned operands");
+    char* sc = static_cast<char*>(scratch);
+    hipStream_t s = be::as_stream(stream);
+    float* wpart = reinterpret_cast<float*>(sc + SCR_WGRAD);
+    double* dbpart = reinterpret_cast<double*>(sc + SCR_DBPART);
+    const int tiles = (cout / 128) * (cin / 128);
+    const int64_t wsize = (int64_t)cout * cin;
+    int S = (512 + tiles - 1) / tiles;
+    if (S > M / 256) S = M / 256;
+    if (S > 128) S = 128;
+    if (S < 1) S = 1;
+    while (S > 1 && (size_t)S * wsize * sizeof(float) > SCR_TOTAL - SCR_WGRAD) --S;
+    int rows = (M + S - 1) / S; rows = (rows + 15) / 16 * 16;
+    S = (M + rows - 1) / rows;
+    LinGradArgs g{};
+    g.w = Wgrad128Args{x, dy, wpart, M, 1, 1, 1, cin, cout, 1, rows, cin / 128};
+    g.wx = tiles; g.n_w = tiles * S;
+    const RowBlocks rb = row_blocks(M, 32);
+    g.dy = dy; g.dbpart = dbpart; g.M = M; g.C = cout; g.rows_per_block = rb.rows; g.cbx = cout / UC;
+    constexpr size_t lds = (size_t)WGRAD128_LDS_FLOATS * sizeof(float);
+    static be::DeviceFlags f{};
+    if (int rc_ = be::ensure_dynamic_lds(reinterpret_cast<const void*>(&k_lin_grads), lds, f)) return rc_;
+    hipLaunchKernelGGL(k_lin_grads, dim3(g.n_w + g.cbx * rb.n), dim3(256), lds, s, g);
+    PostArgs pa{};
+    pa.wpart = wpart; pa.dw = dw; pa.wsize = wsize; pa.wS = S; pa.wtaps = 1; pa.cout1 = cout;
+    pa.nb_w = (int)cap_grid(wsize, 256, 1024);
+    pa.dbpart = dbpart; pa.db = db; pa.nb_rows = rb.n; pa.C = cout; pa.nb_b = cout / 32;
+    hipLaunchKernelGGL(k_bwd_post, dim3(pa.nb_w + pa.nb_b), dim3(256), 0, s, pa);
+    return be::check_launch("be_linear_param_grads_f32");
 }
 
 extern "C" int be_linear_small_fwd_f32(const float* x, const float* w, const float* b, float* y, int M, int K, int J, void* stream) {

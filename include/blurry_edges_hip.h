@@ -413,6 +413,11 @@ int be_train_unit_bwd_f32(const be_conv_desc* desc_host, const float* x, const f
                           const float* dgrad_packed_bias, const float* dx_add, int layout_chw_hw, float* ds, float* dy,
                           float* dgamma, float* dbeta, float* dw, float* db, float* dx, void* scratch, size_t scratch_bytes,
                           void* stream);
+/* Parameter gradients of y = x W^T + b over many rows (the linears of GlobalStage in training, global_training.py:207-213 under
+ * autograd): dw [cout,cin] = dy^T x and db [cout] = column sums of dy, in two launches (weight-gradient tiles + column-sum
+ * workgroups in one grid, then one reduction kernel; fixed order).  cin, cout multiples of 128, M >= 256 rows. */
+int be_linear_param_grads_f32(const float* x, const float* dy, float* dw, float* db, int M, int cin, int cout, void* scratch,
+                              size_t scratch_bytes, void* stream);
 /* Last Linear forward (K -> J, J small; models/local_stage.py:50): y [M,J] = x [M,K] w [J,K]^T + b, raw parameter layout. */
 int be_linear_small_fwd_f32(const float* x, const float* w, const float* b, float* y, int M, int K, int J, void* stream);
 /* nn.MaxPool2d forward on NHWC that also records the winning window element (dy*k + dx of the FIRST maximum, one byte per
