@@ -410,7 +410,7 @@ struct BwdGemmsArgs {
     int n_w, w_real, wx, wy;  // weight-gradient workgroups: padded count, real count, grid x / y of the stand-alone launch
     int cgx;                  // convolution: workgroups per K slice
 };
-constexpr int BWD_GEMMS_LDS_FLOATS = WGRAD64_LDS_FLOATS > WGRAD128_LDS_FLOATS ? WGRAD64_LDS_FLOATS : WGRAD128_LDS_FLOATS;   // > the conv's 2 (64 + 128) 20 = 7680
+constexpr int BWD_GEMMS_LDS_FLOATS = WGRAD64_LDS_FLOATS > WGRAD128_LDS_FLOATS ? WGRAD64_LDS_FLOATS : WGRAD128_LDS_FLOATS;   // > the conv's 6400
 
 template <int CV>
 __global__ __launch_bounds__(256, 3)
@@ -425,8 +425,7 @@ void k_bwd_gemms(BwdGemmsArgs g) {
     } else {
         const int c = b - g.n_w;
         if (CV == 0) be_igemm::conv_igemm_body<2, 2, 1, 1, be_igemm::MODE_TAPS, 16, 0>(g.ca, smem, c % g.cgx, c / g.cgx, 0);
-        else if (CV == 1) be_igemm::conv_igemm_body<4, 1, 1, 1, be_igemm::MODE_TAPS, 16, 0>(g.ca, smem, c % g.cgx, c / g.cgx, 0);
-        else be_igemm::conv_igemm_body<2, 2, 1, 2, be_igemm::MODE_TAPS, 16, 0>(g.ca, smem, c % g.cgx, c / g.cgx, 0);
+        else be_igemm::conv_igemm_body<4, 1, 1, 1, be_igemm::MODE_TAPS, 16, 0>(g.ca, smem, c % g.cgx, c / g.cgx, 0);
     }
 }
 
@@ -1268,14 +1267,10 @@ extern "C" int be_train_unit_bwd_f32(const be_conv_desc* d, const float* x, cons
                 static be::DeviceFlags f0{};
                 if (int rc_ = be::ensure_dynamic_lds(reinterpret_cast<const void*>(&k_bwd_gemms<0>), lds, f0)) return rc_;
                 hipLaunchKernelGGL(k_bwd_gemms<0>, dim3(grid), dim3(256), lds, s, g);
-            } else if (prep.variant == 1) {
+            } else {
                 static be::DeviceFlags f1{};
                 if (int rc_ = be::ensure_dynamic_lds(reinterpret_cast<const void*>(&k_bwd_gemms<1>), lds, f1)) return rc_;
                 hipLaunchKernelGGL(k_bwd_gemms<1>, dim3(grid), dim3(256), lds, s, g);
-            } else {
-                static be::DeviceFlags f2{};
-                if (int rc_ = be::ensure_dynamic_lds(reinterpret_cast<const void*>(&k_bwd_gemms<2>), lds, f2)) return rc_;
-                hipLaunchKernelGGL(k_bwd_gemms<2>, dim3(grid), dim3(256), lds, s, g);
             }
             if (prep.S > 1) {
                 pa.xpart = reinterpret_cast<const float*>(sc + SCR_CONV); pa.xadd = dx_add; pa.dx = dx; pa.xM = M; pa.xC = d->cin;
