@@ -184,6 +184,42 @@ def lib():
     return _lib
 
 
+TORCH_OPS_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libbe_torch_ops.so")
+_ops = None
+
+
+def ops():
+    """torch.ops.be - the C entry points of the LocalStage hot path registered as PyTorch operators (csrc/be_torch_ops.cpp, built
+    by build() next to the C-ABI library) - or None when BE_TORCH_OPS=0 asks for the ctypes binding alone.  Both bindings call the
+    same C symbols; a missing extension file is an error (build() makes both), not a reason to fall back silently."""
+    global _ops
+    if _ops is None:
+        if os.environ.get("BE_TORCH_OPS", "1") == "0":
+            _ops = False
+        else:
+            lib()                                      # the C-ABI library first: the extension links against it
+            if not os.path.exists(TORCH_OPS_PATH):
+                raise RuntimeError(f"{TORCH_OPS_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                                   f"(or set BE_TORCH_OPS=0 to use the ctypes binding alone)")
+            torch.ops.load_library(TORCH_OPS_PATH)
+            _ops = torch.ops.be
+    return _ops or None
+
+
+_struct_cache = {}
+
+
+def struct_tensor(obj) -> torch.Tensor:
+    """A host struct of the C ABI (be_render_opts, be_depth_consts) as the CPU uint8 tensor the torch operators take."""
+    raw = bytes(obj)
+    t = _struct_cache.get(raw)
+    if t is None:
+        if len(_struct_cache) > 64:
+            _struct_cache.clear()
+        t = _struct_cache[raw] = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+    return t
+
+
 def check(rc: int, what: str = ""):
     if rc != 0:
         raise RuntimeError(f"{what or 'libblurry_edges_hip'} failed ({rc}): {lib().be_last_error().decode()}")
@@ -239,6 +275,9 @@ def local_depth(consts: DepthConsts, params10: torch.Tensor, out: torch.Tensor |
     if params10.dim() != 2 or params10.shape[1] != 10 or params10.shape[0] % 2:
         raise RuntimeError(f"local_depth: params10 must be [2P,10], got {tuple(params10.shape)}")
     p = params10.shape[0] // 2
+    o = ops()
+    if o is not None:
+        return o.local_depth(struct_tensor(consts), params10.contiguous(), out)
     if out is None:
         out = torch.empty(p, 2, dtype=torch.float32, device=params10.device)
     check(lib().be_local_depth_f32(C.byref(consts), dptr(params10, "params10"), dptr(out), p,
@@ -253,6 +292,9 @@ def render_colors(opts: RenderOpts, params10: torch.Tensor, patches: torch.Tenso
     if tuple(params10.shape) != (n, 10) or tuple(patches.shape) != (n, 3, BE_R, BE_R):
         raise RuntimeError(f"render_colors: bad shapes {tuple(params10.shape)} / {tuple(patches.shape)}")
     dev = params10.device
+    o = ops() if not want else None
+    if o is not None:                                   # colours only: the registered operator
+        return o.render_colors(struct_tensor(opts), params10.contiguous(), patches.contiguous(), colors), {}
     if colors is None:
         colors = torch.empty(n, 3, 3, dtype=torch.float32, device=dev)
     shapes = dict(recon=(n, 3, BE_R, BE_R), boundary=(n, BE_R, BE_R), dists=(n, 2, BE_R, BE_R),
@@ -386,6 +428,9 @@ def local_stage_pack(tensors, eps=1e-5):
     """tensors: the 86 fp32 state-dict tensors on the GPU, in the order documented in the header."""
     if len(tensors) != NTENSORS:
         raise RuntimeError(f"local_stage_pack: expected {NTENSORS} tensors, got {len(tensors)}")
+    o = ops()
+    if o is not None:
+        return o.local_stage_pack(list(tensors), float(eps))
     keep = [t.contiguous() for t in tensors]
     arr = (_P * NTENSORS)(*[dptr(t, f"tensor[{i}]") for i, t in enumerate(keep)])
     dev = keep[0].device
@@ -404,6 +449,9 @@ def local_stage_forward(packed, x, out=None, workspace=None, winograd=True, chun
     if tuple(x.shape[1:]) != (3, BE_R, BE_R):
         raise RuntimeError(f"LocalStage input must be [N,3,21,21], got {tuple(x.shape)}")
     dev = x.device
+    o = ops()
+    if o is not None:
+        return o.local_stage_forward(packed, x, out, workspace, bool(winograd), int(chunk))
     if out is None:
         out = torch.empty(n, 10, dtype=torch.float32, device=dev)
     need = lib().be_local_stage_workspace_bytes(n, int(chunk))

@@ -68,6 +68,14 @@ class ClipAdamW(torch.optim.Optimizer):
         g = self.param_groups[0]
         base = self._flat_grad()
         dev = self._m.device
+        o = native.ops()
+        if o is not None:
+            ps = self.param_groups[0]["params"]
+            flat = torch.empty(0, dtype=torch.float32, device=dev).set_(ps[0].grad.untyped_storage(), ps[0].grad.storage_offset(), (self._n,))
+            o.clip_adamw(self._table, self._nentries, flat, self._partial, float(max_norm), float(grad_scale), float(g["lr"]),
+                         float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self._step, self._norm,
+                         self.write_back)
+            return self._norm[0]
         check(lib().be_clip_adamw_f32(dptr(self._table, "table", (torch.uint8,)), self._nentries, C.c_void_p(base), self._n,
                                       dptr(self._partial, "partial", (torch.float64,)), self._partial.numel(), float(max_norm),
                                       float(grad_scale), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),

@@ -152,6 +152,10 @@ def _pool_bwd(x, dout, k, stride, pad):
 def _pool_fwd_idx(x, k, stride, pad):
     """max-pool that also records the winning window element per output value (one byte): (y, (idx, input shape))"""
     n, h, w, c = x.shape
+    o = native.ops()
+    if o is not None:
+        y, idx = o.maxpool_fwd_idx(x, k, stride, pad)
+        return y, (idx, (n, h, w, c))
     oh, ow = (h + 2 * pad - k) // stride + 1, (w + 2 * pad - k) // stride + 1
     y = torch.empty(n, oh, ow, c, dtype=torch.float32, device=x.device)
     idx = torch.empty(n, oh, ow, c, dtype=torch.uint8, device=x.device)
@@ -162,6 +166,9 @@ def _pool_fwd_idx(x, k, stride, pad):
 
 def _pool_bwd_idx(saved, dout, k, stride, pad):
     idx, (n, h, w, c) = saved
+    o = native.ops()
+    if o is not None:
+        return o.maxpool_bwd_idx(idx, dout.contiguous(), h, w, k, stride, pad)
     dx = torch.empty(n, h, w, c, dtype=torch.float32, device=dout.device)
     check(lib().be_maxpool_nhwc_bwd_idx_f32(dptr(idx, "idx", (torch.uint8,)), dptr(dout), dptr(dx), n, h, w, c, k, stride, pad,
                                             stream_ptr(dout.device)), "be_maxpool_nhwc_bwd_idx_f32")
@@ -174,6 +181,11 @@ def _unit_fwd(xin, packs, wi, cout, ks, gamma, beta, rm, rv, res, act):
     n, h, w, cin = xin.shape
     dev = xin.device
     pw, pb = packs.fwd[wi]
+    o = native.ops()
+    if o is not None:
+        out, y, mean, invstd, s_in = o.train_unit_fwd(xin, pw, pb, gamma, beta, res, rm, rv, cout, ks, bool(act), BN_EPS, BN_MOMENTUM,
+                                                      _Scratch.get(dev))
+        return out, (y, mean, invstd, s_in if act else None)
     y = torch.empty(n, h, w, cout, dtype=torch.float32, device=dev)
     out = torch.empty_like(y)
     s_in = torch.empty_like(y) if act else None
@@ -193,6 +205,12 @@ def _unit_bwd(xin, dout, saved, gamma, dg_pack, dx_add, ks, chw_hw, dgamma, dbet
     n, h, w, cin = xin.shape
     cout = y.shape[-1]
     dev = xin.device
+    o = native.ops()
+    if o is not None:
+        pw_, pb_ = dg_pack if dg_pack is not None else (None, None)
+        ds, dx = o.train_unit_bwd(xin, dout.contiguous(), s_in, y, mean, invstd, gamma, pw_, pb_, dx_add, ks, int(chw_hw), dgamma, dbeta,
+                                  dw, db, _Scratch.get(dev))
+        return ds, (dx if dg_pack is not None else None)
     ds, dy = torch.empty_like(y), torch.empty_like(y)
     dx = torch.empty(n, h, w, cin, dtype=torch.float32, device=dev) if dg_pack is not None else None
     pw, pb = dg_pack if dg_pack is not None else (None, None)

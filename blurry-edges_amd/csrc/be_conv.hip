@@ -312,6 +312,29 @@ int launch_conv_b3(const ConvArgs& a, hipStream_t s) {
     return be::check_launch("be_conv_nhwc_b3_f32");
 }
 
+// K chunks (of bkt floats) all tiles of a launch walk together: pixel-major tiles visit only the taps inside the image
+double executed_chunks(const ConvArgs& a, bool row8, int bkt) {
+    double chunks = 0.0;
+    const int ntap_all = row8 ? 7 : a.ks * a.ks, ncc = row8 ? 1 : a.nchunk / ntap_all;
+    if (a.pixmaj) {
+        const int half = a.ks >> 1;
+        for (int py = 0; py < a.H; ++py)
+            for (int px = 0; px < a.W; ++px) {
+                int nt = 0;
+                for (int t = 0; t < ntap_all; ++t) {
+                    if (row8) nt += (unsigned)(py + t - 3) < (unsigned)a.H;
+                    else nt += (unsigned)(py + t / a.ks - half) < (unsigned)a.H && (unsigned)(px + t % a.ks - half) < (unsigned)a.W;
+                }
+                chunks += (double)nt * ncc;
+            }
+        chunks *= (double)(a.m_tiles / a.HW) * a.n_tiles * (32 / bkt);
+    } else {
+        chunks = (double)a.m_tiles * a.n_tiles * a.nchunk * (32 / bkt);
+    }
+    if (a.x2) chunks += (double)a.m_tiles * a.n_tiles * (a.Cin2 / 32) * (32 / bkt);
+    return chunks;
+}
+
 template <int WM, int WN, int MT, int NT, int MODE, int BKT = 32, int PRIO = 0>
 int launch_conv(const ConvArgs& a, hipStream_t s, int kernel_id) {
     constexpr int BN = WN * NT * 32;
@@ -327,24 +350,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s, int kernel_id) {
         const double cin_real = MODE == MODE_ROW8 ? 3.0 : (double)a.Cin;
         // MFMA work actually issued: every tile runs (its number of K chunks) x (2*BM*BN*BKT) flops, padding included;
         // pixel-major tiles visit only the taps inside the image
-        double chunks = 0.0;
-        const int ntap_all = MODE == MODE_ROW8 ? 7 : a.ks * a.ks, ncc = MODE == MODE_ROW8 ? 1 : a.nchunk / ntap_all;
-        if (a.pixmaj) {
-            const int half = a.ks >> 1;
-            for (int py = 0; py < a.H; ++py)
-                for (int px = 0; px < a.W; ++px) {
-                    int nt = 0;
-                    for (int t = 0; t < ntap_all; ++t) {
-                        if (MODE == MODE_ROW8) nt += (unsigned)(py + t - 3) < (unsigned)a.H;
-                        else nt += (unsigned)(py + t / a.ks - half) < (unsigned)a.H && (unsigned)(px + t % a.ks - half) < (unsigned)a.W;
-                    }
-                    chunks += (double)nt * ncc;
-                }
-            chunks *= (double)(a.m_tiles / a.HW) * a.n_tiles * (32 / BKT);
-        } else {
-            chunks = (double)a.m_tiles * a.n_tiles * a.nchunk * (32 / BKT);
-        }
-        if (a.x2) chunks += (double)a.m_tiles * a.n_tiles * (a.Cin2 / 32) * (32 / BKT);
+        const double chunks = executed_chunks(a, MODE == MODE_ROW8, BKT);
         const double k2_real = a.x2 ? (double)a.Cin2 : 0.0;
         const double nb = a.nbatch > 1 ? a.nbatch : 1;
         be::ProfileScope prof(s, kernel_id, nb * 2.0 * a.M * (k_real + k2_real) * a.Cout,
@@ -809,6 +815,7 @@ static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2,
                 pr->args = a; pr->variant = t64 ? 0 : 1; pr->S = S > 1 ? S : 1; pr->ldp = S > 1 ? cp : 0;
                 pr->gx = (unsigned)(8 * ((a.m_tiles + 7) / 8) * a.n_tiles);
                 pr->flops = 2.0 * a.M * (double)a.Cin * a.ks * a.ks * a.Cout;
+                pr->flops_exec = executed_chunks(a, false, 16) * 2.0 * (t64 ? 64.0 * 64.0 : 128.0 * 32.0) * 16.0;
                 return BE_OK;
             }
             if (S > 1) {

@@ -298,7 +298,7 @@ namespace be {
 // be_conv.hip: a small-M training convolution PREPARED but not launched: the kernel arguments, the tile variant (0: 64x64 tiles =
 // conv_igemm_body<2,2,1,1,MODE_TAPS,16,0>, 1: 128x32 tiles = <4,1,1,1,...>), its grid (gx workgroups x S K-slices) and where the raw
 // slices go ([S][M][ldp] in scratch when S > 1; S == 1: the epilogue writes y = conv + bias (+ res)).
-struct ConvPrep { be_igemm::ConvArgs args; int variant, S, ldp; unsigned gx; double flops; };
+struct ConvPrep { be_igemm::ConvArgs args; int variant, S, ldp; unsigned gx; double flops, flops_exec; };
 int conv_train_prepare(const be_conv_desc* d, const float* x, const float* pw, const float* pb, const float* res, float* y, int ldy,
                        void* scratch, size_t scratch_bytes, ConvPrep* prep);
 }  // namespace be

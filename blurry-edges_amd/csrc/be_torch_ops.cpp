@@ -1,0 +1,187 @@
+// torch.ops.be.*: the C entry points of libblurry_edges_hip registered as PyTorch operators (north_star: "hand-written HIP C++
+// kernels ... exposed as torch extensions").  This file is host-only glue over the C ABI of include/blurry_edges_hip.h - it
+// allocates outputs with torch, takes the current stream from torch and calls the same symbols the ctypes binding
+// (be_hip/native.py) calls; the C ABI stays the language-neutral boundary.  Registered for the LocalStage hot path: the packed
+// inference forward (models/local_stage.py:63-73), pass-A colours and the depth solve (bench.py's step), and the training
+// units, pooling, loss and optimizer tail of the training step (local_training.py:103-108).
+// Host structs of the C ABI (be_render_opts, be_depth_consts, the device-side job tables) travel as byte tensors.
+#include <ATen/ATen.h>
+#include <c10/hip/HIPStream.h>
+#include <torch/library.h>
+
+#include <tuple>
+#include <vector>
+
+#include "../../include/blurry_edges_hip.h"
+
+namespace {
+
+using at::Tensor;
+using c10::optional;
+
+void* stream_of(const Tensor& t) { return reinterpret_cast<void*>(c10::hip::getCurrentHIPStream(t.device().index()).stream()); }
+
+const float* fp(const Tensor& t, const char* what) {
+    TORCH_CHECK(t.is_cuda(), what, ": expected a tensor on the GPU; the HIP path has no CPU fallback");
+    TORCH_CHECK(t.scalar_type() == at::kFloat && t.is_contiguous(), what, ": expected a contiguous float32 tensor");
+    return t.data_ptr<float>();
+}
+float* fpm(const Tensor& t, const char* what) { return const_cast<float*>(fp(t, what)); }
+const float* fpo(const optional<Tensor>& t, const char* what) { return t.has_value() && t->defined() ? fp(*t, what) : nullptr; }
+
+void check(int rc, const char* what) { TORCH_CHECK(rc == 0, what, ": ", be_last_error()); }
+
+template <class T>
+const T* host_struct(const Tensor& bytes, const char* what) {
+    TORCH_CHECK(!bytes.is_cuda() && bytes.scalar_type() == at::kByte && bytes.is_contiguous() && (size_t)bytes.numel() >= sizeof(T), what,
+                ": expected a CPU uint8 tensor holding the C struct");
+    return reinterpret_cast<const T*>(bytes.data_ptr<uint8_t>());
+}
+
+// ---- inference -----------------------------------------------------------------------------------------------------------
+Tensor local_stage_pack(at::TensorList tensors, double eps) {
+    TORCH_CHECK(tensors.size() == 86, "local_stage_pack: 86 tensors expected (native.local_stage_pack order)");
+    std::vector<const float*> ptrs;
+    std::vector<Tensor> keep;
+    for (const Tensor& t : tensors) { keep.push_back(t.contiguous()); ptrs.push_back(fp(keep.back(), "local_stage_pack")); }
+    Tensor packed = at::empty({(int64_t)be_local_stage_packed_floats()}, keep[0].options());
+    check(be_local_stage_pack_f32(ptrs.data(), (float)eps, packed.data_ptr<float>(), stream_of(packed)), "be_local_stage_pack_f32");
+    return packed;
+}
+
+std::tuple<Tensor, Tensor> local_stage_forward(const Tensor& packed, const Tensor& x, const optional<Tensor>& out_,
+                                               const optional<Tensor>& workspace_, bool winograd, int64_t chunk) {
+    TORCH_CHECK(x.dim() == 4 && x.size(1) == 3 && x.size(2) == BE_R && x.size(3) == BE_R, "local_stage_forward: x must be [N,3,21,21]");
+    const int64_t n = x.size(0);
+    Tensor out = out_.has_value() && out_->defined() ? *out_ : at::empty({n, 10}, x.options());
+    const size_t need = be_local_stage_workspace_bytes(n, (int64_t)chunk);
+    Tensor ws = workspace_.has_value() && workspace_->defined() && (size_t)workspace_->numel() * 4 >= need
+                    ? *workspace_ : at::empty({(int64_t)((need + 3) / 4)}, x.options());
+    be_local_stage_opts o{winograd ? 1 : 0, (int)chunk};
+    check(be_local_stage_forward_f32(fp(packed, "packed"), fp(x, "x"), fpm(out, "out"), n, ws.data_ptr<float>(), (size_t)ws.numel() * 4, &o,
+                                     stream_of(x)), "be_local_stage_forward_f32");
+    return {out, ws};
+}
+
+Tensor render_colors(const Tensor& opts, const Tensor& params10, const Tensor& patches, const optional<Tensor>& colors_) {
+    TORCH_CHECK(params10.is_cuda() && patches.is_cuda(), "render_colors: expected tensors on the GPU; the HIP path has no CPU fallback");
+    const int64_t n = params10.size(0);
+    TORCH_CHECK(params10.dim() == 2 && params10.size(1) == 10 && patches.numel() == n * 3 * BE_NPIX, "render_colors: params10 [N,10], patches [N,3,21,21]");
+    Tensor colors = colors_.has_value() && colors_->defined() ? *colors_ : at::empty({n, 3, 3}, params10.options());
+    check(be_render_colors_f32(host_struct<be_render_opts>(opts, "render_colors(opts)"), fp(params10, "params10"), fp(patches, "patches"),
+                               fpm(colors, "colors"), nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, n, stream_of(params10)),
+          "be_render_colors_f32");
+    return colors;
+}
+
+Tensor local_depth(const Tensor& consts, const Tensor& params10, const optional<Tensor>& out_) {
+    TORCH_CHECK(params10.is_cuda(), "local_depth: expected a tensor on the GPU; the HIP path has no CPU fallback");
+    TORCH_CHECK(params10.dim() == 2 && params10.size(1) == 10 && params10.size(0) % 2 == 0, "local_depth: params10 [2P,10]");
+    const int64_t p = params10.size(0) / 2;
+    Tensor out = out_.has_value() && out_->defined() ? *out_ : at::empty({p, 2}, params10.options());
+    check(be_local_depth_f32(host_struct<be_depth_consts>(consts, "local_depth(consts)"), fp(params10, "params10"), fpm(out, "out"), p,
+                             stream_of(params10)), "be_local_depth_f32");
+    return out;
+}
+
+// ---- training ------------------------------------------------------------------------------------------------------------
+// conv / linear + BatchNorm (batch statistics) [+ res] [+ Smish]: -> (out, y, mean, invstd, s_in or an empty tensor)
+std::tuple<Tensor, Tensor, Tensor, Tensor, Tensor> train_unit_fwd(const Tensor& x, const Tensor& pw, const Tensor& pb, const Tensor& gamma,
+                                                                  const Tensor& beta, const optional<Tensor>& res, Tensor run_mean,
+                                                                  Tensor run_var, int64_t cout, int64_t ksize, bool act, double eps,
+                                                                  double momentum, Tensor scratch) {
+    TORCH_CHECK(x.dim() == 4, "train_unit_fwd: x must be NHWC [N,H,W,C]");
+    const int64_t n = x.size(0), h = x.size(1), w = x.size(2), cin = x.size(3);
+    Tensor y = at::empty({n, h, w, cout}, x.options()), out = at::empty_like(y);
+    Tensor s_in = act ? at::empty_like(y) : at::empty({0}, x.options());
+    Tensor mean = at::empty({cout}, x.options()), invstd = at::empty({cout}, x.options());
+    be_conv_desc d{(int)n, (int)h, (int)w, (int)cin, (int)cout, (int)ksize, 0};
+    check(be_train_unit_fwd_f32(&d, fp(x, "x"), fp(pw, "packed_w"), fp(pb, "packed_bias"), fp(gamma, "gamma"), fp(beta, "beta"), fpo(res, "res"),
+                                (float)eps, (float)momentum, fpm(run_mean, "run_mean"), fpm(run_var, "run_var"), y.data_ptr<float>(),
+                                mean.data_ptr<float>(), invstd.data_ptr<float>(), act ? s_in.data_ptr<float>() : nullptr,
+                                out.data_ptr<float>(), act ? 1 : 0, scratch.data_ptr<float>(), (size_t)scratch.numel() * 4, stream_of(x)),
+          "be_train_unit_fwd_f32");
+    return {out, y, mean, invstd, s_in};
+}
+
+// backward of the unit; the four parameter gradients are written into the given slices of the flat gradient buffer
+std::tuple<Tensor, Tensor> train_unit_bwd(const Tensor& x, const Tensor& dout, const optional<Tensor>& s_in, const Tensor& y, const Tensor& mean,
+                                          const Tensor& invstd, const Tensor& gamma, const optional<Tensor>& dg_pw,
+                                          const optional<Tensor>& dg_pb, const optional<Tensor>& dx_add, int64_t ksize, int64_t chw_hw,
+                                          Tensor dgamma, Tensor dbeta, Tensor dw, Tensor db, Tensor scratch) {
+    const int64_t n = x.size(0), h = x.size(1), w = x.size(2), cin = x.size(3), cout = y.size(-1);
+    Tensor ds = at::empty_like(y), dy = at::empty_like(y);
+    const bool want_dx = dg_pw.has_value() && dg_pw->defined();
+    Tensor dx = want_dx ? at::empty({n, h, w, cin}, x.options()) : at::empty({0}, x.options());
+    be_conv_desc d{(int)n, (int)h, (int)w, (int)cin, (int)cout, (int)ksize, 0};
+    const bool has_s = s_in.has_value() && s_in->defined() && s_in->numel() > 0;
+    check(be_train_unit_bwd_f32(&d, fp(x, "x"), fp(dout, "dout"), has_s ? fp(*s_in, "s_in") : nullptr, fp(y, "y"), fp(mean, "mean"),
+                                fp(invstd, "invstd"), fp(gamma, "gamma"), want_dx ? fp(*dg_pw, "dgrad_w") : nullptr,
+                                want_dx ? fpo(dg_pb, "dgrad_b") : nullptr, fpo(dx_add, "dx_add"), (int)chw_hw, ds.data_ptr<float>(),
+                                dy.data_ptr<float>(), fpm(dgamma, "dgamma"), fpm(dbeta, "dbeta"), fpm(dw, "dw"), fpm(db, "db"),
+                                want_dx ? dx.data_ptr<float>() : nullptr, scratch.data_ptr<float>(), (size_t)scratch.numel() * 4, stream_of(x)),
+          "be_train_unit_bwd_f32");
+    return {ds, dx};
+}
+
+std::tuple<Tensor, Tensor> maxpool_fwd_idx(const Tensor& x, int64_t k, int64_t stride, int64_t pad) {
+    const int64_t n = x.size(0), h = x.size(1), w = x.size(2), c = x.size(3);
+    const int64_t oh = (h + 2 * pad - k) / stride + 1, ow = (w + 2 * pad - k) / stride + 1;
+    Tensor y = at::empty({n, oh, ow, c}, x.options()), idx = at::empty({n, oh, ow, c}, x.options().dtype(at::kByte));
+    check(be_maxpool_nhwc_fwd_idx_f32(fp(x, "x"), y.data_ptr<float>(), idx.data_ptr<uint8_t>(), (int)n, (int)h, (int)w, (int)c, (int)k, (int)stride,
+                                      (int)pad, stream_of(x)), "be_maxpool_nhwc_fwd_idx_f32");
+    return {y, idx};
+}
+
+Tensor maxpool_bwd_idx(const Tensor& idx, const Tensor& dout, int64_t h, int64_t w, int64_t k, int64_t stride, int64_t pad) {
+    const int64_t n = dout.size(0), c = dout.size(3);
+    Tensor dx = at::empty({n, h, w, c}, dout.options());
+    check(be_maxpool_nhwc_bwd_idx_f32(idx.data_ptr<uint8_t>(), fp(dout, "dout"), dx.data_ptr<float>(), (int)n, (int)h, (int)w, (int)c, (int)k,
+                                      (int)stride, (int)pad, stream_of(dout)), "be_maxpool_nhwc_bwd_idx_f32");
+    return dx;
+}
+
+// clip_grad_norm_(max_norm) + AdamW over the flat gradient buffer; returns nothing (grad_norm is written in place)
+void clip_adamw(const Tensor& table, int64_t nentries, Tensor grad_flat, Tensor partial, double max_norm, double grad_scale, double lr,
+                double beta1, double beta2, double eps, double weight_decay, Tensor step, Tensor grad_norm, bool write_back) {
+    TORCH_CHECK(table.is_cuda() && table.scalar_type() == at::kByte && partial.scalar_type() == at::kDouble, "clip_adamw: table (uint8) / partial (float64)");
+    check(be_clip_adamw_f32(reinterpret_cast<const be_adam_entry*>(table.data_ptr<uint8_t>()), (int)nentries, fpm(grad_flat, "grad_flat"),
+                            grad_flat.numel(), partial.data_ptr<double>(), (int)partial.numel(), (float)max_norm, (float)grad_scale, lr, beta1,
+                            beta2, eps, weight_decay, fpm(step, "step"), fpm(grad_norm, "grad_norm"), write_back ? 1 : 0, stream_of(grad_flat)),
+          "be_clip_adamw_f32");
+}
+
+}  // namespace
+
+TORCH_LIBRARY(be, m) {
+    m.def("local_stage_pack(Tensor[] tensors, float eps) -> Tensor");
+    m.def("local_stage_forward(Tensor packed, Tensor x, Tensor(a!)? out, Tensor? workspace, bool winograd, int chunk) -> (Tensor, Tensor)");
+    m.def("render_colors(Tensor opts, Tensor params10, Tensor patches, Tensor(a!)? colors) -> Tensor");
+    m.def("local_depth(Tensor consts, Tensor params10, Tensor(a!)? out) -> Tensor");
+    m.def("train_unit_fwd(Tensor x, Tensor pw, Tensor pb, Tensor gamma, Tensor beta, Tensor? res, Tensor(a!) run_mean, Tensor(b!) run_var, "
+          "int cout, int ksize, bool act, float eps, float momentum, Tensor(c!) scratch) -> (Tensor, Tensor, Tensor, Tensor, Tensor)");
+    m.def("train_unit_bwd(Tensor x, Tensor dout, Tensor? s_in, Tensor y, Tensor mean, Tensor invstd, Tensor gamma, Tensor? dg_pw, Tensor? dg_pb, "
+          "Tensor? dx_add, int ksize, int chw_hw, Tensor(a!) dgamma, Tensor(b!) dbeta, Tensor(c!) dw, Tensor(d!) db, Tensor(e!) scratch) -> (Tensor, Tensor)");
+    m.def("maxpool_fwd_idx(Tensor x, int k, int stride, int pad) -> (Tensor, Tensor)");
+    m.def("maxpool_bwd_idx(Tensor idx, Tensor dout, int h, int w, int k, int stride, int pad) -> Tensor");
+    m.def("clip_adamw(Tensor table, int nentries, Tensor(a!) grad_flat, Tensor(b!) partial, float max_norm, float grad_scale, float lr, float beta1, "
+          "float beta2, float eps, float weight_decay, Tensor(c!) step, Tensor(d!) grad_norm, bool write_back) -> ()");
+}
+
+// on ROCm builds of PyTorch the GPU dispatch key is named CUDA (HIP masquerades as it); ops that take only host structs + GPU tensors
+// dispatch on the GPU tensors
+TORCH_LIBRARY_IMPL(be, CUDA, m) {
+    m.impl("local_stage_pack", local_stage_pack);
+    m.impl("local_stage_forward", local_stage_forward);
+    m.impl("train_unit_fwd", train_unit_fwd);
+    m.impl("train_unit_bwd", train_unit_bwd);
+    m.impl("maxpool_fwd_idx", maxpool_fwd_idx);
+    m.impl("maxpool_bwd_idx", maxpool_bwd_idx);
+    m.impl("clip_adamw", clip_adamw);
+}
+// these two take a CPU byte tensor (the host struct) next to GPU tensors: registered for every backend, they check their GPU
+// arguments themselves (a CPU tensor raises: no fallback)
+TORCH_LIBRARY_IMPL(be, CompositeExplicitAutograd, m) {
+    m.impl("render_colors", render_colors);
+    m.impl("local_depth", local_depth);
+}

@@ -1262,7 +1262,11 @@ extern "C" int be_train_unit_bwd_f32(const be_conv_desc* d, const float* x, cons
             g.cgx = (int)prep.gx;
             const unsigned grid = (unsigned)g.n_w + prep.gx * (unsigned)prep.S;
             constexpr size_t lds = (size_t)BWD_GEMMS_LDS_FLOATS * sizeof(float);
-            be::ProfileScope prof(s, BE_KERNEL_TRAIN_BWD_GEMMS, prep.flops + 2.0 * M * (double)wsize, 0.0, 0.0);
+            // executed: the convolution's visited chunks x tile FLOPs + the weight-gradient tiles (full tiles: channel counts are
+            // multiples of the tile; k_wgrad's 64-wide tiles pad 96 channels to 128)
+            const double w_exec = g.wkind == 1 ? 2.0 * M * (double)wsize
+                                               : 2.0 * M * (double)taps * ((C + 63) / 64 * 64) * ((d->cin + 63) / 64 * 64);
+            be::ProfileScope prof(s, BE_KERNEL_TRAIN_BWD_GEMMS, prep.flops + 2.0 * M * (double)wsize, 0.0, prep.flops_exec + w_exec);
             if (prep.variant == 0) {
                 static be::DeviceFlags f0{};
                 if (int rc_ = be::ensure_dynamic_lds(reinterpret_cast<const void*>(&k_bwd_gemms<0>), lds, f0)) return rc_;

@@ -688,3 +688,34 @@ def test_two_host_threads_on_two_streams_first_calls_race_and_results_are_bit_id
     env = dict(os.environ, BE_ROOT=ROOT)
     r = subprocess.run([sys.executable, "-c", _TWO_THREADS], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "TWO_THREADS_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_torch_operator_binding_and_ctypes_binding_give_identical_results(native):
+    """torch.ops.be.* (csrc/be_torch_ops.cpp) and the ctypes binding call the same C symbols: LocalStage eval forward, pass-A
+    colours and the depth solve must be bit-identical through either, and the operators are what the product path uses."""
+    import models, utils
+    assert native.ops() is not None, "the torch extension did not load"
+    sd = {k: T(v) for k, v in synth.local_stage_state_dict().items()}
+    x = T(synth.uniform_patches(192, name="opsbind")).to(DEV)
+    helper = utils.PostProcessLocalBase(utils.get_args("local_train", argv=[]), DEV)
+    dcal = utils.DepthEtas(utils.get_args("eval", argv=[]), DEV)
+    opts = native.RenderOpts.from_buffer_copy(helper._opts)
+    opts.wrap_angles = 1
+    res = []
+    for use_ops in (True, False):
+        saved = native._ops
+        if not use_ops:
+            native._ops = False                               # what BE_TORCH_OPS=0 selects
+        try:
+            m = models.LocalStage()
+            m.load_state_dict(sd)
+            m = m.to(DEV).eval()
+            with torch.no_grad():
+                est = m(x)
+                col, _ = native.render_colors(opts, est, x)
+                z = native.local_depth(dcal.consts, est)
+            res.append((est.clone(), col.clone(), z.clone()))
+        finally:
+            native._ops = saved
+    for a, b in zip(*res):
+        assert torch.equal(a, b)

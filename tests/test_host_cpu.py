@@ -25,6 +25,23 @@ def test_library_exports_every_symbol_in_the_header():
     assert lib.be_local_stage_packed_floats() > 7254122          # >= parameter count (padding only adds)
 
 
+def test_torch_operators_are_registered_over_the_c_abi():
+    """north_star: the kernels are 'exposed as torch extensions'.  build() makes lib/libbe_torch_ops.so next to the C-ABI library;
+    loading it registers torch.ops.be.* (schemas below); the operators refuse CPU tensors (no fallback)."""
+    from be_hip import native
+    o = native.ops()
+    assert o is not None and os.path.exists(native.TORCH_OPS_PATH)
+    for name in ("local_stage_pack", "local_stage_forward", "render_colors", "local_depth", "train_unit_fwd", "train_unit_bwd",
+                 "maxpool_fwd_idx", "maxpool_bwd_idx", "clip_adamw"):
+        assert hasattr(o, name), name
+    schema = str(torch.ops.be.local_stage_forward.default._schema)
+    assert "Tensor packed" in schema and "bool winograd" in schema and "int chunk" in schema
+    with pytest.raises(RuntimeError):                              # NotImplementedError for the CPU backend is a RuntimeError
+        o.local_stage_forward(torch.zeros(8), torch.zeros(2, 3, 21, 21), None, None, True, 0)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        o.local_depth(torch.zeros(64, dtype=torch.uint8), torch.zeros(4, 10), None)
+
+
 def test_host_side_argument_checks_fail_before_any_launch():
     from be_hip import native
     lib = native.lib()
