@@ -774,3 +774,70 @@ def test_training_unit_matches_the_single_purpose_kernels():
         assert torch.equal(y, native.maxpool_nhwc(x, k, s_, p_))
         d = torch.randn_like(y)
         assert torch.equal(train._pool_bwd_idx(saved, d, k, s_, p_), train._pool_bwd(x, d, k, s_, p_))
+
+
+def test_segmented_graph_step_and_clip_adamw_train_like_the_eager_step_and_the_next_eval_sees_it():
+    """SegmentedGraphStep replays weights and BatchNorm statistics without touching tensor versions - it has to
+    drop LocalStage's BN-folded weight pack like GraphedStep does.  One GPU, no process group (sync=None): eight steps as graph
+    segments against eight eager train_step calls from the same start, both on be_hip.optim.ClipAdamW - identical losses and
+    parameters bit for bit - then an eval forward straight after a replay (no train()/eval() switch) against a fresh model."""
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a GPU")
+    import models, utils
+    from be_hip import train_local
+    from be_hip.optim import ClipAdamW
+    args = utils.get_args("local_train", argv=[])
+    B = 64
+    data = {k: torch.from_numpy(v).to(DEV) for k, v in synth.synthetic_training_patches(B * 4, seed=21).items()}
+    helper = utils.PostProcessLocalBase(args, DEV)
+    sd0 = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.local_stage_state_dict().items()}
+    runs = []
+    for segmented in (False, True):
+        model = models.LocalStage().to(DEV)
+        model.load_state_dict(sd0)
+        model.train()
+        opt = ClipAdamW(model.parameters(), lr=1e-3)
+        seg = train_local.SegmentedGraphStep(model, helper, opt, None) if segmented else None
+        losses = []
+        for it in range(8):
+            b = {k: v[(it % 4) * B:(it % 4 + 1) * B] for k, v in data.items()}
+            if seg is not None:
+                losses.append(float(seg(b, args.beta_bndry_loc, args.beta_smthns)))
+            else:
+                losses.append(float(train_local.train_step(model, helper, opt, b, args.beta_bndry_loc, args.beta_smthns)))
+        torch.cuda.synchronize()
+        runs.append((losses, {k: v.detach().clone() for k, v in model.state_dict().items()}, model, seg))
+    (l_e, sd_e, _, _), (l_s, sd_s, model, seg) = runs
+    assert seg.graphs is not None and len(seg.graphs) == 5              # four buckets + the tail
+    assert l_e == l_s and np.isfinite(l_e).all()
+    for k in sd_e:
+        assert torch.equal(sd_e[k], sd_s[k]), k
+    model.training = False                                               # bypasses LocalStage.train(): only the replay hook is left
+    x_eval = torch.from_numpy(synth.uniform_patches(32, name="seg_eval")).to(DEV)
+    with torch.no_grad():
+        y = model(x_eval).clone()
+    fresh = models.LocalStage().to(DEV)
+    fresh.load_state_dict(model.state_dict())
+    fresh.eval()
+    with torch.no_grad():
+        assert torch.equal(y, fresh(x_eval)), "eval after a segmented replay ran on a stale weight pack"
+
+
+def test_global_stage_dropout_seed_salt_decorrelates_identically_seeded_replicas():
+    """data-parallel ranks seed torch identically (same shuffle); GlobalStage draws its per-step dropout seed from
+    that generator, so be_hip.workflow.global_train gives every rank a salt.  Same torch seed + different salts -> different masks;
+    same salt -> the same output bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a GPU")
+    import models
+    m = models.GlobalStage(device=DEV).to(DEV)
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.global_stage_state_dict().items()})
+    m.train()
+    x = torch.from_numpy(synth.f32(synth.hash_normal(7, "salt_x", (1, 256, 38)))).to(DEV)
+    outs = []
+    for salt in (0, 0, (1 * 0x9E3779B1) & 0x7FFFFFFF):
+        torch.manual_seed(1898)
+        m.dropout_seed_salt = salt
+        with torch.no_grad():
+            outs.append(m(x).clone())
+    assert torch.equal(outs[0], outs[1]) and not torch.equal(outs[0], outs[2])
