@@ -53,7 +53,7 @@ CPU_REPEATS = 3
 # kernel id 6 = the 25 transform-domain GEMMs of one Winograd layer: the hooks count the 25 x 2 x 4n x cin x cout FLOPs they
 # execute; the same layer as a direct 3x3 convolution on a 6x6 map is 2 x 36 x 9 x n x cin x cout
 ALGO_OVER_HOOK = {6: (2.0 * 36 * 9) / (25.0 * 2 * 4)}
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
 
 
 def cpu_baseline(x_np, sd_np):
