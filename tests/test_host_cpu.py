@@ -94,6 +94,34 @@ def test_eight_host_threads_in_the_validation_and_sizing_entry_points():
     assert not errors, errors
 
 
+def test_round3_entry_points_validate_on_the_host_before_any_launch():
+    """The training-unit / optimizer / pooling entry points added in round 3 reject bad arguments with BE_EINVAL and a message
+    before touching the GPU (null pointers, a scratch that is too small, channel counts the tiles do not take)."""
+    import ctypes as C
+    from be_hip import native
+    lib = native.lib()
+    d = native.ConvDesc(64, 6, 6, 256, 384, 3, 0)
+    assert lib.be_train_unit_fwd_f32(C.byref(d), *([None] * 6), 1e-5, 0.1, *([None] * 7), 1, None, 0, None) < 0
+    assert b"null pointer" in lib.be_last_error()
+    buf = (C.c_float * 64)()
+    p = C.cast(buf, C.c_void_p)
+    # all pointers set, scratch too small
+    assert lib.be_train_unit_fwd_f32(C.byref(d), p, p, p, p, p, None, 1e-5, 0.1, None, None, p, p, p, None, p, 0, p, 1024, None) < 0
+    assert b"scratch" in lib.be_last_error()
+    d_bad = native.ConvDesc(64, 6, 6, 256, 100, 3, 0)            # cout not a multiple of 32
+    big = lib.be_train_scratch_bytes()
+    assert lib.be_train_unit_fwd_f32(C.byref(d_bad), p, p, p, p, p, None, 1e-5, 0.1, None, None, p, p, p, None, p, 0, p, big, None) < 0
+    assert b"cout" in lib.be_last_error()
+    assert lib.be_train_unit_bwd_f32(C.byref(d), *([None] * 10), 0, *([None] * 8), 0, None) < 0
+    assert lib.be_linear_small_fwd_f32(p, p, p, p, 4, 10, 3, None) < 0             # K % 4 != 0
+    assert lib.be_maxpool_nhwc_fwd_idx_f32(p, p, p, 1, 6, 6, 6, 2, 2, 0, None) < 0  # c % 4 != 0
+    assert lib.be_maxpool_nhwc_bwd_idx_f32(None, p, p, 1, 6, 6, 8, 2, 2, 0, None) < 0
+    assert lib.be_linear_param_grads_f32(p, p, p, p, 1024, 100, 128, p, big, None) < 0   # cin not a multiple of 128
+    assert lib.be_clip_adamw_f32(None, 0, None, 0, None, 0, 1.0, 1.0, 1e-3, 0.9, 0.999, 1e-8, 1e-2, None, None, 1, None) < 0
+    assert lib.be_local_loss_finish_f32(None, 0, 0.0, 0.0, None, None) < 0
+    assert lib.be_adam_chunk() == 4096
+
+
 def test_local_stage_state_dict_layout_matches_the_reference():
     import models
     m = models.LocalStage()
