@@ -47,12 +47,45 @@ def test_twenty_training_steps_teacher_forced_against_the_fp64_oracle():
     gdata = {k: torch.from_numpy(v).to(DEV) for k, v in data.items()}
     W = dict(loss=0.0, logits=0.0, dest_same=0.0, cnn=0.0, cnn_name="", chain=0.0, chain_name="", e2e_hip=0.0, e2e_f32=0.0,
              norm=0.0, run=0.0, upd_ulp=0.0, upd_name="", dead=0.0)
-    cnn_all, hip_curve, ora_curve = [], [], []
+    cnn_all, hip_curve, ora_curve, events = [], [], [], []
 
     def loss_of(est, cb):
         return orr.local_loss(est, cb["img_gt"], cb["img_gt"], cb["bndry_dist"], cb["deri"], args.beta_bndry_loc,
                               args.beta_smthns, inverse="solve")[0]
     rel = lambda a, r: float((a - r).norm() / r.norm())
+
+    def pool_winner_flips(state, x_gpu):
+        """The three max-pools of one training forward from `state`: which windows does the HIP forward give to a different
+        element than the float64 oracle, and how far apart are the two candidates in float64 (relative to the map's largest value)?
+        -> {pool: (windows whose winner differs, largest float64 gap between the two candidates)}"""
+        import torch.nn.functional as F
+        from be_hip import train
+        probe = models.LocalStage().to(DEV)
+        probe.load_state_dict(state)
+        _, S = train.forward_train(x_gpu.to(torch.float32).contiguous(), [v.detach() for v in probe._tensor_list()])
+        taps = {}
+        sdd = {k: (v.double() if v.is_floating_point() else v) for k, v in state.items()}
+        with torch.no_grad():
+            ols.local_stage_forward(sdd, x_gpu.cpu().double(), training=True, taps=taps)
+        out = {}
+        for pool, src, k, st, pd in (("pool1", "conv1", 3, 2, 1), ("pool2", "layer0", 3, 2, 1), ("pool3", "layer3", 2, 2, 0)):
+            v = taps[src]                                                    # [n,c,h,w] float64
+            n_, c_, h_, w_ = v.shape
+            _, oi = F.max_pool2d(v, k, st, pd, return_indices=True)          # flat y*w + x per [n,c,oh,ow]
+            idx = S[pool][0].permute(0, 3, 1, 2).cpu().long()               # HIP: dy*k + dx of the winner, -> [n,c,oh,ow]
+            oh, ow = idx.shape[2], idx.shape[3]
+            oy = torch.arange(oh).view(1, 1, oh, 1) * st - pd
+            ox = torch.arange(ow).view(1, 1, 1, ow) * st - pd
+            hi = (oy + idx // k) * w_ + (ox + idx % k)
+            diff = hi != oi
+            gap = 0.0
+            if diff.any():
+                flat = v.flatten(2)
+                a_ = torch.gather(flat, 2, oi.flatten(2)).view_as(oi)[diff]
+                b_ = torch.gather(flat, 2, hi.flatten(2)).view_as(hi)[diff]
+                gap = float((a_ - b_).abs().max() / v.abs().max())
+            out[pool] = (int(diff.sum()), gap)
+        return out
     for it in range(steps):
         t = it + 1
         sd_cpu = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
@@ -82,6 +115,8 @@ def test_twenty_training_steps_teacher_forced_against_the_fp64_oracle():
             lo = loss_of(esto, cb)
             dest_o, = torch.autograd.grad(lo, esto, retain_graph=True)
             res[dt] = dict(loss=float(lo.detach()), dest=dest_o.double(), run=run)
+            if dt == torch.float32:
+                res[dt].update(esto=esto, P=P)                  # kept for the fp32 control of (3), run only when an event shows
             if dt == torch.float64:
                 go = dict(zip(names, torch.autograd.grad(lo, P, retain_graph=True)))
                 e_same = est.detach().cpu().double().requires_grad_(True)
@@ -98,6 +133,17 @@ def test_twenty_training_steps_teacher_forced_against_the_fp64_oracle():
             cnn_all.append(e)
             if e > W["cnn"]:
                 W["cnn"], W["cnn_name"] = e, f"{k}@{it}"
+        # control for (3): where a per-tensor error stands out (> 3e-4: a discrete fp32 event such as a max-pool
+        # tie broken the other way, not rounding), push the SAME cotangent through the float32 run of the oracle from the same
+        # state - plain PyTorch-CPU fp32, no HIP involved - and record its error on the same tensors against float64
+        step_err = {k: rel(gh[k], gb[k]) for k in live}
+        hot = [k for k in live if step_err[k] > 3e-4]
+        if hot:
+            r32 = res[torch.float32]
+            g32 = dict(zip(names, torch.autograd.grad(r32["esto"], r32["P"], grad_outputs=dest_h.float())))
+            flips = pool_winner_flips(sd_cpu, b["img_ny"].permute(0, 3, 1, 2))
+            for k in hot:
+                events.append((f"{k}@{it}", step_err[k], rel(g32[k].double(), gb[k]), flips))
         W["dead"] = max(W["dead"], max(float(gh[k].norm()) for k in names if k not in live))
         W["logits"] = max(W["logits"], float((est.detach().cpu().double() - logits_o).abs().max() / logits_o.abs().max()))
         for k in live:                                                                                         # (4)
@@ -147,6 +193,17 @@ def test_twenty_training_steps_teacher_forced_against_the_fp64_oracle():
     assert W["dest_same"] <= 1.5e-6          # measured 4.2e-7
     assert W["cnn"] <= 1e-2 and cnn_med <= 1e-5, W     # measured 2.6e-3 (conv1.1.weight, step 8) / 2.5e-6: worst / median over 20 steps x 46 tensors; the worst cases
     #                                          are discrete fp32 events (a max-pool tie broken the other way), the fp32 oracle has them too
+    # ... and here is the demonstration: on every (tensor, step) where the HIP gradient is more than 3e-4 from float64, either the
+    # float32 oracle's own gradient (same state, same cotangent) is off by at least a third as much, or a pooling window went to the
+    # other of two near-tied elements - the event is fp32's, not the kernels'
+    print("events (tensor@step, hip vs f64, oracle-f32 vs f64, pool windows with another winner than float64 / their float64 gap):",
+          [(n, "%.1e" % a, "%.1e" % b, f) for n, a, b, f in events])
+    for n_, e_hip, e_f32, flips in events:
+        # either the float32 oracle shows the same event, or the HIP forward gave a pooling window to another element than float64
+        # did - and the two candidates are a near-tie in float64 (<= 1e-5 of the map's scale): a rounding-level difference in the
+        # forward picks the other one, and the whole gradient of that window moves
+        tie = any(cnt > 0 and gap <= 1e-5 for cnt, gap in flips.values())
+        assert e_f32 >= e_hip / 3 or tie, (n_, e_hip, e_f32, flips)
     assert W["chain"] <= 1e-2, W             # measured 2.6e-3 (the same event)
     assert W["chain_norm"] <= 1e-4, W        # measured 2.0e-5: the TOTAL gradient norm against the oracle's at the HIP logits
     assert W["logits"] <= 1e-5               # measured 3.5e-6: train-mode logits (batch statistics) at every visited state
