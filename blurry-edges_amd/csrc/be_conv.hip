@@ -33,11 +33,11 @@ using namespace be_igemm;
 
 // __launch_bounds__(256, w): w = workgroups per CU the LDS admits (= waves per SIMD), so the register allocator may
 // use 512/w registers (see be_igemm_body.h)
-template <int WM, int WN, int MT, int NT, int MODE, int BKT, int PRIO>
+template <int WM, int WN, int MT, int NT, int MODE, int BKT, int PRIO, bool UNI = false>
 __global__ __launch_bounds__(256, BKT == 16 ? (PRIO == 2 ? 4 : 3) : (BKT == 8 ? 4 : 2))
 void k_conv_igemm(ConvArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    conv_igemm_body<WM, WN, MT, NT, MODE, BKT, PRIO>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
+    conv_igemm_body<WM, WN, MT, NT, MODE, BKT, PRIO, UNI>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -335,13 +335,13 @@ double executed_chunks(const ConvArgs& a, bool row8, int bkt) {
     return chunks;
 }
 
-template <int WM, int WN, int MT, int NT, int MODE, int BKT = 32, int PRIO = 0>
+template <int WM, int WN, int MT, int NT, int MODE, int BKT = 32, int PRIO = 0, bool UNI = false>
 int launch_conv(const ConvArgs& a, hipStream_t s, int kernel_id) {
     constexpr int BN = WN * NT * 32;
     constexpr int BM = WM * MT * 32;
     constexpr size_t lds = (size_t)2 * (BM + BN) * (BKT + 4) * sizeof(float);
     static be::DeviceFlags attr_set{};                      // dynamic-LDS cap raised once per device (thread-safe)
-    if (int rc_ = be::ensure_dynamic_lds(reinterpret_cast<const void*>(&k_conv_igemm<WM, WN, MT, NT, MODE, BKT, PRIO>), lds, attr_set)) return rc_;
+    if (int rc_ = be::ensure_dynamic_lds(reinterpret_cast<const void*>(&k_conv_igemm<WM, WN, MT, NT, MODE, BKT, PRIO, UNI>), lds, attr_set)) return rc_;
     // slots per XCD: flat tiles are dealt round-robin; pixel-major tiles keep a group of images on one XCD
     const int per_xcd = a.pixmaj == 1 ? ((a.m_tiles / a.HW + 7) / 8) * a.HW : (a.m_tiles + 7) / 8;
     const unsigned grid = (unsigned)(8 * per_xcd * a.n_tiles);
@@ -356,7 +356,7 @@ int launch_conv(const ConvArgs& a, hipStream_t s, int kernel_id) {
         be::ProfileScope prof(s, kernel_id, nb * 2.0 * a.M * (k_real + k2_real) * a.Cout,
                               nb * 4.0 * (a.M * (cin_real + k2_real) + (k_real + k2_real) * a.Cout + (double)a.M * a.Cout * (a.res ? 2 : 1)),
                               nb * chunks * 2.0 * BM * BN * BKT);
-        hipLaunchKernelGGL((k_conv_igemm<WM, WN, MT, NT, MODE, BKT, PRIO>), dim3(grid, a.ksplit > 1 ? a.ksplit : 1, a.nbatch > 1 ? a.nbatch : 1),
+        hipLaunchKernelGGL((k_conv_igemm<WM, WN, MT, NT, MODE, BKT, PRIO, UNI>), dim3(grid, a.ksplit > 1 ? a.ksplit : 1, a.nbatch > 1 ? a.nbatch : 1),
                            dim3(256), lds, s, a);
     }
     return be::check_launch("be_conv_nhwc_f32");
@@ -799,6 +799,11 @@ static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2,
         } else {
             a.n_tiles = cp / 32;
         }
+        // uniform 64 x 64 tiles (be_igemm_body.h, UNI): the pixel-major tiles of whole 64-image groups, and 1x1 convolutions /
+        // linears whose row count is a multiple of 64 - no border test, addresses = per-thread constant + uniform offset
+        static const bool no_uni = getenv("BE_NO_UNI_TILES") != nullptr;              // A/B knob
+        const bool uni = t64 && !no_uni && !x2 && !a.wb3 && a.nbatch <= 1 && M * (int64_t)d->cin * 4 < ((int64_t)1 << 32) &&
+                         (int64_t)cp * a.Ktot * 4 < ((int64_t)1 << 32) && (a.pixmaj == 2 || (d->ksize == 1 && M % 64 == 0));
         // split-K when the caller lent scratch: a few hundred workgroups each walking the whole K loop leave most of
         // the chip idle (batch-64 training: 144-216 tiles, up to 216 chunks each); S slices make S times the
         // workgroups, each 1/S as long, and a small reduce kernel applies bias / residual / activation
@@ -812,7 +817,7 @@ static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2,
             if (defer && defer->prep) {                                     // hand the launch back (be_train.hip: k_bwd_gemms)
                 if (S > 1) { a.ksplit = S; a.ldp = cp; a.partial = static_cast<float*>(scratch); }
                 be::ConvPrep* pr = defer->prep;
-                pr->args = a; pr->variant = t64 ? 0 : 1; pr->S = S > 1 ? S : 1; pr->ldp = S > 1 ? cp : 0;
+                pr->args = a; pr->variant = uni ? 2 : (t64 ? 0 : 1); pr->S = S > 1 ? S : 1; pr->ldp = S > 1 ? cp : 0;
                 pr->gx = (unsigned)(8 * ((a.m_tiles + 7) / 8) * a.n_tiles);
                 pr->flops = 2.0 * a.M * (double)a.Cin * a.ks * a.ks * a.Cout;
                 pr->flops_exec = executed_chunks(a, false, 16) * 2.0 * (t64 ? 64.0 * 64.0 : 128.0 * 32.0) * 16.0;
@@ -820,8 +825,9 @@ static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2,
             }
             if (S > 1) {
                 a.ksplit = S; a.ldp = cp; a.partial = static_cast<float*>(scratch);
-                const int rc = t64 ? launch_conv<2, 2, 1, 1, MODE_TAPS, 16, 0>(a, s, BE_KERNEL_CONV_SMALL)
-                                   : launch_conv<4, 1, 1, 1, MODE_TAPS, 16, 0>(a, s, BE_KERNEL_CONV_SMALL);
+                const int rc = uni ? launch_conv<2, 2, 1, 1, MODE_TAPS, 16, 0, true>(a, s, BE_KERNEL_CONV_SMALL)
+                               : t64 ? launch_conv<2, 2, 1, 1, MODE_TAPS, 16, 0>(a, s, BE_KERNEL_CONV_SMALL)
+                                     : launch_conv<4, 1, 1, 1, MODE_TAPS, 16, 0>(a, s, BE_KERNEL_CONV_SMALL);
                 if (rc) return rc;
                 if (defer) { defer->S = S; defer->ldp = cp; return BE_OK; }
                 const int64_t total = M * d->cout;
@@ -830,8 +836,9 @@ static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2,
                 return be::check_launch("be_conv_nhwc_splitk_f32");
             }
         }
-        return t64 ? launch_conv<2, 2, 1, 1, MODE_TAPS, 16, 0>(a, s, BE_KERNEL_CONV_SMALL)
-                   : launch_conv<4, 1, 1, 1, MODE_TAPS, 16, 0>(a, s, BE_KERNEL_CONV_SMALL);
+        return uni ? launch_conv<2, 2, 1, 1, MODE_TAPS, 16, 0, true>(a, s, BE_KERNEL_CONV_SMALL)
+               : t64 ? launch_conv<2, 2, 1, 1, MODE_TAPS, 16, 0>(a, s, BE_KERNEL_CONV_SMALL)
+                     : launch_conv<4, 1, 1, 1, MODE_TAPS, 16, 0>(a, s, BE_KERNEL_CONV_SMALL);
     }
     // 1x1 convolutions / linears of large batches are plain row GEMMs: the LDS-DMA kernel of be_wino.hip (bit-identical)
     if (d->ksize == 1 && !x2 && cp % 128 == 0 && M >= 4096 && a.nbatch <= 1 && !a.wb3 && !no_rows && d->cin % 16 == 0)

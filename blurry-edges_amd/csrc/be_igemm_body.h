@@ -37,7 +37,12 @@ struct ConvArgs {
 // The kernel body as a device function (round 3): the training step runs a unit's data-gradient convolution and its weight-gradient
 // GEMM in ONE launch (be_train.hip: k_bwd_gemms), a workgroup picking its role from its index; bx / by / bz are what blockIdx.x / y / z
 // are in the stand-alone kernel k_conv_igemm (be_conv.hip) and smem its dynamic LDS (2 (BM + BN) (BKT + 4) floats).
-template <int WM, int WN, int MT, int NT, int MODE, int BKT, int PRIO>
+// UNI (round 3): every row of every tile is inside the problem and every tap a tile visits is inside the image for all of its rows
+// (pixel-major tiles of whole image groups; 1x1 convolutions / linears with M a multiple of the tile): no border test, no zero
+// fill, and the operand addresses are a per-thread constant + a wave-uniform offset - the register-staged loop then issues ~0 VALU
+// instructions per chunk instead of ~30 (the 64 x 64 training tiles issued 4 VALU per MFMA, profiles/r03_train_pmc_summary.json).
+// The host asserts the preconditions (conv_dispatch).  Same arithmetic, same order: bit-identical to UNI = false.
+template <int WM, int WN, int MT, int NT, int MODE, int BKT, int PRIO, bool UNI = false>
 __device__ __forceinline__ void conv_igemm_body(ConvArgs a, float* smem, const int bx, const int by, const int bz) {
     static_assert(WM * WN == 4, "4 waves");
     constexpr int BM = WM * MT * 32;                   // 128 (inference tiles) or 64 (small-M training tile)
@@ -140,8 +145,46 @@ __device__ __forceinline__ void conv_igemm_body(ConvArgs a, float* smem, const i
     // conditionals around the loads): anything else made hipcc keep b_st in scratch memory.
     f32x4 a_st[NA], b_st[NB];
     unsigned a_ok = 0;                                 // bit i: a_st[i] is inside the image (else stored as zeros)
+    // UNI: byte offsets of this thread's staged rows from the (wave-uniform) chunk bases; < 2^32 (host-checked)
+    unsigned a_vo[NA], b_vo[NB];
+    if (UNI) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) a_vo[i] = (unsigned)(a_off[i] * a.Cin + 4 * q) * 4u;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int row_ = (B_PARTIAL && RP * i + r0 >= BN) ? 0 : RP * i + r0;
+            b_vo[i] = (unsigned)(row_ * a.Ktot + 4 * q) * 4u;
+        }
+    }
+    const char* const wbase_u = reinterpret_cast<const char*>(a.w + (size_t)n0 * a.Ktot);      // uniform
+#define BE_LOAD_CHUNK_UNI(KC) BE_LOAD_UNI(KC, a_st, b_st)
+#define BE_LOAD_UNI(KC, AST, BST)                                                                               \
+    do {                                                                                                        \
+        const int k32_ = (KC) / SUB, sub_ = (KC) - k32_ * SUB;                                                  \
+        const int cc_ = k32_ / ntap, j_ = k32_ - cc_ * ntap;                                                    \
+        const int tap_ = (int)((tap_list >> (4 * j_)) & 15ull);                                                 \
+        const int half_ = a.ks >> 1;                                                                            \
+        const int dy_ = tap_ / a.ks - half_, dx_ = tap_ % a.ks - half_;                                         \
+        const int so_ = __builtin_amdgcn_readfirstlane((dy_ * a.W + dx_) * a.Cin + cc_ * 32 + sub_ * BKT);      \
+        const int kw_ = __builtin_amdgcn_readfirstlane(((cc_ * ntap_all + tap_) * SUB + sub_) * BKT);           \
+        const char* ab_ = reinterpret_cast<const char*>(a.x) + (int64_t)so_ * 4;                                \
+        const char* bb_ = wbase_u + (int64_t)kw_ * 4;                                                           \
+        _Pragma("unroll") for (int i_ = 0; i_ < NA; ++i_) AST[i_] = *reinterpret_cast<const f32x4*>(ab_ + a_vo[i_]); \
+        _Pragma("unroll") for (int i_ = 0; i_ < NB; ++i_) BST[i_] = *reinterpret_cast<const f32x4*>(bb_ + b_vo[i_]); \
+    } while (0)
+#define BE_STORE_UNI(BUF, AST, BST)                                                                             \
+    do {                                                                                                        \
+        float* Ad_ = As + (BUF) * BM * LROW;                                                                    \
+        float* Bd_ = Bs + (BUF) * BN * LROW;                                                                    \
+        _Pragma("unroll") for (int i_ = 0; i_ < NA; ++i_)                                                       \
+            *reinterpret_cast<f32x4*>(Ad_ + (r0 + RP * i_) * LROW + 4 * q) = AST[i_];                           \
+        _Pragma("unroll") for (int i_ = 0; i_ < NB; ++i_)                                                       \
+            if (!B_PARTIAL || RP * i_ + r0 < BN)                                                                \
+                *reinterpret_cast<f32x4*>(Bd_ + (r0 + RP * i_) * LROW + 4 * q) = BST[i_];                       \
+    } while (0)
 #define BE_LOAD_CHUNK(KC)                                                                                       \
     do {                                                                                                        \
+        if (UNI) { BE_LOAD_CHUNK_UNI(KC); break; }                                                              \
         int dy_, dx_, coff_;                                                                                    \
         int kw_;   /* chunk index into the packed weights, in BKT units */                                     \
         const bool second_ = MODE == MODE_TAPS && (KC) >= n1;   /* fused 1x1 branch on x2 */                    \
@@ -187,7 +230,7 @@ __device__ __forceinline__ void conv_igemm_body(ConvArgs a, float* smem, const i
         float* Bd_ = Bs + (BUF) * BN * LROW;                                                                    \
         _Pragma("unroll") for (int i_ = 0; i_ < NA; ++i_)                                                       \
             *reinterpret_cast<f32x4*>(Ad_ + (r0 + RP * i_) * LROW + 4 * q) =                                    \
-                ((a_ok >> i_) & 1u) ? a_st[i_] : f32x4{0.f, 0.f, 0.f, 0.f};                                     \
+                (UNI || ((a_ok >> i_) & 1u)) ? a_st[i_] : f32x4{0.f, 0.f, 0.f, 0.f};                            \
         _Pragma("unroll") for (int i_ = 0; i_ < NB; ++i_)                                                       \
             if (!B_PARTIAL || RP * i_ + r0 < BN)                                                                \
                 *reinterpret_cast<f32x4*>(Bd_ + (r0 + RP * i_) * LROW + 4 * q) = b_st[i_];                      \
@@ -213,6 +256,58 @@ __device__ __forceinline__ void conv_igemm_body(ConvArgs a, float* smem, const i
     // split-K (small-M launches): this block walks the chunks [kc0, nchunk) of its K slice
     const int kc0 = a.ksplit > 1 ? (int)((int64_t)nchunk_all * by / a.ksplit) : 0;
     const int nchunk = a.ksplit > 1 ? (int)((int64_t)nchunk_all * (by + 1) / a.ksplit) : nchunk_all;
+#define BE_MFMA_PHASE(BUF)                                                                                      \
+    do {                                                                                                        \
+        const float* Ab = As + (BUF) * BM * LROW + a_frag0;                                                     \
+        const float* Bb = Bs + (BUF) * BN * LROW + b_frag0;                                                     \
+        if (PRIO == 1) __builtin_amdgcn_s_setprio(1);                                                           \
+        _Pragma("unroll") for (int g = 0; g < BKT / 8; ++g) {                                                   \
+            f32x4 af[MT], bf[NT];                                                                               \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LROW + 8 * g); \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LROW + 8 * g); \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                      \
+                _Pragma("unroll") for (int j = 0; j < NT; ++j) {                                                \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);     \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);     \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);     \
+                    /* conv1's row mode: the fourth channel of a pixel is zero in the staging and in the pack (cin <= 3): not issued */ \
+                    if (MODE != MODE_ROW8) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0); \
+                }                                                                                               \
+        }                                                                                                       \
+        if (PRIO == 1) __builtin_amdgcn_s_setprio(0);                                                           \
+    } while (0)
+
+    if (UNI) {
+        // operands TWO chunks ahead in two register sets (the addresses cost nothing here): the loads of chunk k + 2 are issued
+        // before the MFMAs of chunk k and are not needed until the end of step k + 1 - a global load's latency is ~3 MFMA phases of
+        // a 64 x 64 tile, and the one-ahead pipeline of the general path stalled on it every step (matrix pipe 0.37 busy)
+        f32x4 a_s2[NA], b_s2[NB];
+        const int last = nchunk - 1;
+        BE_LOAD_UNI(kc0, a_st, b_st);
+        BE_STORE_UNI(kc0 & 1, a_st, b_st);
+        BE_LOAD_UNI(kc0 + 1 < nchunk ? kc0 + 1 : last, a_st, b_st);
+        __syncthreads();
+        // whole pairs of steps first (no exit between the two MFMA phases of a trip: with one the compiler kept the accumulators
+        // in two register ranges and copied them across), then the odd step
+        const int buf = kc0 & 1;
+        int kc = kc0;
+#pragma unroll 1
+        for (; kc + 1 < nchunk; kc += 2) {
+            BE_LOAD_UNI(kc + 2 < nchunk ? kc + 2 : last, a_s2, b_s2);
+            __builtin_amdgcn_sched_barrier(0);
+            BE_MFMA_PHASE(buf);
+            __builtin_amdgcn_sched_barrier(0);
+            BE_STORE_UNI(buf ^ 1, a_st, b_st);             // chunk kc + 1
+            __syncthreads();
+            BE_LOAD_UNI(kc + 3 < nchunk ? kc + 3 : last, a_st, b_st);
+            __builtin_amdgcn_sched_barrier(0);
+            BE_MFMA_PHASE(buf ^ 1);
+            __builtin_amdgcn_sched_barrier(0);
+            BE_STORE_UNI(buf, a_s2, b_s2);                 // chunk kc + 2
+            __syncthreads();
+        }
+        if (kc < nchunk) BE_MFMA_PHASE(buf);               // odd count: the last chunk is in LDS already
+    } else {
     BE_LOAD_CHUNK(kc0);
     BE_STORE_CHUNK(kc0 & 1);
     __syncthreads();
@@ -223,33 +318,17 @@ __device__ __forceinline__ void conv_igemm_body(ConvArgs a, float* smem, const i
         const int kn = kc + 1 < nchunk ? kc + 1 : kc;
         BE_LOAD_CHUNK(kn);
         __builtin_amdgcn_sched_barrier(0);            // the loads stay ABOVE the MFMA phase (hipcc sank them below it)
-        const float* Ab = As + buf * BM * LROW + a_frag0;
-        const float* Bb = Bs + buf * BN * LROW + b_frag0;
-        if (PRIO == 1) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int g = 0; g < BKT / 8; ++g) {
-            f32x4 af[MT], bf[NT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LROW + 8 * g);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LROW + 8 * g);
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-                    // conv1's row mode: the fourth channel of a pixel is zero in the staging and in the pack (cin <= 3): not issued
-                    if (MODE != MODE_ROW8) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
-                }
-        }
-        if (PRIO == 1) __builtin_amdgcn_s_setprio(0);
+        BE_MFMA_PHASE(buf);
         __builtin_amdgcn_sched_barrier(0);            // ... and the LDS hand-over stays below it
         BE_STORE_CHUNK(buf ^ 1);
         __syncthreads();
     }
+    }
 #undef BE_LOAD_CHUNK
+#undef BE_LOAD_CHUNK_UNI
+#undef BE_LOAD_UNI
+#undef BE_STORE_UNI
+#undef BE_MFMA_PHASE
 #undef BE_STORE_CHUNK
 
     // ---- epilogue: D[row][col], col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -296,7 +375,7 @@ __device__ __forceinline__ void conv_igemm_body(ConvArgs a, float* smem, const i
 
 namespace be {
 // be_conv.hip: a small-M training convolution PREPARED but not launched: the kernel arguments, the tile variant (0: 64x64 tiles =
-// conv_igemm_body<2,2,1,1,MODE_TAPS,16,0>, 1: 128x32 tiles = <4,1,1,1,...>), its grid (gx workgroups x S K-slices) and where the raw
+// conv_igemm_body<2,2,1,1,MODE_TAPS,16,0>, 1: 128x32 tiles = <4,1,1,1,...>, 2: 64x64 uniform tiles = <2,2,1,1,...,UNI>), its grid (gx workgroups x S K-slices) and where the raw
 // slices go ([S][M][ldp] in scratch when S > 1; S == 1: the epilogue writes y = conv + bias (+ res)).
 struct ConvPrep { be_igemm::ConvArgs args; int variant, S, ldp; unsigned gx; double flops, flops_exec; };
 int conv_train_prepare(const be_conv_desc* d, const float* x, const float* pw, const float* pb, const float* res, float* y, int ldy,

@@ -425,7 +425,8 @@ void k_bwd_gemms(BwdGemmsArgs g) {
     } else {
         const int c = b - g.n_w;
         if (CV == 0) be_igemm::conv_igemm_body<2, 2, 1, 1, be_igemm::MODE_TAPS, 16, 0>(g.ca, smem, c % g.cgx, c / g.cgx, 0);
-        else be_igemm::conv_igemm_body<4, 1, 1, 1, be_igemm::MODE_TAPS, 16, 0>(g.ca, smem, c % g.cgx, c / g.cgx, 0);
+        else if (CV == 1) be_igemm::conv_igemm_body<4, 1, 1, 1, be_igemm::MODE_TAPS, 16, 0>(g.ca, smem, c % g.cgx, c / g.cgx, 0);
+        else be_igemm::conv_igemm_body<2, 2, 1, 1, be_igemm::MODE_TAPS, 16, 0, true>(g.ca, smem, c % g.cgx, c / g.cgx, 0);   // uniform tiles
     }
 }
 
@@ -1271,10 +1272,14 @@ extern "C" int be_train_unit_bwd_f32(const be_conv_desc* d, const float* x, cons
                 static be::DeviceFlags f0{};
                 if (int rc_ = be::ensure_dynamic_lds(reinterpret_cast<const void*>(&k_bwd_gemms<0>), lds, f0)) return rc_;
                 hipLaunchKernelGGL(k_bwd_gemms<0>, dim3(grid), dim3(256), lds, s, g);
-            } else {
+            } else if (prep.variant == 1) {
                 static be::DeviceFlags f1{};
                 if (int rc_ = be::ensure_dynamic_lds(reinterpret_cast<const void*>(&k_bwd_gemms<1>), lds, f1)) return rc_;
                 hipLaunchKernelGGL(k_bwd_gemms<1>, dim3(grid), dim3(256), lds, s, g);
+            } else {
+                static be::DeviceFlags f2{};
+                if (int rc_ = be::ensure_dynamic_lds(reinterpret_cast<const void*>(&k_bwd_gemms<2>), lds, f2)) return rc_;
+                hipLaunchKernelGGL(k_bwd_gemms<2>, dim3(grid), dim3(256), lds, s, g);
             }
             if (prep.S > 1) {
                 pa.xpart = reinterpret_cast<const float*>(sc + SCR_CONV); pa.xadd = dx_add; pa.dx = dx; pa.xM = M; pa.xC = d->cin;
