@@ -1154,6 +1154,7 @@ extern "C" int be_train_unit_fwd_f32(const be_conv_desc* d, const float* x, cons
     int rc = be::conv_train(&dc, x, pw, pb, nullptr, y, C, sc + SCR_CONV, SCR_WGRAD - SCR_CONV, &S, &ldp, stream);
     if (rc) return rc;
     const RowBlocks sb = stat_blocks(M, C);
+    BE_REQUIRE((size_t)sb.n * C * 2 * sizeof(double) <= SCR_DBPART - SCR_STATS, "be_train_unit_fwd_f32: statistics region too small");
     StatsArgs sa{S > 1 ? reinterpret_cast<const float*>(sc + SCR_CONV) : nullptr, pb, y, reinterpret_cast<double*>(sc + SCR_STATS),
                  S > 1 ? S : 0, M, C, ldp, sb.rows};
     hipLaunchKernelGGL(k_bn_stats, dim3(C / UC, sb.n), dim3(256), 0, s, sa);
@@ -1190,6 +1191,8 @@ extern "C" int be_train_unit_bwd_f32(const be_conv_desc* d, const float* x, cons
     hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(C / UC, sb.n), dim3(256), 0, s, ra);
     // 2. dgamma / dbeta finished in the prologue; dy; column sums of dy per workgroup
     const RowBlocks ab = apply_blocks(M, C, 128);
+    BE_REQUIRE((size_t)sb.n * C * 2 * sizeof(double) <= SCR_DBPART - SCR_STATS && (size_t)ab.n * C * sizeof(double) <= SCR_CONV - SCR_DBPART,
+               "be_train_unit_bwd_f32: reduction regions too small");
     BwdApplyArgs ba{ds, y, mean, invstd, gamma, part, dy, dgamma, dbeta, dbpart, sb.n, M, C, ab.rows, 1.0f / (float)M};
     hipLaunchKernelGGL(k_bn_bwd_apply, dim3(C / UC, ab.n), dim3(256), 0, s, ba);
     // 3. + 4. the weight-gradient GEMM and the data-gradient convolution (through the transposed / mirrored pack): slices of both
