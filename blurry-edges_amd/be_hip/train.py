@@ -84,6 +84,10 @@ class _Packs:
               "be_conv_pack_jobs_f32")
 
 
+# ---- the single-purpose (layer-level) forms of round 2: conv, BatchNorm forward / backward, weight gradient, column sum, data
+#      gradient, each its own C call.  The training step no longer uses them (it calls the units below); they stay as the
+#      reference chain of tests/test_train_gpu.py::test_training_unit_matches_the_single_purpose_kernels and for GlobalStage's
+#      training path (_col_sum, _wgrad).
 def _conv_fwd(x, packs, wi, cout, ks):
     """plain conv / linear + bias (no BatchNorm fold) with the step's packed weights: x NHWC -> y NHWC."""
     pw, pb = packs.fwd[wi]
