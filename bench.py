@@ -181,6 +181,7 @@ def leg_local_training(dev, native, peak, steps=60):
     last = float(step())
     # dominant matrix kernel of the step: the same step eagerly (a captured graph has no per-launch events)
     eager = lambda: train_local.train_step(model, helper, opt, {k: v[:B] for k, v in data.items()}, args.beta_bndry_loc, args.beta_smthns)
+    eager_ms = timed(eager, 40, warmup=5)                      # the same step as eager launches (4.2 ms in round 2)
     prof, recs = conv_profile(native, eager, 5, peak, per_iter=512)
     try:
         census = native.graph_node_counts(gstep.graph)           # every launch of the replayed step, torch's included
@@ -189,6 +190,7 @@ def leg_local_training(dev, native, peak, steps=60):
     return dict(config="configs[2]: local_training.py step, batch 64 (fwd with batch statistics + LocalLoss + bwd + clip 1.0 + AdamW), "
                        "one replayed hipGraph", ms_per_step=round(ms, 4), patches_per_s=round(B / ms * 1e3, 1), steps=steps,
                 first_loss=first, last_loss=last, graph_nodes=census, launches_per_step=census.get("kernels"),
+                eager_ms_per_step=round(eager_ms, 4),
                 matrix_launches_per_step=len(recs) // 5 if recs else None,
                 matrix_kernel_ms_per_step=round(sum(r[3] for r in recs) / 5, 4) if recs else None, dominant_kernel=prof)
 
