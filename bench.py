@@ -354,7 +354,7 @@ def leg_dp(dev, native, dist, rank, world, steps):
         res["compute_only_step_ms"] = round(clock(lambda: step(False), steps), 4)
         dp.broadcast_bn_stats(model, src=0)
     if sync is not None:
-        # the same step as six hipGraph segments with the RCCL calls between them (train_local.SegmentedGraphStep): what
+        # the same step as hipGraph segments (buckets + 1) with the RCCL calls between them (train_local.SegmentedGraphStep): what
         # `be_hip.workflow local_train` runs under torchrun.  Last, because it is the newest code on the RCCL path.
         seg = train_local.SegmentedGraphStep(model, helper, opt, sync, world=world)
 

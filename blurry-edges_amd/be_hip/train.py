@@ -203,7 +203,7 @@ def _unit_fwd(xin, packs, wi, cout, ks, gamma, beta, rm, rv, res, act):
 
 
 def _unit_bwd(xin, dout, saved, gamma, dg_pack, dx_add, ks, chw_hw, dgamma, dbeta, dw, db):
-    """backward of _unit_fwd in five launches (be_train_unit_bwd_f32): -> (ds, dx); dx is None when dg_pack is None, and
+    """backward of _unit_fwd in four launches (be_train_unit_bwd_f32): -> (ds, dx); dx is None when dg_pack is None, and
     includes dx_add (the other branch of a residual block) when given."""
     y, mean, invstd, s_in = saved
     n, h, w, cin = xin.shape

@@ -111,7 +111,7 @@ class SegmentedGraphStep:
     (be_hip.train.set_grad_hook: fc, layer3, layer2, layer1, conv1 + layer0): segment k ends there, the host replays it and
     issues bucket k's all-reduce on the side stream (GradSync.bucket_ready: event behind the segment, RCCL call), then replays
     segment k + 1, which therefore overlaps that collective; the last segment is the division by the world size, the gradient
-    clipping and AdamW.  Host cost per step: six graph launches + five RCCL calls.
+    clipping and AdamW.  Host cost per step: buckets + 1 graph launches + one RCCL call per bucket (default: 5 + 4).
     The step runs WITHOUT the autograd engine (forward_train / the fused loss kernel / backward_train called directly): the
     engine would run the backward - and the hook that ends and begins captures - on another thread than the one that began the
     capture.  Same kernels, same order, same results as train_step (tests/test_dp_gpu.py)."""
@@ -251,7 +251,7 @@ def main(argv=None):
     losses = []
     step_fn = None
     if a.graph and world > 1:
-        # a collective cannot be captured into a hipGraph on this stack: the data-parallel step is six graph segments with the
+        # a collective cannot be captured into a hipGraph on this stack: the data-parallel step is graph segments (buckets + 1) with the
         # bucket all-reduces issued between them (one whole-step capture here would hang or fail at capture)
         step_fn = SegmentedGraphStep(model, helper, opt, sync, world=world)
     elif a.graph:

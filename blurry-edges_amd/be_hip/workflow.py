@@ -85,7 +85,7 @@ def local_train(args, quiet=False, graph=True):
     model = models.LocalStage().to(dev)
     _xavier_(model)
     # data parallel (configs[4]): every rank keeps a replica, takes every world-th batch of the epoch's (identically shuffled)
-    # batch sequence - a global batch of batch_size x world - and the gradients are averaged by the five-bucket all-reduce that
+    # batch sequence - a global batch of batch_size x world - and the gradients are averaged by the bucketed all-reduce (four buckets) that
     # overlaps the backward (be_hip.dp.GradSync).  graph=True: the step is six hipGraph segments with the RCCL calls between
     # them (train_local.SegmentedGraphStep); one GPU: one hipGraph (GraphedStep)
     sync = dp.GradSync(world) if world > 1 else None

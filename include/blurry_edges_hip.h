@@ -401,7 +401,8 @@ int be_train_unit_fwd_f32(const be_conv_desc* desc_host, const float* x, const f
                           const float* gamma, const float* beta, const float* res, float eps, float momentum, float* run_mean,
                           float* run_var, float* y, float* mean, float* invstd, float* s_in, float* out, int act,
                           void* scratch, size_t scratch_bytes, void* stream);
-/* Backward of that unit (the autograd graph under loss.backward(), local_training.py:106) in five launches: ds = dout *
+/* Backward of that unit (the autograd graph under loss.backward(), local_training.py:106) in four launches (the weight-gradient
+ * GEMM and the data-gradient convolution share one grid): ds = dout *
  * smish'(s_in) (s_in NULL: ds = dout; ds is also the residual's gradient) with its column sums; dgamma / dbeta and
  * dy = gamma*invstd*(ds - dbeta/M - xhat*dgamma/M) with the column sums of dy; the weight-gradient GEMM over x (desc = the
  * FORWARD shape; ksize 7: x is the NHWC4 staging and dw is [cout][3][7][7]; layout_chw_hw as in be_conv_pack_f32); the
