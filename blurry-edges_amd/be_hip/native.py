@@ -54,6 +54,20 @@ class ConvDesc(C.Structure):
     _fields_ = [(n, C.c_int) for n in ("n", "h", "w", "cin", "cout", "ksize", "act")]
 
 
+class TrainUnitFwd(C.Structure):
+    """be_train_unit_fwd: one unit of be_train_unit_pair_fwd_f32 (the arguments of be_train_unit_fwd_f32 as a struct)."""
+    _fields_ = [("desc", ConvDesc)] + [(n, C.c_void_p) for n in
+                ("x", "packed_w", "packed_bias", "gamma", "beta", "res", "run_mean", "run_var", "y", "mean", "invstd", "s_in", "out")] + \
+               [("act", C.c_int)]
+
+
+class TrainUnitBwd(C.Structure):
+    """be_train_unit_bwd: one unit of be_train_unit_pair_bwd_f32."""
+    _fields_ = [("desc", ConvDesc)] + [(n, C.c_void_p) for n in
+                ("x", "dout", "s_in", "y", "mean", "invstd", "gamma", "dgrad_packed_w", "dgrad_packed_bias", "dx_add")] + \
+               [("layout_chw_hw", C.c_int)] + [(n, C.c_void_p) for n in ("ds", "dy", "dgamma", "dbeta", "dw", "db", "dx")]
+
+
 _P = C.c_void_p
 _SIGNATURES = {
     "be_version": (C.c_int, []),
@@ -143,6 +157,8 @@ _SIGNATURES = {
     "be_local_loss_finish_f32": (C.c_int, [_P, C.c_int, C.c_float, C.c_float, _P, _P]),
     "be_train_unit_fwd_f32": (C.c_int, [_P] * 7 + [C.c_float, C.c_float] + [_P] * 7 + [C.c_int, _P, C.c_size_t, _P]),
     "be_train_unit_bwd_f32": (C.c_int, [_P] * 11 + [C.c_int] + [_P] * 8 + [C.c_size_t, _P]),
+    "be_train_unit_pair_fwd_f32": (C.c_int, [C.POINTER(TrainUnitFwd), C.POINTER(TrainUnitFwd), C.c_float, C.c_float, _P, C.c_size_t, _P]),
+    "be_train_unit_pair_bwd_f32": (C.c_int, [C.POINTER(TrainUnitBwd), C.POINTER(TrainUnitBwd), _P, C.c_size_t, _P]),
     "be_linear_param_grads_f32": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
     "be_linear_small_fwd_f32": (C.c_int, [_P] * 4 + [C.c_int] * 3 + [_P]),
     "be_maxpool_nhwc_fwd_idx_f32": (C.c_int, [_P, _P, _P] + [C.c_int] * 7 + [_P]),

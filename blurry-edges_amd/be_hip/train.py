@@ -227,6 +227,65 @@ def _unit_bwd(xin, dout, saved, gamma, dg_pack, dx_add, ks, chw_hw, dgamma, dbet
     return ds, dx
 
 
+def _unit_pair_fwd(xin, packs, ua, ub):
+    """Two units on the same input that produce the same [n,h,w,cout] - a residual block's 3x3 convolution and its 1x1 downsample -
+    with every launch shared (be_train_unit_pair_fwd_f32).  ua / ub = (wi, cout, ks, gamma, beta, run_mean, run_var, act).
+    Returns ((out_a, saved_a), (out_b, saved_b)) as two _unit_fwd calls would, bit for bit."""
+    n, h, w, cin = xin.shape
+    dev = xin.device
+    o = native.ops()
+    if o is not None:
+        (wa, ca, ka, ga, ba, rma, rva, acta), (wb, cb, kb, gb, bb, rmb, rvb, actb) = ua, ub
+        r = o.train_unit_pair_fwd(xin, *packs.fwd[wa], ga, ba, rma, rva, ca, ka, bool(acta), *packs.fwd[wb], gb, bb, rmb, rvb, cb, kb,
+                                  bool(actb), BN_EPS, BN_MOMENTUM, _Scratch.get(dev))
+        return ((r[0], (r[1], r[2], r[3], r[4] if acta else None)), (r[5], (r[6], r[7], r[8], r[9] if actb else None)))
+    sc = _Scratch.get(dev)
+    structs, res = [], []
+    for wi, cout, ks, gamma, beta, rm, rv, act in (ua, ub):
+        pw, pb = packs.fwd[wi]
+        y = torch.empty(n, h, w, cout, dtype=torch.float32, device=dev)
+        out = torch.empty_like(y)
+        s_in = torch.empty_like(y) if act else None
+        mean, invstd = _new(cout, dev), _new(cout, dev)
+        structs.append(native.TrainUnitFwd(native.ConvDesc(n, h, w, cin, cout, ks, 0), dptr(xin), dptr(pw), dptr(pb), dptr(gamma), dptr(beta),
+                                           None, dptr(rm), dptr(rv), dptr(y), dptr(mean), dptr(invstd), dptr(s_in), dptr(out), int(act)))
+        res.append((out, (y, mean, invstd, s_in)))
+    check(lib().be_train_unit_pair_fwd_f32(C.byref(structs[0]), C.byref(structs[1]), BN_EPS, BN_MOMENTUM, dptr(sc), sc.numel() * 4,
+                                           stream_ptr(dev)), "be_train_unit_pair_fwd_f32")
+    return tuple(res)
+
+
+def _unit_pair_bwd(xin, ua, ub):
+    """Backward of _unit_pair_fwd's two units in shared launches (be_train_unit_pair_bwd_f32).
+    ua / ub = (dout, saved, gamma, dg_pack, ks, dgamma, dbeta, dw, db).  Returns (ds_a, ds_b, dx) with dx = the SUM of the two
+    units' input gradients."""
+    n, h, w, cin = xin.shape
+    dev = xin.device
+    o = native.ops()
+    if o is not None:
+        (da, sa, ga, pa, ka, dga, dba, dwa, dbia), (db_, sb, gb, pb_, kb, dgb, dbb, dwb, dbib) = ua, ub
+        r = o.train_unit_pair_bwd(xin, da.contiguous(), sa[3], sa[0], sa[1], sa[2], ga, pa[0], pa[1], ka, dga, dba, dwa, dbia,
+                                  db_.contiguous(), sb[3], sb[0], sb[1], sb[2], gb, pb_[0], pb_[1], kb, dgb, dbb, dwb, dbib, _Scratch.get(dev))
+        return r[0], r[1], r[2]
+    sc = _Scratch.get(dev)
+    structs, dss, dxs, keep = [], [], [], []
+    for dout, saved, gamma, dg_pack, ks, dgamma, dbeta, dw, db in (ua, ub):
+        y, mean, invstd, s_in = saved
+        cout = y.shape[-1]
+        dout = dout.contiguous()
+        ds, dy = torch.empty_like(y), torch.empty_like(y)
+        dx = torch.empty(n, h, w, cin, dtype=torch.float32, device=dev)
+        keep += [dout, dy]
+        structs.append(native.TrainUnitBwd(native.ConvDesc(n, h, w, cin, cout, ks, 0), dptr(xin), dptr(dout), dptr(s_in), dptr(y), dptr(mean),
+                                           dptr(invstd), dptr(gamma), dptr(dg_pack[0]), dptr(dg_pack[1]), None, 0, dptr(ds), dptr(dy),
+                                           dptr(dgamma), dptr(dbeta), dptr(dw), dptr(db), dptr(dx)))
+        dss.append(ds)
+        dxs.append(dx)
+    check(lib().be_train_unit_pair_bwd_f32(C.byref(structs[0]), C.byref(structs[1]), dptr(sc), sc.numel() * 4, stream_ptr(dev)),
+          "be_train_unit_pair_bwd_f32")
+    return dss[0], dss[1], dxs[0]
+
+
 def forward_train(x, t):
     """x [N,3,21,21]; t = the 86 tensors (native.local_stage_pack order).  Returns (logits [N,10], saved)."""
     n = x.shape[0]
@@ -246,8 +305,11 @@ def forward_train(x, t):
     p1, S["pool1"] = _pool_fwd_idx(a1, 3, 2, 1)
 
     def block(tag, base, xin):
-        tt = unit(tag + ".conv1", base, xin)
-        d = unit(tag + ".ds", base + 2, xin, act=False)
+        # conv1 and the downsample read the same input and are independent of each other: one set of launches for the two
+        ua, ub = [(6 * i, CONVS[i][1], CONVS[i][3], t[6 * i + 2], t[6 * i + 3], t[6 * i + 4], t[6 * i + 5], act)
+                  for i, act in ((base, True), (base + 2, False))]
+        (tt, saved_a), (d, saved_b) = _unit_pair_fwd(xin, packs, ua, ub)
+        S[tag + ".conv1"], S[tag + ".ds"] = (xin, saved_a), (xin, saved_b)
         return unit(tag + ".conv2", base + 1, tt, res=d)
 
     l0 = block("layer0", 1, p1)
@@ -332,9 +394,12 @@ def backward_train(dlogits, t, S):
 
     def block_bwd(tag, base, dout):
         ds_, dt = unit_bwd(tag + ".conv2", base + 1, dout)            # ds_ = dout * smish'(.) = grad of the residual too
-        _, dx_ds = unit_bwd(tag + ".ds", base + 2, ds_)
-        _, dx_in = unit_bwd(tag + ".conv1", base, dt, dx_add=dx_ds)   # both branches' input gradients, summed in the last kernel
-        return dx_in
+        # conv1 (gradient dt) and the downsample (gradient ds_): shared launches, both branches' input gradients summed in the last
+        xin, saved_a = S[tag + ".conv1"]
+        _, saved_b = S[tag + ".ds"]
+        ua, ub = [(g_, sv, t[6 * i + 2], packs.dg[6 * i], CONVS[i][3], grads[6 * i + 2], grads[6 * i + 3], grads[6 * i], grads[6 * i + 1])
+                  for i, g_, sv in ((base, dt, saved_a), (base + 2, ds_, saved_b))]
+        return _unit_pair_bwd(xin, ua, ub)[2]
 
     d = block_bwd("layer3", 10, d)
     done(1)

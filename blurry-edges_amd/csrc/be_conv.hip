@@ -436,6 +436,79 @@ __device__ __forceinline__ void pack_body(const PackArgs& p) {
 
 __global__ void k_pack(PackArgs p) { pack_body(p); }
 
+// The job-table form of the same packs (a training step re-packs 29 MB of weights twice, fc.1's 1024 x 3456 matrix being half of
+// it): pack_body's element-per-thread walk spends its time in 64-bit divisions and, for the transposed pack, reads one float per
+// cache line.  Here every source element is read once in runs of >= 64 B and takes its new place through LDS (round 3: 54 -> see
+// profiles/r03_local_train_step_sequence.txt).  Same values in the same places as pack_body (tests compare the two).
+constexpr int PACK_ROW_MAX = 4096;                  // floats of one source row (cin * taps) the forward form stages
+constexpr int PACK_LDS_FLOATS = PACK_ROW_MAX > BK * (16 * 9 + 1) ? PACK_ROW_MAX : BK * (16 * 9 + 1);
+static_assert(BK == 32, "the pack tiles below are laid out for 32-channel chunks");
+
+template <int TAPS>
+__device__ __forceinline__ void pack_fwd_rows(const PackArgs& p, float* lds) {
+    // out[row][(cc * TAPS + tap) * BK + e] = w[row][cc * BK + e][tap] * scale: a permutation of the row, which is contiguous in w
+    const int rowlen = p.cin * TAPS, cpg = p.chw_hw > 0 ? p.cin / p.chw_hw : 1;
+    for (int row = blockIdx.x; row < p.cout_pad; row += gridDim.x) {
+        const bool real = row < p.cout;
+        __syncthreads();
+        if (real)
+            for (int i = threadIdx.x; i < rowlen; i += blockDim.x) lds[i] = p.w[(size_t)row * rowlen + i];
+        __syncthreads();
+        const float scale = real && p.gamma ? p.gamma[row] / sqrtf(p.var[row] + p.eps) : 1.0f;
+        float* out = p.pw + (size_t)row * p.row_stride + p.col_off;
+        for (int k = threadIdx.x; k < p.ktot; k += blockDim.x) {
+            const int kc = k / BK, e = k % BK, cc = kc / TAPS, tap = kc - cc * TAPS, ci = cc * BK + e;
+            int src;
+            if (p.chw_hw > 0) { const int hw = ci / cpg; src = (ci - hw * cpg) * p.chw_hw + hw; }
+            else src = ci * TAPS + tap;
+            out[k] = real ? lds[src] * scale : 0.0f;
+        }
+    }
+}
+
+template <int TAPS>
+__device__ __forceinline__ void pack_dgrad_tiles(const PackArgs& p, float* lds) {
+    // out[row(ci)][(cc * TAPS + tap) * BK + e] = w[cc * BK + e][ci][TAPS - 1 - tap]: tiles of one chunk of 32 output channels x 16
+    // input channels x TAPS, read as 32 runs of 16 * TAPS floats, written as runs of 32
+    constexpr int CT = 16, LD = CT * TAPS + 1;
+    const int ncc = p.cout / BK, nct = p.cout_pad / CT, cpg = p.chw_hw > 0 ? p.cin / p.chw_hw : 1;
+    for (int u = blockIdx.x; u < ncc * nct; u += gridDim.x) {
+        const int cc = u / nct, ct = u - cc * nct, ci0 = ct * CT;
+        __syncthreads();
+        {
+            const int left = p.cin - ci0, run = (left < CT ? (left > 0 ? left : 0) : CT) * TAPS;
+            for (int o = threadIdx.x >> 4; o < BK; o += 16) {
+                const float* src = p.w + ((size_t)(cc * BK + o) * p.cin + ci0) * TAPS;
+                for (int i = threadIdx.x & 15; i < run; i += 16) lds[o * LD + i] = src[i];
+            }
+        }
+        __syncthreads();
+        const int e = threadIdx.x & 31;
+        for (int l = threadIdx.x >> 5; l < CT; l += 8) {
+            const int ci = ci0 + l;                                // the reference's input channel index
+            // our NHWC row of that channel (features flattened from (C,H,W): models/local_stage.py:73)
+            int row = ci;
+            if (p.chw_hw > 0 && ci < p.cin) { const int c_real = ci / p.chw_hw, hw = ci - c_real * p.chw_hw; row = hw * cpg + c_real; }
+            float* out = p.pw + (size_t)row * p.row_stride + p.col_off + (size_t)cc * TAPS * BK + e;
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) out[tap * BK] = ci < p.cin ? lds[e * LD + l * TAPS + (TAPS - 1 - tap)] : 0.0f;
+        }
+    }
+}
+
+__device__ __forceinline__ void pack_bias(const PackArgs& p) {
+    const int stride = gridDim.x * blockDim.x;
+    for (int co = blockIdx.x * blockDim.x + threadIdx.x; co < p.cout_pad; co += stride) {
+        float v = 0.0f;
+        if (!p.dgrad && co < p.cout) {
+            const float b = p.b ? p.b[co] : 0.0f;
+            if (p.gamma) v = (b - p.mean[co]) * (p.gamma[co] / sqrtf(p.var[co] + p.eps)) + p.beta[co];
+            else v = b;
+        }
+        if (p.bias_add) p.pb[co] += v; else p.pb[co] = v;
+    }
+}
+
 // a table of pack jobs in ONE launch (blockIdx.y = job): a training step re-packs every layer's weights for the forward
 // and for the data-gradient convolution, 28 launches of a few microseconds otherwise
 __global__ void k_pack_jobs(const be_pack_job* __restrict__ jobs) {
@@ -447,7 +520,12 @@ __global__ void k_pack_jobs(const be_pack_job* __restrict__ jobs) {
     if (j.dgrad) { p.cout_pad = (j.cin + 31) / 32 * 32; p.ktot = (j.cout / BK) * j.ksize * j.ksize * BK; }
     else { p.cout_pad = (j.cout + 31) / 32 * 32; p.ktot = (j.ksize == 7 ? 7 : (j.cin / BK) * j.ksize * j.ksize) * BK; }
     p.row_stride = p.ktot;
-    pack_body(p);
+    __shared__ float lds[PACK_LDS_FLOATS];
+    const int taps = j.ksize * j.ksize;
+    if (j.ksize == 7 || (!j.dgrad && (j.cin * taps > PACK_ROW_MAX || j.cin % BK))) { pack_body(p); return; }
+    if (j.dgrad) { if (taps == 9) pack_dgrad_tiles<9>(p, lds); else pack_dgrad_tiles<1>(p, lds); }
+    else { if (taps == 9) pack_fwd_rows<9>(p, lds); else pack_fwd_rows<1>(p, lds); }
+    pack_bias(p);
 }
 
 // ------------------------------------------------------------------------------------------- pooling / layout
@@ -739,9 +817,7 @@ int be::conv_train_prepare(const be_conv_desc* d, const float* x, const float* p
     prep->variant = -1;
     SplitOut so{1, 0, prep};
     const int rc = conv_dispatch(d, x, nullptr, 0, pw, pb, res, y, ldy, nullptr, scratch, scratch_bytes, &so);
-    if (rc) return rc;
-    BE_REQUIRE(prep->variant >= 0, "conv_train_prepare: not a small-M convolution (n %d, %dx%d, cin %d, cout %d)", d->n, d->h, d->w, d->cin, d->cout);
-    return BE_OK;
+    return rc;        // prep->variant stays -1 for a shape outside the small-M tiles: the caller launches it on its own instead
 }
 
 static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2, int cin2, const float* pw, const float* pb,

@@ -1,4 +1,4 @@
-// LocalLoss forward + analytic backward in one launch, one wavefront per patch (gfx950).
+// LocalLoss forward + analytic backward in one launch, one wavefront (large batches) or four (the training batch) per patch (gfx950).
 //
 // Replaces LocalLoss.get_patches + LocalLoss.forward (local_training.py:32-52) and everything autograd records
 // under them (params2dists, params2etas, dists2indicators, the ridge solve through inverse_3by3, the composite,
@@ -10,13 +10,17 @@
 // (dC -> v = G^-1 dC -> db = v, dG = -v C^T) -> indicators -> erf -> wedge distances -> vertices / angles / eta).
 // Hard selections (min, where, sign) take the derivative of the selected branch, as autograd does.
 // Per patch the kernel reads 441*3*2 + 441 + 361*3 floats and writes 10 + 3 floats; LDS holds the rendered patch
-// and the two Sobel adjoint images of the wave (14 KB per wave).
+// and the two Sobel adjoint images of the patch (14 KB per patch).
+//
+// WPP = wavefronts per patch.  A training step has 64 patches: with one wavefront each the launch is 64 waves walking 441 pixels in
+// 7 passes of fp64 erf / exp chains, every instruction's latency exposed (59 us, round 3 trace).  WPP = 4 gives a patch a whole
+// workgroup (2 passes); the per-patch sums cross the four waves through LDS in a fixed order, so results stay run-to-run identical.
 #include "be_common.h"
 #include "be_wedge_d.h"
 
 namespace {
 
-constexpr int NPIX = BE_NPIX, R = BE_R, PASSES = 7, WAVES = 4;
+constexpr int NPIX = BE_NPIX, R = BE_R, WAVES = 4;
 constexpr int Q = 19, NQ = Q * Q;                 // valid-Sobel output 19x19
 
 struct LossArgs {
@@ -35,16 +39,45 @@ struct LossArgs {
 
 using namespace be_d;
 
+// sums of N per-lane values over the lanes of a patch: DPP wave sums, then (WPP > 1) the waves' totals through LDS, added in wave order
+template <int WPP, int N, class T>
+__device__ __forceinline__ void patch_sum(T (&v)[N], double* red, int wave, int lane64) {
+#pragma unroll
+    for (int k = 0; k < N; ++k) {
+        if constexpr (sizeof(T) == 8) v[k] = wave_sum_d(v[k]); else v[k] = be::wave_sum(v[k]);
+    }
+    if constexpr (WPP > 1) {
+        T* r = reinterpret_cast<T*>(red);
+        __syncthreads();                                       // the previous sum's readers are done with `red`
+        if (lane64 == 0) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) r[wave * N + k] = v[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            T t = r[k];
+#pragma unroll
+            for (int w = 1; w < WPP; ++w) t += r[w * N + k];
+            v[k] = t;
+        }
+    }
+}
+
+template <int WPP>
 __global__ __launch_bounds__(64 * WAVES)
 void k_local_loss(be_render_opts o, LossArgs a) {
+    constexpr int SLOTS = WAVES / WPP, T = 64 * WPP, PASSES = (NPIX + T - 1) / T;
     __shared__ float lin[R];
-    __shared__ float sPatch[WAVES][3][NPIX];
-    __shared__ float sDx[WAVES][3][NQ];
-    __shared__ float sDy[WAVES][3][NQ];
+    __shared__ float sPatch[SLOTS][3][NPIX];
+    __shared__ float sDx[SLOTS][3][NQ];
+    __shared__ float sDy[SLOTS][3][NQ];
+    __shared__ double red[WAVES * 16];
     if (threadIdx.x < R) lin[threadIdx.x] = o.lin[threadIdx.x];
     __syncthreads();
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int64_t patch_raw = (int64_t)blockIdx.x * WAVES + wv;
+    const int lane = threadIdx.x % T, wv = threadIdx.x / T;      // lane within the patch, patch slot of the workgroup
+    const int lane64 = threadIdx.x & 63, wave = (threadIdx.x >> 6) % WPP;
+    const int64_t patch_raw = (int64_t)blockIdx.x * SLOTS + wv;
     const bool active = patch_raw < a.n;
     const int64_t patch = active ? patch_raw : a.n - 1;        // idle waves shadow the last patch (no stores)
 
@@ -60,7 +93,7 @@ void k_local_loss(be_render_opts o, LossArgs a) {
     float gs[6] = {0, 0, 0, 0, 0, 0}, bs[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int it = 0; it < PASSES; ++it) {
-        const int pix = it * 64 + lane;
+        const int pix = it * T + lane;
         const bool live = pix < NPIX;
         const int pc = live ? pix : 0;
         const int row = pc / R, col = pc - row * R;
@@ -76,10 +109,8 @@ void k_local_loss(be_render_opts o, LossArgs a) {
         bs[3] = fmaf(u1, yr, bs[3]); bs[4] = fmaf(u1, yg, bs[4]); bs[5] = fmaf(u1, yb, bs[5]);
         bs[6] = fmaf(u2, yr, bs[6]); bs[7] = fmaf(u2, yg, bs[7]); bs[8] = fmaf(u2, yb, bs[8]);
     }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) gs[k] = be::wave_sum(gs[k]);
-#pragma unroll
-    for (int k = 0; k < 9; ++k) bs[k] = be::wave_sum(bs[k]);
+    patch_sum<WPP>(gs, red, wave, lane64);
+    patch_sum<WPP>(bs, red, wave, lane64);
     // G (with ridge), its inverse by cofactors (fp64), colours C[c][k]
     const double A00 = (double)gs[0] + o.lambda_ridge, A01 = gs[1], A02 = gs[2], A11 = (double)gs[3] + o.lambda_ridge,
                  A12 = gs[4], A22 = (double)gs[5] + o.lambda_ridge;
@@ -103,7 +134,7 @@ void k_local_loss(be_render_opts o, LossArgs a) {
     float L1 = 0.f;
 #pragma unroll
     for (int it = 0; it < PASSES; ++it) {
-        const int pix = it * 64 + lane;
+        const int pix = it * T + lane;
         const bool live = pix < NPIX;
         const float h1 = h1s[it], h2 = h2s[it];
         const float u0 = (1.0f - h1) * (1.0f - h2), u1 = h1 * (1.0f - h2), u2 = h2;
@@ -124,7 +155,7 @@ void k_local_loss(be_render_opts o, LossArgs a) {
     // ---- Sobel magnitude on the 19x19 interior, smoothness loss and its adjoint images
     float L3 = 0.f;
     const float* dr = a.deri + patch * NQ * 3;
-    for (int q0 = 0; q0 < NQ; q0 += 64) {
+    for (int q0 = 0; q0 < NQ; q0 += T) {
         const int q = q0 + lane;
         if (q < NQ) {
             const int qy = q / Q, qx = q - qy * Q;
@@ -148,7 +179,7 @@ void k_local_loss(be_render_opts o, LossArgs a) {
     // ---- gather the Sobel adjoint back onto the 21x21 grid
 #pragma unroll
     for (int it = 0; it < PASSES; ++it) {
-        const int pix = it * 64 + lane;
+        const int pix = it * T + lane;
         if (pix < NPIX) {
             const int row = pix / R, col = pix - row * R;
 #pragma unroll
@@ -175,7 +206,7 @@ void k_local_loss(be_render_opts o, LossArgs a) {
     float dC[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int it = 0; it < PASSES; ++it) {
-        const bool live = it * 64 + lane < NPIX;
+        const bool live = it * T + lane < NPIX;
         const float h1 = h1s[it], h2 = h2s[it];
         const float u[3] = {live ? (1.0f - h1) * (1.0f - h2) : 0.f, live ? h1 * (1.0f - h2) : 0.f, live ? h2 : 0.f};
 #pragma unroll
@@ -183,8 +214,7 @@ void k_local_loss(be_render_opts o, LossArgs a) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) dC[c * 3 + k] = fmaf(gP[it][c], u[k], dC[c * 3 + k]);
     }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) dC[k] = be::wave_sum(dC[k]);
+    patch_sum<WPP>(dC, red, wave, lane64);
     float V[3][3], S[3][3];                                   // V[c][k]
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -205,7 +235,7 @@ void k_local_loss(be_render_opts o, LossArgs a) {
     float L2 = 0;
 #pragma unroll
     for (int it = 0; it < PASSES; ++it) {
-        const int pix = it * 64 + lane;
+        const int pix = it * T + lane;
         if (pix < NPIX) {
             const int row = pix / R, col = pix - row * R;
             const real px = lin[col], py = lin[row];
@@ -245,12 +275,14 @@ void k_local_loss(be_render_opts o, LossArgs a) {
             wedge_backward(px, py, g.x1, g.y1, g.s21, g.c21, g.s22, g.c22, g.sg2, true, o.w, gd2, gx1, gy1, gt2, gf2);
         }
     }
-    gx0 = wave_sum_d(gx0); gy0 = wave_sum_d(gy0); gx1 = wave_sum_d(gx1); gy1 = wave_sum_d(gy1);
-    gt1 = wave_sum_d(gt1); gf1 = wave_sum_d(gf1); gt2 = wave_sum_d(gt2); gf2 = wave_sum_d(gf2);
-    gr1 = wave_sum_d(gr1); gr2 = wave_sum_d(gr2);
-    L1 = be::wave_sum(L1); L2 = be::wave_sum(L2); L3 = be::wave_sum(L3);
+    real gsum[10] = {gx0, gy0, gx1, gy1, gt1, gf1, gt2, gf2, gr1, gr2};
+    float lsum[3] = {L1, L2, L3};
+    patch_sum<WPP>(gsum, red, wave, lane64);
+    patch_sum<WPP>(lsum, red, wave, lane64);
+    gx0 = gsum[0]; gy0 = gsum[1]; gx1 = gsum[2]; gy1 = gsum[3]; gt1 = gsum[4]; gf1 = gsum[5]; gt2 = gsum[6]; gf2 = gsum[7];
+    gr1 = gsum[8]; gr2 = gsum[9];
     if (lane == 0 && active) {
-        a.partial[patch * 3] = L1; a.partial[patch * 3 + 1] = L2; a.partial[patch * 3 + 2] = L3;
+        a.partial[patch * 3] = lsum[0]; a.partial[patch * 3 + 1] = lsum[1]; a.partial[patch * 3 + 2] = lsum[2];
         if (a.grad) {
             float* go = a.grad + patch * 10;
             go[0] = (float)gx0; go[1] = (float)gy0; go[2] = (float)gx1; go[3] = (float)gy1;
@@ -274,17 +306,22 @@ extern "C" int be_local_loss_f32(const be_render_opts* o, const float* est, cons
     BE_REQUIRE(o && est && img_fit && gt && bdist && deri && partial, "be_local_loss_f32: null pointer");
     LossArgs a{est, img_fit, gt, bdist, deri, partial, grad_est, patches, boundary,
                1.0f / ((float)n * NPIX), beta_bndry / ((float)n * NPIX), beta_smooth / ((float)n * NQ), n};
+    if (n <= 1024) {                     // a training batch: a workgroup per patch (the launch would not fill the chip otherwise)
+        hipLaunchKernelGGL(k_local_loss<WAVES>, dim3((unsigned)n), dim3(64 * WAVES), 0, be::as_stream(stream), *o, a);
+        return be::check_launch("be_local_loss_f32");
+    }
     const int64_t blocks = (n + WAVES - 1) / WAVES;
     BE_REQUIRE(blocks <= 0x7fffffff, "be_local_loss_f32: n too large");
-    hipLaunchKernelGGL(k_local_loss, dim3((unsigned)blocks), dim3(64 * WAVES), 0, be::as_stream(stream), *o, a);
+    hipLaunchKernelGGL(k_local_loss<1>, dim3((unsigned)blocks), dim3(64 * WAVES), 0, be::as_stream(stream), *o, a);
     return be::check_launch("be_local_loss_f32");
 }
 
 namespace {
 __global__ void k_local_loss_finish(const float* __restrict__ partial, int B, float beta_b, float beta_s, float* __restrict__ out) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-    for (int i = 0; i < B; ++i) { s0 += partial[3 * i]; s1 += partial[3 * i + 1]; s2 += partial[3 * i + 2]; }
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;           // one wavefront: lane l takes patches l, l + 64, ...; then the DPP tree (fixed order)
+    for (int i = threadIdx.x; i < B; i += 64) { s0 += partial[3 * i]; s1 += partial[3 * i + 1]; s2 += partial[3 * i + 2]; }
+    s0 = be_d::wave_sum_d(s0); s1 = be_d::wave_sum_d(s1); s2 = be_d::wave_sum_d(s2);
+    if (threadIdx.x != 0) return;
     const double n1 = (double)B * NPIX, n2 = (double)B * NQ;
     out[0] = (float)(s0 / n1 + (double)beta_b * s1 / n1 + (double)beta_s * s2 / n2);
 }

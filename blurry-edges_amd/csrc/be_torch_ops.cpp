@@ -124,6 +124,66 @@ std::tuple<Tensor, Tensor> train_unit_bwd(const Tensor& x, const Tensor& dout, c
     return {ds, dx};
 }
 
+// two units on one input with shared launches (a residual block's 3x3 convolution and 1x1 downsample): the outputs of two
+// train_unit_fwd calls, a's five then b's five
+std::vector<Tensor> train_unit_pair_fwd(const Tensor& x, const Tensor& pw_a, const Tensor& pb_a, const Tensor& gamma_a, const Tensor& beta_a,
+                                        Tensor rm_a, Tensor rv_a, int64_t cout_a, int64_t ks_a, bool act_a, const Tensor& pw_b,
+                                        const Tensor& pb_b, const Tensor& gamma_b, const Tensor& beta_b, Tensor rm_b, Tensor rv_b,
+                                        int64_t cout_b, int64_t ks_b, bool act_b, double eps, double momentum, Tensor scratch) {
+    TORCH_CHECK(x.dim() == 4, "train_unit_pair_fwd: x must be NHWC [N,H,W,C]");
+    const int64_t n = x.size(0), h = x.size(1), w = x.size(2), cin = x.size(3);
+    std::vector<Tensor> r;
+    be_train_unit_fwd u[2];
+    const Tensor* pw[2] = {&pw_a, &pw_b}; const Tensor* pb[2] = {&pb_a, &pb_b};
+    const Tensor* ga[2] = {&gamma_a, &gamma_b}; const Tensor* be[2] = {&beta_a, &beta_b};
+    Tensor* rm[2] = {&rm_a, &rm_b}; Tensor* rv[2] = {&rv_a, &rv_b};
+    const int64_t cout[2] = {cout_a, cout_b}, ks[2] = {ks_a, ks_b};
+    const bool act[2] = {act_a, act_b};
+    for (int j = 0; j < 2; ++j) {
+        Tensor y = at::empty({n, h, w, cout[j]}, x.options()), out = at::empty_like(y);
+        Tensor s_in = act[j] ? at::empty_like(y) : at::empty({0}, x.options());
+        Tensor mean = at::empty({cout[j]}, x.options()), invstd = at::empty({cout[j]}, x.options());
+        u[j] = be_train_unit_fwd{be_conv_desc{(int)n, (int)h, (int)w, (int)cin, (int)cout[j], (int)ks[j], 0}, fp(x, "x"), fp(*pw[j], "packed_w"),
+                                 fp(*pb[j], "packed_bias"), fp(*ga[j], "gamma"), fp(*be[j], "beta"), nullptr, fpm(*rm[j], "run_mean"),
+                                 fpm(*rv[j], "run_var"), y.data_ptr<float>(), mean.data_ptr<float>(), invstd.data_ptr<float>(),
+                                 act[j] ? s_in.data_ptr<float>() : nullptr, out.data_ptr<float>(), act[j] ? 1 : 0};
+        r.insert(r.end(), {out, y, mean, invstd, s_in});
+    }
+    check(be_train_unit_pair_fwd_f32(&u[0], &u[1], (float)eps, (float)momentum, scratch.data_ptr<float>(), (size_t)scratch.numel() * 4,
+                                     stream_of(x)), "be_train_unit_pair_fwd_f32");
+    return r;
+}
+
+// backward of the pair: -> (ds_a, ds_b, dx) with dx = the sum of the two units' input gradients
+std::vector<Tensor> train_unit_pair_bwd(const Tensor& x, const Tensor& dout_a, const optional<Tensor>& s_in_a, const Tensor& y_a,
+                                        const Tensor& mean_a, const Tensor& invstd_a, const Tensor& gamma_a, const Tensor& dg_pw_a,
+                                        const Tensor& dg_pb_a, int64_t ks_a, Tensor dgamma_a, Tensor dbeta_a, Tensor dw_a, Tensor db_a,
+                                        const Tensor& dout_b, const optional<Tensor>& s_in_b, const Tensor& y_b, const Tensor& mean_b,
+                                        const Tensor& invstd_b, const Tensor& gamma_b, const Tensor& dg_pw_b, const Tensor& dg_pb_b,
+                                        int64_t ks_b, Tensor dgamma_b, Tensor dbeta_b, Tensor dw_b, Tensor db_b, Tensor scratch) {
+    const int64_t n = x.size(0), h = x.size(1), w = x.size(2), cin = x.size(3);
+    const Tensor* dout[2] = {&dout_a, &dout_b}; const optional<Tensor>* s_in[2] = {&s_in_a, &s_in_b};
+    const Tensor* y[2] = {&y_a, &y_b}; const Tensor* mean[2] = {&mean_a, &mean_b}; const Tensor* invstd[2] = {&invstd_a, &invstd_b};
+    const Tensor* gamma[2] = {&gamma_a, &gamma_b}; const Tensor* pw[2] = {&dg_pw_a, &dg_pw_b}; const Tensor* pb[2] = {&dg_pb_a, &dg_pb_b};
+    Tensor* dgamma[2] = {&dgamma_a, &dgamma_b}; Tensor* dbeta[2] = {&dbeta_a, &dbeta_b}; Tensor* dw[2] = {&dw_a, &dw_b};
+    Tensor* db[2] = {&db_a, &db_b};
+    const int64_t ks[2] = {ks_a, ks_b};
+    be_train_unit_bwd u[2];
+    std::vector<Tensor> ds, dy, dx;
+    for (int j = 0; j < 2; ++j) {
+        ds.push_back(at::empty_like(*y[j])); dy.push_back(at::empty_like(*y[j])); dx.push_back(at::empty({n, h, w, cin}, x.options()));
+        const bool has_s = s_in[j]->has_value() && (*s_in[j])->defined() && (*s_in[j])->numel() > 0;
+        u[j] = be_train_unit_bwd{be_conv_desc{(int)n, (int)h, (int)w, (int)cin, (int)y[j]->size(-1), (int)ks[j], 0}, fp(x, "x"), fp(*dout[j], "dout"),
+                                 has_s ? fp(**s_in[j], "s_in") : nullptr, fp(*y[j], "y"), fp(*mean[j], "mean"), fp(*invstd[j], "invstd"),
+                                 fp(*gamma[j], "gamma"), fp(*pw[j], "dgrad_w"), fp(*pb[j], "dgrad_b"), nullptr, 0, ds[j].data_ptr<float>(),
+                                 dy[j].data_ptr<float>(), fpm(*dgamma[j], "dgamma"), fpm(*dbeta[j], "dbeta"), fpm(*dw[j], "dw"), fpm(*db[j], "db"),
+                                 dx[j].data_ptr<float>()};
+    }
+    check(be_train_unit_pair_bwd_f32(&u[0], &u[1], scratch.data_ptr<float>(), (size_t)scratch.numel() * 4, stream_of(x)),
+          "be_train_unit_pair_bwd_f32");
+    return {ds[0], ds[1], dx[0]};
+}
+
 std::tuple<Tensor, Tensor> maxpool_fwd_idx(const Tensor& x, int64_t k, int64_t stride, int64_t pad) {
     const int64_t n = x.size(0), h = x.size(1), w = x.size(2), c = x.size(3);
     const int64_t oh = (h + 2 * pad - k) / stride + 1, ow = (w + 2 * pad - k) / stride + 1;
@@ -162,6 +222,13 @@ TORCH_LIBRARY(be, m) {
           "int cout, int ksize, bool act, float eps, float momentum, Tensor(c!) scratch) -> (Tensor, Tensor, Tensor, Tensor, Tensor)");
     m.def("train_unit_bwd(Tensor x, Tensor dout, Tensor? s_in, Tensor y, Tensor mean, Tensor invstd, Tensor gamma, Tensor? dg_pw, Tensor? dg_pb, "
           "Tensor? dx_add, int ksize, int chw_hw, Tensor(a!) dgamma, Tensor(b!) dbeta, Tensor(c!) dw, Tensor(d!) db, Tensor(e!) scratch) -> (Tensor, Tensor)");
+    m.def("train_unit_pair_fwd(Tensor x, Tensor pw_a, Tensor pb_a, Tensor gamma_a, Tensor beta_a, Tensor(a!) rm_a, Tensor(b!) rv_a, int cout_a, "
+          "int ks_a, bool act_a, Tensor pw_b, Tensor pb_b, Tensor gamma_b, Tensor beta_b, Tensor(c!) rm_b, Tensor(d!) rv_b, int cout_b, int ks_b, "
+          "bool act_b, float eps, float momentum, Tensor(e!) scratch) -> Tensor[]");
+    m.def("train_unit_pair_bwd(Tensor x, Tensor dout_a, Tensor? s_in_a, Tensor y_a, Tensor mean_a, Tensor invstd_a, Tensor gamma_a, Tensor dg_pw_a, "
+          "Tensor dg_pb_a, int ks_a, Tensor(a!) dgamma_a, Tensor(b!) dbeta_a, Tensor(c!) dw_a, Tensor(d!) db_a, Tensor dout_b, Tensor? s_in_b, "
+          "Tensor y_b, Tensor mean_b, Tensor invstd_b, Tensor gamma_b, Tensor dg_pw_b, Tensor dg_pb_b, int ks_b, Tensor(e!) dgamma_b, "
+          "Tensor(f!) dbeta_b, Tensor(g!) dw_b, Tensor(h!) db_b, Tensor(i!) scratch) -> Tensor[]");
     m.def("maxpool_fwd_idx(Tensor x, int k, int stride, int pad) -> (Tensor, Tensor)");
     m.def("maxpool_bwd_idx(Tensor idx, Tensor dout, int h, int w, int k, int stride, int pad) -> Tensor");
     m.def("clip_adamw(Tensor table, int nentries, Tensor(a!) grad_flat, Tensor(b!) partial, float max_norm, float grad_scale, float lr, float beta1, "
@@ -175,6 +242,8 @@ TORCH_LIBRARY_IMPL(be, CUDA, m) {
     m.impl("local_stage_forward", local_stage_forward);
     m.impl("train_unit_fwd", train_unit_fwd);
     m.impl("train_unit_bwd", train_unit_bwd);
+    m.impl("train_unit_pair_fwd", train_unit_pair_fwd);
+    m.impl("train_unit_pair_bwd", train_unit_pair_bwd);
     m.impl("maxpool_fwd_idx", maxpool_fwd_idx);
     m.impl("maxpool_bwd_idx", maxpool_bwd_idx);
     m.impl("clip_adamw", clip_adamw);

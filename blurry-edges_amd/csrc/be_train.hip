@@ -399,34 +399,50 @@ void k_wgrad128(Wgrad128Args a) {
 
 // A unit's weight-gradient GEMM and its data-gradient convolution in ONE launch (VERDICT r2 #1a).  Both read dy, neither fills the
 // chip at batch 64 (a 3x3 layer: ~400 weight-gradient workgroups of 20-30 us, ~860 data-gradient workgroups of ~10 us), and a
-// hipGraph replays kernels one after the other: as one grid the two sets of workgroups share the CUs.  Workgroups [0, n_w) take
-// the weight gradient (the long ones first; n_w is a multiple of 8 so that the convolution's XCD-aware tile map - workgroup id mod
-// 8 = XCD - is unchanged), the rest are the convolution's (gx x S).  CV: the convolution's tile variant (be::ConvPrep).
-struct BwdGemmsArgs {
-    be_igemm::ConvArgs ca;
+// hipGraph replays kernels one after the other: as one grid the two sets of workgroups share the CUs.  The grid holds up to TWO
+// units' jobs - the 3x3 convolution and the 1x1 downsample of a residual block read the same input and are independent of each
+// other, forward and backward: workgroups [0, w_end[0]) take the first weight gradient, [w_end[0], w_end[1]) the second (the long
+// ones first), then the convolutions ([.., c_end0) the first, the rest the second; the forward pair is two convolutions and no
+// weight gradient).  Every range is padded to a multiple of 8 so that the convolution's XCD-aware tile map - workgroup id mod
+// 8 = XCD - is unchanged.  CV: the convolutions' tile variant (be::ConvPrep), the same for both.
+struct WJob {
     Wgrad128Args w128;
     WgradArgs w64;
     int wkind;                // 1: k_wgrad128 tiles, 0: k_wgrad tiles
-    int n_w, w_real, wx, wy;  // weight-gradient workgroups: padded count, real count, grid x / y of the stand-alone launch
-    int cgx;                  // convolution: workgroups per K slice
+    int real, wx, wy;         // workgroups of the stand-alone launch and its grid x / y
+};
+struct UnitGemmsArgs {
+    be_igemm::ConvArgs ca[2];
+    WJob w[2];
+    int w_end[2];             // padded ends of the two weight-gradient ranges (w_end[1] = first convolution workgroup)
+    int c_end0, c_real[2];    // padded size of the first convolution's range; real workgroups (gx x S) of both
+    int cgx[2];               // convolution: workgroups per K slice
 };
 constexpr int BWD_GEMMS_LDS_FLOATS = WGRAD64_LDS_FLOATS > WGRAD128_LDS_FLOATS ? WGRAD64_LDS_FLOATS : WGRAD128_LDS_FLOATS;   // > the conv's 6400
 
 template <int CV>
 __global__ __launch_bounds__(256, 3)
-void k_bwd_gemms(BwdGemmsArgs g) {
+void k_unit_gemms(UnitGemmsArgs g) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int b = blockIdx.x;
-    if (b < g.n_w) {
-        if (b >= g.w_real) return;
-        const int bx = b % g.wx, by = (b / g.wx) % g.wy, bz = b / (g.wx * g.wy);
-        if (g.wkind == 1) wgrad128_body(g.w128, smem, bx, by, bz);
-        else wgrad64_body(g.w64, smem, bx, by, bz);
+    int b = blockIdx.x;
+    if (b < g.w_end[1]) {
+        const int j = b >= g.w_end[0];
+        if (j) b -= g.w_end[0];
+        const WJob& w = g.w[j];
+        if (b >= w.real) return;
+        const int bx = b % w.wx, by = (b / w.wx) % w.wy, bz = b / (w.wx * w.wy);
+        if (w.wkind == 1) wgrad128_body(w.w128, smem, bx, by, bz);
+        else wgrad64_body(w.w64, smem, bx, by, bz);
     } else {
-        const int c = b - g.n_w;
-        if (CV == 0) be_igemm::conv_igemm_body<2, 2, 1, 1, be_igemm::MODE_TAPS, 16, 0>(g.ca, smem, c % g.cgx, c / g.cgx, 0);
-        else if (CV == 1) be_igemm::conv_igemm_body<4, 1, 1, 1, be_igemm::MODE_TAPS, 16, 0>(g.ca, smem, c % g.cgx, c / g.cgx, 0);
-        else be_igemm::conv_igemm_body<2, 2, 1, 1, be_igemm::MODE_TAPS, 16, 0, true>(g.ca, smem, c % g.cgx, c / g.cgx, 0);   // uniform tiles
+        int c = b - g.w_end[1];
+        const int j = c >= g.c_end0;
+        if (j) c -= g.c_end0;
+        if (c >= g.c_real[j]) return;
+        const be_igemm::ConvArgs& ca = g.ca[j];
+        const int cgx = g.cgx[j];
+        if (CV == 0) be_igemm::conv_igemm_body<2, 2, 1, 1, be_igemm::MODE_TAPS, 16, 0>(ca, smem, c % cgx, c / cgx, 0);
+        else if (CV == 1) be_igemm::conv_igemm_body<4, 1, 1, 1, be_igemm::MODE_TAPS, 16, 0>(ca, smem, c % cgx, c / cgx, 0);
+        else be_igemm::conv_igemm_body<2, 2, 1, 1, be_igemm::MODE_TAPS, 16, 0, true>(ca, smem, c % cgx, c / cgx, 0);   // uniform tiles
     }
 }
 
@@ -556,6 +572,11 @@ __device__ __forceinline__ void finish_partials(const double* __restrict__ parti
     __syncthreads();
 }
 
+// The four BatchNorm kernels of a unit take up to TWO jobs per launch (blockIdx.z picks one): the two units of a residual block
+// that are independent of each other - conv1 and the 1x1 downsample in the forward (same input), and again in the backward (both
+// gradients are ready once conv2's backward is done) - have the same shape [M, planes] and run side by side (round 3).
+template <class A> struct Two { A j[2]; };
+
 struct StatsArgs {
     const float* partial;   // [S][M][ldp] raw split-K slices, or null (S = 0: y is final already)
     const float* bias;      // [C] added to the slice sum (S > 0)
@@ -565,7 +586,8 @@ struct StatsArgs {
 };
 
 __global__ __launch_bounds__(256)
-void k_bn_stats(StatsArgs a) {
+void k_bn_stats(Two<StatsArgs> two) {
+    const StatsArgs a = two.j[blockIdx.z];
     __shared__ double lds[UR * UC * 2];
     const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
     const int c_base = blockIdx.x * UC, c = c_base + tx * 4;
@@ -605,7 +627,8 @@ struct FwdApplyArgs {
 };
 
 __global__ __launch_bounds__(256)
-void k_bn_fwd_apply(FwdApplyArgs a) {
+void k_bn_fwd_apply(Two<FwdApplyArgs> two) {
+    const FwdApplyArgs a = two.j[blockIdx.z];
     __shared__ double part[8 * UC * 2];
     __shared__ double tot[UC * 2];
     __shared__ float s_mu[UC], s_is[UC];
@@ -658,7 +681,8 @@ struct BwdReduceArgs {
 };
 
 __global__ __launch_bounds__(256)
-void k_bn_bwd_reduce(BwdReduceArgs a) {
+void k_bn_bwd_reduce(Two<BwdReduceArgs> two) {
+    const BwdReduceArgs a = two.j[blockIdx.z];
     __shared__ double lds[UR * UC * 2];
     const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
     const int c_base = blockIdx.x * UC, c = c_base + tx * 4;
@@ -692,7 +716,8 @@ struct BwdApplyArgs {
 };
 
 __global__ __launch_bounds__(256)
-void k_bn_bwd_apply(BwdApplyArgs a) {
+void k_bn_bwd_apply(Two<BwdApplyArgs> two) {
+    const BwdApplyArgs a = two.j[blockIdx.z];
     __shared__ double part[8 * UC * 2];
     __shared__ double tot[UC * 2];
     __shared__ double lds[UR * UC];
@@ -734,17 +759,20 @@ void k_bn_bwd_apply(BwdApplyArgs a) {
 // ONE launch after a unit's weight-gradient GEMM and data-gradient convolution: workgroups [0, nb_w) sum the weight-gradient
 // slices into dW, [nb_w, nb_w + nb_b) finish the bias gradient, the rest sum the data-gradient split-K slices (+ the other
 // branch's dx of a residual block) into dx.  Fixed order everywhere.
-struct PostArgs {
+struct PostJob {              // one unit's parameter-gradient roles
     const float* wpart; float* dw; int64_t wsize; int wS; int conv1_map, cout1;   // conv1_map: slices are [cout][7][8 px][4 ch]
     int wtaps;                // > 0: slices are [S][tap][cout][cin] (k_wgrad128), transposed here
     const double* dbpart; float* db; int nb_rows, C;
-    const float* xpart; const float* xadd; float* dx; int64_t xM; int xC, xldp, xS;
     int nb_w, nb_b;
 };
+struct PostArgs {             // up to two units (a residual block's conv1 and downsample: their input gradients are summed here)
+    PostJob j[2];
+    int nj;
+    const float* xpart; const float* xadd; float* dx; int64_t xM; int xC, xldp, xS;
+    const float* xpart2; int xldp2, xS2;         // the second unit's data-gradient slices (xS2 = 0: none)
+};
 
-__global__ __launch_bounds__(256)
-void k_bwd_post(PostArgs a) {
-    const int b = blockIdx.x;
+__device__ __forceinline__ void post_job(const PostJob& a, const int b) {
     if (b < a.nb_w) {
         if (a.conv1_map) {                                  // dW[co][ci][kh][kw] <- slice[co][kh][kw][ci] of a 224-column row
             const int64_t total = (int64_t)a.cout1 * 147;
@@ -818,8 +846,20 @@ void k_bwd_post(PostArgs a) {
             for (int r = 0; r < 8; ++r) t += red[r * 32 + col];
             a.db[c] = (float)t;
         }
+    }
+}
+
+__global__ __launch_bounds__(256)
+void k_bwd_post(PostArgs g) {
+    int b = blockIdx.x;
+    const int n_j0 = g.j[0].nb_w + g.j[0].nb_b, n_j1 = g.nj > 1 ? g.j[1].nb_w + g.j[1].nb_b : 0;
+    if (b < n_j0) {
+        post_job(g.j[0], b);
+    } else if (b < n_j0 + n_j1) {
+        post_job(g.j[1], b - n_j0);
     } else {
-        const int nb_x = gridDim.x - a.nb_w - a.nb_b, bx = b - a.nb_w - a.nb_b;
+        const PostArgs& a = g;
+        const int bx = b - n_j0 - n_j1, nb_x = gridDim.x - n_j0 - n_j1;
         const int c4n = a.xC >> 2;
         const int64_t total = a.xM * c4n;
         for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < total; i += (int64_t)nb_x * 256) {
@@ -832,6 +872,18 @@ void k_bwd_post(PostArgs a) {
             f32x4 s = p[0];
 #pragma unroll
             for (int k = 1; k < 8; ++k) if (k < a.xS) s += p[k];
+            if (a.xS2) {                                        // the second unit's slices: summed on their own in slice order, then
+                f32x4 s2 = {0.f, 0.f, 0.f, 0.f};                // added - the bits of two single-unit calls (dx_add = the second's dx)
+                for (int k0 = 0; k0 < a.xS2; k0 += 4) {         // four loads in flight
+                    f32x4 q[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+                        if (k0 + k < a.xS2) q[k] = *reinterpret_cast<const f32x4*>(a.xpart2 + ((int64_t)(k0 + k) * a.xM + m) * a.xldp2 + c);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) if (k0 + k < a.xS2) { if (k0 + k == 0) s2 = q[k]; else s2 += q[k]; }
+                }
+                s += s2;
+            }
             if (a.xadd) s += *reinterpret_cast<const f32x4*>(a.xadd + m * a.xC + c);
             *reinterpret_cast<f32x4*>(a.dx + m * a.xC + c) = s;
         }
@@ -1135,169 +1187,268 @@ inline RowBlocks apply_blocks(int M, int C, int cap) {
 }
 }  // namespace
 
+// ---- host side of the units.  One or TWO units per call: a pair shares every launch (see k_unit_gemms); each unit of a pair works
+// in its own half of every scratch region.
+namespace {
+struct ScrPart { char *stats, *dbpart, *conv, *wgrad; size_t stats_b, dbpart_b, conv_b, wgrad_b; };
+inline ScrPart scr_part(char* sc, int j, int nu) {
+    const size_t st = (SCR_DBPART - SCR_STATS) / nu, db = (SCR_CONV - SCR_DBPART) / nu, cv = ((SCR_WGRAD - SCR_CONV) / nu) & ~(size_t)255,
+                 wg = ((SCR_TOTAL - SCR_WGRAD) / nu) & ~(size_t)255;
+    return ScrPart{sc + SCR_STATS + j * st, sc + SCR_DBPART + j * db, sc + SCR_CONV + j * cv, sc + SCR_WGRAD + j * wg, st, db, cv, wg};
+}
+
+template <int CV>
+int launch_unit_gemms(const UnitGemmsArgs& g, unsigned grid, hipStream_t s) {
+    constexpr size_t lds = (size_t)BWD_GEMMS_LDS_FLOATS * sizeof(float);
+    static be::DeviceFlags flags{};
+    if (int rc_ = be::ensure_dynamic_lds(reinterpret_cast<const void*>(&k_unit_gemms<CV>), lds, flags)) return rc_;
+    hipLaunchKernelGGL(k_unit_gemms<CV>, dim3(grid), dim3(256), lds, s, g);
+    return BE_OK;
+}
+inline int launch_unit_gemms(int variant, const UnitGemmsArgs& g, unsigned grid, hipStream_t s) {
+    return variant == 0 ? launch_unit_gemms<0>(g, grid, s) : variant == 1 ? launch_unit_gemms<1>(g, grid, s) : launch_unit_gemms<2>(g, grid, s);
+}
+inline int pad8(int v) { return (v + 7) / 8 * 8; }
+
+int check_fwd_unit(const be_train_unit_fwd& u, const char* who) {
+    BE_REQUIRE(u.x && u.packed_w && u.packed_bias && u.gamma && u.beta && u.y && u.mean && u.invstd && u.out, "%s: null pointer", who);
+    const int64_t M64 = (int64_t)u.desc.n * u.desc.h * u.desc.w;
+    const int C = u.desc.cout;
+    BE_REQUIRE(M64 > 0 && M64 < ((int64_t)1 << 31) && C > 0 && C % UC == 0 && C <= 1024, "%s: cout %% 32 == 0, <= 1024", who);
+    BE_REQUIRE(be::aligned16(u.y) && be::aligned16(u.out) && be::aligned16(u.gamma) && be::aligned16(u.beta) && be::aligned16(u.packed_bias) &&
+               (!u.res || be::aligned16(u.res)) && (!u.s_in || be::aligned16(u.s_in)), "%s: 16-byte alignment", who);
+    return BE_OK;
+}
+
+// the two BatchNorm launches of the forward for nu units of the same [M, C]; S / ldp: the convolutions' K slices (S = 1: y is final)
+int fwd_bn_launches(const be_train_unit_fwd* const* u, int nu, const int* S, const int* ldp, float eps, float momentum, char* sc,
+                    hipStream_t s, const char* who) {
+    const int M = u[0]->desc.n * u[0]->desc.h * u[0]->desc.w, C = u[0]->desc.cout;
+    const RowBlocks sb = stat_blocks(M, C);
+    const RowBlocks ab = apply_blocks(M, C, 256);
+    Two<StatsArgs> st{};
+    Two<FwdApplyArgs> fa{};
+    for (int j = 0; j < nu; ++j) {
+        const ScrPart sp = scr_part(sc, j, nu);
+        BE_REQUIRE((size_t)sb.n * C * 2 * sizeof(double) <= sp.stats_b, "%s: statistics region too small", who);
+        st.j[j] = StatsArgs{S[j] > 1 ? reinterpret_cast<const float*>(sp.conv) : nullptr, u[j]->packed_bias, u[j]->y,
+                            reinterpret_cast<double*>(sp.stats), S[j] > 1 ? S[j] : 0, M, C, ldp[j], sb.rows};
+        fa.j[j] = FwdApplyArgs{u[j]->y, reinterpret_cast<const double*>(sp.stats), u[j]->gamma, u[j]->beta, u[j]->res, u[j]->run_mean,
+                               u[j]->run_var, u[j]->mean, u[j]->invstd, u[j]->s_in, u[j]->out, sb.n, M, C, ab.rows, u[j]->act, eps, momentum};
+    }
+    hipLaunchKernelGGL(k_bn_stats, dim3(C / UC, sb.n, nu), dim3(256), 0, s, st);
+    hipLaunchKernelGGL(k_bn_fwd_apply, dim3(C / UC, ab.n, nu), dim3(256), 0, s, fa);
+    return BE_OK;
+}
+
+int unit_fwd_one(const be_train_unit_fwd& u, float eps, float momentum, char* sc, void* stream, const char* who) {
+    if (int rc = check_fwd_unit(u, who)) return rc;
+    be_conv_desc dc = u.desc; dc.act = 0;
+    int S = 1, ldp = 0;
+    if (int rc = be::conv_train(&dc, u.x, u.packed_w, u.packed_bias, nullptr, u.y, dc.cout, sc + SCR_CONV, SCR_WGRAD - SCR_CONV, &S, &ldp, stream))
+        return rc;
+    const be_train_unit_fwd* one[1] = {&u};
+    return fwd_bn_launches(one, 1, &S, &ldp, eps, momentum, sc, be::as_stream(stream), who);
+}
+}  // namespace
+
 extern "C" int be_train_unit_fwd_f32(const be_conv_desc* d, const float* x, const float* pw, const float* pb, const float* gamma,
                                      const float* beta, const float* res, float eps, float momentum, float* run_mean,
                                      float* run_var, float* y, float* mean, float* invstd, float* s_in, float* out, int act,
                                      void* scratch, size_t scratch_bytes, void* stream) {
-    BE_REQUIRE(d && x && pw && pb && gamma && beta && y && mean && invstd && out && scratch, "be_train_unit_fwd_f32: null pointer");
+    BE_REQUIRE(d && scratch, "be_train_unit_fwd_f32: null pointer");
     BE_REQUIRE(scratch_bytes >= SCR_TOTAL && be::aligned16(scratch), "be_train_unit_fwd_f32: scratch of be_train_scratch_bytes() bytes required");
-    const int64_t M64 = (int64_t)d->n * d->h * d->w;
-    const int C = d->cout;
-    BE_REQUIRE(M64 > 0 && M64 < ((int64_t)1 << 31) && C > 0 && C % UC == 0 && C <= 1024, "be_train_unit_fwd_f32: cout %% 32 == 0, <= 1024");
-    BE_REQUIRE(be::aligned16(y) && be::aligned16(out) && be::aligned16(gamma) && be::aligned16(beta) && be::aligned16(pb) &&
-               (!res || be::aligned16(res)) && (!s_in || be::aligned16(s_in)), "be_train_unit_fwd_f32: 16-byte alignment");
-    const int M = (int)M64;
-    char* sc = static_cast<char*>(scratch);
-    hipStream_t s = be::as_stream(stream);
-    be_conv_desc dc = *d; dc.act = 0;
-    int S = 1, ldp = 0;
-    int rc = be::conv_train(&dc, x, pw, pb, nullptr, y, C, sc + SCR_CONV, SCR_WGRAD - SCR_CONV, &S, &ldp, stream);
-    if (rc) return rc;
-    const RowBlocks sb = stat_blocks(M, C);
-    BE_REQUIRE((size_t)sb.n * C * 2 * sizeof(double) <= SCR_DBPART - SCR_STATS, "be_train_unit_fwd_f32: statistics region too small");
-    StatsArgs sa{S > 1 ? reinterpret_cast<const float*>(sc + SCR_CONV) : nullptr, pb, y, reinterpret_cast<double*>(sc + SCR_STATS),
-                 S > 1 ? S : 0, M, C, ldp, sb.rows};
-    hipLaunchKernelGGL(k_bn_stats, dim3(C / UC, sb.n), dim3(256), 0, s, sa);
-    const RowBlocks ab = apply_blocks(M, C, 256);
-    FwdApplyArgs fa{y, reinterpret_cast<const double*>(sc + SCR_STATS), gamma, beta, res, run_mean, run_var, mean, invstd, s_in, out,
-                    sb.n, M, C, ab.rows, act, eps, momentum};
-    hipLaunchKernelGGL(k_bn_fwd_apply, dim3(C / UC, ab.n), dim3(256), 0, s, fa);
+    const be_train_unit_fwd u{*d, x, pw, pb, gamma, beta, res, run_mean, run_var, y, mean, invstd, s_in, out, act};
+    if (int rc = unit_fwd_one(u, eps, momentum, static_cast<char*>(scratch), stream, "be_train_unit_fwd_f32")) return rc;
     return be::check_launch("be_train_unit_fwd_f32");
 }
 
-extern "C" int be_train_unit_bwd_f32(const be_conv_desc* d, const float* x, const float* dout, const float* s_in, const float* y,
-                                     const float* mean, const float* invstd, const float* gamma, const float* dgrad_pw,
-                                     const float* dgrad_pb, const float* dx_add, int layout_chw_hw, float* ds, float* dy,
-                                     float* dgamma, float* dbeta, float* dw, float* db, float* dx, void* scratch,
-                                     size_t scratch_bytes, void* stream) {
-    BE_REQUIRE(d && x && dout && y && mean && invstd && gamma && ds && dy && dgamma && dbeta && dw && db && scratch,
-               "be_train_unit_bwd_f32: null pointer");
-    BE_REQUIRE(scratch_bytes >= SCR_TOTAL && be::aligned16(scratch), "be_train_unit_bwd_f32: scratch of be_train_scratch_bytes() bytes required");
-    BE_REQUIRE((dx != nullptr) == (dgrad_pw != nullptr), "be_train_unit_bwd_f32: dx and the data-gradient pack go together");
-    const int64_t M64 = (int64_t)d->n * d->h * d->w;
-    const int C = d->cout;
-    BE_REQUIRE(M64 > 0 && M64 < ((int64_t)1 << 31) && C > 0 && C % UC == 0 && C <= 1024, "be_train_unit_bwd_f32: cout %% 32 == 0, <= 1024");
-    BE_REQUIRE(be::aligned16(dout) && be::aligned16(y) && be::aligned16(ds) && be::aligned16(dy) && be::aligned16(mean) &&
-               be::aligned16(invstd) && be::aligned16(gamma) && (!s_in || be::aligned16(s_in)) && be::aligned16(dw) &&
-               (!dx || be::aligned16(dx)) && (!dx_add || be::aligned16(dx_add)), "be_train_unit_bwd_f32: 16-byte alignment");
-    const int M = (int)M64;
+extern "C" int be_train_unit_pair_fwd_f32(const be_train_unit_fwd* a, const be_train_unit_fwd* b, float eps, float momentum,
+                                          void* scratch, size_t scratch_bytes, void* stream) {
+    const char* who = "be_train_unit_pair_fwd_f32";
+    BE_REQUIRE(a && b && scratch, "%s: null pointer", who);
+    BE_REQUIRE(scratch_bytes >= SCR_TOTAL && be::aligned16(scratch), "%s: scratch of be_train_scratch_bytes() bytes required", who);
+    if (int rc = check_fwd_unit(*a, who)) return rc;
+    if (int rc = check_fwd_unit(*b, who)) return rc;
+    BE_REQUIRE(a->desc.n == b->desc.n && a->desc.h == b->desc.h && a->desc.w == b->desc.w && a->desc.cout == b->desc.cout,
+               "%s: the two units must produce the same [n,h,w,cout]", who);
     char* sc = static_cast<char*>(scratch);
     hipStream_t s = be::as_stream(stream);
-    double* part = reinterpret_cast<double*>(sc + SCR_STATS);
-    double* dbpart = reinterpret_cast<double*>(sc + SCR_DBPART);
-    // 1. ds = dout * smish'(s_in); row-block column sums of ds and ds * xhat
+    const be_train_unit_fwd* u[2] = {a, b};
+    static const bool no_pair = getenv("BE_NO_UNIT_PAIR") != nullptr;             // A/B knob
+    be::ConvPrep prep[2];
+    bool together = !no_pair;
+    for (int j = 0; j < 2 && together; ++j) {
+        const ScrPart sp = scr_part(sc, j, 2);
+        be_conv_desc dc = u[j]->desc; dc.act = 0;
+        if (int rc = be::conv_train_prepare(&dc, u[j]->x, u[j]->packed_w, u[j]->packed_bias, nullptr, u[j]->y, dc.cout, sp.conv, sp.conv_b, &prep[j]))
+            return rc;
+        together = prep[j].variant >= 0 && (j == 0 || prep[j].variant == prep[0].variant);
+    }
+    if (!together) {          // shapes the merged launch does not take: one after the other (same results)
+        if (int rc = unit_fwd_one(*a, eps, momentum, sc, stream, who)) return rc;
+        if (int rc = unit_fwd_one(*b, eps, momentum, sc, stream, who)) return rc;
+        return be::check_launch(who);
+    }
+    UnitGemmsArgs g{};
+    int S[2], ldp[2];
+    for (int j = 0; j < 2; ++j) {
+        g.ca[j] = prep[j].args; g.cgx[j] = (int)prep[j].gx; g.c_real[j] = (int)prep[j].gx * prep[j].S;
+        S[j] = prep[j].S; ldp[j] = prep[j].ldp;
+    }
+    g.w_end[0] = g.w_end[1] = 0;
+    g.c_end0 = pad8(g.c_real[0]);
+    {
+        be::ProfileScope prof(s, BE_KERNEL_TRAIN_BWD_GEMMS, prep[0].flops + prep[1].flops, 0.0, prep[0].flops_exec + prep[1].flops_exec);
+        if (int rc = launch_unit_gemms(prep[0].variant, g, (unsigned)(g.c_end0 + g.c_real[1]), s)) return rc;
+    }
+    if (int rc = fwd_bn_launches(u, 2, S, ldp, eps, momentum, sc, s, who)) return rc;
+    return be::check_launch(who);
+}
+
+namespace {
+int check_bwd_unit(const be_train_unit_bwd& u, const char* who) {
+    BE_REQUIRE(u.x && u.dout && u.y && u.mean && u.invstd && u.gamma && u.ds && u.dy && u.dgamma && u.dbeta && u.dw && u.db, "%s: null pointer", who);
+    BE_REQUIRE((u.dx != nullptr) == (u.dgrad_packed_w != nullptr), "%s: dx and the data-gradient pack go together", who);
+    const int64_t M64 = (int64_t)u.desc.n * u.desc.h * u.desc.w;
+    const int C = u.desc.cout;
+    BE_REQUIRE(M64 > 0 && M64 < ((int64_t)1 << 31) && C > 0 && C % UC == 0 && C <= 1024, "%s: cout %% 32 == 0, <= 1024", who);
+    BE_REQUIRE(be::aligned16(u.dout) && be::aligned16(u.y) && be::aligned16(u.ds) && be::aligned16(u.dy) && be::aligned16(u.mean) &&
+               be::aligned16(u.invstd) && be::aligned16(u.gamma) && (!u.s_in || be::aligned16(u.s_in)) && be::aligned16(u.dw) &&
+               (!u.dx || be::aligned16(u.dx)) && (!u.dx_add || be::aligned16(u.dx_add)), "%s: 16-byte alignment", who);
+    if (u.desc.ksize != 7) {
+        BE_REQUIRE((u.desc.ksize == 1 || u.desc.ksize == 3) && u.desc.cin % 4 == 0 && C % 4 == 0, "%s: ksize 1|3, channels %% 4 == 0", who);
+        BE_REQUIRE(u.layout_chw_hw == 0 || (u.desc.ksize == 1 && u.desc.cin % u.layout_chw_hw == 0), "%s: bad layout_chw_hw", who);
+        BE_REQUIRE(be::aligned16(u.x), "%s: x must be 16-byte aligned", who);
+    }
+    return BE_OK;
+}
+
+// the two BatchNorm launches of the backward for nu units of the same [M, C]: ds and its column sums; dgamma / dbeta, dy and the
+// bias-gradient partials.  -> row blocks of the second (the partials k_bwd_post sums)
+int bwd_bn_launches(const be_train_unit_bwd* const* u, int nu, char* sc, hipStream_t s, int* nb_rows, const char* who) {
+    const int M = u[0]->desc.n * u[0]->desc.h * u[0]->desc.w, C = u[0]->desc.cout;
     const RowBlocks sb = stat_blocks(M, C);
-    BwdReduceArgs ra{dout, s_in, y, mean, invstd, ds, part, M, C, sb.rows};
-    hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(C / UC, sb.n), dim3(256), 0, s, ra);
-    // 2. dgamma / dbeta finished in the prologue; dy; column sums of dy per workgroup
     const RowBlocks ab = apply_blocks(M, C, 128);
-    BE_REQUIRE((size_t)sb.n * C * 2 * sizeof(double) <= SCR_DBPART - SCR_STATS && (size_t)ab.n * C * sizeof(double) <= SCR_CONV - SCR_DBPART,
-               "be_train_unit_bwd_f32: reduction regions too small");
-    BwdApplyArgs ba{ds, y, mean, invstd, gamma, part, dy, dgamma, dbeta, dbpart, sb.n, M, C, ab.rows, 1.0f / (float)M};
-    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(C / UC, ab.n), dim3(256), 0, s, ba);
+    Two<BwdReduceArgs> ra{};
+    Two<BwdApplyArgs> ba{};
+    for (int j = 0; j < nu; ++j) {
+        const ScrPart sp = scr_part(sc, j, nu);
+        BE_REQUIRE((size_t)sb.n * C * 2 * sizeof(double) <= sp.stats_b && (size_t)ab.n * C * sizeof(double) <= sp.dbpart_b,
+                   "%s: reduction regions too small", who);
+        double* part = reinterpret_cast<double*>(sp.stats);
+        ra.j[j] = BwdReduceArgs{u[j]->dout, u[j]->s_in, u[j]->y, u[j]->mean, u[j]->invstd, u[j]->ds, part, M, C, sb.rows};
+        ba.j[j] = BwdApplyArgs{u[j]->ds, u[j]->y, u[j]->mean, u[j]->invstd, u[j]->gamma, part, u[j]->dy, u[j]->dgamma, u[j]->dbeta,
+                               reinterpret_cast<double*>(sp.dbpart), sb.n, M, C, ab.rows, 1.0f / (float)M};
+    }
+    // 1. ds = dout * smish'(s_in); row-block column sums of ds and ds * xhat
+    hipLaunchKernelGGL(k_bn_bwd_reduce, dim3(C / UC, sb.n, nu), dim3(256), 0, s, ra);
+    // 2. dgamma / dbeta finished in the prologue; dy; column sums of dy per workgroup
+    hipLaunchKernelGGL(k_bn_bwd_apply, dim3(C / UC, ab.n, nu), dim3(256), 0, s, ba);
+    *nb_rows = ab.n;
+    return BE_OK;
+}
+
+// the weight-gradient job of a 1x1 / 3x3 unit: tiles, K slices (partials at wpart, at most wpart_bytes) and the matching post role
+int plan_wgrad(const be_train_unit_bwd& u, float* wpart, size_t wpart_bytes, WJob* wj, PostJob* pj, double* flops_exec, const char* who) {
+    const be_conv_desc* d = &u.desc;
+    const int M = d->n * d->h * d->w, C = d->cout;
+    const int taps = d->ksize * d->ksize;
+    const int64_t wsize = (int64_t)C * d->cin * taps;
+    static const bool no128 = getenv("BE_NO_WGRAD128") != nullptr;            // A/B knob
+    if (!no128 && u.layout_chw_hw == 0 && C % 128 == 0 && d->cin % 128 == 0 && M >= 256) {
+        const int tiles = (C / 128) * (d->cin / 128) * taps;
+        // slices: every one is another copy of dW to write and to sum (a 3x3 layer: 2.4-5.3 MB each), so few of them -
+        // ~400 workgroups, at most 8 slices for the 3x3 layers, 24 for the (small) 1x1 ones
+        int S = (400 + tiles - 1) / tiles;
+        const int s_cap = taps == 9 ? 8 : 24;
+        if (S > s_cap) S = s_cap;
+        if (S < 1) S = 1;
+        if (S > M / 64) S = M / 64;
+        while (S > 1 && (size_t)S * wsize * sizeof(float) > wpart_bytes) --S;
+        BE_REQUIRE((size_t)S * wsize * sizeof(float) <= wpart_bytes, "%s: scratch too small", who);
+        int rows = (M + S - 1) / S; rows = (rows + 15) / 16 * 16;
+        S = (M + rows - 1) / rows;
+        wj->wkind = 1;
+        wj->w128 = Wgrad128Args{u.x, u.dy, wpart, M, d->h, d->w, d->h * d->w, d->cin, C, d->ksize, rows, d->cin / 128};
+        wj->wx = (C / 128) * (d->cin / 128); wj->wy = taps; wj->real = wj->wx * taps * S;
+        pj->wpart = wpart; pj->dw = u.dw; pj->wsize = wsize; pj->wS = S; pj->conv1_map = 0; pj->cout1 = C; pj->wtaps = taps;
+        pj->nb_w = (int)cap_grid(wsize / taps, 256, 1024);
+        *flops_exec = 2.0 * M * (double)wsize;
+    } else {
+        const int ct = (C + 63) / 64, it = (d->cin + 63) / 64;
+        int S = pick_splits(M, ct * it * taps, 64, 512);       // every split is another full copy of dW to sum
+        while (S > 1 && (size_t)S * wsize * sizeof(float) > wpart_bytes) --S;
+        BE_REQUIRE((size_t)S * wsize * sizeof(float) <= wpart_bytes, "%s: scratch too small", who);
+        int rows = (M + S - 1) / S; rows = (rows + 31) / 32 * 32;
+        S = (M + rows - 1) / rows;
+        wj->wkind = 0;
+        wj->w64 = WgradArgs{u.x, u.dy, wpart, M, d->h, d->w, d->h * d->w, d->cin, C, d->ksize, rows, u.layout_chw_hw, it};
+        wj->wx = ct * it; wj->wy = taps; wj->real = ct * it * taps * S;
+        pj->wpart = wpart; pj->dw = u.dw; pj->wsize = wsize; pj->wS = S; pj->conv1_map = 0; pj->cout1 = C; pj->wtaps = 0;
+        pj->nb_w = (int)cap_grid(wsize / 4, 256, 1024);
+        // executed: full tiles (k_wgrad's 64-wide tiles pad 96 channels to 128)
+        *flops_exec = 2.0 * M * (double)taps * ((C + 63) / 64 * 64) * ((d->cin + 63) / 64 * 64);
+    }
+    return BE_OK;
+}
+inline dim3 wjob_grid(const WJob& w) { return dim3(w.wx, w.wy, w.real / (w.wx * w.wy)); }
+
+int unit_bwd_one(const be_train_unit_bwd& u, char* sc, void* stream, const char* who) {
+    if (int rc = check_bwd_unit(u, who)) return rc;
+    const be_conv_desc* d = &u.desc;
+    const int M = d->n * d->h * d->w, C = d->cout;
+    hipStream_t s = be::as_stream(stream);
+    const be_train_unit_bwd* one[1] = {&u};
+    int nb_rows = 0;
+    if (int rc = bwd_bn_launches(one, 1, sc, s, &nb_rows, who)) return rc;
     // 3. + 4. the weight-gradient GEMM and the data-gradient convolution (through the transposed / mirrored pack): slices of both
-    //    stay in scratch.  With an input gradient wanted the two run as ONE launch (k_bwd_gemms), else the weight gradient alone.
+    //    stay in scratch.  With an input gradient wanted the two run as ONE launch (k_unit_gemms), else the weight gradient alone.
     PostArgs pa{};
+    pa.nj = 1;
+    PostJob& pj = pa.j[0];
     float* wpart = reinterpret_cast<float*>(sc + SCR_WGRAD);
-    pa.dbpart = dbpart; pa.db = db; pa.nb_rows = ab.n; pa.C = C; pa.nb_b = C / 32;
-    pa.xS = 0;
+    pj.dbpart = reinterpret_cast<const double*>(sc + SCR_DBPART); pj.db = u.db; pj.nb_rows = nb_rows; pj.C = C; pj.nb_b = C / 32;
     if (d->ksize == 7) {
-        BE_REQUIRE(d->cin == 4 && C == 64 && !dx, "be_train_unit_bwd_f32: ksize 7 is conv1 (NHWC4 staging, 64 outputs, no input gradient)");
+        BE_REQUIRE(d->cin == 4 && C == 64 && !u.dx, "%s: ksize 7 is conv1 (NHWC4 staging, 64 outputs, no input gradient)", who);
         int rows = (M + 63) / 64; rows = (rows + 31) / 32 * 32;
         const int S = (M + rows - 1) / rows;
-        BE_REQUIRE((size_t)S * C * 224 * sizeof(float) <= SCR_TOTAL - SCR_WGRAD, "be_train_unit_bwd_f32: scratch too small");
-        WgradC1Args wa{x, dy, wpart, M, d->h, d->w, d->h * d->w, C, rows};
+        BE_REQUIRE((size_t)S * C * 224 * sizeof(float) <= SCR_TOTAL - SCR_WGRAD, "%s: scratch too small", who);
+        WgradC1Args wa{u.x, u.dy, wpart, M, d->h, d->w, d->h * d->w, C, rows};
         hipLaunchKernelGGL(k_wgrad_conv1_mfma, dim3(1, 4, S), dim3(256), 0, s, wa);
-        pa.wpart = wpart; pa.dw = dw; pa.wsize = (int64_t)C * 147; pa.wS = S; pa.conv1_map = 1; pa.cout1 = C;
-        pa.nb_w = (C * 147 + 255) / 256;
+        pj.wpart = wpart; pj.dw = u.dw; pj.wsize = (int64_t)C * 147; pj.wS = S; pj.conv1_map = 1; pj.cout1 = C;
+        pj.nb_w = (C * 147 + 255) / 256;
     } else {
-        BE_REQUIRE((d->ksize == 1 || d->ksize == 3) && d->cin % 4 == 0 && C % 4 == 0, "be_train_unit_bwd_f32: ksize 1|3, channels %% 4 == 0");
-        BE_REQUIRE(layout_chw_hw == 0 || (d->ksize == 1 && d->cin % layout_chw_hw == 0), "be_train_unit_bwd_f32: bad layout_chw_hw");
-        BE_REQUIRE(be::aligned16(x), "be_train_unit_bwd_f32: x must be 16-byte aligned");
-        const int taps = d->ksize * d->ksize;
-        const int64_t wsize = (int64_t)C * d->cin * taps;
-        BwdGemmsArgs g{};
-        static const bool no128 = getenv("BE_NO_WGRAD128") != nullptr;            // A/B knobs
-        static const bool no_merge = getenv("BE_NO_BWD_MERGE") != nullptr;
-        dim3 wgrid;
-        if (!no128 && layout_chw_hw == 0 && C % 128 == 0 && d->cin % 128 == 0 && M >= 256) {
-            const int tiles = (C / 128) * (d->cin / 128) * taps;
-            // slices: every one is another copy of dW to write and to sum (a 3x3 layer: 2.4-5.3 MB each), so few of them -
-            // ~400 workgroups, at most 8 slices for the 3x3 layers, 24 for the (small) 1x1 ones
-            int S = (400 + tiles - 1) / tiles;
-            const int s_cap = taps == 9 ? 8 : 24;
-            if (S > s_cap) S = s_cap;
-            if (S < 1) S = 1;
-            if (S > M / 64) S = M / 64;
-            while (S > 1 && (size_t)S * wsize * sizeof(float) > SCR_TOTAL - SCR_WGRAD) --S;
-            int rows = (M + S - 1) / S; rows = (rows + 15) / 16 * 16;
-            S = (M + rows - 1) / rows;
-            g.wkind = 1;
-            g.w128 = Wgrad128Args{x, dy, wpart, M, d->h, d->w, d->h * d->w, d->cin, C, d->ksize, rows, d->cin / 128};
-            wgrid = dim3((C / 128) * (d->cin / 128), taps, S);
-            pa.wpart = wpart; pa.dw = dw; pa.wsize = wsize; pa.wS = S; pa.conv1_map = 0; pa.cout1 = C; pa.wtaps = taps;
-            pa.nb_w = (int)cap_grid(wsize / taps, 256, 1024);
-        } else {
-            const int ct = (C + 63) / 64, it = (d->cin + 63) / 64;
-            int S = pick_splits(M, ct * it * taps, 64, 512);       // every split is another full copy of dW to sum
-            while (S > 1 && (size_t)S * wsize * sizeof(float) > SCR_TOTAL - SCR_WGRAD) --S;
-            BE_REQUIRE((size_t)S * wsize * sizeof(float) <= SCR_TOTAL - SCR_WGRAD, "be_train_unit_bwd_f32: scratch too small");
-            int rows = (M + S - 1) / S; rows = (rows + 31) / 32 * 32;
-            S = (M + rows - 1) / rows;
-            g.wkind = 0;
-            g.w64 = WgradArgs{x, dy, wpart, M, d->h, d->w, d->h * d->w, d->cin, C, d->ksize, rows, layout_chw_hw, it};
-            wgrid = dim3(ct * it, taps, S);
-            pa.wpart = wpart; pa.dw = dw; pa.wsize = wsize; pa.wS = S; pa.conv1_map = 0; pa.cout1 = C;
-            pa.nb_w = (int)cap_grid(wsize / 4, 256, 1024);
-        }
+        UnitGemmsArgs g{};
+        double w_exec = 0.0;
+        if (int rc = plan_wgrad(u, wpart, SCR_TOTAL - SCR_WGRAD, &g.w[0], &pj, &w_exec, who)) return rc;
+        static const bool no_merge = getenv("BE_NO_BWD_MERGE") != nullptr;        // A/B knob
         be::ConvPrep prep;
         prep.variant = -1;
-        if (dx) {
-            be_conv_desc dd{d->n, d->h, d->w, C, d->cin, d->ksize, 0};
-            BE_REQUIRE(d->cin % 4 == 0, "be_train_unit_bwd_f32: cin %% 4 == 0");
-            if (!no_merge) {
-                const int rc = be::conv_train_prepare(&dd, dy, dgrad_pw, dgrad_pb, dx_add, dx, d->cin, sc + SCR_CONV, SCR_WGRAD - SCR_CONV, &prep);
-                if (rc) return rc;
-            }
-        }
+        be_conv_desc dd{d->n, d->h, d->w, C, d->cin, d->ksize, 0};
+        if (u.dx && !no_merge)
+            if (int rc = be::conv_train_prepare(&dd, u.dy, u.dgrad_packed_w, u.dgrad_packed_bias, u.dx_add, u.dx, d->cin, sc + SCR_CONV,
+                                                SCR_WGRAD - SCR_CONV, &prep)) return rc;
         if (prep.variant >= 0) {
-            g.ca = prep.args;
-            g.w_real = (int)(wgrid.x * wgrid.y * wgrid.z); g.n_w = (g.w_real + 7) / 8 * 8; g.wx = (int)wgrid.x; g.wy = (int)wgrid.y;
-            g.cgx = (int)prep.gx;
-            const unsigned grid = (unsigned)g.n_w + prep.gx * (unsigned)prep.S;
-            constexpr size_t lds = (size_t)BWD_GEMMS_LDS_FLOATS * sizeof(float);
-            // executed: the convolution's visited chunks x tile FLOPs + the weight-gradient tiles (full tiles: channel counts are
-            // multiples of the tile; k_wgrad's 64-wide tiles pad 96 channels to 128)
-            const double w_exec = g.wkind == 1 ? 2.0 * M * (double)wsize
-                                               : 2.0 * M * (double)taps * ((C + 63) / 64 * 64) * ((d->cin + 63) / 64 * 64);
-            be::ProfileScope prof(s, BE_KERNEL_TRAIN_BWD_GEMMS, prep.flops + 2.0 * M * (double)wsize, 0.0, prep.flops_exec + w_exec);
-            if (prep.variant == 0) {
-                static be::DeviceFlags f0{};
-                if (int rc_ = be::ensure_dynamic_lds(reinterpret_cast<const void*>(&k_bwd_gemms<0>), lds, f0)) return rc_;
-                hipLaunchKernelGGL(k_bwd_gemms<0>, dim3(grid), dim3(256), lds, s, g);
-            } else if (prep.variant == 1) {
-                static be::DeviceFlags f1{};
-                if (int rc_ = be::ensure_dynamic_lds(reinterpret_cast<const void*>(&k_bwd_gemms<1>), lds, f1)) return rc_;
-                hipLaunchKernelGGL(k_bwd_gemms<1>, dim3(grid), dim3(256), lds, s, g);
-            } else {
-                static be::DeviceFlags f2{};
-                if (int rc_ = be::ensure_dynamic_lds(reinterpret_cast<const void*>(&k_bwd_gemms<2>), lds, f2)) return rc_;
-                hipLaunchKernelGGL(k_bwd_gemms<2>, dim3(grid), dim3(256), lds, s, g);
-            }
+            g.ca[0] = prep.args; g.cgx[0] = (int)prep.gx; g.c_real[0] = (int)prep.gx * prep.S; g.c_real[1] = 0;
+            g.w_end[0] = g.w_end[1] = pad8(g.w[0].real);
+            g.c_end0 = g.c_real[0];
+            const double wflops = 2.0 * M * (double)pj.wsize;
+            be::ProfileScope prof(s, BE_KERNEL_TRAIN_BWD_GEMMS, prep.flops + wflops, 0.0, prep.flops_exec + w_exec);
+            if (int rc = launch_unit_gemms(prep.variant, g, (unsigned)(g.w_end[1] + g.c_real[0]), s)) return rc;
             if (prep.S > 1) {
-                pa.xpart = reinterpret_cast<const float*>(sc + SCR_CONV); pa.xadd = dx_add; pa.dx = dx; pa.xM = M; pa.xC = d->cin;
+                pa.xpart = reinterpret_cast<const float*>(sc + SCR_CONV); pa.xadd = u.dx_add; pa.dx = u.dx; pa.xM = M; pa.xC = d->cin;
                 pa.xldp = prep.ldp; pa.xS = prep.S;
             }
         } else {
-            if (g.wkind == 1) hipLaunchKernelGGL(k_wgrad128, wgrid, dim3(256), 0, s, g.w128);
-            else hipLaunchKernelGGL(k_wgrad, wgrid, dim3(256), 0, s, g.w64);
-            if (dx) {
-                be_conv_desc dd{d->n, d->h, d->w, C, d->cin, d->ksize, 0};
+            if (g.w[0].wkind == 1) hipLaunchKernelGGL(k_wgrad128, wjob_grid(g.w[0]), dim3(256), 0, s, g.w[0].w128);
+            else hipLaunchKernelGGL(k_wgrad, wjob_grid(g.w[0]), dim3(256), 0, s, g.w[0].w64);
+            if (u.dx) {
                 int S = 1, ldp = 0;
-                const int rc = be::conv_train(&dd, dy, dgrad_pw, dgrad_pb, dx_add, dx, d->cin, sc + SCR_CONV, SCR_WGRAD - SCR_CONV, &S, &ldp, stream);
-                if (rc) return rc;
+                if (int rc = be::conv_train(&dd, u.dy, u.dgrad_packed_w, u.dgrad_packed_bias, u.dx_add, u.dx, d->cin, sc + SCR_CONV,
+                                            SCR_WGRAD - SCR_CONV, &S, &ldp, stream)) return rc;
                 if (S > 1) {
-                    pa.xpart = reinterpret_cast<const float*>(sc + SCR_CONV); pa.xadd = dx_add; pa.dx = dx; pa.xM = M; pa.xC = d->cin;
+                    pa.xpart = reinterpret_cast<const float*>(sc + SCR_CONV); pa.xadd = u.dx_add; pa.dx = u.dx; pa.xM = M; pa.xC = d->cin;
                     pa.xldp = ldp; pa.xS = S;
                 }
             }
@@ -1305,8 +1456,87 @@ extern "C" int be_train_unit_bwd_f32(const be_conv_desc* d, const float* x, cons
     }
     const int nb_x = pa.xS ? (int)cap_grid((int64_t)M * (d->cin / 4), 256, 2048) : 0;
     // 5. slices -> dW, partials -> db, slices (+ the other branch) -> dx: one launch
-    hipLaunchKernelGGL(k_bwd_post, dim3(pa.nb_w + pa.nb_b + nb_x), dim3(256), 0, s, pa);
+    hipLaunchKernelGGL(k_bwd_post, dim3(pj.nb_w + pj.nb_b + nb_x), dim3(256), 0, s, pa);
+    return BE_OK;
+}
+}  // namespace
+
+extern "C" int be_train_unit_bwd_f32(const be_conv_desc* d, const float* x, const float* dout, const float* s_in, const float* y,
+                                     const float* mean, const float* invstd, const float* gamma, const float* dgrad_pw,
+                                     const float* dgrad_pb, const float* dx_add, int layout_chw_hw, float* ds, float* dy,
+                                     float* dgamma, float* dbeta, float* dw, float* db, float* dx, void* scratch,
+                                     size_t scratch_bytes, void* stream) {
+    BE_REQUIRE(d && scratch, "be_train_unit_bwd_f32: null pointer");
+    BE_REQUIRE(scratch_bytes >= SCR_TOTAL && be::aligned16(scratch), "be_train_unit_bwd_f32: scratch of be_train_scratch_bytes() bytes required");
+    const be_train_unit_bwd u{*d, x, dout, s_in, y, mean, invstd, gamma, dgrad_pw, dgrad_pb, dx_add, layout_chw_hw, ds, dy, dgamma, dbeta, dw, db, dx};
+    if (int rc = unit_bwd_one(u, static_cast<char*>(scratch), stream, "be_train_unit_bwd_f32")) return rc;
     return be::check_launch("be_train_unit_bwd_f32");
+}
+
+extern "C" int be_train_unit_pair_bwd_f32(const be_train_unit_bwd* a, const be_train_unit_bwd* b, void* scratch, size_t scratch_bytes,
+                                          void* stream) {
+    const char* who = "be_train_unit_pair_bwd_f32";
+    BE_REQUIRE(a && b && scratch, "%s: null pointer", who);
+    BE_REQUIRE(scratch_bytes >= SCR_TOTAL && be::aligned16(scratch), "%s: scratch of be_train_scratch_bytes() bytes required", who);
+    if (int rc = check_bwd_unit(*a, who)) return rc;
+    if (int rc = check_bwd_unit(*b, who)) return rc;
+    BE_REQUIRE(a->desc.ksize != 7 && b->desc.ksize != 7, "%s: ksize 1|3", who);
+    BE_REQUIRE(a->desc.n == b->desc.n && a->desc.h == b->desc.h && a->desc.w == b->desc.w && a->desc.cout == b->desc.cout &&
+               a->desc.cin == b->desc.cin && a->x == b->x, "%s: the two units must share the input and produce the same [n,h,w,cout]", who);
+    BE_REQUIRE(a->dx && b->dx && a->dx != b->dx && !a->dx_add && !b->dx_add,
+               "%s: both dx buffers required (a->dx receives the sum, b->dx is working space), dx_add must be NULL", who);
+    char* sc = static_cast<char*>(scratch);
+    hipStream_t s = be::as_stream(stream);
+    const be_train_unit_bwd* u[2] = {a, b};
+    const be_conv_desc* d = &a->desc;
+    const int M = d->n * d->h * d->w, C = d->cout;
+    static const bool no_pair = getenv("BE_NO_UNIT_PAIR") != nullptr;             // A/B knob
+    be::ConvPrep prep[2];
+    bool together = !no_pair;
+    for (int j = 0; j < 2 && together; ++j) {
+        const ScrPart sp = scr_part(sc, j, 2);
+        be_conv_desc dd{d->n, d->h, d->w, C, d->cin, u[j]->desc.ksize, 0};
+        // b with a single K slice writes its input gradient straight into b->dx, which the last kernel then adds
+        if (int rc = be::conv_train_prepare(&dd, u[j]->dy, u[j]->dgrad_packed_w, u[j]->dgrad_packed_bias, nullptr, u[j]->dx, d->cin, sp.conv,
+                                            sp.conv_b, &prep[j])) return rc;
+        together = prep[j].variant >= 0 && (j == 0 ? prep[j].S > 1 && prep[j].S <= 8 : prep[j].variant == prep[0].variant && prep[j].S <= 8);
+    }
+    if (!together) {          // shapes the merged launches do not take: b, then a with b's input gradient added (same sums)
+        if (int rc = unit_bwd_one(*b, sc, stream, who)) return rc;
+        be_train_unit_bwd a2 = *a;
+        a2.dx_add = b->dx;
+        if (int rc = unit_bwd_one(a2, sc, stream, who)) return rc;
+        return be::check_launch(who);
+    }
+    int nb_rows = 0;
+    if (int rc = bwd_bn_launches(u, 2, sc, s, &nb_rows, who)) return rc;
+    UnitGemmsArgs g{};
+    PostArgs pa{};
+    pa.nj = 2;
+    double w_exec[2] = {0.0, 0.0}, wflops = 0.0;
+    for (int j = 0; j < 2; ++j) {
+        const ScrPart sp = scr_part(sc, j, 2);
+        PostJob& pj = pa.j[j];
+        pj.dbpart = reinterpret_cast<const double*>(sp.dbpart); pj.db = u[j]->db; pj.nb_rows = nb_rows; pj.C = C; pj.nb_b = C / 32;
+        if (int rc = plan_wgrad(*u[j], reinterpret_cast<float*>(sp.wgrad), sp.wgrad_b, &g.w[j], &pj, &w_exec[j], who)) return rc;
+        wflops += 2.0 * M * (double)pj.wsize;
+        g.ca[j] = prep[j].args; g.cgx[j] = (int)prep[j].gx; g.c_real[j] = (int)prep[j].gx * prep[j].S;
+    }
+    g.w_end[0] = pad8(g.w[0].real);
+    g.w_end[1] = g.w_end[0] + pad8(g.w[1].real);
+    g.c_end0 = pad8(g.c_real[0]);
+    {
+        be::ProfileScope prof(s, BE_KERNEL_TRAIN_BWD_GEMMS, prep[0].flops + prep[1].flops + wflops, 0.0,
+                              prep[0].flops_exec + prep[1].flops_exec + w_exec[0] + w_exec[1]);
+        if (int rc = launch_unit_gemms(prep[0].variant, g, (unsigned)(g.w_end[1] + g.c_end0 + g.c_real[1]), s)) return rc;
+    }
+    pa.xpart = reinterpret_cast<const float*>(scr_part(sc, 0, 2).conv); pa.xldp = prep[0].ldp; pa.xS = prep[0].S;
+    pa.dx = a->dx; pa.xM = M; pa.xC = d->cin;
+    if (prep[1].S > 1) { pa.xpart2 = reinterpret_cast<const float*>(scr_part(sc, 1, 2).conv); pa.xldp2 = prep[1].ldp; pa.xS2 = prep[1].S; }
+    else pa.xadd = b->dx;
+    const int nb_x = (int)cap_grid((int64_t)M * (d->cin / 4), 256, 2048);
+    hipLaunchKernelGGL(k_bwd_post, dim3(pa.j[0].nb_w + pa.j[0].nb_b + pa.j[1].nb_w + pa.j[1].nb_b + nb_x), dim3(256), 0, s, pa);
+    return be::check_launch(who);
 }
 
 // Parameter gradients of a Linear over many rows (GlobalStage at 8 x 4096 tokens: y = x W^T + b): dW = dy^T x and db = column
@@ -1365,10 +1595,12 @@ extern "C" int be_linear_param_grads_f32(const float* x, const float* dy, float*
     if (int rc_ = be::ensure_dynamic_lds(reinterpret_cast<const void*>(&k_lin_grads), lds, f)) return rc_;
     hipLaunchKernelGGL(k_lin_grads, dim3(g.n_w + g.cbx * rb.n), dim3(256), lds, s, g);
     PostArgs pa{};
-    pa.wpart = wpart; pa.dw = dw; pa.wsize = wsize; pa.wS = S; pa.wtaps = 1; pa.cout1 = cout;
-    pa.nb_w = (int)cap_grid(wsize, 256, 1024);
-    pa.dbpart = dbpart; pa.db = db; pa.nb_rows = rb.n; pa.C = cout; pa.nb_b = cout / 32;
-    hipLaunchKernelGGL(k_bwd_post, dim3(pa.nb_w + pa.nb_b), dim3(256), 0, s, pa);
+    pa.nj = 1;
+    PostJob& pj = pa.j[0];
+    pj.wpart = wpart; pj.dw = dw; pj.wsize = wsize; pj.wS = S; pj.wtaps = 1; pj.cout1 = cout;
+    pj.nb_w = (int)cap_grid(wsize, 256, 1024);
+    pj.dbpart = dbpart; pj.db = db; pj.nb_rows = rb.n; pj.C = cout; pj.nb_b = cout / 32;
+    hipLaunchKernelGGL(k_bwd_post, dim3(pj.nb_w + pj.nb_b), dim3(256), 0, s, pa);
     return be::check_launch("be_linear_param_grads_f32");
 }
 

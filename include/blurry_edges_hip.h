@@ -414,6 +414,31 @@ int be_train_unit_bwd_f32(const be_conv_desc* desc_host, const float* x, const f
                           const float* dgrad_packed_bias, const float* dx_add, int layout_chw_hw, float* ds, float* dy,
                           float* dgamma, float* dbeta, float* dw, float* db, float* dx, void* scratch, size_t scratch_bytes,
                           void* stream);
+/* The same two entry points for TWO units that are independent of each other and share their input - the 3x3 convolution
+ * (unit a) and the 1x1 downsample (unit b) of a ResidualBlock (models/local_stage.py:20-28): every launch of the single form
+ * carries both units' workgroups (the two convolutions in one grid, the BatchNorm kernels with one grid slice per unit, one
+ * closing kernel), each unit in its own half of the scratch regions.  Results are those of the single calls, bit for bit.
+ * Forward: both units produce the same [n,h,w,cout].  Backward: the units also share x and cin; a->dx receives the SUM of
+ * both input gradients (what ResidualBlock's autograd node accumulates), b->dx [M,cin] is working space (contents
+ * unspecified afterwards), dx_add must be NULL in both.  Shapes the merged launches do not take run one unit after the
+ * other inside the call. */
+typedef struct be_train_unit_fwd {
+    be_conv_desc desc;
+    const float *x, *packed_w, *packed_bias, *gamma, *beta, *res;
+    float *run_mean, *run_var, *y, *mean, *invstd, *s_in, *out;
+    int act;
+} be_train_unit_fwd;
+typedef struct be_train_unit_bwd {
+    be_conv_desc desc;
+    const float *x, *dout, *s_in, *y, *mean, *invstd, *gamma, *dgrad_packed_w, *dgrad_packed_bias, *dx_add;
+    int layout_chw_hw;
+    float *ds, *dy, *dgamma, *dbeta, *dw, *db, *dx;
+} be_train_unit_bwd;
+int be_train_unit_pair_fwd_f32(const be_train_unit_fwd* a, const be_train_unit_fwd* b, float eps, float momentum,
+                               void* scratch, size_t scratch_bytes, void* stream);
+int be_train_unit_pair_bwd_f32(const be_train_unit_bwd* a, const be_train_unit_bwd* b, void* scratch, size_t scratch_bytes,
+                               void* stream);
+
 /* Parameter gradients of y = x W^T + b over many rows (the linears of GlobalStage in training, global_training.py:207-213 under
  * autograd): dw [cout,cin] = dy^T x and db [cout] = column sums of dy, in two launches (weight-gradient tiles + column-sum
  * workgroups in one grid, then one reduction kernel; fixed order).  cin, cout multiples of 128, M >= 256 rows. */
