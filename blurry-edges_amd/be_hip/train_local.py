@@ -57,7 +57,7 @@ def train_step(model, helper, opt, batch, beta_b, beta_s, flat=None, world=1, cl
         loss.backward()
         if flat is not None and world > 1:
             dp.allreduce_mean_(dp.grads_as_flat(list(model.parameters()), flat), world)      # zero-copy when the backward wrote one buffer
-    if hasattr(opt, "clip_and_step"):    # be_hip.optim.ClipAdamW: norm + clip + AdamW over the flat gradient buffer, three launches
+    if hasattr(opt, "clip_and_step"):    # be_hip.optim.ClipAdamW: norm + clip + AdamW over the flat gradient buffer, two launches
         norm = opt.clip_and_step(clip)
     else:
         norm = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=clip, norm_type=2)
@@ -239,7 +239,7 @@ def main(argv=None):
     model.load_state_dict({k: torch.from_numpy(np.asarray(v)).to(dev) for k, v in synth.local_stage_state_dict().items()})
     helper = utils.PostProcessLocalBase(args, dev)
     from .optim import ClipAdamW
-    opt = ClipAdamW(model.parameters(), lr=a.lr)            # clip + AdamW over the flat gradient buffer (three launches)
+    opt = ClipAdamW(model.parameters(), lr=a.lr)            # clip + AdamW over the flat gradient buffer (two launches)
     flat = None
     sync = dp.GradSync(world) if world > 1 else None       # four buckets, each all-reduced while the backward goes on
     if world > 1:

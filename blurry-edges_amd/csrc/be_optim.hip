@@ -12,8 +12,11 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int CHUNK = 4096;          // elements per workgroup (= per table entry)
 
 __global__ __launch_bounds__(256)
-void k_grad_sqsum(const float* __restrict__ g, int64_t n, double* __restrict__ partial) {
+void k_grad_sqsum(const float* __restrict__ g, int64_t n, double* __restrict__ partial, float* __restrict__ step) {
     __shared__ double red[256];
+    // the step counter moves here, one launch ahead of its readers (every workgroup of k_clip_adamw reads it: none of them can
+    // know when the others have) - a launch of its own in the first version
+    if (blockIdx.x == 0 && threadIdx.x == 0) step[0] += 1.0f;
     const int64_t lo = (int64_t)blockIdx.x * CHUNK, hi = lo + CHUNK < n ? lo + CHUNK : n;
     double s = 0.0;
     if (((uintptr_t)g & 15u) == 0) {
@@ -42,7 +45,7 @@ struct AdamArgs {
     float max_norm, grad_scale;
     double lr, beta1, beta2, eps, weight_decay;   // hyper-parameters stay doubles (Python floats) until the last moment, as in torch: 1 - beta2 formed
                                                   // from the FLOAT 0.999 is off by 1.3e-5 relative
-    float* step;                     // device scalar, incremented by workgroup 0 AFTER every workgroup has read it ... see below
+    const float* step;               // device scalar: the number of this step (k_grad_sqsum has already counted it)
     float* grad_norm;                // device scalar out (the norm before clipping), may be null
     int write_back;
 };
@@ -66,9 +69,7 @@ void k_clip_adamw(AdamArgs a) {
         if (coef > 1.0f) coef = 1.0f;
         if (a.max_norm <= 0.0f) coef = 1.0f;                  // clipping off
         s_coef = coef * a.grad_scale;
-        // `step` holds the number of steps taken BEFORE this one; the host-side wrapper bumps it with its own tiny launch
-        // after this kernel (a workgroup cannot know when the others have read it)
-        const double t = (double)a.step[0] + 1.0;
+        const double t = (double)a.step[0];
         s_bc1 = (float)(1.0 - pow(a.beta1, t));
         s_bc2s = (float)sqrt(1.0 - pow(a.beta2, t));
         if (blockIdx.x == 0 && a.grad_norm) a.grad_norm[0] = total;
@@ -111,8 +112,6 @@ void k_clip_adamw(AdamArgs a) {
     }
 }
 
-__global__ void k_step_inc(float* step) { if (threadIdx.x == 0 && blockIdx.x == 0) step[0] += 1.0f; }
-
 }  // namespace
 
 extern "C" int be_adam_chunk(void) { return CHUNK; }
@@ -124,10 +123,9 @@ extern "C" int be_clip_adamw_f32(const be_adam_entry* table_device, int nentries
     const int nblk = (int)((n_flat + CHUNK - 1) / CHUNK);
     BE_REQUIRE(nblk <= npartial_cap, "be_clip_adamw_f32: partial buffer too small (%d blocks)", nblk);
     hipStream_t s = be::as_stream(stream);
-    hipLaunchKernelGGL(k_grad_sqsum, dim3(nblk), dim3(256), 0, s, grad_flat, n_flat, partial);
+    hipLaunchKernelGGL(k_grad_sqsum, dim3(nblk), dim3(256), 0, s, grad_flat, n_flat, partial, step_device);
     AdamArgs a{table_device, grad_flat, partial, nblk, max_norm, grad_scale, lr, beta1, beta2, eps, weight_decay, step_device,
                grad_norm_out, write_back};
     hipLaunchKernelGGL(k_clip_adamw, dim3(nentries), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(64), 0, s, step_device);
     return be::check_launch("be_clip_adamw_f32");
 }

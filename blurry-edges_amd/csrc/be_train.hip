@@ -490,24 +490,33 @@ __global__ void k_wgrad_conv1(const float* __restrict__ x4, const float* __restr
 
 // last Linear (1024 -> 10): dx[m][k] = sum_j dy[m][j] W[j][k]; dW[j][k] = sum_m dy[m][j] x[m][k]; db[j] = sum_m dy[m][j]
 __global__ void k_linear_small_bwd(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ dy,
-                                   float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db, int M, int K, int J) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx < M * K) {                                    // dx
-        const int m = idx / K, k = idx % K;
-        float s = 0.f;
-        for (int j = 0; j < J; ++j) s = fmaf(dy[m * J + j], w[j * K + k], s);
-        dx[idx] = s;
-    }
-    if (idx < J * K) {                                    // dW
-        const int j = idx / K, k = idx % K;
-        float s = 0.f;
-        for (int m = 0; m < M; ++m) s = fmaf(dy[m * J + j], x[m * K + k], s);
-        dw[idx] = s;
-    }
-    if (idx < J) {
-        float s = 0.f;
-        for (int m = 0; m < M; ++m) s += dy[m * J + idx];
-        db[idx] = s;
+                                   float* __restrict__ dx, float* __restrict__ dw, float* __restrict__ db, int M, int K, int J,
+                                   int nb_dx, int nb_dw) {
+    // three roles side by side (a thread that did dx, then dW, then db in turn made the launch three dependent chains long: 19 us)
+    const int b = blockIdx.x;
+    if (b < nb_dx) {                                      // dx
+        const int idx = b * blockDim.x + threadIdx.x;
+        if (idx < M * K) {
+            const int m = idx / K, k = idx % K;
+            float s = 0.f;
+            for (int j = 0; j < J; ++j) s = fmaf(dy[m * J + j], w[j * K + k], s);
+            dx[idx] = s;
+        }
+    } else if (b < nb_dx + nb_dw) {                       // dW
+        const int idx = (b - nb_dx) * blockDim.x + threadIdx.x;
+        if (idx < J * K) {
+            const int j = idx / K, k = idx % K;
+            float s = 0.f;
+            for (int m = 0; m < M; ++m) s = fmaf(dy[m * J + j], x[m * K + k], s);
+            dw[idx] = s;
+        }
+    } else {
+        const int idx = threadIdx.x;
+        if (idx < J) {
+            float s = 0.f;
+            for (int m = 0; m < M; ++m) s += dy[m * J + idx];
+            db[idx] = s;
+        }
     }
 }
 
@@ -1636,8 +1645,9 @@ extern "C" int be_maxpool_nhwc_bwd_idx_f32(const unsigned char* idx, const float
 extern "C" int be_linear_small_bwd_f32(const float* x, const float* w, const float* dy, float* dx, float* dw, float* db,
                                        int M, int K, int J, void* stream) {
     BE_REQUIRE(x && w && dy && dx && dw && db && M > 0 && K > 0 && J > 0, "be_linear_small_bwd_f32: bad arguments");
-    const int total = (M > J ? M : J) * K;
-    hipLaunchKernelGGL(k_linear_small_bwd, dim3((total + 255) / 256), dim3(256), 0, be::as_stream(stream), x, w, dy, dx, dw, db,
-                       M, K, J);
+    BE_REQUIRE(J <= 256 && (int64_t)M * K < ((int64_t)1 << 31), "be_linear_small_bwd_f32: J <= 256");
+    const int nb_dx = (M * K + 255) / 256, nb_dw = (J * K + 255) / 256;
+    hipLaunchKernelGGL(k_linear_small_bwd, dim3(nb_dx + nb_dw + 1), dim3(256), 0, be::as_stream(stream), x, w, dy, dx, dw, db,
+                       M, K, J, nb_dx, nb_dw);
     return be::check_launch("be_linear_small_bwd_f32");
 }

@@ -454,8 +454,8 @@ int be_maxpool_nhwc_bwd_idx_f32(const unsigned char* idx, const float* dout, flo
                                 int stride, int pad, void* stream);
 
 /* Tail of a training step (local_training.py:107-108): torch.nn.utils.clip_grad_norm_(max_norm, 2) + torch.optim.AdamW.step()
- * for parameters whose gradients are slices of ONE flat buffer (what the LocalStage backward writes), in three launches: squared-
- * norm partials (fp64), the update, the step counter.  table (device): one entry per workgroup, at most be_adam_chunk() elements
+ * for parameters whose gradients are slices of ONE flat buffer (what the LocalStage backward writes), in two launches: squared-
+ * norm partials (fp64; this launch also counts the step), the update.  table (device): one entry per workgroup, at most be_adam_chunk() elements
  * each: parameter / exp_avg / exp_avg_sq pointers, offset of the slice in grad_flat, count.  grad_scale multiplies the gradient
  * first (1/world after a summing all-reduce).  max_norm <= 0: no clipping.  step_device: float scalar = steps taken so far
  * (incremented here); grad_norm_out (may be NULL): the norm before clipping.  write_back: store the scaled + clipped gradient
