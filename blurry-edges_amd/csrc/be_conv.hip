@@ -890,7 +890,7 @@ static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2,
             if (S > 8) S = 8;
             while (S > 1 && kchunks / S < 12) --S;
             while (S > 1 && (size_t)S * M * cp * sizeof(float) > scratch_bytes) --S;
-            if (defer && defer->prep) {                                     // hand the launch back (be_train.hip: k_bwd_gemms)
+            if (defer && defer->prep) {                                     // hand the launch back (be_train.hip: k_unit_gemms)
                 if (S > 1) { a.ksplit = S; a.ldp = cp; a.partial = static_cast<float*>(scratch); }
                 be::ConvPrep* pr = defer->prep;
                 pr->args = a; pr->variant = uni ? 2 : (t64 ? 0 : 1); pr->S = S > 1 ? S : 1; pr->ldp = S > 1 ? cp : 0;

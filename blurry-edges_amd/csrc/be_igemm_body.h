@@ -35,7 +35,7 @@ struct ConvArgs {
 // loads BEFORE the MFMA phase (v1: 60 % MFMA-busy).
 // BKT = K-chunk in floats; PRIO = 1: s_setprio around the MFMA phase (measured: no effect; kept for A/B runs).
 // The kernel body as a device function (round 3): the training step runs a unit's data-gradient convolution and its weight-gradient
-// GEMM in ONE launch (be_train.hip: k_bwd_gemms), a workgroup picking its role from its index; bx / by / bz are what blockIdx.x / y / z
+// GEMM in ONE launch (be_train.hip: k_unit_gemms), a workgroup picking its role from its index; bx / by / bz are what blockIdx.x / y / z
 // are in the stand-alone kernel k_conv_igemm (be_conv.hip) and smem its dynamic LDS (2 (BM + BN) (BKT + 4) floats).
 // UNI (round 3): every row of every tile is inside the problem and every tap a tile visits is inside the image for all of its rows
 // (pixel-major tiles of whole image groups; 1x1 convolutions / linears with M a multiple of the tile): no border test, no zero

@@ -113,6 +113,20 @@ def test_round3_entry_points_validate_on_the_host_before_any_launch():
     assert lib.be_train_unit_fwd_f32(C.byref(d_bad), p, p, p, p, p, None, 1e-5, 0.1, None, None, p, p, p, None, p, 0, p, big, None) < 0
     assert b"cout" in lib.be_last_error()
     assert lib.be_train_unit_bwd_f32(C.byref(d), *([None] * 10), 0, *([None] * 8), 0, None) < 0
+    # the two-unit forms: struct arguments, the same checks per unit + the pairing rules
+    pv = p.value
+    fa = native.TrainUnitFwd(native.ConvDesc(64, 6, 6, 256, 384, 3, 0), pv, pv, pv, pv, pv, None, None, None, pv, pv, pv, pv, pv, 1)
+    fb = native.TrainUnitFwd(native.ConvDesc(64, 6, 6, 256, 256, 1, 0), pv, pv, pv, pv, pv, None, None, None, pv, pv, pv, None, pv, 0)
+    assert lib.be_train_unit_pair_fwd_f32(None, None, 1e-5, 0.1, None, 0, None) < 0
+    assert lib.be_train_unit_pair_fwd_f32(C.byref(fa), C.byref(fb), 1e-5, 0.1, p, 1024, None) < 0
+    assert b"scratch" in lib.be_last_error()
+    assert lib.be_train_unit_pair_fwd_f32(C.byref(fa), C.byref(fb), 1e-5, 0.1, p, big, None) < 0      # 384 vs 256 output channels
+    assert b"same [n,h,w,cout]" in lib.be_last_error()
+    ba = native.TrainUnitBwd(native.ConvDesc(64, 6, 6, 256, 384, 3, 0), pv, pv, pv, pv, pv, pv, pv, pv, pv, None, 0, pv, pv, pv, pv, pv, pv, pv)
+    bb = native.TrainUnitBwd(native.ConvDesc(64, 6, 6, 256, 384, 1, 0), pv, pv, None, pv, pv, pv, pv, pv, pv, None, 0, pv, pv, pv, pv, pv, pv, pv)
+    assert lib.be_train_unit_pair_bwd_f32(C.byref(ba), None, p, big, None) < 0
+    assert lib.be_train_unit_pair_bwd_f32(C.byref(ba), C.byref(bb), p, big, None) < 0                  # one dx buffer for both
+    assert b"dx" in lib.be_last_error()
     assert lib.be_linear_small_fwd_f32(p, p, p, p, 4, 10, 3, None) < 0             # K % 4 != 0
     assert lib.be_maxpool_nhwc_fwd_idx_f32(p, p, p, 1, 6, 6, 6, 2, 2, 0, None) < 0  # c % 4 != 0
     assert lib.be_maxpool_nhwc_bwd_idx_f32(None, p, p, 1, 6, 6, 8, 2, 2, 0, None) < 0
