@@ -31,7 +31,7 @@ def test_torch_operators_are_registered_over_the_c_abi():
     from be_hip import native
     o = native.ops()
     assert o is not None and os.path.exists(native.TORCH_OPS_PATH)
-    for name in ("local_stage_pack", "local_stage_forward", "render_colors", "local_depth", "train_unit_fwd", "train_unit_bwd",
+    for name in ("local_stage_pack", "local_stage_forward", "render_colors", "local_depth", "train_unit_fwd", "train_unit_bwd", "train_unit_pair_fwd", "train_unit_pair_bwd",
                  "maxpool_fwd_idx", "maxpool_bwd_idx", "clip_adamw"):
         assert hasattr(o, name), name
     schema = str(torch.ops.be.local_stage_forward.default._schema)
