@@ -566,9 +566,19 @@ __device__ __forceinline__ void finish_partials(const double* __restrict__ parti
 #pragma unroll
     for (int k = 0; k < NV; ++k) a[k] = 0.0;
     if (c_base + col < C)
-        for (int rb = pr; rb < nrb; rb += 8)
+        for (int rb0 = pr; rb0 < nrb; rb0 += 64) {      // this lane's partials rb0, rb0 + 8, ...: eight loads in flight (a load per
+            double t[8][NV];                             // add left the prologue waiting on 16 L2 round trips), added in that order
 #pragma unroll
-            for (int k = 0; k < NV; ++k) a[k] += partial[((size_t)rb * C + c_base + col) * NV + k];
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int k = 0; k < NV; ++k)
+                    if (rb0 + 8 * j < nrb) t[j][k] = partial[((size_t)(rb0 + 8 * j) * C + c_base + col) * NV + k];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int k = 0; k < NV; ++k)
+                    if (rb0 + 8 * j < nrb) a[k] += t[j][k];
+        }
 #pragma unroll
     for (int k = 0; k < NV; ++k) part_lds[(pr * UC + col) * NV + k] = a[k];
     __syncthreads();
@@ -605,24 +615,35 @@ void k_bn_stats(Two<StatsArgs> two) {
     if (c < a.C) {
         f32x4 b4 = {0.f, 0.f, 0.f, 0.f};
         if (a.S > 0 && a.bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + c);
-        for (int r = r0 + ty; r < r1; r += UR) {
-            f32x4 t;
-            if (a.S > 0) {
+        if (a.S > 0) {
+            for (int r = r0 + ty; r < r1; r += UR) {
                 // the (<= 8) slices of a row are independent loads: issue them together, then add in slice order
                 f32x4 p[8];
 #pragma unroll
                 for (int s = 0; s < 8; ++s)
                     if (s < a.S) p[s] = *reinterpret_cast<const f32x4*>(a.partial + ((size_t)s * a.M + r) * a.ldp + c);
-                t = p[0];
+                f32x4 t = p[0];
 #pragma unroll
                 for (int s = 1; s < 8; ++s) if (s < a.S) t += p[s];
                 t += b4;
                 *reinterpret_cast<f32x4*>(a.y + (size_t)r * a.C + c) = t;
-            } else {
-                t = *reinterpret_cast<const f32x4*>(a.y + (size_t)r * a.C + c);
-            }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[0][e] += t[e]; v[1][e] += (double)t[e] * t[e]; }
+                for (int e = 0; e < 4; ++e) { v[0][e] += t[e]; v[1][e] += (double)t[e] * t[e]; }
+            }
+        } else {
+            // four rows in flight (conv1: 7 rows per thread, each an HBM / L2 round trip when loaded one by one), summed in row order
+            for (int rb = r0 + ty; rb < r1; rb += 4 * UR) {
+                f32x4 t[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (rb + j * UR < r1) t[j] = *reinterpret_cast<const f32x4*>(a.y + (size_t)(rb + j * UR) * a.C + c);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (rb + j * UR < r1) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { v[0][e] += t[j][e]; v[1][e] += (double)t[j][e] * t[j][e]; }
+                    }
+            }
         }
     }
     block_col_sums<2>(v, lds, a.stats + (size_t)blockIdx.y * a.C * 2, 2, a.C, c_base);
@@ -667,19 +688,30 @@ void k_bn_fwd_apply(Two<FwdApplyArgs> two) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) { mu[e] = s_mu[tx * 4 + e]; is[e] = s_is[tx * 4 + e]; }
     const int r0 = blockIdx.y * a.rows_per_block, r1 = min(a.M, r0 + a.rows_per_block);
-    for (int r = r0 + ty; r < r1; r += UR) {
-        const size_t at = (size_t)r * a.C + c;
-        const f32x4 yv = *reinterpret_cast<const f32x4*>(a.y + at);
-        f32x4 z;
+    for (int rb = r0 + ty; rb < r1; rb += 4 * UR) {         // four rows in flight
+        f32x4 yv[4], rv[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) z[e] = (yv[e] - mu[e]) * is[e] * g[e] + b[e];
-        if (a.res) z += *reinterpret_cast<const f32x4*>(a.res + at);
-        if (a.s_in) *reinterpret_cast<f32x4*>(a.s_in + at) = z;
-        if (a.act) {
+        for (int j = 0; j < 4; ++j)
+            if (rb + j * UR < r1) {
+                const size_t at = (size_t)(rb + j * UR) * a.C + c;
+                yv[j] = *reinterpret_cast<const f32x4*>(a.y + at);
+                if (a.res) rv[j] = *reinterpret_cast<const f32x4*>(a.res + at);
+            }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) z[e] = be::smish(z[e]);
-        }
-        *reinterpret_cast<f32x4*>(a.out + at) = z;
+        for (int j = 0; j < 4; ++j)
+            if (rb + j * UR < r1) {
+                const size_t at = (size_t)(rb + j * UR) * a.C + c;
+                f32x4 z;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) z[e] = (yv[j][e] - mu[e]) * is[e] * g[e] + b[e];
+                if (a.res) z += rv[j];
+                if (a.s_in) *reinterpret_cast<f32x4*>(a.s_in + at) = z;
+                if (a.act) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) z[e] = be::smish(z[e]);
+                }
+                *reinterpret_cast<f32x4*>(a.out + at) = z;
+            }
     }
 }
 
@@ -699,18 +731,29 @@ void k_bn_bwd_reduce(Two<BwdReduceArgs> two) {
     double v[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
     if (c < a.C) {
         const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + c), is = *reinterpret_cast<const f32x4*>(a.invstd + c);
-        for (int r = r0 + ty; r < r1; r += UR) {
-            const size_t at = (size_t)r * a.C + c;
-            f32x4 d = *reinterpret_cast<const f32x4*>(a.dout + at);
-            if (a.s_in) {
-                const f32x4 si = *reinterpret_cast<const f32x4*>(a.s_in + at);
+        for (int rb = r0 + ty; rb < r1; rb += 4 * UR) {         // four rows in flight, accumulated in row order
+            f32x4 dv[4], sv[4], yv[4];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) d[e] *= smish_grad(si[e]);
-            }
-            *reinterpret_cast<f32x4*>(a.ds + at) = d;
-            const f32x4 yv = *reinterpret_cast<const f32x4*>(a.y + at);
+            for (int j = 0; j < 4; ++j)
+                if (rb + j * UR < r1) {
+                    const size_t at = (size_t)(rb + j * UR) * a.C + c;
+                    dv[j] = *reinterpret_cast<const f32x4*>(a.dout + at);
+                    if (a.s_in) sv[j] = *reinterpret_cast<const f32x4*>(a.s_in + at);
+                    yv[j] = *reinterpret_cast<const f32x4*>(a.y + at);
+                }
 #pragma unroll
-            for (int e = 0; e < 4; ++e) { v[0][e] += d[e]; v[1][e] += (double)d[e] * ((yv[e] - mu[e]) * is[e]); }
+            for (int j = 0; j < 4; ++j)
+                if (rb + j * UR < r1) {
+                    const size_t at = (size_t)(rb + j * UR) * a.C + c;
+                    f32x4 d = dv[j];
+                    if (a.s_in) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) d[e] *= smish_grad(sv[j][e]);
+                    }
+                    *reinterpret_cast<f32x4*>(a.ds + at) = d;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { v[0][e] += d[e]; v[1][e] += (double)d[e] * ((yv[j][e] - mu[e]) * is[e]); }
+                }
         }
     }
     block_col_sums<2>(v, lds, a.partial + (size_t)blockIdx.y * a.C * 2, 2, a.C, c_base);
@@ -749,17 +792,27 @@ void k_bn_bwd_apply(Two<BwdApplyArgs> two) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) { db[e] = s_db[tx * 4 + e]; dg[e] = s_dg[tx * 4 + e]; }
         const int r0 = blockIdx.y * a.rows_per_block, r1 = min(a.M, r0 + a.rows_per_block);
-        for (int r = r0 + ty; r < r1; r += UR) {
-            const size_t at = (size_t)r * a.C + c;
-            const f32x4 d = *reinterpret_cast<const f32x4*>(a.ds + at), yv = *reinterpret_cast<const f32x4*>(a.y + at);
-            f32x4 o;
+        for (int rb = r0 + ty; rb < r1; rb += 4 * UR) {         // four rows in flight, accumulated in row order
+            f32x4 dv[4], yv[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float xh = (yv[e] - mu[e]) * is[e];
-                o[e] = g[e] * is[e] * (d[e] - db[e] * a.inv_m - xh * dg[e] * a.inv_m);
-                v[0][e] += o[e];
-            }
-            *reinterpret_cast<f32x4*>(a.dy + at) = o;
+            for (int j = 0; j < 4; ++j)
+                if (rb + j * UR < r1) {
+                    const size_t at = (size_t)(rb + j * UR) * a.C + c;
+                    dv[j] = *reinterpret_cast<const f32x4*>(a.ds + at);
+                    yv[j] = *reinterpret_cast<const f32x4*>(a.y + at);
+                }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (rb + j * UR < r1) {
+                    f32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float xh = (yv[j][e] - mu[e]) * is[e];
+                        o[e] = g[e] * is[e] * (dv[j][e] - db[e] * a.inv_m - xh * dg[e] * a.inv_m);
+                        v[0][e] += o[e];
+                    }
+                    *reinterpret_cast<f32x4*>(a.dy + (size_t)(rb + j * UR) * a.C + c) = o;
+                }
         }
     }
     block_col_sums<1>(v, lds, a.dbpart + (size_t)blockIdx.y * a.C, 1, a.C, c_base);
@@ -847,7 +900,13 @@ __device__ __forceinline__ void post_job(const PostJob& a, const int b) {
         const int col = threadIdx.x & 31, pr = threadIdx.x >> 5, c = (b - a.nb_w) * 32 + col;
         double s = 0.0;
         if (c < a.C)
-            for (int r = pr; r < a.nb_rows; r += 8) s += a.dbpart[(size_t)r * a.C + c];
+            for (int r0 = pr; r0 < a.nb_rows; r0 += 64) {   // eight loads in flight, added in the same order
+                double t[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (r0 + 8 * j < a.nb_rows) t[j] = a.dbpart[(size_t)(r0 + 8 * j) * a.C + c];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) if (r0 + 8 * j < a.nb_rows) s += t[j];
+            }
         red[pr * 32 + col] = s;
         __syncthreads();
         if (threadIdx.x < 32 && c < a.C) {
