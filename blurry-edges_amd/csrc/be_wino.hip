@@ -78,7 +78,16 @@ __global__ void k_wino_pack(const float* __restrict__ w, const float* __restrict
     }
 }
 
+// streaming accesses of the transform kernels: NT bit 0 = non-temporal loads, bit 1 = non-temporal stores (A/B: BE_WINO_NT)
+template <int NT> __device__ __forceinline__ f32x4 ld_s(const f32x4* p) {
+    if constexpr (NT & 1) return __builtin_nontemporal_load(p); else return *p;
+}
+template <int NT> __device__ __forceinline__ void st_s(f32x4* p, f32x4 v) {
+    if constexpr (NT & 2) __builtin_nontemporal_store(v, p); else *p = v;
+}
+
 // one thread = one tile (patch, ty, tx) x one channel quad; arithmetic: be_wino_math.h (shared with the fused GEMM epilogue)
+template <int NT>
 __global__ __launch_bounds__(256)
 void k_wino_in(const float* __restrict__ x, float* __restrict__ V, int64_t n, int c4, int tm) {
     const int64_t total = n * 4 * c4;
@@ -99,12 +108,12 @@ void k_wino_in(const float* __restrict__ x, float* __restrict__ V, int64_t n, in
 #pragma unroll
             for (int c = 0; c < 5; ++c) {
                 const int yy = 3 * ty - 1 + r, xx = 3 * tx - 1 + c;
-                d[r][c] = ((unsigned)xx < 6u && (unsigned)yy < 6u) ? src[(size_t)(yy * 6 + xx) * c4] : zero;
+                d[r][c] = ((unsigned)xx < 6u && (unsigned)yy < 6u) ? ld_s<NT>(src + (size_t)(yy * 6 + xx) * c4) : zero;
             }
         be::wino_in25(d, v);
         f32x4* dst = reinterpret_cast<f32x4*>(V) + tile * ts + cq;
 #pragma unroll
-        for (int z = 0; z < 25; ++z) dst[(size_t)z * plane] = v[z];
+        for (int z = 0; z < 25; ++z) st_s<NT>(dst + (size_t)z * plane, v[z]);
     }
 }
 
@@ -114,6 +123,7 @@ __device__ __forceinline__ f32x4 wino_act(f32x4 v, int act) {
     return v;
 }
 
+template <int NT>
 __global__ __launch_bounds__(256)
 void k_wino_out(const float* __restrict__ M, const float* __restrict__ bias, const float* __restrict__ res,
                 float* __restrict__ y, int64_t n, int c4, int act, int tm) {
@@ -128,7 +138,7 @@ void k_wino_out(const float* __restrict__ M, const float* __restrict__ bias, con
         const f32x4* src = reinterpret_cast<const f32x4*>(M) + tile * ts + cq;
         f32x4 m[25], o[9];
 #pragma unroll
-        for (int z = 0; z < 25; ++z) m[z] = src[(size_t)z * plane];
+        for (int z = 0; z < 25; ++z) m[z] = ld_s<NT>(src + (size_t)z * plane);
         be::wino_out9(m, o);
         const f32x4 bv = reinterpret_cast<const f32x4*>(bias)[cq];
 #pragma unroll
@@ -138,7 +148,7 @@ void k_wino_out(const float* __restrict__ M, const float* __restrict__ bias, con
                 const size_t e = ((size_t)img * 36 + (3 * ty + r) * 6 + 3 * tx + c) * c4 + cq;
                 f32x4 v = o[3 * r + c] + bv;
                 if (res) v += reinterpret_cast<const f32x4*>(res)[e];
-                reinterpret_cast<f32x4*>(y)[e] = wino_act(v, act);
+                st_s<NT>(reinterpret_cast<f32x4*>(y) + e, wino_act(v, act));
             }
     }
 }
@@ -146,6 +156,7 @@ void k_wino_out(const float* __restrict__ M, const float* __restrict__ bias, con
 // conv1 -> conv2 of a residual block without the intermediate map in HBM: one thread = one image x one channel quad reads the
 // 100 transform-domain values of conv1's result, forms the 6x6 map (+ bias, Smish) in registers and writes the 100
 // transform-domain values conv2's GEMMs read.  Saves the 36 values written and re-read (4x, tile overlap) per channel.
+template <int NT>
 __global__ __launch_bounds__(256, 1)
 void k_wino_out_in(const float* __restrict__ M, const float* __restrict__ bias, float* __restrict__ V, int64_t n, int c4, int act,
                    int tm_in, int tm_out) {
@@ -165,7 +176,7 @@ void k_wino_out_in(const float* __restrict__ M, const float* __restrict__ bias, 
                 const f32x4* src = reinterpret_cast<const f32x4*>(M) + (img * 4 + ty * 2 + tx) * ts + cq;
                 f32x4 m[25], o[9];
 #pragma unroll
-                for (int z = 0; z < 25; ++z) m[z] = src[(size_t)z * plane];
+                for (int z = 0; z < 25; ++z) m[z] = ld_s<NT>(src + (size_t)z * plane);
                 be::wino_out9(m, o);
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
@@ -188,7 +199,7 @@ void k_wino_out_in(const float* __restrict__ M, const float* __restrict__ bias, 
                 be::wino_in25(d, v);
                 f32x4* dst = reinterpret_cast<f32x4*>(V) + (img * 4 + ty * 2 + tx) * ts_o + cq;
 #pragma unroll
-                for (int z = 0; z < 25; ++z) dst[(size_t)z * plane_o] = v[z];
+                for (int z = 0; z < 25; ++z) st_s<NT>(dst + (size_t)z * plane_o, v[z]);
             }
     }
 }
@@ -196,6 +207,7 @@ void k_wino_out_in(const float* __restrict__ M, const float* __restrict__ bias, 
 // Last block of LocalStage: output transform + bias + residual + activation + the 2x2 max-pool that follows it
 // (models/local_stage.py:42,67: maxpool after layer3), one thread per image and channel quad: the 6x6 map exists only in
 // registers, [N,3,3,C] is written (saves the map's round trip through HBM and the pooling launch).
+template <int NT>
 __global__ __launch_bounds__(256, 1)
 void k_wino_out_pool2(const float* __restrict__ M, const float* __restrict__ bias, const float* __restrict__ res,
                       float* __restrict__ y, int64_t n, int c4, int act, int tm) {
@@ -214,7 +226,7 @@ void k_wino_out_pool2(const float* __restrict__ M, const float* __restrict__ bia
                 const f32x4* src = reinterpret_cast<const f32x4*>(M) + (img * 4 + ty * 2 + tx) * ts + cq;
                 f32x4 m[25], o[9];
 #pragma unroll
-                for (int z = 0; z < 25; ++z) m[z] = src[(size_t)z * plane];
+                for (int z = 0; z < 25; ++z) m[z] = ld_s<NT>(src + (size_t)z * plane);
                 be::wino_out9(m, o);
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
@@ -233,7 +245,7 @@ void k_wino_out_pool2(const float* __restrict__ M, const float* __restrict__ bia
 #pragma unroll
                 for (int k = 0; k < 4; ++k)
                     m[k] = fmaxf(fmaxf(v[2 * py][2 * px][k], v[2 * py][2 * px + 1][k]), fmaxf(v[2 * py + 1][2 * px][k], v[2 * py + 1][2 * px + 1][k]));
-                reinterpret_cast<f32x4*>(y)[((size_t)img * 9 + py * 3 + px) * c4 + cq] = m;
+                st_s<NT>(reinterpret_cast<f32x4*>(y) + ((size_t)img * 9 + py * 3 + px) * c4 + cq, m);
             }
     }
 }
@@ -721,6 +733,20 @@ int be::gemm_rows_ws(const float* x, int64_t M, int K, const float* packed_w, in
     return launch_ws<24, 1>(g, s, M, K, N, BE_KERNEL_GEMM_ROWS);
 }
 
+// The transform kernels read every byte once: non-temporal loads (default) move 5.42-5.46 TB/s where plain loads move 5.24-5.28
+// (2.65 -> 2.56 ms of transforms per step; stores: no effect; the max-pool, whose windows overlap, loses a third with them).
+// A/B knob: BE_WINO_NT = 0 plain | 1 non-temporal loads (default) | 2 non-temporal stores | 3 both
+static int wino_nt() { static const int v = getenv("BE_WINO_NT") ? atoi(getenv("BE_WINO_NT")) & 3 : 1; return v; }
+#define BE_WINO_LAUNCH(K, GRID, BLOCK, LDS, STREAM, ...)                                                        \
+    do {                                                                                                        \
+        switch (wino_nt()) {                                                                                    \
+            case 1: hipLaunchKernelGGL(K<1>, GRID, BLOCK, LDS, STREAM, __VA_ARGS__); break;                     \
+            case 2: hipLaunchKernelGGL(K<2>, GRID, BLOCK, LDS, STREAM, __VA_ARGS__); break;                     \
+            case 3: hipLaunchKernelGGL(K<3>, GRID, BLOCK, LDS, STREAM, __VA_ARGS__); break;                     \
+            default: hipLaunchKernelGGL(K<0>, GRID, BLOCK, LDS, STREAM, __VA_ARGS__); break;                    \
+        }                                                                                                       \
+    } while (0)
+
 extern "C" int be_wino_conv3x3_6x6_f32(const float* x, const float* packed_w, const float* packed_bias, const float* residual,
                                        float* y, int64_t n, int cin, int cout, int act, float* workspace,
                                        size_t workspace_floats, void* stream) {
@@ -733,15 +759,15 @@ extern "C" int be_wino_conv3x3_6x6_f32(const float* x, const float* packed_w, co
     float* V = workspace;
     float* M = workspace + (size_t)100 * n * cin;
     if (be::wino_fused_ok(n, cin, cout)) {              // large batches: output transform in the GEMM's epilogue, no M
-        hipLaunchKernelGGL(k_wino_in, dim3(grid_cap(n * 4 * (cin / 4), 256)), dim3(256), 0, s, x, V, n, cin / 4, 1);
+        BE_WINO_LAUNCH(k_wino_in, dim3(grid_cap(n * 4 * (cin / 4), 256)), dim3(256), 0, s, x, V, n, cin / 4, 1);
         if (int rc = be::check_launch("be_wino_conv3x3_6x6_f32(in)")) return rc;
         return be::wino_fused(V, packed_w, packed_bias, residual, act, y, nullptr, n, cin, cout, 1, stream);
     }
     const int tm = wino_large(n, cout);
-    hipLaunchKernelGGL(k_wino_in, dim3(grid_cap(n * 4 * (cin / 4), 256)), dim3(256), 0, s, x, V, n, cin / 4, tm);
+    BE_WINO_LAUNCH(k_wino_in, dim3(grid_cap(n * 4 * (cin / 4), 256)), dim3(256), 0, s, x, V, n, cin / 4, tm);
     if (int rc = be::check_launch("be_wino_conv3x3_6x6_f32(in)")) return rc;
     if (int rc = wino_gemms(V, packed_w, M, n, cin, cout, s, stream)) return rc;
-    hipLaunchKernelGGL(k_wino_out, dim3(grid_cap(n * 4 * (cout / 4), 256)), dim3(256), 0, s, M, packed_bias, residual, y, n, cout / 4,
+    BE_WINO_LAUNCH(k_wino_out, dim3(grid_cap(n * 4 * (cout / 4), 256)), dim3(256), 0, s, M, packed_bias, residual, y, n, cout / 4,
                        act, tm);
     return be::check_launch("be_wino_conv3x3_6x6_f32(out)");
 }
@@ -770,7 +796,7 @@ int be::wino_pair(const float* x, const float* packed_w1, const float* packed_bi
     if (be::wino_fused_ok(n, cin, cmid) && be::wino_fused_ok(n, cmid, cout)) {
         // large batches (be_wino_fused.hip): conv1's GEMM writes conv2's transform-domain input straight from its epilogue,
         // conv2's GEMM writes the block's output (or its 2x2 max-pool); no M buffer, no separate output transforms
-        hipLaunchKernelGGL(k_wino_in, dim3(grid_cap(n * 4 * (cin / 4), 256)), dim3(256), 0, s, x, V, n, cin / 4, 1);
+        BE_WINO_LAUNCH(k_wino_in, dim3(grid_cap(n * 4 * (cin / 4), 256)), dim3(256), 0, s, x, V, n, cin / 4, 1);
         if (int rc = be::check_launch("be_wino_conv3x3_pair_6x6_f32(in)")) return rc;
         if (int rc = be::wino_fused(V, packed_w1, packed_bias1, nullptr, act1, nullptr, M, n, cin, cmid, 2, stream)) return rc;
         return be::wino_fused(M, packed_w2, packed_bias2, residual, act2, y, nullptr, n, cmid, cout, pool2 ? 4 : 1, stream);
@@ -778,13 +804,13 @@ int be::wino_pair(const float* x, const float* packed_w1, const float* packed_bi
     const int tm1 = wino_large(n, cmid), tm2 = wino_large(n, cout);
     {
         be::ProfileScope prof(s, BE_KERNEL_WINO_TRANSFORM, 0.0, 4.0 * n * cin * (36.0 + 100.0), 0.0);
-        hipLaunchKernelGGL(k_wino_in, dim3(grid_cap(n * 4 * (cin / 4), 256)), dim3(256), 0, s, x, V, n, cin / 4, tm1);
+        BE_WINO_LAUNCH(k_wino_in, dim3(grid_cap(n * 4 * (cin / 4), 256)), dim3(256), 0, s, x, V, n, cin / 4, tm1);
     }
     if (int rc = be::check_launch("be_wino_conv3x3_pair_6x6_f32(in)")) return rc;
     if (int rc = wino_gemms(V, packed_w1, M, n, cin, cmid, s, stream)) return rc;
     {
         be::ProfileScope prof(s, BE_KERNEL_WINO_TRANSFORM, 0.0, 4.0 * n * cmid * (100.0 + 100.0), 0.0);
-        hipLaunchKernelGGL(k_wino_out_in, dim3(grid_cap(n * (cmid / 4), 256)), dim3(256), 0, s, M, packed_bias1, V, n, cmid / 4, act1,
+        BE_WINO_LAUNCH(k_wino_out_in, dim3(grid_cap(n * (cmid / 4), 256)), dim3(256), 0, s, M, packed_bias1, V, n, cmid / 4, act1,
                            tm1, tm2);
     }
     if (int rc = be::check_launch("be_wino_conv3x3_pair_6x6_f32(out_in)")) return rc;
@@ -792,10 +818,10 @@ int be::wino_pair(const float* x, const float* packed_w1, const float* packed_bi
     {
         be::ProfileScope prof(s, BE_KERNEL_WINO_TRANSFORM, 0.0, 4.0 * n * cout * (100.0 + (residual ? 36.0 : 0.0) + (pool2 ? 9.0 : 36.0)), 0.0);
         if (pool2)
-            hipLaunchKernelGGL(k_wino_out_pool2, dim3(grid_cap(n * (cout / 4), 256)), dim3(256), 0, s, M, packed_bias2, residual, y, n,
+            BE_WINO_LAUNCH(k_wino_out_pool2, dim3(grid_cap(n * (cout / 4), 256)), dim3(256), 0, s, M, packed_bias2, residual, y, n,
                                cout / 4, act2, tm2);
         else
-            hipLaunchKernelGGL(k_wino_out, dim3(grid_cap(n * 4 * (cout / 4), 256)), dim3(256), 0, s, M, packed_bias2, residual, y, n,
+            BE_WINO_LAUNCH(k_wino_out, dim3(grid_cap(n * 4 * (cout / 4), 256)), dim3(256), 0, s, M, packed_bias2, residual, y, n,
                                cout / 4, act2, tm2);
     }
     return be::check_launch("be_wino_conv3x3_pair_6x6_f32(out)");
@@ -809,7 +835,7 @@ int be::wino_pair_chained(const float* x, const float* packed_w1, const float* p
     BE_REQUIRE(!(pool2 && v_next), "wino_pair_chained: the pooled block is the last one");
     hipStream_t s = be::as_stream(stream);
     if (x) {
-        hipLaunchKernelGGL(k_wino_in, dim3(grid_cap(n * 4 * (cin / 4), 256)), dim3(256), 0, s, x, v_in, n, cin / 4, 1);
+        BE_WINO_LAUNCH(k_wino_in, dim3(grid_cap(n * 4 * (cin / 4), 256)), dim3(256), 0, s, x, v_in, n, cin / 4, 1);
         if (int rc = be::check_launch("wino_pair_chained(in)")) return rc;
     }
     if (int rc = be::wino_fused(v_in, packed_w1, packed_bias1, nullptr, act1, nullptr, v_mid, n, cin, cmid, 2, stream)) return rc;
