@@ -770,7 +770,8 @@ __global__ void k_splitk_reduce(const float* __restrict__ partial, int S, int64_
 
 // defer (training units): when the K loop was split the S raw slices stay in scratch [S][M][ldp] and NO reduce kernel is launched -
 // the caller's own kernel sums them (with the bias) while it does its other work on the tile; S = 1: y = conv + bias as always
-struct SplitOut { int S, ldp; be::ConvPrep* prep; };   // prep != null: do not launch at all - hand the prepared launch back
+struct SplitOut { int S, ldp; be::ConvPrep* prep; bool pad64; };   // prep != null: do not launch at all - hand the prepared launch back;
+                                                                    // pad64: 96 output channels may run as two 64-wide uniform tiles
 static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2, int cin2, const float* pw, const float* pb,
                          const float* res, float* y, int ldy, void* stream, void* scratch = nullptr, size_t scratch_bytes = 0,
                          SplitOut* defer = nullptr);
@@ -806,16 +807,16 @@ extern "C" int be_conv_nhwc_splitk_f32(const be_conv_desc* d, const float* x, co
 
 int be::conv_train(const be_conv_desc* d, const float* x, const float* pw, const float* pb, const float* res, float* y, int ldy,
                    void* scratch, size_t scratch_bytes, int* S_out, int* ldp_out, void* stream) {
-    SplitOut so{1, 0, nullptr};
+    SplitOut so{1, 0, nullptr, false};
     const int rc = conv_dispatch(d, x, nullptr, 0, pw, pb, res, y, ldy, stream, scratch, scratch_bytes, &so);
     *S_out = so.S; *ldp_out = so.ldp;
     return rc;
 }
 
 int be::conv_train_prepare(const be_conv_desc* d, const float* x, const float* pw, const float* pb, const float* res, float* y, int ldy,
-                           void* scratch, size_t scratch_bytes, be::ConvPrep* prep) {
+                           void* scratch, size_t scratch_bytes, be::ConvPrep* prep, bool pad64) {
     prep->variant = -1;
-    SplitOut so{1, 0, prep};
+    SplitOut so{1, 0, prep, pad64};
     const int rc = conv_dispatch(d, x, nullptr, 0, pw, pb, res, y, ldy, nullptr, scratch, scratch_bytes, &so);
     return rc;        // prep->variant stays -1 for a shape outside the small-M tiles: the caller launches it on its own instead
 }
@@ -859,13 +860,20 @@ static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2,
     if (d->ksize == 1 && !x2 && cp == 128 && M >= 16384 && a.nbatch <= 1 && !a.wb3 && !no_rows && d->cin % 16 == 0)
         return be::gemm_rows(x, M, d->cin, pw, d->cout, pb, res, d->act, y, ldy, stream);
     if (!row8 && (int64_t)a.m_tiles * ((cp + 127) / 128) < 384) {
-        const bool t64 = cp % 64 == 0;
+        // 96 output channels (the data gradients that flow into layer0 / layer1, whose inputs have 96 channels) as TWO 64-wide uniform
+        // tiles, the second half empty (a third more MFMA work, on tiles that are twice as fast as the bordered 128 x 32 ones).  Only
+        // where the caller allows it - the backward: the forward keeps its tiles, and with them its bits (pad64)
+        const bool pad64 = defer && defer->pad64 && cp % 64 == 32 && cp > 64 && !x2 && !a.wb3 && a.nbatch <= 1 &&
+                           ((d->ksize > 1 && d->n >= 64 && d->n % 64 == 0 && conv_variant() != 99) || (d->ksize == 1 && M % 64 == 0)) &&
+                           M * (int64_t)d->cin * 4 < ((int64_t)1 << 32) && (int64_t)cp * a.Ktot * 4 < ((int64_t)1 << 32) &&
+                           getenv("BE_NO_UNI_TILES") == nullptr && getenv("BE_NO_PAD64") == nullptr;      // = every condition of `uni` below
+        const bool t64 = cp % 64 == 0 || pad64;
         // (round 3 tried 64 x 128 tiles - a wave owning 32 x 64 - for the training convolutions onto 384 channels: 79 -> 66 us and
         // 56 -> 48 us for those two layers, 1 % of the step; the narrower layers lose.  Not kept: the different split of the K loop
         // moves the train-mode logits by 1e-6, and on the teacher-forced test's worst-conditioned batch that is a 7e-6 loss
         // difference against a 3e-6 bound written for the 64 x 64 tiles)
         if (t64) {
-            a.m_tiles = (int)((M + 63) / 64); a.n_tiles = cp / 64;
+            a.m_tiles = (int)((M + 63) / 64); a.n_tiles = (cp + 63) / 64;
             if (d->ksize > 1 && d->n >= 64 && d->n % 64 == 0 && conv_variant() != 99) {
                 // full 64-image tiles (the training batch): pixel-major here too, tiles dealt round-robin over the
                 // XCDs because there are only a few image groups

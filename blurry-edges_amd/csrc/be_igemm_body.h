@@ -152,7 +152,8 @@ __device__ __forceinline__ void conv_igemm_body(ConvArgs a, float* smem, const i
         for (int i = 0; i < NA; ++i) a_vo[i] = (unsigned)(a_off[i] * a.Cin + 4 * q) * 4u;
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
-            const int row_ = (B_PARTIAL && RP * i + r0 >= BN) ? 0 : RP * i + r0;
+            // rows past the packed weights (the empty half of a 96-channel layer's second tile): re-read row 0, never stored
+            const int row_ = ((B_PARTIAL && RP * i + r0 >= BN) || n0 + RP * i + r0 >= ((a.Cout + 31) & ~31)) ? 0 : RP * i + r0;
             b_vo[i] = (unsigned)(row_ * a.Ktot + 4 * q) * 4u;
         }
     }
@@ -379,5 +380,5 @@ namespace be {
 // slices go ([S][M][ldp] in scratch when S > 1; S == 1: the epilogue writes y = conv + bias (+ res)).
 struct ConvPrep { be_igemm::ConvArgs args; int variant, S, ldp; unsigned gx; double flops, flops_exec; };
 int conv_train_prepare(const be_conv_desc* d, const float* x, const float* pw, const float* pb, const float* res, float* y, int ldy,
-                       void* scratch, size_t scratch_bytes, ConvPrep* prep);
+                       void* scratch, size_t scratch_bytes, ConvPrep* prep, bool pad64 = false);
 }  // namespace be

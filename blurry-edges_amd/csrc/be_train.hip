@@ -225,6 +225,9 @@ __device__ __forceinline__ void wgrad64_body(const WgradArgs& a, float* smem, co
     const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
     const bool a_col_ok = co0 + 4 * q < a.Cout, b_col_ok = ci0 + 4 * q < a.Cin;
+    // a wave whose 32 x 32 sub-tile lies outside the matrix (96 channels = a full tile + half a tile) stages its share of the
+    // operands but issues no MFMA: the matrix pipe goes to the workgroups that share the CU
+    const bool live = co0 + wm * 32 < a.Cout && ci0 + wn * 32 < a.Cin;
 
     f32x16 acc;
 #pragma unroll
@@ -272,10 +275,12 @@ __device__ __forceinline__ void wgrad64_body(const WgradArgs& a, float* smem, co
     for (int kc = 0; kc < nchunk; ++kc) {
         const int buf = kc & 1;
         if (kc + 1 < nchunk) load(m_begin + 32 * (kc + 1));
+        if (live) {
 #pragma unroll
-        for (int s = 0; s < 16; ++s)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[buf][2 * s + lh][wm * 32 + li], Bs[buf][2 * s + lh][wn * 32 + li],
-                                                       acc, 0, 0, 0);
+            for (int s = 0; s < 16; ++s)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[buf][2 * s + lh][wm * 32 + li], Bs[buf][2 * s + lh][wn * 32 + li],
+                                                           acc, 0, 0, 0);
+        }
         if (kc + 1 < nchunk) store(buf ^ 1);
         __syncthreads();
     }
@@ -1455,8 +1460,8 @@ int plan_wgrad(const be_train_unit_bwd& u, float* wpart, size_t wpart_bytes, WJo
         wj->wx = ct * it; wj->wy = taps; wj->real = ct * it * taps * S;
         pj->wpart = wpart; pj->dw = u.dw; pj->wsize = wsize; pj->wS = S; pj->conv1_map = 0; pj->cout1 = C; pj->wtaps = 0;
         pj->nb_w = (int)cap_grid(wsize / 4, 256, 1024);
-        // executed: full tiles (k_wgrad's 64-wide tiles pad 96 channels to 128)
-        *flops_exec = 2.0 * M * (double)taps * ((C + 63) / 64 * 64) * ((d->cin + 63) / 64 * 64);
+        // executed: 32 x 32 sub-tiles (waves whose sub-tile lies outside the matrix issue nothing)
+        *flops_exec = 2.0 * M * (double)taps * ((C + 31) / 32 * 32) * ((d->cin + 31) / 32 * 32);
     }
     return BE_OK;
 }
@@ -1496,7 +1501,7 @@ int unit_bwd_one(const be_train_unit_bwd& u, char* sc, void* stream, const char*
         be_conv_desc dd{d->n, d->h, d->w, C, d->cin, d->ksize, 0};
         if (u.dx && !no_merge)
             if (int rc = be::conv_train_prepare(&dd, u.dy, u.dgrad_packed_w, u.dgrad_packed_bias, u.dx_add, u.dx, d->cin, sc + SCR_CONV,
-                                                SCR_WGRAD - SCR_CONV, &prep)) return rc;
+                                                SCR_WGRAD - SCR_CONV, &prep, true)) return rc;
         if (prep.variant >= 0) {
             g.ca[0] = prep.args; g.cgx[0] = (int)prep.gx; g.c_real[0] = (int)prep.gx * prep.S; g.c_real[1] = 0;
             g.w_end[0] = g.w_end[1] = pad8(g.w[0].real);
@@ -1566,7 +1571,7 @@ extern "C" int be_train_unit_pair_bwd_f32(const be_train_unit_bwd* a, const be_t
         be_conv_desc dd{d->n, d->h, d->w, C, d->cin, u[j]->desc.ksize, 0};
         // b with a single K slice writes its input gradient straight into b->dx, which the last kernel then adds
         if (int rc = be::conv_train_prepare(&dd, u[j]->dy, u[j]->dgrad_packed_w, u[j]->dgrad_packed_bias, nullptr, u[j]->dx, d->cin, sp.conv,
-                                            sp.conv_b, &prep[j])) return rc;
+                                            sp.conv_b, &prep[j], true)) return rc;
         together = prep[j].variant >= 0 && (j == 0 ? prep[j].S > 1 && prep[j].S <= 8 : prep[j].variant == prep[0].variant && prep[j].S <= 8);
     }
     if (!together) {          // shapes the merged launches do not take: b, then a with b's input gradient added (same sums)
