@@ -136,9 +136,18 @@ void k_wino_out(const float* __restrict__ M, const float* __restrict__ bias, con
         const int64_t img = tile >> 2;
         const int ty = (int)(tile >> 1) & 1, tx = (int)tile & 1;
         const f32x4* src = reinterpret_cast<const f32x4*>(M) + tile * ts + cq;
-        f32x4 m[25], o[9];
+        f32x4 m[25], o[9], rv[9];
 #pragma unroll
         for (int z = 0; z < 25; ++z) m[z] = ld_s<NT>(src + (size_t)z * plane);
+        // the residual's nine values are fetched with the 25 transform-domain ones (inside the store loop each was a round trip of
+        // its own: the kernel sat 58 % of its wave cycles in s_waitcnt)
+        if (res) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r)
+#pragma unroll
+                for (int c = 0; c < 3; ++c)
+                    rv[3 * r + c] = ld_s<NT>(reinterpret_cast<const f32x4*>(res) + ((size_t)img * 36 + (3 * ty + r) * 6 + 3 * tx + c) * c4 + cq);
+        }
         be::wino_out9(m, o);
         const f32x4 bv = reinterpret_cast<const f32x4*>(bias)[cq];
 #pragma unroll
@@ -147,7 +156,7 @@ void k_wino_out(const float* __restrict__ M, const float* __restrict__ bias, con
             for (int c = 0; c < 3; ++c) {
                 const size_t e = ((size_t)img * 36 + (3 * ty + r) * 6 + 3 * tx + c) * c4 + cq;
                 f32x4 v = o[3 * r + c] + bv;
-                if (res) v += reinterpret_cast<const f32x4*>(res)[e];
+                if (res) v += rv[3 * r + c];
                 st_s<NT>(reinterpret_cast<f32x4*>(y) + e, wino_act(v, act));
             }
     }
@@ -224,16 +233,23 @@ void k_wino_out_pool2(const float* __restrict__ M, const float* __restrict__ bia
 #pragma unroll
             for (int tx = 0; tx < 2; ++tx) {
                 const f32x4* src = reinterpret_cast<const f32x4*>(M) + (img * 4 + ty * 2 + tx) * ts + cq;
-                f32x4 m[25], o[9];
+                f32x4 m[25], o[9], rv[9];
 #pragma unroll
                 for (int z = 0; z < 25; ++z) m[z] = ld_s<NT>(src + (size_t)z * plane);
+                if (res) {                                   // with the tile's 25 loads, not one by one behind the transform
+#pragma unroll
+                    for (int r = 0; r < 3; ++r)
+#pragma unroll
+                        for (int c = 0; c < 3; ++c)
+                            rv[3 * r + c] = ld_s<NT>(reinterpret_cast<const f32x4*>(res) + ((size_t)img * 36 + (3 * ty + r) * 6 + 3 * tx + c) * c4 + cq);
+                }
                 be::wino_out9(m, o);
 #pragma unroll
                 for (int r = 0; r < 3; ++r)
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         f32x4 w = o[3 * r + c] + bv;
-                        if (res) w += reinterpret_cast<const f32x4*>(res)[((size_t)img * 36 + (3 * ty + r) * 6 + 3 * tx + c) * c4 + cq];
+                        if (res) w += rv[3 * r + c];
                         v[3 * ty + r][3 * tx + c] = wino_act(w, act);
                     }
             }
