@@ -504,7 +504,15 @@ __global__ void k_linear_small_bwd(const float* __restrict__ x, const float* __r
         if (idx < M * K) {
             const int m = idx / K, k = idx % K;
             float s = 0.f;
-            for (int j = 0; j < J; ++j) s = fmaf(dy[m * J + j], w[j * K + k], s);
+            for (int j0 = 0; j0 < J; j0 += 8) {           // eight loads in flight, accumulated in order
+                float a[8], b[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (j0 + u < J) { a[u] = dy[m * J + j0 + u]; b[u] = w[(j0 + u) * K + k]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (j0 + u < J) s = fmaf(a[u], b[u], s);
+            }
             dx[idx] = s;
         }
     } else if (b < nb_dx + nb_dw) {                       // dW
@@ -512,7 +520,15 @@ __global__ void k_linear_small_bwd(const float* __restrict__ x, const float* __r
         if (idx < J * K) {
             const int j = idx / K, k = idx % K;
             float s = 0.f;
-            for (int m = 0; m < M; ++m) s = fmaf(dy[m * J + j], x[m * K + k], s);
+            for (int m0 = 0; m0 < M; m0 += 8) {
+                float a[8], b[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (m0 + u < M) { a[u] = dy[(m0 + u) * J + j]; b[u] = x[(m0 + u) * K + k]; }
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+                    if (m0 + u < M) s = fmaf(a[u], b[u], s);
+            }
             dw[idx] = s;
         }
     } else {
@@ -1062,6 +1078,27 @@ __global__ void k_maxpool_fwd_idx(const float* __restrict__ x, float* __restrict
         const int64_t img = t / oh;
         f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         unsigned wi[4] = {0, 0, 0, 0};
+        if (k <= 3) {
+            // all taps as independent loads (a tap outside the image loads the nearest pixel inside and is not compared), then the
+            // scan in the same order: the first maximum wins, as before
+            f32x4 v[9];
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+                    if (dy < k && dx < k) {
+                        const int yy = min(max(oy * stride - pad + dy, 0), h - 1), xx = min(max(ox * stride - pad + dx, 0), w - 1);
+                        v[3 * dy + dx] = reinterpret_cast<const f32x4*>(x)[((img * h + yy) * w + xx) * c4 + cq];
+                    }
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx)
+                    if (dy < k && dx < k && (unsigned)(oy * stride - pad + dy) < (unsigned)h && (unsigned)(ox * stride - pad + dx) < (unsigned)w) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) if (v[3 * dy + dx][e] > m[e]) { m[e] = v[3 * dy + dx][e]; wi[e] = (unsigned)(dy * k + dx); }
+                    }
+        } else
         for (int dy = 0; dy < k; ++dy) {
             const int yy = oy * stride - pad + dy;
             if ((unsigned)yy >= (unsigned)h) continue;
