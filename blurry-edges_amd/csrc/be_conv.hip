@@ -452,7 +452,15 @@ __device__ __forceinline__ void pack_fwd_rows(const PackArgs& p, float* lds) {
         const bool real = row < p.cout;
         __syncthreads();
         if (real)
-            for (int i = threadIdx.x; i < rowlen; i += blockDim.x) lds[i] = p.w[(size_t)row * rowlen + i];
+            for (int i0 = threadIdx.x; i0 < rowlen; i0 += 4 * blockDim.x) {      // four loads in flight per thread
+                float t[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (i0 + j * (int)blockDim.x < rowlen) t[j] = p.w[(size_t)row * rowlen + i0 + j * blockDim.x];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (i0 + j * (int)blockDim.x < rowlen) lds[i0 + j * blockDim.x] = t[j];
+            }
         __syncthreads();
         const float scale = real && p.gamma ? p.gamma[row] / sqrtf(p.var[row] + p.eps) : 1.0f;
         float* out = p.pw + (size_t)row * p.row_stride + p.col_off;
@@ -477,10 +485,21 @@ __device__ __forceinline__ void pack_dgrad_tiles(const PackArgs& p, float* lds) 
         __syncthreads();
         {
             const int left = p.cin - ci0, run = (left < CT ? (left > 0 ? left : 0) : CT) * TAPS;
-            for (int o = threadIdx.x >> 4; o < BK; o += 16) {
-                const float* src = p.w + ((size_t)(cc * BK + o) * p.cin + ci0) * TAPS;
-                for (int i = threadIdx.x & 15; i < run; i += 16) lds[o * LD + i] = src[i];
+            // (both output-channel halves and all positions of a run as independent loads: up to 2 x 9 in flight per thread)
+            constexpr int NI = (CT * TAPS + 15) / 16;
+            float t[2][NI];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const float* src = p.w + ((size_t)(cc * BK + (threadIdx.x >> 4) + 16 * h) * p.cin + ci0) * TAPS;
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    if ((int)(threadIdx.x & 15) + 16 * j < run) t[h][j] = src[(threadIdx.x & 15) + 16 * j];
             }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int j = 0; j < NI; ++j)
+                    if ((int)(threadIdx.x & 15) + 16 * j < run) lds[((threadIdx.x >> 4) + 16 * h) * LD + (threadIdx.x & 15) + 16 * j] = t[h][j];
         }
         __syncthreads();
         const int e = threadIdx.x & 31;
@@ -715,7 +734,9 @@ extern "C" int be_conv_pack_dgrad_f32(const float* w, int cout, int cin, int ksi
 
 extern "C" int be_conv_pack_jobs_f32(const be_pack_job* jobs_device, int njobs, void* stream) {
     BE_REQUIRE(jobs_device && njobs > 0 && njobs <= 65535, "be_conv_pack_jobs_f32: bad arguments");
-    hipLaunchKernelGGL(k_pack_jobs, dim3(1024, njobs), dim3(256), 0, be::as_stream(stream), jobs_device);
+    // 512 workgroups per job: the launch costs ~0.5 ns per workgroup whether or not it has work (4096 per job: 62 us, all dispatch);
+    // 256 ... 1536 differ by 3 us of a 1.52 ms step
+    hipLaunchKernelGGL(k_pack_jobs, dim3(512, njobs), dim3(256), 0, be::as_stream(stream), jobs_device);
     return be::check_launch("be_conv_pack_jobs_f32");
 }
 
