@@ -626,6 +626,23 @@ void k_attn_keep_bits(uint16_t* __restrict__ keep, int64_t lines, int L, uint32_
 __global__ void k_dropout(const float* __restrict__ x, const float* __restrict__ gate, float* __restrict__ y, int64_t n,
                           uint32_t key, uint32_t thresh, float inv_keep) {
     const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+    if (((n & 3) | ((uintptr_t)x & 15) | ((uintptr_t)y & 15) | ((uintptr_t)gate & 15)) == 0) {
+        // four elements per lane as 16-byte accesses (the scalar form below moved 2.2 TB/s on the 16.8 MB activations)
+        typedef float v4 __attribute__((ext_vector_type(4)));
+        const int64_t n4 = n >> 2;
+        for (int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += gs) {
+            v4 v = reinterpret_cast<const v4*>(x)[q] * inv_keep;
+            v4 g = {1.f, 1.f, 1.f, 1.f};
+            if (gate) g = reinterpret_cast<const v4*>(gate)[q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (thresh && mix32((uint32_t)(4 * q + e) ^ key) < thresh) v[e] = 0.f;
+                if (!(g[e] > 0.f)) v[e] = 0.f;
+            }
+            reinterpret_cast<v4*>(y)[q] = v;
+        }
+        return;
+    }
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gs) {
         float v = x[i] * inv_keep;
         if (thresh && mix32((uint32_t)i ^ key) < thresh) v = 0.f;
@@ -881,7 +898,7 @@ extern "C" int be_dropout_f32(const float* x, const float* gate, float* y, int64
                               uint32_t site, void* stream) {
     BE_REQUIRE(x && y && n > 0 && n < ((int64_t)1 << 32), "be_dropout_f32: bad arguments");
     BE_REQUIRE(dropout_p >= 0.f && dropout_p < 1.f, "be_dropout_f32: dropout probability outside [0,1)");
-    int64_t g = (n + 255) / 256; if (g > 4096) g = 4096;
+    int64_t g = (n / 4 + 255) / 256; if (g > 4096) g = 4096; if (g < 1) g = 1;
     hipLaunchKernelGGL(k_dropout, dim3((unsigned)g), dim3(256), 0, be::as_stream(stream), x, gate, y, n, site_key(seed, site),
                        drop_threshold(dropout_p), 1.0f / (1.0f - dropout_p));
     return be::check_launch("be_dropout_f32");
