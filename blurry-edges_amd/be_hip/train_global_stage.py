@@ -16,6 +16,8 @@ attention probabilities themselves are never stored (recomputed from the saved l
 """
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import native
@@ -57,9 +59,36 @@ def _wgrad_lin(x, dy, w_shape):
     return _wgrad(x.view(t, 1, 1, x.shape[1]), dy.view(t, 1, 1, dy.shape[1]), tuple(w_shape), 1)
 
 
+class _Side:
+    """The parameter gradients of the encoder's linears are off the data-gradient chain (nothing in the backward reads them) and
+    their launches fill half the chip (one 128 x 128 weight tile x <= 128 row slices): they run on a side stream, one after the
+    other (they share the scratch buffer), beside the attention / LayerNorm kernels of the main chain.  fork(): the side stream
+    waits for everything enqueued so far; join(): the main stream waits for the side stream (end of the backward).  Operands are
+    kept alive until the join (the caching allocator would otherwise hand a freed dy to the main stream while the side stream still
+    reads it).  BE_GLOBAL_SIDE=0: everything on the caller's stream."""
+    enabled = os.environ.get("BE_GLOBAL_SIDE", "1") != "0"
+    stream = None
+    scratch = None                   # the side stream's own be_train scratch (the main stream's kernels use train._Scratch meanwhile)
+    keep = []
+
+    @classmethod
+    def get(cls, dev):
+        if cls.stream is None or cls.stream.device != dev:
+            cls.stream = torch.cuda.Stream(device=dev)
+            cls.scratch = torch.empty(lib().be_train_scratch_bytes() // 4, dtype=torch.float32, device=dev)
+        return cls.stream
+
+    @classmethod
+    def join(cls, dev):
+        if cls.enabled and cls.stream is not None and cls.keep:
+            torch.cuda.current_stream(dev).wait_stream(cls.stream)
+        cls.keep = []
+
+
 def _lin_param_grads(x, dy, w_shape):
     """(dW, db) of y = x W^T + b.  Channel counts that are multiples of 128 (every linear of an encoder layer): two launches
-    (be_linear_param_grads_f32); otherwise the weight-gradient GEMM and the column sum on their own."""
+    (be_linear_param_grads_f32) on the side stream (_Side; the caller joins before it hands the gradients out); otherwise the
+    weight-gradient GEMM and the column sum on their own."""
     cout, cin = w_shape
     t = x.shape[0]
     if cout % 128 == 0 and cin % 128 == 0 and t >= 256:
@@ -67,7 +96,18 @@ def _lin_param_grads(x, dy, w_shape):
         dev = x.device
         dw, db = _new((cout, cin), dev), _new(cout, dev)
         sc = _Scratch.get(dev)
-        check(lib().be_linear_param_grads_f32(dptr(x, "x"), dptr(dy.contiguous(), "dy"), dptr(dw), dptr(db), t, cin, cout, dptr(sc),
+        dyc = dy.contiguous()
+        side = _Side.enabled and not torch.cuda.is_current_stream_capturing()
+        if side:
+            st = _Side.get(dev)
+            st.wait_stream(torch.cuda.current_stream(dev))
+            _Side.keep.append((x, dyc, dw, db))
+            sc = _Side.scratch
+            with torch.cuda.stream(st):
+                check(lib().be_linear_param_grads_f32(dptr(x, "x"), dptr(dyc, "dy"), dptr(dw), dptr(db), t, cin, cout, dptr(sc),
+                                                      sc.numel() * 4, stream_ptr(dev)), "be_linear_param_grads_f32")
+            return dw, db
+        check(lib().be_linear_param_grads_f32(dptr(x, "x"), dptr(dyc, "dy"), dptr(dw), dptr(db), t, cin, cout, dptr(sc),
                                               sc.numel() * 4, stream_ptr(dev)), "be_linear_param_grads_f32")
         return dw, db
     return _wgrad_lin(x, dy, w_shape), _col_sum(dy)
@@ -310,6 +350,7 @@ def backward_train(dout, seed, p, H, eps, t, S):
     x0 = S["x0"]
     grads[0] = _wgrad_lin(x0, dh, (t[0].shape[0], x0.shape[1]))[:, :cin].contiguous()
     grads[1] = _col_sum(dh)
+    _Side.join(dev)                                                       # the linears' parameter gradients are complete
     return grads
 
 
