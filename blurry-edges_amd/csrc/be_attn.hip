@@ -65,36 +65,46 @@ __global__ void k_qkv_split(const float* __restrict__ qkv, float* __restrict__ Q
 // training: every operand the forward and the two backward kernels read, row-major [BH][L][16] and transposed
 // [BH][16][L] (Q pre-scaled in both).  One thread = one (batch, head, token), token fastest: 64-byte row reads and
 // writes, and for each d the transposed stores of consecutive threads are consecutive floats.
-__global__ void k_qkv_split_train(const float* __restrict__ qkv, float* __restrict__ Q, float* __restrict__ K,
-                                  float* __restrict__ V, float* __restrict__ Qt, float* __restrict__ Kt,
-                                  float* __restrict__ Vt, int B, int L, int H, float qscale) {
-    const int64_t total = (int64_t)B * H * L;
-    const int64_t gs = (int64_t)gridDim.x * blockDim.x;
+__global__ __launch_bounds__(256)
+void k_qkv_split_train(const float* __restrict__ qkv, float* __restrict__ Q, float* __restrict__ K,
+                       float* __restrict__ V, float* __restrict__ Qt, float* __restrict__ Kt,
+                       float* __restrict__ Vt, int B, int L, int H, float qscale) {
+    // one workgroup = 64 consecutive tokens of one (batch, head).  Reads: a quarter-wave fetches a token's 64-byte q / k / v row
+    // of this head (the first version had every lane walk its own row in four pieces: 64 lines touched per instruction for 16
+    // useful bytes each); the row-major copies go straight out (4 KB contiguous per matrix), the transposed ones through LDS so
+    // that 64 consecutive tokens of one d are one 256-byte store.
+    __shared__ float t[3][64][17];
     const int D = H * DH;
-    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gs) {
-        const int64_t l = idx % L, bh = idx / L;
-        const int64_t b = bh / H, h = bh % H;
-        const float* row = qkv + (b * L + l) * 3 * D + h * DH;
-        f32x4 q[4], k[4], v[4];
+    const int tiles = L / 64;
+    const int64_t wg = blockIdx.x;
+    const int lt = (int)(wg % tiles);
+    const int64_t bh = wg / tiles;
+    const int64_t b = bh / H, h = bh % H;
+    const int l0 = lt * 64;
+    const int tok = threadIdx.x >> 2, q4 = threadIdx.x & 3;
+    const float* row = qkv + (b * L + l0 + tok) * 3 * D + h * DH + 4 * q4;
+    f32x4 v[3];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            q[i] = *reinterpret_cast<const f32x4*>(row + 4 * i) * qscale;
-            k[i] = *reinterpret_cast<const f32x4*>(row + D + 4 * i);
-            v[i] = *reinterpret_cast<const f32x4*>(row + 2 * D + 4 * i);
+    for (int m = 0; m < 3; ++m) v[m] = *reinterpret_cast<const f32x4*>(row + m * D);
+    v[0] *= qscale;
+    const int64_t rm = (bh * L + l0 + tok) * DH + 4 * q4;
+    *reinterpret_cast<f32x4*>(Q + rm) = v[0];
+    *reinterpret_cast<f32x4*>(K + rm) = v[1];
+    *reinterpret_cast<f32x4*>(V + rm) = v[2];
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[m][tok][4 * q4 + e] = v[m][e];
+    __syncthreads();
+    float* const outs[3] = {Qt, Kt, Vt};
+    const int tk = threadIdx.x & 63, d0 = threadIdx.x >> 6;
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+        for (int dd = 0; dd < 4; ++dd) {
+            const int d = d0 + 4 * dd;
+            outs[m][(bh * DH + d) * L + l0 + tk] = t[m][tk][d];
         }
-        const int64_t rm = (bh * L + l) * DH;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            *reinterpret_cast<f32x4*>(Q + rm + 4 * i) = q[i];
-            *reinterpret_cast<f32x4*>(K + rm + 4 * i) = k[i];
-            *reinterpret_cast<f32x4*>(V + rm + 4 * i) = v[i];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int64_t tr = (bh * DH + 4 * i + e) * L + l;
-                Qt[tr] = q[i][e]; Kt[tr] = k[i][e]; Vt[tr] = v[i][e];
-            }
-        }
-    }
 }
 
 // ---- attention on v_mfma_f32_16x16x4_f32 -----------------------------------------------------------------------
@@ -818,9 +828,8 @@ extern "C" int be_attention_train_fwd_f32(const float* qkv, float* out, float* l
     BE_REQUIRE(be::aligned16(qkv) && be::aligned16(out) && be::aligned16(workspace), "be_attention_train_fwd_f32: 16-byte alignment");
     hipStream_t s = be::as_stream(stream);
     const TrainWs w = train_ws(workspace, B, L, H);
-    int64_t g = ((int64_t)B * H * L + 255) / 256; if (g > 8192) g = 8192;
-    hipLaunchKernelGGL(k_qkv_split_train, dim3((unsigned)g), dim3(256), 0, s, qkv, w.Q, w.K, w.V, w.Qt, w.Kt, w.Vt, B, L, H,
-                       0.25f * 1.44269504088896340736f);
+    hipLaunchKernelGGL(k_qkv_split_train, dim3((unsigned)((int64_t)B * H * (L / 64))), dim3(256), 0, s, qkv, w.Q, w.K, w.V, w.Qt, w.Kt, w.Vt,
+                       B, L, H, 0.25f * 1.44269504088896340736f);
     if (l_valid == L)
         hipLaunchKernelGGL((k_attention<true, false>), dim3(L / 128, B * H), dim3(256), 0, s, w.Q, w.K, w.Vt, out, lse, L, L, H, seed,
                            drop_threshold(dropout_p), 1.0f / (1.0f - dropout_p), (float*)nullptr, w.keep);
@@ -848,8 +857,8 @@ extern "C" int be_attention_bwd_f32(const float* qkv, const float* out, const fl
     const float ik = 1.0f / (1.0f - dropout_p);
     if (!operands_ready) {        // the workspace of this layer's forward call was reused in between: split q/k/v again, and
         //                           write the keep bits the forward left there again
-        hipLaunchKernelGGL(k_qkv_split_train, dim3((unsigned)g), dim3(256), 0, s, qkv, w.Q, w.K, w.V, w.Qt, w.Kt, w.Vt, B, L,
-                           H, 0.25f * 1.44269504088896340736f);
+        hipLaunchKernelGGL(k_qkv_split_train, dim3((unsigned)((int64_t)B * H * (L / 64))), dim3(256), 0, s, qkv, w.Q, w.K, w.V, w.Qt, w.Kt,
+                           w.Vt, B, L, H, 0.25f * 1.44269504088896340736f);
         if (th) {
             const int64_t lines = (int64_t)keep_lines(B, L, H);
             hipLaunchKernelGGL(k_attn_keep_bits, dim3((unsigned)((lines + 3) / 4 > 16384 ? 16384 : (lines + 3) / 4)), dim3(256), 0, s,
