@@ -208,6 +208,7 @@ struct WgradArgs {
     const float* dy;       // [N,H,W,Cout]
     float* partial;        // [S][Cout*Cin*taps] in the reference's OIHW order
     int M, H, W, HW, Cin, Cout, ks, rows_per_split, chw_hw, cin_tiles;
+    int pm;                // 1: pixel-major K walk (3x3, batch a multiple of 32): a chunk = ONE pixel of 32 consecutive images
 };
 
 constexpr int WGRAD64_LDS_FLOATS = 2 * 2 * 32 * 68;
@@ -269,6 +270,46 @@ __device__ __forceinline__ void wgrad64_body(const WgradArgs& a, float* smem, co
             *reinterpret_cast<f32x4*>(&Bs[buf][r0 + 16 * i][4 * q]) = b_st[i];
         }
     };
+    if (a.pm) {
+        // pixel-major K walk (see wgrad128_body): a chunk = one pixel of 32 consecutive images; chunks whose tap falls outside the
+        // image are skipped, the others need no border test and no zero fill
+        const int u_begin = bz * (a.rows_per_split / 32), u_end = min(a.M / 32, u_begin + a.rows_per_split / 32);
+        const int64_t tap_off = (int64_t)(tdy * a.W + tdx) * a.Cin;
+        auto next_valid = [&](int u) {
+            for (; u < u_end; ++u) {
+                const int pp = u % a.HW, yy = pp / a.W + tdy, xx = pp % a.W + tdx;
+                if ((unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) break;
+            }
+            return u;
+        };
+        auto load_u = [&](int u) {
+            const int ic = u / a.HW, pp = u - ic * a.HW;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int64_t m = (int64_t)(ic * 32 + r0 + 16 * i) * a.HW + pp;
+                a_st[i] = a_col_ok ? *reinterpret_cast<const f32x4*>(a.dy + m * a.Cout + co0 + 4 * q) : zero;
+                b_st[i] = b_col_ok ? *reinterpret_cast<const f32x4*>(a.x + m * a.Cin + tap_off + ci0 + 4 * q) : zero;
+            }
+        };
+        int u = next_valid(u_begin);
+        if (u < u_end) { load_u(u); store(0); }
+        __syncthreads();
+        int buf = 0;
+        while (u < u_end) {
+            const int un = next_valid(u + 1);
+            if (un < u_end) load_u(un);
+            if (live) {
+#pragma unroll
+                for (int s = 0; s < 16; ++s)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(As[buf][2 * s + lh][wm * 32 + li], Bs[buf][2 * s + lh][wn * 32 + li],
+                                                               acc, 0, 0, 0);
+            }
+            if (un < u_end) store(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+            u = un;
+        }
+    } else {
     const int nchunk = (m_end - m_begin + 31) / 32;
     if (nchunk > 0) { load(m_begin); store(0); }
     __syncthreads();
@@ -283,6 +324,7 @@ __device__ __forceinline__ void wgrad64_body(const WgradArgs& a, float* smem, co
         }
         if (kc + 1 < nchunk) store(buf ^ 1);
         __syncthreads();
+    }
     }
     // D[i = co][j = ci]: lane holds column j = lane&31, rows (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int taps = a.ks * a.ks;
@@ -1541,7 +1583,9 @@ int plan_wgrad(const be_train_unit_bwd& u, float* wpart, size_t wpart_bytes, WJo
         int rows = (M + S - 1) / S; rows = (rows + 31) / 32 * 32;
         S = (M + rows - 1) / rows;
         wj->wkind = 0;
-        wj->w64 = WgradArgs{u.x, u.dy, wpart, M, d->h, d->w, d->h * d->w, d->cin, C, d->ksize, rows, u.layout_chw_hw, it};
+        static const bool no_pm64 = getenv("BE_NO_WGRAD_PM") != nullptr;        // A/B knob
+        const int pm64 = !no_pm64 && d->ksize == 3 && d->n % 32 == 0 && u.layout_chw_hw == 0;
+        wj->w64 = WgradArgs{u.x, u.dy, wpart, M, d->h, d->w, d->h * d->w, d->cin, C, d->ksize, rows, u.layout_chw_hw, it, pm64};
         wj->wx = ct * it; wj->wy = taps; wj->real = ct * it * taps * S;
         pj->wpart = wpart; pj->dw = u.dw; pj->wsize = wsize; pj->wS = S; pj->conv1_map = 0; pj->cout1 = C; pj->wtaps = 0;
         pj->nb_w = (int)cap_grid(wsize / 4, 256, 1024);
