@@ -1574,7 +1574,8 @@ int plan_wgrad(const be_train_unit_bwd& u, float* wpart, size_t wpart_bytes, WJo
         wj->wx = (C / 128) * (d->cin / 128); wj->wy = taps; wj->real = wj->wx * taps * S;
         pj->wpart = wpart; pj->dw = u.dw; pj->wsize = wsize; pj->wS = S; pj->conv1_map = 0; pj->cout1 = C; pj->wtaps = taps;
         pj->nb_w = (int)cap_grid(wsize / taps, 256, 1024);
-        *flops_exec = 2.0 * M * (double)wsize;
+        // executed: the pixel-major walk skips the (pixel, tap) pairs outside the image: (3H - 2)(3W - 2) of 9 HW remain
+        *flops_exec = pm ? 2.0 * d->n * (3.0 * d->h - 2.0) * (3.0 * d->w - 2.0) * C * d->cin : 2.0 * M * (double)wsize;
     } else {
         const int ct = (C + 63) / 64, it = (d->cin + 63) / 64;
         int S = pick_splits(M, ct * it * taps, 64, 512);       // every split is another full copy of dW to sum
@@ -1590,7 +1591,7 @@ int plan_wgrad(const be_train_unit_bwd& u, float* wpart, size_t wpart_bytes, WJo
         pj->wpart = wpart; pj->dw = u.dw; pj->wsize = wsize; pj->wS = S; pj->conv1_map = 0; pj->cout1 = C; pj->wtaps = 0;
         pj->nb_w = (int)cap_grid(wsize / 4, 256, 1024);
         // executed: 32 x 32 sub-tiles (waves whose sub-tile lies outside the matrix issue nothing)
-        *flops_exec = 2.0 * M * (double)taps * ((C + 31) / 32 * 32) * ((d->cin + 31) / 32 * 32);
+        *flops_exec = (pm64 ? 2.0 * d->n * (3.0 * d->h - 2.0) * (3.0 * d->w - 2.0) : 2.0 * M * (double)taps) * ((C + 31) / 32 * 32) * ((d->cin + 31) / 32 * 32);
     }
     return BE_OK;
 }
