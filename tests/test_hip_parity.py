@@ -427,11 +427,12 @@ def test_local_stage_train_forward_backward_vs_golden(native):
     assert relmax(ye.cpu(), yo) <= 1e-5
 
 
-@pytest.mark.parametrize("n", [24, 100])
+@pytest.mark.parametrize("n", [24, 48, 100])
 def test_local_stage_train_forward_backward_ragged_batches_vs_fp64_oracle(native, n):
     """The training units at batch sizes that are NOT the reference's 64 (a last partial batch, another --batch_size): 24 patches
-    (864 rows at 6x6: flat tiles, row blocks with ragged ends, fewer weight-gradient slices) and 100 (not a multiple of 64: no
-    pixel-major tiles, 3600 rows) against the float64 oracle under autograd on the same weights: train-mode logits 1e-5, every live
+    (864 rows at 6x6: flat tiles, row blocks with ragged ends, fewer weight-gradient slices), 48 (a multiple of 16 but not of 32 or 64:
+    the 128-wide weight-gradient tiles walk K pixel-major, everything else is flat) and 100 (not a multiple of 64: no pixel-major
+    tiles, 3600 rows) against the float64 oracle under autograd on the same weights: train-mode logits 1e-5, every live
     parameter gradient at equal cotangent 1e-3 (measured ~1e-5 typical), running statistics 1e-5."""
     from oracle import local_stage as ols
     m = _load_train_model().train()
