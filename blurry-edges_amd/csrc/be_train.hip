@@ -773,7 +773,7 @@ void k_bn_fwd_apply(Two<FwdApplyArgs> two) {
     __shared__ float s_mu[UC], s_is[UC];
     const int c_base = blockIdx.x * UC;
     finish_partials<2>(a.stats, a.nrb, a.C, c_base, part, tot);
-    if (threadIdx.x < UC && c_base + threadIdx.x < a.C) {
+    if (threadIdx.x < UC && c_base + (int)threadIdx.x < a.C) {
         const int col = threadIdx.x, c = c_base + col;
         const double mu = tot[col * 2] / a.M;
         double var = tot[col * 2 + 1] / a.M - mu * mu;
@@ -885,7 +885,7 @@ void k_bn_bwd_apply(Two<BwdApplyArgs> two) {
     __shared__ float s_db[UC], s_dg[UC];
     const int c_base = blockIdx.x * UC;
     finish_partials<2>(a.partial, a.nrb, a.C, c_base, part, tot);
-    if (threadIdx.x < UC && c_base + threadIdx.x < a.C) {
+    if (threadIdx.x < UC && c_base + (int)threadIdx.x < a.C) {
         const int col = threadIdx.x;
         const float db = (float)tot[col * 2], dg = (float)tot[col * 2 + 1];
         s_db[col] = db; s_dg[col] = dg;
@@ -1331,7 +1331,7 @@ static int wgrad_slices(const float* x, const float* dy, float* partial, size_t 
     BE_REQUIRE((size_t)S * wsize * sizeof(float) <= partial_bytes, "be_conv_wgrad_f32: scratch too small");
     int rows = (M + S - 1) / S; rows = (rows + 31) / 32 * 32;
     S = (M + rows - 1) / rows;
-    WgradArgs a{x, dy, partial, M, h, w, h * w, cin, cout, ksize, rows, layout_chw_hw, it};
+    WgradArgs a{x, dy, partial, M, h, w, h * w, cin, cout, ksize, rows, layout_chw_hw, it, 0};
     hipLaunchKernelGGL(k_wgrad, dim3(ct * it, taps, S), dim3(256), 0, s, a);
     *S_out = S; *wsize_out = wsize;
     return be::check_launch("be_conv_wgrad_f32");
