@@ -168,6 +168,17 @@ _SIGNATURES = {
     "be_inverse3x3_f32": (C.c_int, [_P, _P, C.c_int64, _P]),
     "be_image_derivative_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, _P]),
     "be_fold_patches_f32": (C.c_int, [_P, _P, _P] + [C.c_int] * 7 + [C.c_int64] * 6 + [C.c_int, _P]),
+    "be_params2dists_bwd_f32": (C.c_int, [C.POINTER(RenderOpts), _P, _P, _P, C.c_int64, _P]),
+    "be_dists2indicators_bwd_f32": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, _P]),
+    "be_inverse3x3_bwd_f32": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
+    "be_image_derivative_bwd_f32": (C.c_int, [_P, _P, _P, C.c_int64, C.c_int, C.c_int, _P]),
+    "be_params2etas_bwd_f32": (C.c_int, [_P, _P, _P, C.c_int64, _P]),
+    "be_normalized_gaussian_f32": (C.c_int, [_P, _P, C.c_float, C.c_int64, _P]),
+    "be_normalized_gaussian_bwd_f32": (C.c_int, [_P, _P, _P, C.c_float, C.c_int64, _P]),
+    "be_etas2depth_bwd_f32": (C.c_int, [C.POINTER(DepthConsts), _P, _P, _P, _P, _P, C.c_int64, _P]),
+    "be_depth2sigma_bwd_f32": (C.c_int, [C.POINTER(DepthConsts), _P, C.c_float, _P, _P, C.c_int64, _P]),
+    "be_fold_patches_bwd_f32": (C.c_int, [_P, _P] + [C.c_int] * 7 + [C.c_int64] * 6 + [C.c_int, _P]),
+    "be_wrap_angles_inplace_f32": (C.c_int, [_P, C.c_int64, C.c_int, C.c_int, C.c_int, _P]),
     "be_attention_workspace_floats": (C.c_size_t, [C.c_int, C.c_int, C.c_int]),
     "be_attention_f32": (C.c_int, [_P, _P, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P]),
     "be_add_layernorm_f32": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int, C.c_float, _P]),
@@ -263,14 +274,31 @@ def stream_ptr(device=None):
 
 def params2etas(p: torch.Tensor) -> torch.Tensor:
     p = p.contiguous()
+    o = ops()
+    if o is not None:
+        return o.params2etas(p)
     out = torch.empty_like(p)
     check(lib().be_params2etas_f32(dptr(p, "params"), dptr(out), p.numel(), stream_ptr(p.device)), "be_params2etas_f32")
     return out
 
 
+def params2etas_bwd(p: torch.Tensor, geta: torch.Tensor) -> torch.Tensor:
+    p, geta = p.contiguous(), geta.contiguous()
+    o = ops()
+    if o is not None:
+        return o.params2etas_bwd(p, geta)
+    gp = torch.empty_like(p)
+    check(lib().be_params2etas_bwd_f32(dptr(p, "params"), dptr(geta, "geta"), dptr(gp), p.numel(), stream_ptr(p.device)),
+          "be_params2etas_bwd_f32")
+    return gp
+
+
 def etas2depth(consts: DepthConsts, eta1: torch.Tensor, eta2: torch.Tensor, want_branch=False):
     eta1, eta2 = torch.broadcast_tensors(eta1, eta2)
     eta1, eta2 = eta1.contiguous(), eta2.contiguous()
+    o = ops() if not want_branch else None
+    if o is not None:
+        return o.etas2depth(struct_tensor(consts), eta1, eta2)
     z = torch.empty_like(eta1)
     br = torch.empty(eta1.shape, dtype=torch.int32, device=eta1.device) if want_branch else None
     check(lib().be_etas2depth_f32(C.byref(consts), dptr(eta1, "eta1"), dptr(eta2, "eta2"), dptr(z), dptr(br),
@@ -278,12 +306,181 @@ def etas2depth(consts: DepthConsts, eta1: torch.Tensor, eta2: torch.Tensor, want
     return (z, br) if want_branch else z
 
 
+def etas2depth_bwd(consts: DepthConsts, eta1, eta2, gz):
+    """eta1, eta2, gz: contiguous, one shape -> (geta1, geta2)."""
+    o = ops()
+    if o is not None:
+        return o.etas2depth_bwd(struct_tensor(consts), eta1, eta2, gz)
+    g1, g2 = torch.empty_like(eta1), torch.empty_like(eta1)
+    check(lib().be_etas2depth_bwd_f32(C.byref(consts), dptr(eta1, "eta1"), dptr(eta2, "eta2"), dptr(gz, "gdepth"), dptr(g1), dptr(g2),
+                                      eta1.numel(), stream_ptr(eta1.device)), "be_etas2depth_bwd_f32")
+    return g1, g2
+
+
 def depth2sigma(consts: DepthConsts, depth: torch.Tensor, rho_prime: float) -> torch.Tensor:
     depth = depth.contiguous()
+    o = ops()
+    if o is not None:
+        return o.depth2sigma(struct_tensor(consts), depth, float(rho_prime))
     out = torch.empty_like(depth)
     check(lib().be_depth2sigma_f32(C.byref(consts), dptr(depth, "depth"), float(rho_prime), dptr(out), depth.numel(),
                                    stream_ptr(depth.device)), "be_depth2sigma_f32")
     return out
+
+
+def depth2sigma_bwd(consts: DepthConsts, depth, rho_prime, geta):
+    o = ops()
+    if o is not None:
+        return o.depth2sigma_bwd(struct_tensor(consts), depth, float(rho_prime), geta)
+    g = torch.empty_like(depth)
+    check(lib().be_depth2sigma_bwd_f32(C.byref(consts), dptr(depth, "depth"), float(rho_prime), dptr(geta, "geta"), dptr(g),
+                                       depth.numel(), stream_ptr(depth.device)), "be_depth2sigma_bwd_f32")
+    return g
+
+
+# ---- the fine-grained PostProcess methods and their adjoints (flat one-row-per-patch layouts, contiguous float32 on the GPU) ----
+
+def params2dists(opts: RenderOpts, params8):
+    """params8 [N,8] -> dists [N,2,21,21]."""
+    o = ops()
+    if o is not None:
+        return o.params2dists(struct_tensor(opts), params8)
+    n = params8.shape[0]
+    out = torch.empty(n, 2, BE_R, BE_R, dtype=torch.float32, device=params8.device)
+    check(lib().be_params2dists_f32(C.byref(opts), dptr(params8, "params"), dptr(out), n, stream_ptr(params8.device)), "be_params2dists_f32")
+    return out
+
+
+def params2dists_bwd(opts: RenderOpts, params8, gdists):
+    o = ops()
+    if o is not None:
+        return o.params2dists_bwd(struct_tensor(opts), params8, gdists)
+    g = torch.empty_like(params8)
+    check(lib().be_params2dists_bwd_f32(C.byref(opts), dptr(params8, "params"), dptr(gdists, "gdists"), dptr(g), params8.shape[0],
+                                        stream_ptr(params8.device)), "be_params2dists_bwd_f32")
+    return g
+
+
+def dists2indicators(dists, etas):
+    """dists [N,2,21,21], etas [N,2] -> wedges [N,3,21,21]."""
+    o = ops()
+    if o is not None:
+        return o.dists2indicators(dists, etas)
+    n = dists.shape[0]
+    out = torch.empty(n, 3, BE_R, BE_R, dtype=torch.float32, device=dists.device)
+    check(lib().be_dists2indicators_f32(dptr(dists, "dists"), dptr(etas, "etas"), dptr(out), n, stream_ptr(dists.device)),
+          "be_dists2indicators_f32")
+    return out
+
+
+def dists2indicators_bwd(dists, etas, gwedges):
+    o = ops()
+    if o is not None:
+        return o.dists2indicators_bwd(dists, etas, gwedges)
+    gd, ge = torch.empty_like(dists), torch.empty_like(etas)
+    check(lib().be_dists2indicators_bwd_f32(dptr(dists, "dists"), dptr(etas, "etas"), dptr(gwedges, "gwedges"), dptr(gd), dptr(ge),
+                                            dists.shape[0], stream_ptr(dists.device)), "be_dists2indicators_bwd_f32")
+    return gd, ge
+
+
+def inverse3x3(a):
+    o = ops()
+    if o is not None:
+        return o.inverse3x3(a)
+    out = torch.empty_like(a)
+    check(lib().be_inverse3x3_f32(dptr(a, "A"), dptr(out), a.numel() // 9, stream_ptr(a.device)), "be_inverse3x3_f32")
+    return out
+
+
+def inverse3x3_bwd(inv, gout):
+    o = ops()
+    if o is not None:
+        return o.inverse3x3_bwd(inv, gout)
+    ga = torch.empty_like(inv)
+    check(lib().be_inverse3x3_bwd_f32(dptr(inv, "inv"), dptr(gout, "gout"), dptr(ga), inv.numel() // 9, stream_ptr(inv.device)),
+          "be_inverse3x3_bwd_f32")
+    return ga
+
+
+def image_derivative(img):
+    """img [N,C,H,W] -> Sobel magnitude [N,C,H-2,W-2]."""
+    o = ops()
+    if o is not None:
+        return o.image_derivative(img)
+    n, c, h, w = img.shape
+    out = torch.empty(n, c, h - 2, w - 2, dtype=torch.float32, device=img.device)
+    check(lib().be_image_derivative_f32(dptr(img, "img"), dptr(out), n * c, h, w, stream_ptr(img.device)), "be_image_derivative_f32")
+    return out
+
+
+def image_derivative_bwd(img, gout):
+    o = ops()
+    if o is not None:
+        return o.image_derivative_bwd(img, gout)
+    n, c, h, w = img.shape
+    g = torch.empty_like(img)
+    check(lib().be_image_derivative_bwd_f32(dptr(img, "img"), dptr(gout, "gout"), dptr(g), n * c, h, w, stream_ptr(img.device)),
+          "be_image_derivative_bwd_f32")
+    return g
+
+
+def normalized_gaussian(x, delta_sq: float):
+    o = ops()
+    if o is not None:
+        return o.normalized_gaussian(x, float(delta_sq))
+    y = torch.empty_like(x)
+    check(lib().be_normalized_gaussian_f32(dptr(x, "x"), dptr(y), float(delta_sq), x.numel(), stream_ptr(x.device)),
+          "be_normalized_gaussian_f32")
+    return y
+
+
+def normalized_gaussian_bwd(x, gy, delta_sq: float):
+    o = ops()
+    if o is not None:
+        return o.normalized_gaussian_bwd(x, gy, float(delta_sq))
+    gx = torch.empty_like(x)
+    check(lib().be_normalized_gaussian_bwd_f32(dptr(x, "x"), dptr(gy, "gy"), dptr(gx), float(delta_sq), x.numel(), stream_ptr(x.device)),
+          "be_normalized_gaussian_bwd_f32")
+    return gx
+
+
+def fold_patches(src, B, C, hp, wp, H, W, stride, mode):
+    """nn.Fold of a contiguous [B,C,21,21,Hp,Wp] tensor -> [B,C,H,W]; mode 0 sum, 1 mean over the overlap, 2 number of covering
+    patches whose entry is > 0 (src may be int32 then)."""
+    o = ops()
+    if o is not None:
+        return o.fold_patches(src, B, C, hp, wp, H, W, stride, mode)
+    p = hp * wp
+    out = torch.empty(B, C, H, W, dtype=torch.float32, device=src.device)
+    is_int = src.dtype == torch.int32
+    check(lib().be_fold_patches_f32(None if is_int else dptr(src, "patches"), dptr(src, "mask") if is_int else None, dptr(out), B, C, hp, wp,
+                                    H, W, stride, C * NPIX * p, NPIX * p, BE_R * p, p, wp, 1, mode, stream_ptr(src.device)),
+          "be_fold_patches_f32")
+    return out
+
+
+def fold_patches_bwd(gout, hp, wp, stride, mode):
+    """gout [B,C,H,W] -> the cotangent of fold_patches' source, [B,C,21,21,Hp,Wp]."""
+    o = ops()
+    if o is not None:
+        return o.fold_patches_bwd(gout, hp, wp, stride, mode)
+    B, Cc, H, W = gout.shape
+    p = hp * wp
+    g = torch.empty(B, Cc, BE_R, BE_R, hp, wp, dtype=torch.float32, device=gout.device)
+    check(lib().be_fold_patches_bwd_f32(dptr(gout, "gout"), dptr(g), B, Cc, hp, wp, H, W, stride, Cc * NPIX * p, NPIX * p, BE_R * p, p, wp, 1,
+                                        mode, stream_ptr(gout.device)), "be_fold_patches_bwd_f32")
+    return g
+
+
+def wrap_angles_(est, col0=4, col1=8):
+    """est[:, col0:col1] <- remainder(., 2 pi) in place (est [N,ld] contiguous)."""
+    o = ops()
+    if o is not None:
+        o.wrap_angles_(est, col0, col1)
+        return est
+    check(lib().be_wrap_angles_inplace_f32(dptr(est, "est"), est.shape[0], est.shape[1], col0, col1, stream_ptr(est.device)),
+          "be_wrap_angles_inplace_f32")
+    return est
 
 
 def local_depth(consts: DepthConsts, params10: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:

@@ -2,8 +2,14 @@
 three HIP launches over the ONE flat gradient buffer the LocalStage backward writes (be_hip.train.backward_train): the stock
 path is 13 multi-tensor launches, 0.16 ms of a 2.5 ms step.
 
-It is a torch.optim.Optimizer: param_groups (ReduceLROnPlateau moves `lr`), zero_grad, state_dict / load_state_dict work as
-usual; state[p] holds `exp_avg` / `exp_avg_sq` as views of two flat buffers and one shared device scalar `step`.  `step()`
+It is a torch.optim.Optimizer: param_groups (ReduceLROnPlateau moves `lr`), zero_grad and state_dict work as usual; state[p]
+holds `exp_avg` / `exp_avg_sq` as views of two flat buffers and one shared device scalar `step`.  `load_state_dict` (a resume:
+its own checkpoints or a stock `torch.optim.AdamW` one - same keys) copies the loaded moments and step count INTO those flat
+buffers, which are what the kernel reads, and points state[p] back at the views (the inherited method rebuilt
+`state` with fresh tensors the kernel never saw).  The kernel writes the parameters through a device pointer table; every
+eager `clip_and_step` therefore bumps their version counters (`torch.autograd.graph.increment_version`, host side only) so that
+caches keyed on `_version` - LocalStage's BN-folded weight pack - see the update; a replayed hipGraph cannot do that, which is
+why GraphedStep / SegmentedGraphStep call `model.invalidate_packed()` themselves.  `step()`
 alone is AdamW without clipping; `clip_and_step(max_norm)` is the fused tail of the training step and returns the gradient norm
 before clipping (a device scalar).  Gradients that are not one flat buffer in parameter order are refused (no silent fallback)."""
 from __future__ import annotations
@@ -75,13 +81,38 @@ class ClipAdamW(torch.optim.Optimizer):
             o.clip_adamw(self._table, self._nentries, flat, self._partial, float(max_norm), float(grad_scale), float(g["lr"]),
                          float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), self._step, self._norm,
                          self.write_back)
+            self._bump_versions()
             return self._norm[0]
         check(lib().be_clip_adamw_f32(dptr(self._table, "table", (torch.uint8,)), self._nentries, C.c_void_p(base), self._n,
                                       dptr(self._partial, "partial", (torch.float64,)), self._partial.numel(), float(max_norm),
                                       float(grad_scale), float(g["lr"]), float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]),
                                       float(g["weight_decay"]), dptr(self._step), dptr(self._norm), int(self.write_back),
                                       stream_ptr(dev)), "be_clip_adamw_f32")
+        self._bump_versions()
         return self._norm[0]
+
+    def _bump_versions(self):
+        if self.write_back and not torch.cuda.is_current_stream_capturing():
+            torch.autograd.graph.increment_version(self.param_groups[0]["params"])
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        ps = self.param_groups[0]["params"]
+        if tuple(p.data_ptr() for p in ps) != self._ptrs:
+            raise RuntimeError("ClipAdamW: a parameter's storage moved after the optimizer was built")
+        steps = set()
+        with torch.no_grad():
+            for p, off in zip(ps, self._offsets):
+                st, n = self.state.get(p), p.numel()
+                if not st:                                              # a parameter the checkpoint had no state for: zeros, step 0
+                    self._m[off:off + n].zero_(); self._v[off:off + n].zero_()
+                else:
+                    self._m[off:off + n].copy_(st["exp_avg"].reshape(-1)); self._v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1))
+                    steps.add(float(st["step"]))
+                self.state[p] = dict(step=self._step, exp_avg=self._m[off:off + n].view_as(p), exp_avg_sq=self._v[off:off + n].view_as(p))
+            if len(steps) > 1:
+                raise ValueError(f"ClipAdamW.load_state_dict: one shared step count expected, the checkpoint holds {sorted(steps)}")
+            self._step.fill_(steps.pop() if steps else 0.0)
 
     @torch.no_grad()
     def step(self, closure=None):

@@ -45,7 +45,7 @@ def train_step(model, helper, opt, batch, beta_b, beta_s, flat=None, world=1, cl
     from . import train
     est = model(batch["img_ny"].permute(0, 3, 1, 2))
     opt.zero_grad(set_to_none=True)      # backward then SETS .grad (no fill, no accumulate launch per parameter)
-    loss = utils.local_loss(helper, est, batch["img_gt"], batch["img_gt"], batch["bndry_dist"], batch["deri"], beta_b, beta_s)
+    loss = utils.local_loss(helper, est, batch["img_gt"], batch["img_gt"], batch["bndry_dist"], batch["deri"], beta_b, beta_s, write_back=False)
     if sync is not None and (world > 1 or sync.always):
         train.set_grad_hook(sync.bucket_ready, sync.groups)
         try:

@@ -898,8 +898,16 @@ static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2,
     // linears over many rows with a 128-wide output (GlobalStage at 8 x 4096 tokens: out-projection, second feed-forward linear
     // and three of the four data gradients): 256 row tiles x ONE column tile is "few tiles" for the rule below, which sent them to
     // 64x64 tiles (33 us per launch); they are plain row GEMMs for the LDS-DMA kernel (bit-identical, see further down)
-    if (d->ksize == 1 && !x2 && cp == 128 && M >= 16384 && a.nbatch <= 1 && !a.wb3 && !no_rows && d->cin % 16 == 0)
+    // prepare-only calls (be::conv_train_prepare: `stream` is not the caller's stream and the operands may not be final yet): a
+    // shape that is not handed back as a prepared small-M launch must leave WITHOUT launching anything - prep->variant stays -1
+    // and the caller runs the unit on its own (layer0 at batch >= 406 and wide linears over >= 16384 rows fell
+    // through to a launch on the null stream here, inside a hipGraph capture among others)
+    const bool prep_only = defer && defer->prep;
+    if (d->ksize == 1 && !x2 && cp == 128 && M >= 16384 && a.nbatch <= 1 && !a.wb3 && !no_rows && d->cin % 16 == 0) {
+        if (prep_only) return BE_OK;
         return be::gemm_rows(x, M, d->cin, pw, d->cout, pb, res, d->act, y, ldy, stream);
+    }
+    if (prep_only && !(!row8 && (int64_t)a.m_tiles * ((cp + 127) / 128) < 384 && scratch)) return BE_OK;
     if (!row8 && (int64_t)a.m_tiles * ((cp + 127) / 128) < 384) {
         // 96 output channels (the data gradients that flow into layer0 / layer1, whose inputs have 96 channels) as TWO 64-wide uniform
         // tiles, the second half empty (a third more MFMA work, on tiles that are twice as fast as the bordered 128 x 32 ones).  Only

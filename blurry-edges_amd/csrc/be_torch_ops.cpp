@@ -19,7 +19,11 @@ namespace {
 using at::Tensor;
 using c10::optional;
 
-void* stream_of(const Tensor& t) { return reinterpret_cast<void*>(c10::hip::getCurrentHIPStream(t.device().index()).stream()); }
+void* stream_of(const Tensor& t) {
+    // arguments are evaluated in any order: refuse a CPU tensor here too, before its device index reaches the HIP runtime
+    TORCH_CHECK(t.is_cuda(), "expected a tensor on the GPU; the HIP path has no CPU fallback");
+    return reinterpret_cast<void*>(c10::hip::getCurrentHIPStream(t.device().index()).stream());
+}
 
 const float* fp(const Tensor& t, const char* what) {
     TORCH_CHECK(t.is_cuda(), what, ": expected a tensor on the GPU; the HIP path has no CPU fallback");
@@ -211,6 +215,152 @@ void clip_adamw(const Tensor& table, int64_t nentries, Tensor grad_flat, Tensor 
           "be_clip_adamw_f32");
 }
 
+
+// ---- the fine-grained PostProcess / DepthEtas methods and their adjoints (be_compat.hip, be_compat_bwd.hip, be_elementwise.hip) ------
+// flat one-row-per-patch layouts; the Python classes permute the reference's [B,K,...,Hp,Wp] layout to and from them
+Tensor params2etas(const Tensor& p) {
+    Tensor out = at::empty_like(p);
+    check(be_params2etas_f32(fp(p, "params"), out.data_ptr<float>(), p.numel(), stream_of(p)), "be_params2etas_f32");
+    return out;
+}
+Tensor params2etas_bwd(const Tensor& p, const Tensor& geta) {
+    TORCH_CHECK(geta.numel() == p.numel(), "params2etas_bwd: cotangent size");
+    Tensor gp = at::empty_like(p);
+    check(be_params2etas_bwd_f32(fp(p, "params"), fp(geta, "geta"), gp.data_ptr<float>(), p.numel(), stream_of(p)), "be_params2etas_bwd_f32");
+    return gp;
+}
+Tensor params2dists(const Tensor& opts, const Tensor& params8) {
+    TORCH_CHECK(params8.dim() == 2 && params8.size(1) == 8, "params2dists: params8 [N,8]");
+    const int64_t n = params8.size(0);
+    fp(params8, "params8");
+    Tensor out = at::empty({n, 2, BE_R, BE_R}, params8.options());
+    check(be_params2dists_f32(host_struct<be_render_opts>(opts, "params2dists(opts)"), params8.data_ptr<float>(), out.data_ptr<float>(), n,
+                              stream_of(params8)), "be_params2dists_f32");
+    return out;
+}
+Tensor params2dists_bwd(const Tensor& opts, const Tensor& params8, const Tensor& gdists) {
+    TORCH_CHECK(params8.dim() == 2 && params8.size(1) == 8, "params2dists_bwd: params8 [N,8]");
+    const int64_t n = params8.size(0);
+    TORCH_CHECK(gdists.numel() == n * 2 * BE_NPIX, "params2dists_bwd: gdists [N,2,21,21]");
+    fp(params8, "params8");
+    Tensor g = at::empty_like(params8);
+    check(be_params2dists_bwd_f32(host_struct<be_render_opts>(opts, "params2dists_bwd(opts)"), params8.data_ptr<float>(), fp(gdists, "gdists"),
+                                  g.data_ptr<float>(), n, stream_of(params8)), "be_params2dists_bwd_f32");
+    return g;
+}
+Tensor dists2indicators(const Tensor& dists, const Tensor& etas) {
+    const int64_t n = etas.numel() / 2;
+    TORCH_CHECK(dists.numel() == n * 2 * BE_NPIX && etas.numel() == 2 * n, "dists2indicators: dists [N,2,21,21], etas [N,2]");
+    Tensor out = at::empty({n, 3, BE_R, BE_R}, dists.options());
+    check(be_dists2indicators_f32(fp(dists, "dists"), fp(etas, "etas"), out.data_ptr<float>(), n, stream_of(dists)), "be_dists2indicators_f32");
+    return out;
+}
+std::tuple<Tensor, Tensor> dists2indicators_bwd(const Tensor& dists, const Tensor& etas, const Tensor& gw) {
+    const int64_t n = etas.numel() / 2;
+    TORCH_CHECK(dists.numel() == n * 2 * BE_NPIX && gw.numel() == n * 3 * BE_NPIX, "dists2indicators_bwd: dists [N,2,21,21], gwedges [N,3,21,21]");
+    Tensor gd = at::empty_like(dists), ge = at::empty_like(etas);
+    check(be_dists2indicators_bwd_f32(fp(dists, "dists"), fp(etas, "etas"), fp(gw, "gwedges"), gd.data_ptr<float>(), ge.data_ptr<float>(), n,
+                                      stream_of(dists)), "be_dists2indicators_bwd_f32");
+    return {gd, ge};
+}
+Tensor inverse3x3(const Tensor& a) {
+    TORCH_CHECK(a.numel() % 9 == 0, "inverse3x3: [...,3,3]");
+    Tensor out = at::empty_like(a);
+    check(be_inverse3x3_f32(fp(a, "A"), out.data_ptr<float>(), a.numel() / 9, stream_of(a)), "be_inverse3x3_f32");
+    return out;
+}
+Tensor inverse3x3_bwd(const Tensor& inv, const Tensor& gout) {
+    TORCH_CHECK(inv.numel() % 9 == 0 && gout.numel() == inv.numel(), "inverse3x3_bwd: [...,3,3]");
+    Tensor ga = at::empty_like(inv);
+    check(be_inverse3x3_bwd_f32(fp(inv, "inv"), fp(gout, "gout"), ga.data_ptr<float>(), inv.numel() / 9, stream_of(inv)), "be_inverse3x3_bwd_f32");
+    return ga;
+}
+Tensor image_derivative(const Tensor& img) {
+    TORCH_CHECK(img.dim() == 4, "image_derivative: img [N,C,H,W]");
+    const int64_t n = img.size(0), c = img.size(1), h = img.size(2), w = img.size(3);
+    Tensor out = at::empty({n, c, h - 2, w - 2}, img.options());
+    check(be_image_derivative_f32(fp(img, "img"), out.data_ptr<float>(), n * c, (int)h, (int)w, stream_of(img)), "be_image_derivative_f32");
+    return out;
+}
+Tensor image_derivative_bwd(const Tensor& img, const Tensor& gout) {
+    TORCH_CHECK(img.dim() == 4, "image_derivative_bwd: img [N,C,H,W]");
+    const int64_t n = img.size(0), c = img.size(1), h = img.size(2), w = img.size(3);
+    TORCH_CHECK(gout.numel() == n * c * (h - 2) * (w - 2), "image_derivative_bwd: gout [N,C,H-2,W-2]");
+    Tensor g = at::empty_like(img);
+    check(be_image_derivative_bwd_f32(fp(img, "img"), fp(gout, "gout"), g.data_ptr<float>(), n * c, (int)h, (int)w, stream_of(img)),
+          "be_image_derivative_bwd_f32");
+    return g;
+}
+Tensor normalized_gaussian(const Tensor& x, double delta_sq) {
+    Tensor y = at::empty_like(x);
+    check(be_normalized_gaussian_f32(fp(x, "x"), y.data_ptr<float>(), (float)delta_sq, x.numel(), stream_of(x)), "be_normalized_gaussian_f32");
+    return y;
+}
+Tensor normalized_gaussian_bwd(const Tensor& x, const Tensor& gy, double delta_sq) {
+    TORCH_CHECK(gy.numel() == x.numel(), "normalized_gaussian_bwd: cotangent size");
+    Tensor gx = at::empty_like(x);
+    check(be_normalized_gaussian_bwd_f32(fp(x, "x"), fp(gy, "gy"), gx.data_ptr<float>(), (float)delta_sq, x.numel(), stream_of(x)),
+          "be_normalized_gaussian_bwd_f32");
+    return gx;
+}
+Tensor etas2depth(const Tensor& consts, const Tensor& eta1, const Tensor& eta2) {
+    TORCH_CHECK(eta1.numel() == eta2.numel(), "etas2depth: eta1 / eta2 sizes");
+    fp(eta1, "eta1");
+    Tensor z = at::empty_like(eta1);
+    check(be_etas2depth_f32(host_struct<be_depth_consts>(consts, "etas2depth(consts)"), eta1.data_ptr<float>(), fp(eta2, "eta2"), z.data_ptr<float>(),
+                            nullptr, eta1.numel(), stream_of(eta1)), "be_etas2depth_f32");
+    return z;
+}
+std::tuple<Tensor, Tensor> etas2depth_bwd(const Tensor& consts, const Tensor& eta1, const Tensor& eta2, const Tensor& gz) {
+    TORCH_CHECK(eta1.numel() == eta2.numel() && gz.numel() == eta1.numel(), "etas2depth_bwd: sizes");
+    fp(eta1, "eta1");
+    Tensor g1 = at::empty_like(eta1), g2 = at::empty_like(eta1);
+    check(be_etas2depth_bwd_f32(host_struct<be_depth_consts>(consts, "etas2depth_bwd(consts)"), eta1.data_ptr<float>(), fp(eta2, "eta2"),
+                                fp(gz, "gdepth"), g1.data_ptr<float>(), g2.data_ptr<float>(), eta1.numel(), stream_of(eta1)), "be_etas2depth_bwd_f32");
+    return {g1, g2};
+}
+Tensor depth2sigma(const Tensor& consts, const Tensor& depth, double rho_prime) {
+    fp(depth, "depth");
+    Tensor out = at::empty_like(depth);
+    check(be_depth2sigma_f32(host_struct<be_depth_consts>(consts, "depth2sigma(consts)"), depth.data_ptr<float>(), (float)rho_prime,
+                             out.data_ptr<float>(), depth.numel(), stream_of(depth)), "be_depth2sigma_f32");
+    return out;
+}
+Tensor depth2sigma_bwd(const Tensor& consts, const Tensor& depth, double rho_prime, const Tensor& geta) {
+    TORCH_CHECK(geta.numel() == depth.numel(), "depth2sigma_bwd: cotangent size");
+    fp(depth, "depth");
+    Tensor g = at::empty_like(depth);
+    check(be_depth2sigma_bwd_f32(host_struct<be_depth_consts>(consts, "depth2sigma_bwd(consts)"), depth.data_ptr<float>(), (float)rho_prime,
+                                 fp(geta, "geta"), g.data_ptr<float>(), depth.numel(), stream_of(depth)), "be_depth2sigma_bwd_f32");
+    return g;
+}
+// nn.Fold of a [B,C,21,21,Hp,Wp] patch tensor (contiguous) -> [B,C,H,W]; mode 0 sum, 1 mean, 2 count of positive entries
+Tensor fold_patches(const Tensor& src, int64_t B, int64_t C, int64_t hp, int64_t wp, int64_t H, int64_t W, int64_t stride, int64_t mode) {
+    TORCH_CHECK(src.is_cuda() && src.is_contiguous(), "fold_patches: expected a contiguous tensor on the GPU; the HIP path has no CPU fallback");
+    const int64_t p = hp * wp;
+    TORCH_CHECK(src.numel() == B * C * BE_NPIX * p, "fold_patches: src [B,C,21,21,Hp,Wp]");
+    const bool is_int = src.scalar_type() == at::kInt;
+    TORCH_CHECK(is_int ? mode == 2 : src.scalar_type() == at::kFloat, "fold_patches: float32 source (int32 only for mode 2)");
+    Tensor out = at::empty({B, C, H, W}, src.options().dtype(at::kFloat));
+    check(be_fold_patches_f32(is_int ? nullptr : src.data_ptr<float>(), is_int ? src.data_ptr<int32_t>() : nullptr, out.data_ptr<float>(), (int)B,
+                              (int)C, (int)hp, (int)wp, (int)H, (int)W, (int)stride, C * BE_NPIX * p, BE_NPIX * p, BE_R * p, p, wp, 1, (int)mode,
+                              stream_of(src)), "be_fold_patches_f32");
+    return out;
+}
+Tensor fold_patches_bwd(const Tensor& gout, int64_t hp, int64_t wp, int64_t stride, int64_t mode) {
+    TORCH_CHECK(gout.dim() == 4, "fold_patches_bwd: gout [B,C,H,W]");
+    const int64_t B = gout.size(0), C = gout.size(1), H = gout.size(2), W = gout.size(3), p = hp * wp;
+    Tensor g = at::empty({B, C, BE_R, BE_R, hp, wp}, gout.options());
+    check(be_fold_patches_bwd_f32(fp(gout, "gout"), g.data_ptr<float>(), (int)B, (int)C, (int)hp, (int)wp, (int)H, (int)W, (int)stride,
+                                  C * BE_NPIX * p, BE_NPIX * p, BE_R * p, p, wp, 1, (int)mode, stream_of(gout)), "be_fold_patches_bwd_f32");
+    return g;
+}
+void wrap_angles_(Tensor est, int64_t col0, int64_t col1) {
+    TORCH_CHECK(est.dim() == 2, "wrap_angles_: est [N,ld]");
+    check(be_wrap_angles_inplace_f32(fpm(est, "est"), est.size(0), (int)est.size(1), (int)col0, (int)col1, stream_of(est)),
+          "be_wrap_angles_inplace_f32");
+}
+
 }  // namespace
 
 TORCH_LIBRARY(be, m) {
@@ -233,6 +383,25 @@ TORCH_LIBRARY(be, m) {
     m.def("maxpool_bwd_idx(Tensor idx, Tensor dout, int h, int w, int k, int stride, int pad) -> Tensor");
     m.def("clip_adamw(Tensor table, int nentries, Tensor(a!) grad_flat, Tensor(b!) partial, float max_norm, float grad_scale, float lr, float beta1, "
           "float beta2, float eps, float weight_decay, Tensor(c!) step, Tensor(d!) grad_norm, bool write_back) -> ()");
+    m.def("params2etas(Tensor p) -> Tensor");
+    m.def("params2etas_bwd(Tensor p, Tensor geta) -> Tensor");
+    m.def("params2dists(Tensor opts, Tensor params8) -> Tensor");
+    m.def("params2dists_bwd(Tensor opts, Tensor params8, Tensor gdists) -> Tensor");
+    m.def("dists2indicators(Tensor dists, Tensor etas) -> Tensor");
+    m.def("dists2indicators_bwd(Tensor dists, Tensor etas, Tensor gwedges) -> (Tensor, Tensor)");
+    m.def("inverse3x3(Tensor a) -> Tensor");
+    m.def("inverse3x3_bwd(Tensor inv, Tensor gout) -> Tensor");
+    m.def("image_derivative(Tensor img) -> Tensor");
+    m.def("image_derivative_bwd(Tensor img, Tensor gout) -> Tensor");
+    m.def("normalized_gaussian(Tensor x, float delta_sq) -> Tensor");
+    m.def("normalized_gaussian_bwd(Tensor x, Tensor gy, float delta_sq) -> Tensor");
+    m.def("etas2depth(Tensor consts, Tensor eta1, Tensor eta2) -> Tensor");
+    m.def("etas2depth_bwd(Tensor consts, Tensor eta1, Tensor eta2, Tensor gz) -> (Tensor, Tensor)");
+    m.def("depth2sigma(Tensor consts, Tensor depth, float rho_prime) -> Tensor");
+    m.def("depth2sigma_bwd(Tensor consts, Tensor depth, float rho_prime, Tensor geta) -> Tensor");
+    m.def("fold_patches(Tensor src, int B, int C, int hp, int wp, int H, int W, int stride, int mode) -> Tensor");
+    m.def("fold_patches_bwd(Tensor gout, int hp, int wp, int stride, int mode) -> Tensor");
+    m.def("wrap_angles_(Tensor(a!) est, int col0, int col1) -> ()");
 }
 
 // on ROCm builds of PyTorch the GPU dispatch key is named CUDA (HIP masquerades as it); ops that take only host structs + GPU tensors
@@ -248,9 +417,29 @@ TORCH_LIBRARY_IMPL(be, CUDA, m) {
     m.impl("maxpool_bwd_idx", maxpool_bwd_idx);
     m.impl("clip_adamw", clip_adamw);
 }
-// these two take a CPU byte tensor (the host struct) next to GPU tensors: registered for every backend, they check their GPU
-// arguments themselves (a CPU tensor raises: no fallback)
+// registered for every backend: these check their GPU arguments themselves, so that a CPU tensor raises the library's own
+// "no CPU fallback" error instead of the dispatcher's missing-kernel message (some also take a CPU byte tensor - the host struct -
+// next to their GPU tensors)
 TORCH_LIBRARY_IMPL(be, CompositeExplicitAutograd, m) {
     m.impl("render_colors", render_colors);
     m.impl("local_depth", local_depth);
+    m.impl("params2dists", params2dists);
+    m.impl("params2dists_bwd", params2dists_bwd);
+    m.impl("etas2depth", etas2depth);
+    m.impl("etas2depth_bwd", etas2depth_bwd);
+    m.impl("depth2sigma", depth2sigma);
+    m.impl("depth2sigma_bwd", depth2sigma_bwd);
+    m.impl("params2etas", params2etas);
+    m.impl("params2etas_bwd", params2etas_bwd);
+    m.impl("dists2indicators", dists2indicators);
+    m.impl("dists2indicators_bwd", dists2indicators_bwd);
+    m.impl("inverse3x3", inverse3x3);
+    m.impl("inverse3x3_bwd", inverse3x3_bwd);
+    m.impl("image_derivative", image_derivative);
+    m.impl("image_derivative_bwd", image_derivative_bwd);
+    m.impl("normalized_gaussian", normalized_gaussian);
+    m.impl("normalized_gaussian_bwd", normalized_gaussian_bwd);
+    m.impl("fold_patches", fold_patches);
+    m.impl("fold_patches_bwd", fold_patches_bwd);
+    m.impl("wrap_angles_", wrap_angles_);
 }

@@ -9,6 +9,7 @@ import math
 
 import torch
 
+from be_hip import autograd_ops as ag
 from be_hip import native
 
 
@@ -41,7 +42,7 @@ class DepthEtas:
         return self._consts
 
     def etas2depth(self, eta1, eta2):
-        return native.etas2depth(self._consts, eta1, eta2)
+        return ag.Etas2Depth.apply(eta1, eta2, self._consts)            # differentiable (global_training.py:91-92)
 
     def depth2sigma(self, depth, rho_prime):
-        return native.depth2sigma(self._consts, depth, rho_prime)
+        return ag.Depth2Sigma.apply(depth, self._consts, rho_prime)

@@ -11,6 +11,7 @@ import numpy as np
 import torch
 import torch.nn as nn
 
+from be_hip import autograd_ops as ag
 from be_hip import native
 
 
@@ -59,47 +60,30 @@ class PostProcessBase(nn.Module, ABC):
         return t.view(b, hp, wp, t.shape[1], t.shape[2], t.shape[3]).permute(0, 3, 4, 5, 1, 2)
 
     def params2etas(self, params):
-        return native.params2etas(params)
+        return ag.Params2Etas.apply(params)
 
     def params2dists(self, params):
         p, grid = self._flat_params(params)
-        n = p.shape[0]
-        out = torch.empty(n, 2, self.R, self.R, dtype=torch.float32, device=p.device)
-        native.check(native.lib().be_params2dists_f32(native.C.byref(self.render_opts(False)), native.dptr(p, "params"),
-                                                      native.dptr(out), n, native.stream_ptr(p.device)), "be_params2dists_f32")
-        return self._unflat_pixels(out, grid)
+        return self._unflat_pixels(ag.Params2Dists.apply(p, self.render_opts(False)), grid)
 
     def dists2indicators(self, dists, etas):
         if dists.dim() == 6:                                   # global layout [B,2,21,21,Hp,Wp]
             b, _, _, _, hp, wp = dists.shape
-            d = dists.permute(0, 4, 5, 1, 2, 3).reshape(-1, 2, self.R, self.R).contiguous()
+            d = dists.permute(0, 4, 5, 1, 2, 3).reshape(-1, 2, self.R, self.R)
             grid = (b, hp, wp)
         else:
-            d, grid = dists.contiguous(), None
+            d, grid = dists, None
         e, _ = self._flat_params(etas)
-        n = d.shape[0]
-        out = torch.empty(n, 3, self.R, self.R, dtype=torch.float32, device=d.device)
-        native.check(native.lib().be_dists2indicators_f32(native.dptr(d, "dists"), native.dptr(e, "etas"), native.dptr(out),
-                                                          n, native.stream_ptr(d.device)), "be_dists2indicators_f32")
-        return self._unflat_pixels(out, grid)
+        return self._unflat_pixels(ag.Dists2Indicators.apply(d, e), grid)
 
     def normalized_gaussian(self, x, delta=0.07):
-        return torch.exp(-x ** 2 / delta ** 2)
+        return ag.NormalizedGaussian.apply(x, float(torch.tensor(delta ** 2, dtype=torch.float32)))
 
     def inverse_3by3(self, A):
-        a = A.contiguous()
-        out = torch.empty_like(a)
-        native.check(native.lib().be_inverse3x3_f32(native.dptr(a, "A"), native.dptr(out), a.numel() // 9,
-                                                    native.stream_ptr(a.device)), "be_inverse3x3_f32")
-        return out
+        return ag.Inverse3x3.apply(A)
 
     def get_image_derivative(self, img):
-        x = img.contiguous()
-        n, c, h, w = x.shape
-        out = torch.empty(n, c, h - 2, w - 2, dtype=torch.float32, device=x.device)
-        native.check(native.lib().be_image_derivative_f32(native.dptr(x, "img"), native.dptr(out), n * c, h, w,
-                                                          native.stream_ptr(x.device)), "be_image_derivative_f32")
-        return out
+        return ag.ImageDerivative.apply(img)
 
     # ---- fused passes (flat layout)
     def render_opts(self, wrap_angles=False):
@@ -142,18 +126,11 @@ class PostProcessGlobalBase(PostProcessBase):
         return (xx.view(1, self.R, self.R, 1, 1).to(self.device), yy.view(1, self.R, self.R, 1, 1).to(self.device))
 
     # ---- nn.Fold aggregations of the reference (:151-173) on materialised patch tensors [.., 21,21,Hp,Wp]
-    def _fold(self, t, lead, mode, int_src=False):
-        """t viewed as [lead, C, 21, 21, Hp, Wp] contiguous -> [lead, C, H, W]."""
+    def _fold(self, t, lead, mode):
+        """t viewed as [lead, C, 21, 21, Hp, Wp] contiguous -> [lead, C, H, W]; differentiable for modes 0 / 1."""
         p = self.H_patches * self.W_patches
         c = t.numel() // (lead * self.R * self.R * p)
-        t = t.contiguous()
-        out = torch.empty(lead, c, self.H, self.W, dtype=torch.float32, device=t.device)
-        src, src_i = (None, native.dptr(t, "mask")) if int_src else (native.dptr(t, "patches"), None)
-        native.check(native.lib().be_fold_patches_f32(src, src_i, native.dptr(out), lead, c, self.H_patches, self.W_patches,
-                                                      self.H, self.W, self.stride, c * self.R * self.R * p,
-                                                      self.R * self.R * p, self.R * p, p, self.W_patches, 1, mode,
-                                                      native.stream_ptr(t.device)), "be_fold_patches_f32")
-        return out
+        return ag.FoldPatches.apply(t, lead, c, self.H_patches, self.W_patches, self.H, self.W, self.stride, mode)
 
     def local2global_color(self, patches, pair=True):
         if pair:
@@ -165,7 +142,8 @@ class PostProcessGlobalBase(PostProcessBase):
 
     def local2global_depth(self, depth_map, depth_mask):
         is_int = depth_mask.dtype == torch.int32
-        cnt = self._fold(depth_mask if is_int else depth_mask.to(torch.float32), self.batch_size, 2, int_src=is_int)
+        with torch.no_grad():                                   # a count: piecewise constant in the mask
+            cnt = self._fold(depth_mask if is_int else depth_mask.to(torch.float32), self.batch_size, 2)
         cnt = cnt.view(self.batch_size, self.H, self.W)
         tot = self._fold(depth_map.to(torch.float32), self.batch_size, 0).view(self.batch_size, self.H, self.W)
         conf = cnt / self.num_patches.unsqueeze(0)
@@ -190,9 +168,14 @@ class _LocalLossFn(torch.autograd.Function):
         return g * grad, None, None, None, None, None, None, None
 
 
-def local_loss(helper, est, img_fit, gt_img, bndry_dist, deri, beta_bndry_loc, beta_smthns):
+def local_loss(helper, est, img_fit, gt_img, bndry_dist, deri, beta_bndry_loc, beta_smthns, write_back=True):
     """LocalLoss.forward (local_training.py:47-52) as one fused HIP forward+backward; differentiable w.r.t. est.
-    Unlike the reference it does NOT write the wrapped angles back into est."""
+    write_back=True (default, the reference's behaviour): `est[:, 4:8] = remainder(est[:, 4:8], 2 pi)` is written into the
+    caller's tensor first (local_training.py:33; float32 remainder, one kernel, the cotangent passes through) - like the
+    reference this refuses a leaf tensor that requires grad.  write_back=False leaves est untouched; the loss kernel then wraps
+    the raw angles itself in float64 (what the build's own training loops use: 2e-7 rad closer to the float64 reference)."""
+    if write_back:
+        est = ag.WrapAnglesInplace.apply(est)
     return _LocalLossFn.apply(est, helper, img_fit, gt_img, bndry_dist, deri, float(beta_bndry_loc), float(beta_smthns))
 
 

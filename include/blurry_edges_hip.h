@@ -177,6 +177,35 @@ int be_fold_patches_f32(const float* src, const int32_t* src_int, float* out, in
                         int stride, int64_t s_b, int64_t s_c, int64_t s_r, int64_t s_col, int64_t s_pi, int64_t s_pj,
                         int mode, void* stream);
 
+/* Adjoints of the methods above and of DepthEtas, for `loss.backward()` through a caller's own LocalLoss / GlobalLoss subclass
+ * (local_training.py:32-52,106; global_training.py:62-157,212).  g* = cotangent (dL/d.) with the shape of the tensor it
+ * belongs to; derivatives are evaluated in fp64 from the fp32 operands; per-patch sums have a fixed order. */
+/* params2dists: gdists [N,2,21,21] -> gparams8 [N,8] (d/d x0,y0,x1,y1,theta1,phi1,theta2,phi2; remainder has slope 1). */
+int be_params2dists_bwd_f32(const be_render_opts* opts_host, const float* params8, const float* gdists, float* gparams8, int64_t n,
+                            void* stream);
+/* dists2indicators: gwedges [N,3,21,21] -> gdists [N,2,21,21], getas [N,2]. */
+int be_dists2indicators_bwd_f32(const float* dists, const float* etas, const float* gwedges, float* gdists, float* getas, int64_t n,
+                                void* stream);
+/* inverse_3by3: inv = the forward's output, gout [n,3,3] -> ga = -inv^T gout inv^T. */
+int be_inverse3x3_bwd_f32(const float* inv, const float* gout, float* ga, int64_t n, void* stream);
+/* get_image_derivative: img [planes,H,W], gout [planes,H-2,W-2] -> gimg [planes,H,W]. */
+int be_image_derivative_bwd_f32(const float* img, const float* gout, float* gimg, int64_t planes, int H, int W, void* stream);
+/* params2etas: gp = geta * d eta / d p. */
+int be_params2etas_bwd_f32(const float* p, const float* geta, float* gp, int64_t n, void* stream);
+/* normalized_gaussian (utils/postprocessing_loss.py:97-98): y = exp(-x^2 / delta_sq), and its adjoint. */
+int be_normalized_gaussian_f32(const float* x, float* y, float delta_sq, int64_t n, void* stream);
+int be_normalized_gaussian_bwd_f32(const float* x, const float* gy, float* gx, float delta_sq, int64_t n, void* stream);
+/* DepthEtas.etas2depth / depth2sigma (utils/depth_etas.py:23-37): the branch taken is the forward's. */
+int be_etas2depth_bwd_f32(const be_depth_consts* consts_host, const float* eta1, const float* eta2, const float* gdepth,
+                          float* geta1, float* geta2, int64_t n, void* stream);
+int be_depth2sigma_bwd_f32(const be_depth_consts* consts_host, const float* depth, float rho_prime, const float* geta, float* gdepth,
+                           int64_t n, void* stream);
+/* be_fold_patches_f32, modes 0 (sum) and 1 (mean): gout [B,C,H,W] -> gsrc in the source's strided layout. */
+int be_fold_patches_bwd_f32(const float* gout, float* gsrc, int B, int C, int hp, int wp, int H, int W, int stride, int64_t s_b,
+                            int64_t s_c, int64_t s_r, int64_t s_col, int64_t s_pi, int64_t s_pj, int mode, void* stream);
+/* est[:, col0:col1] <- remainder(est[:, col0:col1], 2 pi) IN PLACE, est [n,ld] (LocalLoss.get_patches, local_training.py:33). */
+int be_wrap_angles_inplace_f32(float* est, int64_t n, int ld, int col0, int col1, void* stream);
+
 /* ---------------------------------------------------------------------------------------------------
  * LocalLoss forward + backward (training)
  *   replaces LocalLoss.get_patches + LocalLoss.forward (local_training.py:32-52) and the autograd graph under

@@ -781,6 +781,61 @@ def test_clip_adamw_matches_clip_grad_norm_and_torch_adamw():
         oa.clip_and_step(1.0)
 
 
+def test_clip_adamw_save_load_continue_matches_the_uninterrupted_run_and_torch_adamw():
+    """a resume.  ClipAdamW.load_state_dict must put the loaded moments and step count into the flat buffers the kernel
+    reads (the inherited method only rebuilt `state` with tensors the kernel never saw).  Three steps, save, build a fresh
+    optimizer over copied parameters, load, three more steps: identical bits to the uninterrupted run; loading a stock
+    torch.optim.AdamW checkpoint (same keys) continues like the stock optimizer; state_dict() after the resume shows the LIVE
+    moments; and an eager step bumps the parameters' version counters (caches keyed on them see the update)."""
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a GPU")
+    from be_hip.optim import ClipAdamW
+    g = torch.Generator(device="cpu").manual_seed(5)
+    shapes = [(64, 3, 7, 7), (64,), (96, 64, 3, 3), (10, 1024), (10,)]
+    n = sum(int(np.prod(sh)) for sh in shapes)
+    init = [torch.randn(sh, generator=g).to(DEV) for sh in shapes]
+    grads = [torch.randn(n, generator=g).to(DEV) * 1e-2 for _ in range(6)]
+
+    def make(cls, src=None):
+        ps = [torch.nn.Parameter(t.clone()) for t in (init if src is None else src)]
+        return ps, cls(ps, lr=1e-3)
+
+    def set_grads(ps, flat):
+        buf, off = flat.clone(), 0
+        for p in ps:
+            p.grad = buf[off:off + p.numel()].view_as(p)
+            off += p.numel()
+
+    def run(ps, opt, steps):
+        for k in steps:
+            set_grads(ps, grads[k])
+            if hasattr(opt, "clip_and_step"):
+                opt.clip_and_step(1.0)
+            else:
+                torch.nn.utils.clip_grad_norm_(ps, max_norm=1.0)
+                opt.step()
+
+    pa, oa = make(ClipAdamW)
+    pb, ob = make(torch.optim.AdamW)
+    v0 = pa[0]._version
+    run(pa, oa, range(3)); run(pb, ob, range(3))
+    assert pa[0]._version > v0
+    sd_a = {k: (v if k != "state" else {i: {kk: vv.clone() for kk, vv in st.items()} for i, st in v.items()}) for k, v in oa.state_dict().items()}
+    sd_b = ob.state_dict()
+    p2, o2 = make(ClipAdamW, [p.detach() for p in pa]); o2.load_state_dict(sd_a)          # resume from its own checkpoint
+    p3, o3 = make(ClipAdamW, [p.detach() for p in pb]); o3.load_state_dict(sd_b)          # resume from a stock AdamW checkpoint
+    assert float(o2._step) == 3.0 and float(o3._step) == 3.0
+    assert o2.state[p2[2]]["exp_avg"].data_ptr() == o2._m[o2._offsets[2]:].data_ptr()     # state[p] are views of the kernel's buffers again
+    run(pa, oa, range(3, 6)); run(pb, ob, range(3, 6)); run(p2, o2, range(3, 6)); run(p3, o3, range(3, 6))
+    for a, b in zip(pa, p2):
+        assert torch.equal(a, b)
+    for a, b in zip(p3, pb):
+        assert float((a - b).abs().max()) <= 2e-6 * float(b.abs().max())
+    live = o2.state_dict()["state"]
+    assert float(live[0]["step"]) == 6.0
+    assert torch.equal(live[2]["exp_avg"], oa.state[pa[2]]["exp_avg"]) and not torch.equal(live[2]["exp_avg"], sd_a["state"][2]["exp_avg"])
+
+
 def test_training_unit_matches_the_single_purpose_kernels():
     """be_train_unit_fwd_f32 / be_train_unit_bwd_f32 (round 3: a unit's forward in 3 launches, its backward in 5) against the
     layer-level entry points they replace in the step (conv, be_bn_train_fwd/bwd_f32, be_conv_wgrad_f32, be_col_sum_f32, the
@@ -860,7 +915,9 @@ def test_unit_pair_launches_equal_two_single_unit_calls_bit_for_bit(binding, mon
     if binding == "torch_ops":
         assert native.ops() is not None
     g = torch.Generator(device="cpu").manual_seed(23)
-    for (n, hw, cin, cout) in ((64, 11, 64, 96), (64, 6, 96, 256), (64, 6, 256, 384), (64, 6, 384, 256), (24, 6, 96, 256)):
+    # (512, 11, 64, 96): layer0 at a user-chosen --batch_size of 512 - M = 61 952 rows is outside the small-M tiles, the
+    # prepare call must hand NOTHING back and launch NOTHING (it used to launch the convolution on the null stream)
+    for (n, hw, cin, cout) in ((64, 11, 64, 96), (64, 6, 96, 256), (64, 6, 256, 384), (64, 6, 384, 256), (24, 6, 96, 256), (512, 11, 64, 96)):
         x = torch.randn(n, hw, hw, cin, generator=g).to(DEV)
 
         class P:
@@ -904,6 +961,22 @@ def test_unit_pair_launches_equal_two_single_unit_calls_bit_for_bit(binding, mon
             assert all(torch.equal(p, q) for p, q in zip(st1[wi], st2[wi])), (n, cin, cout, wi)
             assert all(torch.equal(p, q) for p, q in zip(g1[wi], g2[wi])), (n, cin, cout, wi)
         assert torch.equal(ds_a1, ds_a2) and torch.equal(ds_b1, ds_b2) and torch.equal(dx_1, dx_2), (n, cin, cout)
+        if n == 512:
+            # ... and the same calls captured into a hipGraph on a side stream: a launch on the null stream would end the capture
+            st3, g3 = stats(), grads()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                ua, ub = [(wi, cout, par[wi]["ks"], par[wi]["gamma"], par[wi]["beta"], *st3[wi], act) for wi, act in ((0, True), (6, False))]
+                (out_a3, sv_a3), (out_b3, sv_b3) = train._unit_pair_fwd(x, P, ua, ub)
+                ua, ub = [(par[wi]["dout"], sv, par[wi]["gamma"], P.dg[wi], par[wi]["ks"], *g3[wi]) for wi, sv in ((0, sv_a3), (6, sv_b3))]
+                ds_a3, ds_b3, dx_3 = train._unit_pair_bwd(x, ua, ub)
+            graph.replay()
+            torch.cuda.synchronize()
+            assert same(out_a1, out_a3) and same(out_b1, out_b3)
+            for wi in (0, 6):
+                assert all(torch.equal(p, q) for p, q in zip(st1[wi], st3[wi])), wi
+                assert all(torch.equal(p, q) for p, q in zip(g1[wi], g3[wi])), wi
+            assert torch.equal(ds_a1, ds_a3) and torch.equal(ds_b1, ds_b3) and torch.equal(dx_1, dx_3)
 
 
 def test_segmented_graph_step_and_clip_adamw_train_like_the_eager_step_and_the_next_eval_sees_it():
