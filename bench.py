@@ -53,7 +53,7 @@ CPU_REPEATS = 3
 # kernel id 6 = the 25 transform-domain GEMMs of one Winograd layer: the hooks count the 25 x 2 x 4n x cin x cout FLOPs they
 # execute; the same layer as a direct 3x3 convolution on a 6x6 map is 2 x 36 x 9 x n x cin x cout
 ALGO_OVER_HOOK = {6: (2.0 * 36 * 9) / (25.0 * 2 * 4)}
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
 
 
 def cpu_baseline(x_np, sd_np):
@@ -147,11 +147,30 @@ def timed(fn, iters, warmup=2):
 
 
 def git_head():
+    """the source revision: `git rev-parse` where there is a .git, else what build() baked next to the libraries (the GPU box
+    receives a snapshot without .git; `+dirty` = the tree had uncommitted changes when it was built)"""
     try:
-        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
-                              timeout=10).stdout.strip() or None
+        head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True,
+                              timeout=10).stdout.strip()
+        if head:
+            return head
+    except Exception:
+        pass
+    try:
+        info = json.load(open(os.path.join(ROOT, "blurry-edges_amd", "lib", "BUILD_INFO.json")))
+        return info["git_head"] + ("+dirty" if info.get("dirty") else "")
     except Exception:
         return None
+
+
+def kernel_source_sha(files):
+    """sha256 over the named kernel sources (relative to csrc/): what a recorded counter measurement is valid for"""
+    import hashlib
+    h = hashlib.sha256()
+    for f in files:
+        with open(os.path.join(ROOT, "blurry-edges_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def leg_local_training(dev, native, peak, steps=60):
@@ -263,7 +282,7 @@ def leg_global_training(dev, steps=12):
                 images_per_s=round(B / ms * 1e3, 1), steps=steps, first_loss=float(losses[0]), last_loss=float(losses[-1]))
 
 
-def leg_dp(dev, native, dist, rank, world, steps):
+def leg_dp(dev, native, dist, rank, world, steps, algorithm="allreduce"):
     """configs[4], local half: `steps` data-parallel training steps, per-GPU batch 64, gradients averaged by the bucketed
     all-reduce that overlaps the backward (be_hip.dp.GradSync over RCCL); plus the same step without the exchange and the
     exchange alone, so that the exposed communication can be read off.  world = 1 runs the identical code without a group."""
@@ -289,7 +308,7 @@ def leg_dp(dev, native, dist, rank, world, steps):
             port = sk.getsockname()[1]
         dist1.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
         own_group = True
-    sync = dp.GradSync(world, always=own_group) if (world > 1 or own_group) else None
+    sync = dp.GradSync(world, always=own_group, algorithm=algorithm) if (world > 1 or own_group) else None
     if world > 1 or own_group:
         dp.broadcast_parameters(model, src=0)
     it = [0]
@@ -313,17 +332,20 @@ def leg_dp(dev, native, dist, rank, world, steps):
             dist.barrier()
         torch.cuda.synchronize()
         t = time.perf_counter() - t0
+        local.append(round(t / n * 1e3, 4))               # this rank's own clock (the barrier above bounds it by the slowest rank's)
         if dist is not None:
             tt = torch.tensor([t], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             t = float(tt.item())
         return t / n * 1e3
+    local = []
     ms = clock(step, steps)
     res = dict(config="configs[4] (LocalStage half): data-parallel local training, per-GPU batch 64, eager launches, "
                       "gradient buckets (fc | layer3 | layer2 | layer1 + layer0 + conv1) all-reduced on a side stream while the backward runs",
                world=world, global_batch=B * world, steps=steps, dp_step_ms=round(ms, 4),
                patches_per_s=round(B * world / ms * 1e3, 1), allreduce_bytes=4 * sum(p.numel() for p in model.parameters()),
-               allreduce_buckets=len(sync.groups) if sync is not None else 0)
+               allreduce_buckets=len(sync.groups) if sync is not None else 0, algorithm=algorithm)
+    mine = dict(rank=rank, dp_step_ms=local[-1])
     if world > 1:
         res["compute_only_step_ms"] = round(clock(lambda: step(False), steps), 4)
         flat = torch.zeros(res["allreduce_bytes"] // 4, dtype=torch.float32, device=dev)
@@ -333,7 +355,9 @@ def leg_dp(dev, native, dist, rank, world, steps):
             for lo, hi in ranges:
                 sync.bucket_ready(flat, lo, hi)
             sync.finish()
+        mine["compute_only_step_ms"] = local[-1]
         res["allreduce_ms"] = round(clock(exchange, 20), 4)
+        mine["allreduce_ms"] = local[-1]
         res["exposed_comm_ms"] = round(res["dp_step_ms"] - res["compute_only_step_ms"], 4)
         res["allreduce_busbw_GBps"] = round(2 * (world - 1) / world * res["allreduce_bytes"] / (res["allreduce_ms"] * 1e-3) / 1e9, 1)
         dp.broadcast_bn_stats(model, src=0)
@@ -349,6 +373,7 @@ def leg_dp(dev, native, dist, rank, world, steps):
         sync.timing = False
         if per:
             res["buckets"] = [dict(bytes=b, issue_to_complete_ms=round(m / 5, 4)) for b, m in per]
+            mine["buckets_issue_to_complete_ms"] = [round(m / 5, 4) for _, m in per]
     if own_group:
         res["rccl_one_rank_group"] = True
         res["compute_only_step_ms"] = round(clock(lambda: step(False), steps), 4)
@@ -363,7 +388,17 @@ def leg_dp(dev, native, dist, rank, world, steps):
             it[0] += 1
             return seg({k: v[lo:lo + B] for k, v in data.items()}, args.beta_bndry_loc, args.beta_smthns)
         res["segmented_graph_step_ms"] = round(clock(seg_step, steps), 4)
+        mine["segmented_graph_step_ms"] = local[-1]
         res["segmented_graph_patches_per_s"] = round(B * world / res["segmented_graph_step_ms"] * 1e3, 1)
+    # every rank reports its OWN clocks (rank 0 alone hides a straggler): one line per rank on stderr, and the
+    # list of all ranks in rank 0's JSON line.  The `*_ms` figures above are the MAX over ranks of the same clocks.
+    print(f"[bench rank {rank}] dp: {json.dumps(mine)}", file=sys.stderr, flush=True)
+    if dist is not None and world > 1:
+        every = [None] * world
+        dist.all_gather_object(every, mine)
+        res["per_rank"] = every
+    else:
+        res["per_rank"] = [mine]
     if own_group:
         dist1.destroy_process_group()
     return res
@@ -379,6 +414,8 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="LocalStage sub-batch (patches); 0 = library default")
     ap.add_argument("--streams", type=int, default=0, help="LocalStage eval schedule: 2 = two half-batches on two side streams "
                                                            "(default), 1 = one stream (what profiles/ are taken with)")
+    ap.add_argument("--dp-algorithm", default=os.environ.get("BE_DP_ALGORITHM", "allreduce"), choices=("allreduce", "rs_ag"),
+                    help="gradient exchange of the dp leg: one all_reduce per bucket, or reduce_scatter + all_gather (be_hip.dp.GradSync)")
     ap.add_argument("--layers", action="store_true", help="print the per-launch conv timing table to stderr")
     args = ap.parse_args()
 
@@ -499,17 +536,22 @@ def main():
                                     "end_to_end_frac prices the whole step that way.  direct_conv_equivalent_*: the same durations priced in "
                                     "the reference's direct-convolution FLOPs (SURVEY 8d: 2*MAC incl. zero-padding taps, 324 multiplies per "
                                     "map and channel pair where F(3x3,3x3) does 100): exceeds 1 by the arithmetic saving, not by skipped work")
-            # HBM bytes per launch come from separate rocprofv3 --pmc passes (profiles/), never from this run: reported
-            # as a RECORDED value with its provenance, and only while it still describes the dominant kernel
+            # HBM bytes per launch come from separate rocprofv3 --pmc passes (profiles/), never from this run.  The record names
+            # the kernel sources it was measured on (sha256): while those are byte-identical to the sources of the library that
+            # is running, the counters describe the running kernel and `traffic` is filled; otherwise only `traffic_recorded`
             try:
                 tr = json.load(open(TRAFFIC_FILE))
-                if tr.get("kernel_id") == prof["kernel_id"]:
-                    roof["traffic_recorded"] = dict(bytes_per_launch=tr["bytes_per_launch"], source=os.path.relpath(TRAFFIC_FILE, ROOT),
-                                                    measured_at_git_head=tr.get("git_head"), kernel=tr.get("kernel"),
-                                                    algo_bytes_per_launch=tr.get("algo_bytes_per_launch"))
-                else:
-                    roof["traffic_recorded"] = None
+                roof["traffic_recorded"] = dict(bytes_per_launch=tr["bytes_per_launch"], source=os.path.relpath(TRAFFIC_FILE, ROOT),
+                                                measured_at_git_head=tr.get("git_head"), kernel=tr.get("kernel"),
+                                                algo_bytes_per_launch=tr.get("algo_bytes_per_launch"),
+                                                kernel_sources=tr.get("kernel_sources"), kernel_source_sha=tr.get("kernel_source_sha"))
+                if tr.get("kernel_id") != prof["kernel_id"]:
                     roof["traffic_note"] = f"{os.path.relpath(TRAFFIC_FILE, ROOT)} describes kernel id {tr.get('kernel_id')}, not the dominant one"
+                elif tr.get("kernel_sources") and kernel_source_sha(tr["kernel_sources"]) == tr.get("kernel_source_sha"):
+                    roof["traffic"] = tr["bytes_per_launch"]
+                    roof["traffic_over_algorithmic"] = round(tr["bytes_per_launch"] / tr["algo_bytes_per_launch"], 3)
+                else:
+                    roof["traffic_note"] = "the dominant kernel's sources changed since the counters were collected: traffic left null"
             except Exception:
                 roof["traffic_recorded"] = None
 
@@ -561,7 +603,7 @@ def main():
             watchdog.daemon = True
             watchdog.start()
         try:
-            dp_leg = leg_dp(dev, native, dist, rank, world, max(10, args.steps))
+            dp_leg = leg_dp(dev, native, dist, rank, world, max(10, args.steps), algorithm=args.dp_algorithm)
         except Exception as e:
             dp_leg = dict(error=f"{type(e).__name__}: {e}")
             print(f"[bench rank {rank}] dp leg failed: {dp_leg['error']}", file=sys.stderr, flush=True)

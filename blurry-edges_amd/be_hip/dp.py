@@ -146,12 +146,24 @@ class GradSync:
     what a first multi-GPU run needs to attribute `exposed_comm_ms` (a bucket's time includes waiting for the bucket before it:
     the collectives of one step are serialised on the side stream)."""
 
-    def __init__(self, world, group=None, always=False, groups=DEFAULT_GROUPS, timing=False):
+    ALGORITHMS = ("allreduce", "rs_ag")
+
+    def __init__(self, world, group=None, always=False, groups=DEFAULT_GROUPS, timing=False, algorithm="allreduce"):
         """always: run the exchange even for world == 1 (a one-rank group: the sum is the identity) - how the RCCL path is
-        exercised on a single GPU (tests, bench.py at N = 1)."""
+        exercised on a single GPU (tests, bench.py at N = 1).
+        algorithm: "allreduce" (default) - one `all_reduce` per bucket, RCCL chooses ring / tree; "rs_ag" - the same sum written as
+        `reduce_scatter_tensor` into this rank's 1/world shard of the bucket followed by `all_gather_into_tensor` back into the
+        bucket (on a full xGMI mesh a direct reduce-scatter + all-gather moves (world-1)/world of a bucket per phase
+        spread over all 7 links, where a single ring pushes 2 (world-1)/world of it through each link in turn); the < world elements
+        that do not divide take a tiny all_reduce.  Same sums: both give every rank the same buffer, and for world = 2 the very
+        same bits.  A knob for the first run on a real 8-GPU node (`bench.py --dp-algorithm`, BE_DP_ALGORITHM)."""
+        if algorithm not in self.ALGORITHMS:
+            raise ValueError(f"GradSync: algorithm must be one of {self.ALGORITHMS}, got {algorithm!r}")
         self.world, self.group, self.always = world, group, always
         self.groups = check_groups(groups)
         self.timing = timing
+        self.algorithm = algorithm
+        self._shards = {}
         self.handles, self.flat, self.side = [], None, None
         self.bytes = 0
         self._events, self._timed_side = [], False
@@ -170,21 +182,45 @@ class GradSync:
             ev.record()                                               # behind the last kernel that wrote flat[lo:hi]
             with torch.cuda.stream(self.side):
                 self.side.wait_event(ev)
-                h = dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                hs = self._issue(piece, dist)
                 if self.timing:
-                    h.wait()                                          # the SIDE stream waits for the collective ...
+                    for h in hs:
+                        h.wait()                                      # the SIDE stream waits for the collective(s) ...
                     done = torch.cuda.Event(enable_timing=True)
-                    done.record()                                     # ... so this event is its completion
+                    done.record()                                     # ... so this event is their completion
                     self._events.append((piece.numel() * 4, ev, done))
                     self._timed_side = True
                 else:
-                    self.handles.append(h)
+                    self.handles.extend(hs)
         elif piece.is_cuda:
             host = piece.cpu()
-            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=self.group)
+            for h in self._issue(host, dist):
+                h.wait()
             piece.copy_(host)
         else:
-            self.handles.append(dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self.handles.extend(self._issue(piece, dist))
+
+    def _issue(self, piece, dist):
+        """the bucket's sum over the ranks, in place, as asynchronous collective(s) in issue order -> their handles"""
+        w = dist.get_world_size(self.group)
+        if self.algorithm == "allreduce" or w == 1 or piece.numel() < w:
+            return [dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
+        r = dist.get_rank(self.group)
+        s = piece.numel() // w                                        # shard length; [w * s, n) is the remainder
+        main = piece[:w * s]
+        key = (piece.device, s)
+        shard = self._shards.get(key)                                 # one scratch shard per bucket size, reused every step
+        if shard is None:
+            shard = self._shards[key] = torch.empty(s, dtype=piece.dtype, device=piece.device)
+        hs = [dist.reduce_scatter_tensor(shard, main, op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
+        # collectives of one process group run in issue order (one stream under RCCL; gloo's worker queue): the gather reads the
+        # shard the scatter wrote, the remainder's all_reduce touches elements neither of them does
+        if not piece.is_cuda:
+            hs[0].wait()
+        hs.append(dist.all_gather_into_tensor(main, shard, group=self.group, async_op=True))
+        if piece.numel() > w * s:
+            hs.append(dist.all_reduce(piece[w * s:], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        return hs
 
     def wait(self):
         """The current (compute) stream waits for every collective issued so far; nothing is divided."""

@@ -189,6 +189,7 @@ std::vector<Tensor> train_unit_pair_bwd(const Tensor& x, const Tensor& dout_a, c
 }
 
 std::tuple<Tensor, Tensor> maxpool_fwd_idx(const Tensor& x, int64_t k, int64_t stride, int64_t pad) {
+    TORCH_CHECK(x.dim() == 4, "maxpool_fwd_idx: x must be NHWC [N,H,W,C]");
     const int64_t n = x.size(0), h = x.size(1), w = x.size(2), c = x.size(3);
     const int64_t oh = (h + 2 * pad - k) / stride + 1, ow = (w + 2 * pad - k) / stride + 1;
     Tensor y = at::empty({n, oh, ow, c}, x.options()), idx = at::empty({n, oh, ow, c}, x.options().dtype(at::kByte));
@@ -198,6 +199,8 @@ std::tuple<Tensor, Tensor> maxpool_fwd_idx(const Tensor& x, int64_t k, int64_t s
 }
 
 Tensor maxpool_bwd_idx(const Tensor& idx, const Tensor& dout, int64_t h, int64_t w, int64_t k, int64_t stride, int64_t pad) {
+    TORCH_CHECK(dout.dim() == 4 && idx.is_cuda() && idx.scalar_type() == at::kByte && idx.is_contiguous() && idx.numel() == dout.numel(),
+                "maxpool_bwd_idx: dout [N,oh,ow,C] float32 and idx = the uint8 winners of maxpool_fwd_idx (same shape) on the GPU");
     const int64_t n = dout.size(0), c = dout.size(3);
     Tensor dx = at::empty({n, h, w, c}, dout.options());
     check(be_maxpool_nhwc_bwd_idx_f32(idx.data_ptr<uint8_t>(), fp(dout, "dout"), dx.data_ptr<float>(), (int)n, (int)h, (int)w, (int)c, (int)k,
@@ -361,13 +364,145 @@ void wrap_angles_(Tensor est, int64_t col0, int64_t col1) {
           "be_wrap_angles_inplace_f32");
 }
 
+
+// ---- pass B, folds, the two fused losses, attention (the rest of north_star's "exposed as torch extensions") ----------
+// a be_patch_view travels as its bytes (it holds the device pointer of `pixels`, which is passed next to it so that the operator
+// sees - and keeps alive - the tensor the view points into)
+std::vector<Tensor> render_full(const Tensor& opts, const Tensor& consts, double rho_prime, bool densify_w, const Tensor& params12,
+                                const Tensor& view, const Tensor& pixels, int64_t want) {
+    TORCH_CHECK(params12.dim() == 2 && params12.size(1) == 12, "render_full: params12 [P,12]");
+    TORCH_CHECK(pixels.is_cuda(), "render_full: expected the viewed pixels on the GPU; the HIP path has no CPU fallback");
+    fp(params12, "params12");
+    const int64_t n = params12.size(0);
+    const be_patch_view* v = host_struct<be_patch_view>(view, "render_full(view)");
+    auto o = params12.options();
+    Tensor rec = at::empty({n, BE_RECORD_FLOATS}, o);
+    Tensor t[6];
+    if (want & 1) t[0] = at::empty({n, 2, 3, BE_R, BE_R}, o);
+    if (want & 2) t[1] = at::empty({n, 3, BE_R, BE_R}, o);
+    if (want & 4) t[2] = at::empty({n, 3, BE_R, BE_R}, o);
+    if (want & 8) t[3] = at::empty({n, BE_R, BE_R}, o);
+    if (want & 16) t[4] = at::empty({n, BE_R, BE_R}, o);
+    if (want & 32) t[5] = at::empty({n, BE_R, BE_R}, o.dtype(at::kInt));
+    auto f = [&](int i) { return t[i].defined() ? t[i].data_ptr<float>() : nullptr; };
+    check(be_render_full_f32(host_struct<be_render_opts>(opts, "render_full(opts)"), host_struct<be_depth_consts>(consts, "render_full(consts)"),
+                             (float)rho_prime, densify_w ? 1 : 0, params12.data_ptr<float>(), v, rec.data_ptr<float>(), f(0), f(1), f(2), f(3), f(4),
+                             t[5].defined() ? t[5].data_ptr<int32_t>() : nullptr, n, stream_of(params12)), "be_render_full_f32");
+    std::vector<Tensor> r{rec};
+    for (int i = 0; i < 6; ++i) if (t[i].defined()) r.push_back(t[i]);
+    return r;
+}
+
+// records [P,32] or [B,P,32] -> the maps named by `want` (bit 0 image, 1 shpd, 2 refoc, 3 bndry, 4 depth, 5 conf), in that order
+std::vector<Tensor> fold_records(const Tensor& opts, const Tensor& records, int64_t hp, int64_t wp, int64_t H, int64_t W, int64_t stride,
+                                 bool densify_w, int64_t want) {
+    fp(records, "records");
+    const bool batched = records.dim() == 3;
+    TORCH_CHECK((batched || records.dim() == 2) && records.size(-1) == BE_RECORD_FLOATS && records.size(-2) == hp * wp,
+                "fold_records: records [P,32] or [B,P,32] with P = hp * wp");
+    const int64_t B = batched ? records.size(0) : 1;
+    auto o = records.options();
+    auto shape = [&](std::vector<int64_t> s) { if (batched) s.insert(s.begin(), B); return s; };
+    Tensor t[6];
+    if (want & 1) t[0] = at::empty(shape({2, 3, H, W}), o);
+    if (want & 2) t[1] = at::empty(shape({3, H, W}), o);
+    if (want & 4) t[2] = at::empty(shape({3, H, W}), o);
+    if (want & 8) t[3] = at::empty(shape({H, W}), o);
+    if (want & 16) t[4] = at::empty(shape({H, W}), o);
+    if (want & 32) t[5] = at::empty(shape({H, W}), o);
+    auto f = [&](int i) { return t[i].defined() ? t[i].data_ptr<float>() : nullptr; };
+    const be_render_opts* ro = host_struct<be_render_opts>(opts, "fold_records(opts)");
+    if (batched)
+        check(be_fold_records_batch_f32(ro, records.data_ptr<float>(), (int)B, (int)hp, (int)wp, (int)H, (int)W, (int)stride, densify_w ? 1 : 0, f(0),
+                                        f(1), f(2), f(3), f(4), f(5), stream_of(records)), "be_fold_records_batch_f32");
+    else
+        check(be_fold_records_f32(ro, records.data_ptr<float>(), (int)hp, (int)wp, (int)H, (int)W, (int)stride, densify_w ? 1 : 0, f(0), f(1), f(2),
+                                  f(3), f(4), f(5), stream_of(records)), "be_fold_records_f32");
+    std::vector<Tensor> r;
+    for (int i = 0; i < 6; ++i) if (t[i].defined()) r.push_back(t[i]);
+    return r;
+}
+
+// LocalLoss forward + analytic backward in one launch -> (partial [B,3], grad_est [B,10] or an empty tensor)
+std::tuple<Tensor, Tensor> local_loss(const Tensor& opts, const Tensor& est, const Tensor& img_fit, const Tensor& gt, const Tensor& bdist,
+                                      const Tensor& deri, double beta_b, double beta_s, bool want_grad) {
+    TORCH_CHECK(est.dim() == 2 && est.size(1) == 10, "local_loss: est [B,10]");
+    fp(est, "est");
+    const int64_t b = est.size(0);
+    TORCH_CHECK(img_fit.numel() == b * BE_NPIX * 3 && gt.numel() == b * BE_NPIX * 3 && bdist.numel() == b * BE_NPIX && deri.numel() == b * 361 * 3,
+                "local_loss: img / gt [B,21,21,3], bdist [B,21,21], deri [B,19,19,3]");
+    Tensor partial = at::empty({b, 3}, est.options());
+    Tensor grad = want_grad ? at::empty({b, 10}, est.options()) : at::empty({0}, est.options());
+    check(be_local_loss_f32(host_struct<be_render_opts>(opts, "local_loss(opts)"), est.data_ptr<float>(), fp(img_fit, "img_fit"), fp(gt, "gt"),
+                            fp(bdist, "bdist"), fp(deri, "deri"), (float)beta_b, (float)beta_s, partial.data_ptr<float>(),
+                            want_grad ? grad.data_ptr<float>() : nullptr, nullptr, nullptr, b, stream_of(est)), "be_local_loss_f32");
+    return {partial, grad};
+}
+Tensor local_loss_finish(const Tensor& partial, double beta_b, double beta_s) {
+    TORCH_CHECK(partial.dim() == 2 && partial.size(1) == 3, "local_loss_finish: partial [B,3]");
+    Tensor out = at::empty({1}, partial.options());
+    check(be_local_loss_finish_f32(fp(partial, "partial"), (int)partial.size(0), (float)beta_b, (float)beta_s, out.data_ptr<float>(),
+                                   stream_of(partial)), "be_local_loss_finish_f32");
+    return out;
+}
+
+// GlobalLoss terms + analytic gradient in one launch -> (partial [B*P,8], grad [B*P,12], grad_depth [B*P,4])
+std::tuple<Tensor, Tensor, Tensor> global_loss(const Tensor& opts, const Tensor& consts, const Tensor& est, const Tensor& img_fit, const Tensor& img_gt,
+                                               const Tensor& G, const Tensor& Gd, const Tensor& Gb, const Tensor& bdist, const Tensor& deri,
+                                               const Tensor& bdepth, at::ArrayRef<double> gamma6, int64_t hp, int64_t wp, int64_t stride) {
+    TORCH_CHECK(est.dim() == 3 && est.size(2) == 12 && est.size(1) == hp * wp, "global_loss: est [B,P,12] with P = hp * wp");
+    TORCH_CHECK(img_gt.dim() == 5 && gamma6.size() == 6, "global_loss: img_gt [B,2,H,W,3], six gammas");
+    fp(est, "est");
+    const int64_t B = est.size(0), P = est.size(1), H = img_gt.size(2), W = img_gt.size(3);
+    float g6[6];
+    for (int i = 0; i < 6; ++i) g6[i] = (float)gamma6[i];
+    Tensor partial = at::empty({B * P, 8}, est.options()), grad = at::empty({B * P, 12}, est.options()), gdep = at::empty({B * P, 4}, est.options());
+    check(be_global_loss_f32(host_struct<be_render_opts>(opts, "global_loss(opts)"), host_struct<be_depth_consts>(consts, "global_loss(consts)"),
+                             est.data_ptr<float>(), fp(img_fit, "img_fit"), fp(img_gt, "img_gt"), fp(G, "G"), fp(Gd, "Gderi"), fp(Gb, "Gbndry"),
+                             fp(bdist, "bdist"), fp(deri, "deri"), fp(bdepth, "bdepth"), g6, partial.data_ptr<float>(), grad.data_ptr<float>(),
+                             gdep.data_ptr<float>(), (int)B, (int)hp, (int)wp, (int)H, (int)W, (int)stride, stream_of(est)), "be_global_loss_f32");
+    return {partial, grad, gdep};
+}
+
+// multi-head self-attention (head dim 16), inference / training forward / backward; workspaces are the caller's (reused across layers)
+std::tuple<Tensor, Tensor> attention(const Tensor& qkv, int64_t B, int64_t L, int64_t l_valid, int64_t H, const optional<Tensor>& workspace_) {
+    fp(qkv, "qkv");
+    const size_t need = be_attention_workspace_floats((int)B, (int)L, (int)H);
+    Tensor ws = workspace_.has_value() && workspace_->defined() && (size_t)workspace_->numel() >= need ? *workspace_
+                                                                                                        : at::empty({(int64_t)need}, qkv.options());
+    Tensor out = at::empty({B * L, H * 16}, qkv.options());
+    check(be_attention_f32(qkv.data_ptr<float>(), out.data_ptr<float>(), fpm(ws, "workspace"), (int)B, (int)L, (int)l_valid, (int)H, stream_of(qkv)),
+          "be_attention_f32");
+    return {out, ws};
+}
+std::tuple<Tensor, Tensor> attention_train_fwd(const Tensor& qkv, Tensor workspace, int64_t B, int64_t L, int64_t l_valid, int64_t H, double p,
+                                               int64_t seed) {
+    fp(qkv, "qkv");
+    TORCH_CHECK((size_t)workspace.numel() >= be_attention_train_workspace_floats((int)B, (int)L, (int)H), "attention_train_fwd: workspace too small");
+    Tensor out = at::empty({B * L, H * 16}, qkv.options()), lse = at::empty({B * H, L}, qkv.options());
+    check(be_attention_train_fwd_f32(qkv.data_ptr<float>(), out.data_ptr<float>(), lse.data_ptr<float>(), fpm(workspace, "workspace"), (int)B, (int)L,
+                                     (int)l_valid, (int)H, (float)p, (uint32_t)seed, stream_of(qkv)), "be_attention_train_fwd_f32");
+    return {out, lse};
+}
+Tensor attention_bwd(const Tensor& qkv, const Tensor& out, const Tensor& lse, const Tensor& dout, Tensor workspace, Tensor scratch,
+                     bool operands_ready, int64_t B, int64_t L, int64_t l_valid, int64_t H, double p, int64_t seed) {
+    fp(qkv, "qkv");
+    TORCH_CHECK((size_t)workspace.numel() >= be_attention_train_workspace_floats((int)B, (int)L, (int)H) &&
+                (size_t)scratch.numel() >= be_attention_bwd_scratch_floats((int)B, (int)L, (int)H), "attention_bwd: workspace / scratch too small");
+    Tensor dqkv = at::empty_like(qkv);
+    check(be_attention_bwd_f32(qkv.data_ptr<float>(), fp(out, "out"), fp(lse, "lse"), fp(dout, "dout"), dqkv.data_ptr<float>(),
+                               fpm(workspace, "workspace"), fpm(scratch, "scratch"), operands_ready ? 1 : 0, (int)B, (int)L, (int)l_valid, (int)H,
+                               (float)p, (uint32_t)seed, stream_of(qkv)), "be_attention_bwd_f32");
+    return dqkv;
+}
+
 }  // namespace
 
 TORCH_LIBRARY(be, m) {
     m.def("local_stage_pack(Tensor[] tensors, float eps) -> Tensor");
-    m.def("local_stage_forward(Tensor packed, Tensor x, Tensor(a!)? out, Tensor? workspace, bool winograd, int chunk) -> (Tensor, Tensor)");
-    m.def("render_colors(Tensor opts, Tensor params10, Tensor patches, Tensor(a!)? colors) -> Tensor");
-    m.def("local_depth(Tensor consts, Tensor params10, Tensor(a!)? out) -> Tensor");
+    m.def("local_stage_forward(Tensor packed, Tensor x, Tensor(a!)? out, Tensor(b!)? workspace, bool winograd, int chunk) -> (Tensor(a!), Tensor(b!))");
+    m.def("render_colors(Tensor opts, Tensor params10, Tensor patches, Tensor(a!)? colors) -> Tensor(a!)");
+    m.def("local_depth(Tensor consts, Tensor params10, Tensor(a!)? out) -> Tensor(a!)");
     m.def("train_unit_fwd(Tensor x, Tensor pw, Tensor pb, Tensor gamma, Tensor beta, Tensor? res, Tensor(a!) run_mean, Tensor(b!) run_var, "
           "int cout, int ksize, bool act, float eps, float momentum, Tensor(c!) scratch) -> (Tensor, Tensor, Tensor, Tensor, Tensor)");
     m.def("train_unit_bwd(Tensor x, Tensor dout, Tensor? s_in, Tensor y, Tensor mean, Tensor invstd, Tensor gamma, Tensor? dg_pw, Tensor? dg_pb, "
@@ -402,6 +537,16 @@ TORCH_LIBRARY(be, m) {
     m.def("fold_patches(Tensor src, int B, int C, int hp, int wp, int H, int W, int stride, int mode) -> Tensor");
     m.def("fold_patches_bwd(Tensor gout, int hp, int wp, int stride, int mode) -> Tensor");
     m.def("wrap_angles_(Tensor(a!) est, int col0, int col1) -> ()");
+    m.def("render_full(Tensor opts, Tensor consts, float rho_prime, bool densify_w, Tensor params12, Tensor view, Tensor pixels, int want) -> Tensor[]");
+    m.def("fold_records(Tensor opts, Tensor records, int hp, int wp, int H, int W, int stride, bool densify_w, int want) -> Tensor[]");
+    m.def("local_loss(Tensor opts, Tensor est, Tensor img_fit, Tensor gt, Tensor bdist, Tensor deri, float beta_b, float beta_s, bool want_grad) -> (Tensor, Tensor)");
+    m.def("local_loss_finish(Tensor partial, float beta_b, float beta_s) -> Tensor");
+    m.def("global_loss(Tensor opts, Tensor consts, Tensor est, Tensor img_fit, Tensor img_gt, Tensor G, Tensor Gd, Tensor Gb, Tensor bdist, Tensor deri, "
+          "Tensor bdepth, float[] gamma6, int hp, int wp, int stride) -> (Tensor, Tensor, Tensor)");
+    m.def("attention(Tensor qkv, int B, int L, int l_valid, int H, Tensor? workspace) -> (Tensor, Tensor)");
+    m.def("attention_train_fwd(Tensor qkv, Tensor(a!) workspace, int B, int L, int l_valid, int H, float p, int seed) -> (Tensor, Tensor)");
+    m.def("attention_bwd(Tensor qkv, Tensor out, Tensor lse, Tensor dout, Tensor(a!) workspace, Tensor(b!) scratch, bool operands_ready, int B, int L, "
+          "int l_valid, int H, float p, int seed) -> Tensor");
 }
 
 // on ROCm builds of PyTorch the GPU dispatch key is named CUDA (HIP masquerades as it); ops that take only host structs + GPU tensors
@@ -442,4 +587,12 @@ TORCH_LIBRARY_IMPL(be, CompositeExplicitAutograd, m) {
     m.impl("fold_patches", fold_patches);
     m.impl("fold_patches_bwd", fold_patches_bwd);
     m.impl("wrap_angles_", wrap_angles_);
+    m.impl("render_full", render_full);
+    m.impl("fold_records", fold_records);
+    m.impl("local_loss", local_loss);
+    m.impl("local_loss_finish", local_loss_finish);
+    m.impl("global_loss", global_loss);
+    m.impl("attention", attention);
+    m.impl("attention_train_fwd", attention_train_fwd);
+    m.impl("attention_bwd", attention_bwd);
 }

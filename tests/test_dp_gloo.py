@@ -93,7 +93,7 @@ def test_grads_as_flat_is_zero_copy_for_a_backward_that_writes_one_buffer():
 
 
 # ------------------------------------------------------------------ the real buffer: 7 254 122 floats in its gradient buckets
-def _sync_worker(rank, world, port, q, groups):
+def _sync_worker(rank, world, port, q, groups, algorithm="allreduce"):
     for p in (ROOT, PKG):
         if p not in sys.path:
             sys.path.insert(0, p)
@@ -109,11 +109,16 @@ def _sync_worker(rank, world, port, q, groups):
     ranges = dp.bucket_ranges([v.numel() for v in t], groups)
     n = sum(p.numel() for p in m.parameters())
     flat = torch.from_numpy(synth.f32(synth.hash_normal(100 + rank, "dp_flat", (n,))))
-    sync = dp.GradSync(world, groups=groups)
+    sync = dp.GradSync(world, groups=groups, algorithm=algorithm)
     for lo, hi in ranges:                                             # the order the backward completes them: tail first
         sync.bucket_ready(flat, lo, hi)
     out = sync.finish()
     assert out.data_ptr() == flat.data_ptr() and sync.bytes == 4 * n
+    odd = torch.arange(1001, dtype=torch.float32) * (rank + 1)       # a bucket the world size does not divide: shard + remainder
+    s2 = dp.GradSync(world, algorithm=algorithm)
+    s2.bucket_ready(odd, 0, 1001)
+    s2.finish()
+    assert torch.equal(odd, torch.arange(1001, dtype=torch.float32) * 1.5)
     # replicas are aligned from rank 0, and rank 0's BatchNorm statistics reach everyone before a checkpoint
     with torch.no_grad():
         for prm in m.parameters():
@@ -132,12 +137,16 @@ def _sync_worker(rank, world, port, q, groups):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("five", [False, True])
-def test_bucketed_gradient_sync_on_the_real_local_stage_buffer(five):
+@pytest.mark.parametrize("five,algorithm", [(False, "allreduce"), (True, "allreduce"), (False, "rs_ag"), (True, "rs_ag")])
+def test_bucketed_gradient_sync_on_the_real_local_stage_buffer(five, algorithm):
     """be_hip.dp.GradSync on the 7 254 122-float buffer the LocalStage backward writes, bucket by bucket in completion order, two
     gloo ranks: every element is the mean, nothing is skipped or reduced twice; parameter / BatchNorm-statistics broadcasts align
     the replicas.  Default buckets (round 3): fc, layer3, layer2, layer1 + layer0 + conv1 - the 0.6 MB head rides
-    with layer1; `groups=dp.GRAD_POINTS` gives round 2's five; a split that is not made of completion points is refused."""
+    with layer1; `groups=dp.GRAD_POINTS` gives round 2's five; a split that is not made of completion points is refused.
+    algorithm "rs_ag" (round 4): every bucket as reduce_scatter_tensor + all_gather_into_tensor (+ an all_reduce of the odd
+    element of an odd-sized bucket) - the same bits as the all_reduce path on two ranks."""
+    with pytest.raises(ValueError):
+        __import__("be_hip.dp").dp.GradSync(2, algorithm="ring")
     from be_hip import dp, synth
     with pytest.raises(ValueError):
         dp.check_groups(((78, 86), (50, 78), (0, 50)))
@@ -146,7 +155,7 @@ def test_bucketed_gradient_sync_on_the_real_local_stage_buffer(five):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_sync_worker, args=(r, 2, port, q, dp.GRAD_POINTS if five else None)) for r in range(2)]
+    procs = [ctx.Process(target=_sync_worker, args=(r, 2, port, q, dp.GRAD_POINTS if five else None, algorithm)) for r in range(2)]
     for p in procs:
         p.start()
     ranges, sub, total, ok = q.get(timeout=300)

@@ -97,7 +97,8 @@ def test_twenty_training_steps_teacher_forced_against_the_fp64_oracle():
         est = model(b["img_ny"].permute(0, 3, 1, 2))
         est.retain_grad()
         opt.zero_grad(set_to_none=True)
-        loss = utils.local_loss(helper, est, b["img_gt"], b["img_gt"], b["bndry_dist"], b["deri"], args.beta_bndry_loc, args.beta_smthns)
+        loss = utils.local_loss(helper, est, b["img_gt"], b["img_gt"], b["bndry_dist"], b["deri"], args.beta_bndry_loc, args.beta_smthns,
+                                write_back=False)                                    # as be_hip.train_local.train_step calls it
         loss.backward()
         gh = {k: hp[k].grad.detach().cpu().double() for k in names}
         dest_h = est.grad.detach().cpu().double()

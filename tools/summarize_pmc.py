@@ -51,6 +51,18 @@ for k, cs in out.items():
         cs.setdefault("derived", {})["l2_hit_rate"] = h / (h + m)
 json.dump(out, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
 head = sys.argv[3] if len(sys.argv) > 3 else None
+SOURCES = ["be_wino.hip"]
+
+
+def source_sha(files):
+    import hashlib, os
+    h = hashlib.sha256()
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "blurry-edges_amd", "csrc")
+    for f in files:
+        h.update(open(os.path.join(root, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 dom = out.get("wino_gemm") or out.get("conv128x128", {})
 if "FETCH_SIZE" in dom and "WRITE_SIZE" in dom:
     rd = dom["FETCH_SIZE"]["mean_per_launch"] * 1024 * 2
@@ -61,6 +73,8 @@ if "FETCH_SIZE" in dom and "WRITE_SIZE" in dom:
                "bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr,
                # 25 x 4 B x (4n x cin + cin x cout + 4n x cout) averaged over the six launches of a step, n = 8192
                "algo_bytes_per_launch": 1878289066.67 if wino else None, "git_head": head,
+               # bench.py fills roofline.traffic from this record only while these sources are byte-identical to the running library's
+               "kernel_sources": SOURCES, "kernel_source_sha": source_sha(SOURCES),
                "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/pmc_passes.sh); FETCH_SIZE x2 (gfx950), KiB -> B; "
                          "counts L2 misses, i.e. Infinity-Cache hits too",
                "launches_averaged": dom["FETCH_SIZE"]["launches"]}, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
