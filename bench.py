@@ -45,9 +45,6 @@ FLOP_PER_PATCH = 387.716e6            # SURVEY.md A.2 (2*MAC, convs + linears)
 FLOP_PER_PAIR = 2 * FLOP_PER_PATCH    # 775.43 MFLOP, SURVEY.md 8d
 PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_HBM_TBPS = 8.0                   # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s is what a float4 copy reaches)
-# opt-in experiment (BE_CONV_PRECISION=bf16x3, never the default): six bf16 MFMAs per fp32 product -> the price is a
-# sixth of the dense bf16 peak (~2.5 PFLOP/s)
-PEAK_BF16X3_TFLOPS = 2500.0 / 6
 CPU_SAMPLE_PAIRS = 1024               # bounded sample, 3 repeats, median (~2 s per run on 16 threads)
 CPU_REPEATS = 3
 # kernel id 6 = the 25 transform-domain GEMMs of one Winograd layer: the hooks count the 25 x 2 x 4n x cin x cout FLOPs they
@@ -491,7 +488,7 @@ def main():
 
     # ---- roofline leg: the same K steps again with a hipEvent pair around every matrix-kernel launch (on the launch
     #      stream = torch's current stream); dominant kernel = whichever kernel id takes the most time in the step
-    peak = PEAK_FP32_MFMA_TFLOPS if model.conv_precision == "f32" else PEAK_BF16X3_TFLOPS
+    peak = PEAK_FP32_MFMA_TFLOPS
     roof = None
     if rank == 0:
         # per-kernel durations mean something only when nothing else shares the chip: this pass runs the ONE-stream schedule
@@ -565,7 +562,7 @@ def main():
             "metric": "patch-pairs/s (local CNN + render + depth) on 21x21 synth",
             "value": round(pairs_per_s, 1), "unit": "patch-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if model.conv_precision == "f32" else "f32 operands split exactly into 3 bf16 pieces, 6 bf16 MFMAs per product, f32 accumulate (opt-in experiment)", "data": "synthetic",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "configs[1]: batch of 4096 synthetic 21x21 two-aperture patch pairs per GPU "
                                    "(8192 CNN patches): LocalStage inference + pass-A colour solve + depth solve",
                        "pairs_per_gpu": PAIRS, "streams": model.streams, "weights": "portable-generator random init (no checkpoint offline)",

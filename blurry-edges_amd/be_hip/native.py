@@ -98,9 +98,6 @@ _SIGNATURES = {
     "be_wino_pair_workspace_floats": (C.c_size_t, [C.c_int64, C.c_int, C.c_int, C.c_int]),
     "be_wino_conv3x3_pair_6x6_f32": (C.c_int, [_P, _P, _P, C.c_int, _P, _P, _P, C.c_int, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P,
                                                C.c_size_t, _P]),
-    "be_conv_split_b3_f32": (C.c_int, [_P, C.c_size_t, _P, _P]),
-    "be_conv_use_b3": (C.c_int, [_P, _P, C.c_size_t]),
-    "be_conv_b3_active": (C.c_int, [_P]),
     "be_conv_fused2_packed_floats": (C.c_size_t, [C.c_int] * 4),
     "be_conv_pack_fused2_f32": (C.c_int, [_P] * 12 + [C.c_float] + [C.c_int] * 4 + [_P, _P, _P]),
     "be_conv_nhwc_fused2_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, C.c_int, _P, _P, _P, C.c_int, _P]),
@@ -718,27 +715,6 @@ def wino_conv3x3_pair(x, pw1, pb1, cmid, pw2, pb2, cout, act1=1, act2=1, residua
     return y, workspace
 
 
-def conv_use_b3(packed=None, on=True):
-    """Opt-in split-bf16 mode for the convolutions reading `packed` (a float32 GPU buffer of packed weights).  on=False takes
-    that buffer back to exact fp32; packed=None forgets every registration.  Returns the bf16 planes tensor (None when
-    switching off), which the caller must keep alive while the mode is on.  The registration belongs to the buffer: other
-    models in the process are not affected."""
-    if packed is None:
-        check(lib().be_conv_use_b3(None, None, 0), "be_conv_use_b3")
-        return None
-    if not on:
-        check(lib().be_conv_use_b3(dptr(packed, "packed"), None, 0), "be_conv_use_b3")
-        return None
-    n = packed.numel()
-    if n % 16:
-        raise RuntimeError("conv_use_b3: packed buffer length must be a multiple of 16 floats")
-    planes = torch.empty(3 * n, dtype=torch.int16, device=packed.device)
-    check(lib().be_conv_split_b3_f32(dptr(packed, "packed"), n, C.c_void_p(planes.data_ptr()), stream_ptr(packed.device)),
-          "be_conv_split_b3_f32")
-    check(lib().be_conv_use_b3(dptr(packed), C.c_void_p(planes.data_ptr()), n), "be_conv_use_b3")
-    return planes
-
-
 def local_stage_forward_view(packed, view, patches_per_image: int, n: int, device, out=None, workspace=None, winograd=True,
                              chunk=0):
     """LocalStage eval forward over the n = A*P patches of a PatchView (no unfolded copy) -> [n,10]."""
@@ -818,13 +794,23 @@ def view_unfolded(t: torch.Tensor) -> PatchView:
     return PatchView(t.data_ptr(), 3 * NPIX * p, NPIX * p, BE_R * p, p, wp, 1, wp)
 
 
-def render_full(opts, consts, rho_prime, densify_w, params12, view: PatchView, want=()):
+RENDER_EXTRAS = ("patches", "shpd", "refoc", "boundary", "depth_map", "depth_mask")
+
+
+def render_full(opts, consts, rho_prime, densify_w, params12, view: PatchView, want=(), pixels=None):
     """params12 [P,12] -> records [P,32] (+ optional per-patch tensors named in `want`:
-    'patches','shpd','refoc','boundary','depth_map','depth_mask')."""
+    'patches','shpd','refoc','boundary','depth_map','depth_mask').  pixels: the tensor `view` points into (the torch operator
+    wants to see it; without it the ctypes binding is used)."""
     n = params12.shape[0]
     if tuple(params12.shape) != (n, 12):
         raise RuntimeError(f"render_full: params12 must be [P,12], got {tuple(params12.shape)}")
     dev = params12.device
+    o = ops() if pixels is not None else None
+    if o is not None:
+        mask = sum(1 << i for i, k in enumerate(RENDER_EXTRAS) if k in want)
+        r = o.render_full(struct_tensor(opts), struct_tensor(consts), float(rho_prime), bool(densify_w), params12.contiguous(),
+                          torch.frombuffer(bytearray(bytes(view)), dtype=torch.uint8), pixels, mask)
+        return r[0], dict(zip([k for k in RENDER_EXTRAS if k in want], r[1:]))
     rec = torch.empty(n, RECORD_FLOATS, dtype=torch.float32, device=dev)
     shapes = dict(patches=(n, 2, 3, BE_R, BE_R), shpd=(n, 3, BE_R, BE_R), refoc=(n, 3, BE_R, BE_R),
                   boundary=(n, BE_R, BE_R), depth_map=(n, BE_R, BE_R), depth_mask=(n, BE_R, BE_R))
@@ -844,6 +830,11 @@ def fold_records(opts, records, hp, wp, H, W, stride=2, densify_w=False, want=FO
     if tuple(records.shape) != (hp * wp, RECORD_FLOATS):
         raise RuntimeError(f"fold_records: records must be [{hp * wp},{RECORD_FLOATS}], got {tuple(records.shape)}")
     dev = records.device
+    o = ops()
+    if o is not None:
+        mask = sum(1 << i for i, k in enumerate(FOLD_MAPS) if k in want)
+        r = o.fold_records(struct_tensor(opts), records.contiguous(), hp, wp, H, W, stride, bool(densify_w), mask)
+        return dict(zip([k for k in FOLD_MAPS if k in want], r))
     shapes = dict(image=(2, 3, H, W), shpd=(3, H, W), refoc=(3, H, W), bndry=(H, W), depth=(H, W), conf=(H, W))
     out = {k: torch.empty(shapes[k], dtype=torch.float32, device=dev) for k in want}
     g = lambda k: dptr(out.get(k))
@@ -858,6 +849,11 @@ def fold_records_batch(opts, records, hp, wp, H, W, stride=2, densify_w=False, w
     if records.dim() != 3 or tuple(records.shape[1:]) != (hp * wp, RECORD_FLOATS):
         raise RuntimeError(f"fold_records_batch: records must be [B,{hp * wp},{RECORD_FLOATS}], got {tuple(records.shape)}")
     dev, B = records.device, records.shape[0]
+    o = ops()
+    if o is not None:
+        mask = sum(1 << i for i, k in enumerate(FOLD_MAPS) if k in want)
+        r = o.fold_records(struct_tensor(opts), records.contiguous(), hp, wp, H, W, stride, bool(densify_w), mask)
+        return dict(zip([k for k in FOLD_MAPS if k in want], r))
     shapes = dict(image=(B, 2, 3, H, W), shpd=(B, 3, H, W), refoc=(B, 3, H, W), bndry=(B, H, W), depth=(B, H, W), conf=(B, H, W))
     out = {k: torch.empty(shapes[k], dtype=torch.float32, device=dev) for k in want}
     g = lambda k: dptr(out.get(k))
@@ -901,6 +897,10 @@ def local_loss(opts, est, img_fit, gt, bdist, deri, beta_bndry, beta_smooth, wan
             or tuple(bdist.shape) != (b, BE_R, BE_R) or tuple(deri.shape) != (b, 19, 19, 3):
         raise RuntimeError("local_loss: bad shapes (est [B,10], img/gt [B,21,21,3], bdist [B,21,21], deri [B,19,19,3])")
     dev = est.device
+    o = ops() if not want else None
+    if o is not None:
+        partial, grad = o.local_loss(struct_tensor(opts), est, img_fit, gt, bdist, deri, float(beta_bndry), float(beta_smooth), bool(want_grad))
+        return partial, (grad if want_grad else None), {}
     partial = torch.empty(b, 3, dtype=torch.float32, device=dev)
     grad = torch.empty(b, 10, dtype=torch.float32, device=dev) if want_grad else None
     shapes = dict(patches=(b, 3, BE_R, BE_R), boundary=(b, BE_R, BE_R))
@@ -916,6 +916,9 @@ def local_loss(opts, est, img_fit, gt, bdist, deri, beta_bndry, beta_smooth, wan
 
 def local_loss_finish(partial, beta_bndry, beta_smooth):
     """partial [B,3] of local_loss -> the scalar loss (0-dim tensor): S0/(441 B) + beta_b S1/(441 B) + beta_s S2/(361 B)."""
+    o = ops()
+    if o is not None:
+        return o.local_loss_finish(partial, float(beta_bndry), float(beta_smooth))[0]
     out = torch.empty(1, dtype=torch.float32, device=partial.device)
     check(lib().be_local_loss_finish_f32(dptr(partial, "partial"), partial.shape[0], float(beta_bndry), float(beta_smooth), dptr(out),
                                          stream_ptr(partial.device)), "be_local_loss_finish_f32")
@@ -932,6 +935,9 @@ def linear(x2d, pw, pb, cout, act=0, residual=None):
 def attention(qkv, B, L, H, workspace=None, l_valid=None):
     """qkv [B*L, 3*H*16] -> [B*L, H*16].  l_valid: real tokens per sequence when L is padded to a multiple of 128."""
     dev = qkv.device
+    o = ops()
+    if o is not None:
+        return o.attention(qkv, B, L, L if l_valid is None else int(l_valid), H, workspace)
     need = lib().be_attention_workspace_floats(B, L, H)
     if workspace is None or workspace.numel() < need:
         workspace = torch.empty(need, dtype=torch.float32, device=dev)
@@ -971,6 +977,10 @@ def global_loss(opts, consts, est, img_fit, img_gt, G, Gd, Gb, bdist, deri, bdep
     B, P = est.shape[0], est.shape[1]
     H, W = img_gt.shape[2], img_gt.shape[3]
     dev = est.device
+    o = ops()
+    if o is not None:
+        return o.global_loss(struct_tensor(opts), struct_tensor(consts), est, img_fit, img_gt, G, Gd, Gb, bdist, deri, bdepth,
+                             [float(v) for v in gamma6], hp, wp, stride)
     partial = torch.empty(B * P, 8, dtype=torch.float32, device=dev)
     grad = torch.empty(B * P, 12, dtype=torch.float32, device=dev)
     gdep = torch.empty(B * P, 4, dtype=torch.float32, device=dev)

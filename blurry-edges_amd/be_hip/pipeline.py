@@ -56,7 +56,7 @@ class DepthPipeline:
     def records(self, est12, img, want=(), window=None):
         opts = self.helper.render_opts(wrap_angles=False)
         return native.render_full(opts, self.dcal.consts, self.rho_prime, self.densify == "w", est12,
-                                  native.view_image_pair(img, self.stride, window), want=want)
+                                  native.view_image_pair(img, self.stride, window), want=want, pixels=img)
 
     # ---- one 147x147 pair (blurry_edges_test.py:117-145) ---------------------------------------------
     @torch.no_grad()

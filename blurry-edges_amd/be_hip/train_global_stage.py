@@ -185,6 +185,10 @@ def attention_train_fwd(qkv, B, L, H, p, seed, ws=None, l_valid=None):
     need = lib().be_attention_train_workspace_floats(B, L, H)
     if ws is None or ws.numel() < need:
         ws = _new(need, dev)
+    o = native.ops()
+    if o is not None:
+        out, lse = o.attention_train_fwd(qkv, ws, B, L, L if l_valid is None else int(l_valid), H, float(p), int(seed) & 0xffffffff)
+        return out, lse, ws
     out = _new((B * L, H * 16), dev)
     lse = _new((B * H, L), dev)
     check(lib().be_attention_train_fwd_f32(dptr(qkv, "qkv"), dptr(out), dptr(lse), dptr(ws), B, L, L if l_valid is None else int(l_valid),
@@ -198,6 +202,10 @@ def attention_bwd(qkv, out, lse, dout, B, L, H, p, seed, ws=None, operands_ready
     need = lib().be_attention_train_workspace_floats(B, L, H)
     if ws is None or ws.numel() < need:
         ws, operands_ready = _new(need, dev), False
+    o = native.ops()
+    if o is not None:
+        return o.attention_bwd(qkv, out, lse, dout.contiguous(), ws, _bwd_scratch(B, L, H, dev), bool(operands_ready), B, L,
+                               L if l_valid is None else int(l_valid), H, float(p), int(seed) & 0xffffffff), ws
     dqkv = torch.empty_like(qkv)
     check(lib().be_attention_bwd_f32(dptr(qkv, "qkv"), dptr(out), dptr(lse), dptr(dout.contiguous(), "dout"), dptr(dqkv),
                                      dptr(ws), dptr(_bwd_scratch(B, L, H, dev)), int(bool(operands_ready)), B, L,

@@ -86,20 +86,6 @@ int conv_pm(const be_conv_desc* d, const float* x, int wrow, const float* x2, in
 int wino_pair(const float* x, const float* packed_w1, const float* packed_bias1, int act1, const float* packed_w2,
               const float* packed_bias2, const float* residual, int act2, float* y, int64_t n, int cin, int cmid, int cout,
               float* workspace, size_t workspace_floats, void* stream, int pool2);
-// the same block on the fused kernels of be_wino_fused.hip with the transform-domain buffers handed over between blocks:
-// v_in [4n][25][cin] is read (x -> v_in first when x != nullptr), v_mid [4n][25][cmid] is conv1's output, and when v_next is
-// not null conv2 also writes the NEXT block's input transform [4n][25][cout] there (v_next may be v_in: it is dead by then).
-// Returns 1 when the shapes are not ones the fused kernels take (the caller uses wino_pair).
-int wino_pair_chained(const float* x, const float* packed_w1, const float* packed_bias1, int act1, const float* packed_w2,
-                      const float* packed_bias2, const float* residual, int act2, float* y, int64_t n, int cin, int cmid, int cout,
-                      float* v_in, float* v_mid, float* v_next, void* stream, int pool2);
-
-// be_wino_fused.hip: one Winograd layer of a large batch with the transforms in the GEMM epilogue.  V tile-major [4n][25][cin];
-// mode 1: y [n,6,6,cout]; 2: the next layer's V [4n][25][cout]; 3: both; 4: y = maxpool2x2 -> [n,3,3,cout]
-bool wino_fused_ok(int64_t n, int cin, int cout);
-int wino_fused(const float* V, const float* packed_w, const float* packed_bias, const float* residual, int act, float* y,
-               float* Vout, int64_t n, int cin, int cout, int mode, void* stream);
-
 // be_conv.hip: convolution / linear of a training unit (small M).  With scratch the K loop may be split: then the S raw slices
 // are LEFT in scratch as [S][M][ldp] (S > 1 reported, nothing written to y, bias / res not applied) for the caller's kernel to sum;
 // S == 1: y = conv + bias (+ res).

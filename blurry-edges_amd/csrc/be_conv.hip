@@ -40,278 +40,6 @@ void k_conv_igemm(ConvArgs a) {
     conv_igemm_body<WM, WN, MT, NT, MODE, BKT, PRIO, UNI>(a, smem, blockIdx.x, blockIdx.y, blockIdx.z);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// EXPERIMENTAL, opt-in (be_local_stage_use_b3 / be_conv_nhwc_b3_f32): the same 128x128 implicit-GEMM tile with every
-// fp32 operand split EXACTLY into three bf16 pieces, x = hi + mid + lo (8 + 8 + 8 significant bits, by truncation; the
-// residuals are exact in fp32), and the product evaluated as six bf16 MFMAs with fp32 accumulation:
-//   a*b = hi*hi + hi*mid + mid*hi + mid*mid + hi*lo + lo*hi   (+ three dropped terms <= 2^-24 |a b|, the size of the
-// rounding of one fp32 product).  v_mfma_f32_32x32x16_bf16 runs at 16x the FLOP rate of the f32-input MFMA, so six of
-// them cost 3/8 of the fp32 path.  Weights are split once at pack time, activations while they are staged into LDS.
-// LDS image per operand and stage: [3 planes][128 rows][16 k] bf16, 32 B per row; the two 16-byte halves of a row are
-// swapped on rows 8..15 (mod 16) so that the 16 lanes of a ds_read_b128 phase cover all banks without padding.
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ void split3(const f32x4 v, u32x2& hi, u32x2& mid, u32x2& lo) {
-    unsigned h[4], m[4], l[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float x = v[e];
-        const unsigned hb = __float_as_uint(x) & 0xffff0000u;
-        const float r1 = x - __uint_as_float(hb);
-        const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
-        const float r2 = r1 - __uint_as_float(mb);
-        h[e] = hb; m[e] = mb; l[e] = __float_as_uint(r2) & 0xffff0000u;
-    }
-    hi = u32x2{(h[0] >> 16) | h[1], (h[2] >> 16) | h[3]};
-    mid = u32x2{(m[0] >> 16) | m[1], (m[2] >> 16) | m[3]};
-    lo = u32x2{(l[0] >> 16) | l[1], (l[2] >> 16) | l[3]};
-}
-
-__global__ void k_split_b3(const float* __restrict__ w, unsigned short* __restrict__ planes, size_t n) {
-    const size_t gs = (size_t)gridDim.x * blockDim.x;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gs) {
-        const float x = w[i];
-        const unsigned hb = __float_as_uint(x) & 0xffff0000u;
-        const float r1 = x - __uint_as_float(hb);
-        const unsigned mb = __float_as_uint(r1) & 0xffff0000u;
-        const float r2 = r1 - __uint_as_float(mb);
-        // chunk-interleaved: the 16 floats of K chunk u become 48 consecutive bf16 = [hi x16 | mid x16 | lo x16] (96 B), so
-        // one staged chunk row is one contiguous piece of a cache line instead of three 32-byte pieces of three lines
-        const size_t o = (i >> 4) * 48 + (i & 15);
-        planes[o] = (unsigned short)(hb >> 16);
-        planes[o + 16] = (unsigned short)(mb >> 16);
-        planes[o + 32] = (unsigned short)(__float_as_uint(r2) >> 16);
-    }
-}
-
-__global__ __launch_bounds__(256, 3)
-void k_conv_b3(ConvArgs a) {
-    constexpr int BM = 128, BN = 128, BKT = 16, SUB = 2, QL = 4, RP = 64, NA = 2, NB = 2;
-    constexpr int ROWB = 32;                              // bytes per LDS row (16 bf16)
-    constexpr int PLANE = BM * ROWB;                      // 4 KB
-    constexpr int STAGE = 3 * PLANE;                      // per operand and stage
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b3[];
-    unsigned char* As = smem_b3;                          // [2][3][128][32 B]
-    unsigned char* Bs = smem_b3 + 2 * STAGE;
-
-    const int bid = blockIdx.x;
-    const int xcd = bid & 7, slot = bid >> 3;
-    const int n_tile = slot % a.n_tiles;
-    int m_tile;
-    if (a.pixmaj == 1) {
-        const int t = slot / a.n_tiles;
-        const int grp = (t / a.HW) * 8 + xcd;
-        m_tile = grp * a.HW + t % a.HW;
-    } else {
-        m_tile = (slot / a.n_tiles) * 8 + xcd;
-    }
-    if (m_tile >= a.m_tiles) return;
-    const int n0 = n_tile * BN;
-    int pix_u = 0;
-    if (a.pixmaj) {
-        const int idx = m_tile % a.HW, ni = (a.H - 2) * (a.W - 2);
-        int py, px;
-        if (idx < ni) { py = 1 + idx / (a.W - 2); px = 1 + idx % (a.W - 2); }
-        else {
-            const int e = idx - ni;
-            if (e < a.W) { py = 0; px = e; }
-            else if (e < 2 * a.W) { py = a.H - 1; px = e - a.W; }
-            else if (e < 2 * a.W + a.H - 2) { px = 0; py = 1 + e - 2 * a.W; }
-            else { px = a.W - 1; py = 1 + e - 2 * a.W - (a.H - 2); }
-        }
-        pix_u = py * a.W + px;
-    }
-    const int row_base = a.pixmaj ? (m_tile / a.HW) * BM : m_tile * BM;
-    const int tid = threadIdx.x;
-    const int q = tid % QL, r0 = tid / QL;
-
-    int a_off[NA], a_yx[NA];
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-        const int rr = row_base + r0 + RP * i;
-        const bool live = a.pixmaj ? rr < a.Nimg : rr < a.M;
-        const int m = a.pixmaj ? rr * a.HW + pix_u : rr;
-        if (live) {
-            const int pp = a.pixmaj ? pix_u : m % a.HW;
-            const int yy = pp / a.W, xx = pp - yy * a.W;
-            a_yx[i] = (yy << 16) | xx;
-            a_off[i] = m;
-        } else {
-            a_yx[i] = -1;
-            a_off[i] = 0;
-        }
-    }
-    const int ntap_all = a.ks * a.ks;
-    unsigned long long tap_list = 0;
-    int ntap = 0;
-    {
-        const int py = pix_u / a.W, px = pix_u - py * a.W, half = a.ks >> 1;
-        for (int t = 0; t < ntap_all; ++t) {
-            bool ok = true;
-            if (a.pixmaj) {
-                const int yy = py + t / a.ks - half, xx = px + t % a.ks - half;
-                ok = (unsigned)yy < (unsigned)a.H && (unsigned)xx < (unsigned)a.W;
-            }
-            if (ok) { tap_list |= (unsigned long long)t << (4 * ntap); ++ntap; }
-        }
-    }
-    const unsigned short* wbase = a.wb3 + (size_t)3 * n0 * a.Ktot + 4 * q;
-    const int n1 = (a.nchunk / ntap_all) * ntap * SUB;
-    const int nchunk = n1 + (a.x2 ? (a.Cin2 / 32) * SUB : 0);
-
-    // two register sets: the two K chunks of one 32-channel unit (adjacent 64-byte halves of a 128-byte line of the
-    // activations, adjacent 96-byte pieces of the weights) are loaded back to back, so every line is fetched from L2 once
-    f32x4 a_st[2][NA];
-    u32x2 b_st[2][NB][3];
-    unsigned a_ok[2] = {0, 0};
-    // chunk walker: (cc, j, sub) of the chunk about to be loaded, advanced incrementally (no divisions in the loop)
-    int w_cc = 0, w_j = 0, w_sub = 0;
-#define B3_LOAD(KC, SET)                                                                                        \
-    do {                                                                                                        \
-        int dy_, dx_, coff_, kw_;                                                                               \
-        const bool second_ = (KC) >= n1;                                                                        \
-        if (second_) {                                                                                          \
-            const int k2_ = (KC) - n1;                                                                          \
-            dy_ = 0; dx_ = 0; coff_ = k2_ * BKT + 4 * q; kw_ = a.nchunk * SUB + k2_;                            \
-        } else {                                                                                                \
-            const int tap_ = (int)((tap_list >> (4 * w_j)) & 15ull);                                            \
-            const int ty_ = (tap_ * 11) >> 5;              /* tap / 3 for tap < 9; ks = 1 has tap = 0 only */    \
-            dy_ = ty_ - (a.ks >> 1); dx_ = tap_ - a.ks * ty_ - (a.ks >> 1);                                     \
-            coff_ = (dy_ * a.W + dx_) * a.Cin + w_cc * 32 + w_sub * BKT + 4 * q;                                \
-            kw_ = (w_cc * ntap_all + tap_) * SUB + w_sub;                                                       \
-            w_sub ^= 1;                                                                                         \
-            if (w_sub == 0) { if (++w_j == ntap) { w_j = 0; ++w_cc; } }                                         \
-        }                                                                                                       \
-        a_ok[SET] = 0;                                                                                          \
-        _Pragma("unroll") for (int i_ = 0; i_ < NA; ++i_) {                                                     \
-            const int yy_ = (a_yx[i_] >> 16) + dy_, xx_ = (a_yx[i_] & 0xffff) + dx_;                            \
-            const bool ok_ = a_yx[i_] >= 0 && (unsigned)yy_ < (unsigned)a.H && (unsigned)xx_ < (unsigned)a.W;   \
-            int64_t off_ = ok_ ? (int64_t)a_off[i_] * (second_ ? a.Cin2 : a.Cin) + coff_ : 0;                   \
-            asm volatile("" : "+v"(off_));                                                                      \
-            a_st[SET][i_] = *reinterpret_cast<const f32x4*>((second_ ? a.x2 : a.x) + off_);                     \
-            a_ok[SET] |= (ok_ ? 1u : 0u) << i_;                                                                 \
-        }                                                                                                       \
-        _Pragma("unroll") for (int i_ = 0; i_ < NB; ++i_)                                                       \
-            _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_)                                                    \
-                b_st[SET][i_][p_] = *reinterpret_cast<const u32x2*>(wbase + 3 * ((size_t)(RP * i_ + r0) * a.Ktot + kw_ * BKT) + 16 * p_); \
-    } while (0)
-#define B3_STORE(BUF, SET)                                                                                           \
-    do {                                                                                                        \
-        _Pragma("unroll") for (int i_ = 0; i_ < NA; ++i_) {                                                     \
-            const int row_ = r0 + RP * i_;                                                                      \
-            const int at_ = row_ * ROWB + 16 * ((q >> 1) ^ ((row_ >> 3) & 1)) + 8 * (q & 1);                    \
-            u32x2 h_, m_, l_;                                                                                   \
-            split3(((a_ok[SET] >> i_) & 1u) ? a_st[SET][i_] : f32x4{0.f, 0.f, 0.f, 0.f}, h_, m_, l_);           \
-            unsigned char* Ad_ = As + (BUF) * STAGE + at_;                                                      \
-            *reinterpret_cast<u32x2*>(Ad_) = h_;                                                                \
-            *reinterpret_cast<u32x2*>(Ad_ + PLANE) = m_;                                                        \
-            *reinterpret_cast<u32x2*>(Ad_ + 2 * PLANE) = l_;                                                    \
-            unsigned char* Bd_ = Bs + (BUF) * STAGE + at_;                                                      \
-            _Pragma("unroll") for (int p_ = 0; p_ < 3; ++p_) *reinterpret_cast<u32x2*>(Bd_ + p_ * PLANE) = b_st[SET][i_][p_]; \
-        }                                                                                                       \
-    } while (0)
-
-    const int wave = tid >> 6, lane = tid & 63;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int li = lane & 31, lh = lane >> 5;
-    int a_fr[2], b_fr[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int ra = (wm * 2 + i) * 32 + li, rb = (wn * 2 + i) * 32 + li;
-        a_fr[i] = ra * ROWB + 16 * (lh ^ ((ra >> 3) & 1));
-        b_fr[i] = rb * ROWB + 16 * (lh ^ ((rb >> 3) & 1));
-    }
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-#define B3_MMA(BUF)                                                                                             \
-    do {                                                                                                        \
-        const unsigned char* Ab = As + (BUF) * STAGE;                                                           \
-        const unsigned char* Bb = Bs + (BUF) * STAGE;                                                           \
-        bf16x8 af[2][3], bfr[2][3];                                                                             \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                           \
-            _Pragma("unroll") for (int p = 0; p < 3; ++p) {                                                     \
-                af[i][p] = *reinterpret_cast<const bf16x8*>(Ab + p * PLANE + a_fr[i]);                          \
-                bfr[i][p] = *reinterpret_cast<const bf16x8*>(Bb + p * PLANE + b_fr[i]);                         \
-            }                                                                                                   \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                           \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j) {          /* small terms first */                    \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][2], bfr[j][0], acc[i][j], 0, 0, 0);   \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][2], acc[i][j], 0, 0, 0);   \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][1], acc[i][j], 0, 0, 0);   \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][1], bfr[j][0], acc[i][j], 0, 0, 0);   \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][1], acc[i][j], 0, 0, 0);   \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][0], bfr[j][0], acc[i][j], 0, 0, 0);   \
-            }                                                                                                   \
-    } while (0)
-    // tried and measured no faster: loading two chunks AHEAD (second register stage, two workgroups per CU), and letting
-    // the compiler interleave the split arithmetic with the MFMAs (no sched barriers)
-    B3_LOAD(0, 0);
-    B3_LOAD(1, 1);                                     // nchunk is even: chunks (2m, 2m+1) are the halves of one unit
-    B3_STORE(0, 0);
-    __syncthreads();
-    for (int kc = 0; kc < nchunk; kc += 2) {
-        // LDS buffer 0 = chunk kc, register set 1 = chunk kc+1
-        __builtin_amdgcn_sched_barrier(0);
-        B3_MMA(0);
-        __builtin_amdgcn_sched_barrier(0);
-        B3_STORE(1, 1);
-        __syncthreads();
-        if (kc + 2 < nchunk) { B3_LOAD(kc + 2, 0); B3_LOAD(kc + 3, 1); }
-        __builtin_amdgcn_sched_barrier(0);
-        B3_MMA(1);
-        __builtin_amdgcn_sched_barrier(0);
-        B3_STORE(0, 0);
-        __syncthreads();
-    }
-#undef B3_MMA
-#undef B3_LOAD
-#undef B3_STORE
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int c = n0 + (wn * 2 + j) * 32 + li;
-        const bool c_ok = c < a.Cout;
-        const float bias = c_ok ? a.bias[c] : 0.0f;
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = row_base + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int m = a.pixmaj ? rr * a.HW + pix_u : rr;
-                if (c_ok && (a.pixmaj ? rr < a.Nimg : rr < a.M)) {
-                    float v = acc[i][j][r] + bias;
-                    if (a.res) v += a.res[(size_t)m * a.ldy + c];
-                    if (a.act == 1) v = be::smish(v);
-                    else if (a.act == 2) v = fmaxf(v, 0.0f);
-                    a.y[(size_t)m * a.ldy + c] = v;
-                }
-            }
-        }
-    }
-}
-
-int launch_conv_b3(const ConvArgs& a, hipStream_t s) {
-    constexpr size_t lds = 2 * 2 * 3 * 128 * 32;       // 48 KB
-    static be::DeviceFlags attr_set{};                      // dynamic-LDS cap raised once per device (thread-safe)
-    if (int rc_ = be::ensure_dynamic_lds(reinterpret_cast<const void*>(&k_conv_b3), lds, attr_set)) return rc_;
-    const int per_xcd = a.pixmaj == 1 ? ((a.m_tiles / a.HW + 7) / 8) * a.HW : (a.m_tiles + 7) / 8;
-    const unsigned grid = (unsigned)(8 * per_xcd * a.n_tiles);
-    {
-        const double k_real = (double)a.Cin * a.ks * a.ks + (a.x2 ? (double)a.Cin2 : 0.0);
-        be::ProfileScope prof(s, BE_KERNEL_CONV_128x128, 2.0 * a.M * k_real * a.Cout,
-                              4.0 * (a.M * ((double)a.Cin + (a.x2 ? a.Cin2 : 0)) + 1.5 * k_real * a.Cout + (double)a.M * a.Cout), 0.0);
-        hipLaunchKernelGGL(k_conv_b3, dim3(grid), dim3(256), lds, s, a);
-    }
-    return be::check_launch("be_conv_nhwc_b3_f32");
-}
-
 // K chunks (of bkt floats) all tiles of a launch walk together: pixel-major tiles visit only the taps inside the image
 double executed_chunks(const ConvArgs& a, bool row8, int bkt) {
     double chunks = 0.0;
@@ -740,55 +468,8 @@ extern "C" int be_conv_pack_jobs_f32(const be_pack_job* jobs_device, int njobs, 
     return be::check_launch("be_conv_pack_jobs_f32");
 }
 
-// opt-in split-bf16 mode: convolutions whose packed weights lie inside [g_b3_base, g_b3_base + g_b3_plane) and that take the
-// 128x128 tile run k_conv_b3 on the bf16 planes registered for that buffer
 struct BatchParams { int n; int64_t xb, wb, yb; };
 static thread_local BatchParams g_batch = {1, 0, 0, 0};   // set around one dispatch by be_conv_nhwc_batched_f32
-
-// registry of packed-weight buffers that run in split-bf16 mode: keyed by the buffer, so models with and without the mode (and
-// several models with it) coexist in one process; guarded by a mutex (registration is rare, lookup is a short scan)
-struct B3Entry { const float* base; const unsigned short* planes; size_t n; };
-constexpr int kB3Slots = 8;
-static B3Entry g_b3[kB3Slots] = {};
-static std::mutex g_b3_mu;
-static bool b3_lookup(const float* pw, B3Entry* out) {
-    std::lock_guard<std::mutex> lk(g_b3_mu);
-    for (int i = 0; i < kB3Slots; ++i)
-        if (g_b3[i].base && pw >= g_b3[i].base && pw < g_b3[i].base + g_b3[i].n) { *out = g_b3[i]; return true; }
-    return false;
-}
-
-extern "C" int be_conv_split_b3_f32(const float* packed, size_t n, void* planes, void* stream) {
-    BE_REQUIRE(packed && planes && n > 0, "be_conv_split_b3_f32: bad arguments");
-    hipLaunchKernelGGL(k_split_b3, dim3(grid_cap((int64_t)n, 256)), dim3(256), 0, be::as_stream(stream), packed,
-                       static_cast<unsigned short*>(planes), n);
-    return be::check_launch("be_conv_split_b3_f32");
-}
-
-extern "C" int be_conv_b3_active(const float* packed) {
-    B3Entry e;
-    return packed && b3_lookup(packed, &e) ? 1 : 0;
-}
-
-extern "C" int be_conv_use_b3(const float* packed, const void* planes, size_t n) {
-    BE_REQUIRE(packed || (!planes && n == 0), "be_conv_use_b3: pass (packed, planes, n), (packed, NULL, 0) or (NULL, NULL, 0)");
-    BE_REQUIRE(!planes || (be::aligned16(planes) && n % 16 == 0 && n > 0), "be_conv_use_b3: planes must be 16-byte aligned, n %% 16 == 0");
-    std::lock_guard<std::mutex> lk(g_b3_mu);
-    if (!packed) {                                         // (NULL, NULL, 0): forget every registration
-        for (int i = 0; i < kB3Slots; ++i) g_b3[i] = B3Entry{};
-        return BE_OK;
-    }
-    int slot = -1;
-    for (int i = 0; i < kB3Slots; ++i) if (g_b3[i].base == packed) slot = i;
-    if (!planes) {                                         // (packed, NULL, 0): this buffer goes back to exact fp32
-        if (slot >= 0) g_b3[slot] = B3Entry{};
-        return BE_OK;
-    }
-    for (int i = 0; i < kB3Slots && slot < 0; ++i) if (!g_b3[i].base) slot = i;
-    if (slot < 0) return be::fail(BE_EINVAL, "be_conv_use_b3: all %d registration slots are taken", kB3Slots);
-    g_b3[slot] = B3Entry{packed, static_cast<const unsigned short*>(planes), n};
-    return BE_OK;
-}
 
 // y = act(sum_s partial[s] + bias (+ res)): the epilogue of a split-K launch, fixed summation order
 __global__ void k_splitk_reduce(const float* __restrict__ partial, int S, int64_t M, int Cout, int ldp,
@@ -884,11 +565,6 @@ static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2,
     a.pixmaj = 0; a.Nimg = d->n;
     a.ksplit = 1; a.ldp = 0; a.partial = nullptr;
     a.nbatch = g_batch.n; a.xb = g_batch.xb; a.wb = g_batch.wb; a.yb = g_batch.yb;
-    a.wb3 = nullptr; a.plane = 0;
-    {
-        B3Entry e;
-        if (b3_lookup(pw, &e)) { a.wb3 = e.planes + 3 * (pw - e.base); a.plane = e.n; }
-    }
     const int cp = round_up(d->cout, 32);
     hipStream_t s = be::as_stream(stream);
     // Small-M regime (training at batch 64: M = 2304 rows at 6x6): the 128-row tiles give a few dozen workgroups on
@@ -903,7 +579,7 @@ static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2,
     // and the caller runs the unit on its own (layer0 at batch >= 406 and wide linears over >= 16384 rows fell
     // through to a launch on the null stream here, inside a hipGraph capture among others)
     const bool prep_only = defer && defer->prep;
-    if (d->ksize == 1 && !x2 && cp == 128 && M >= 16384 && a.nbatch <= 1 && !a.wb3 && !no_rows && d->cin % 16 == 0) {
+    if (d->ksize == 1 && !x2 && cp == 128 && M >= 16384 && a.nbatch <= 1 && !no_rows && d->cin % 16 == 0) {
         if (prep_only) return BE_OK;
         return be::gemm_rows(x, M, d->cin, pw, d->cout, pb, res, d->act, y, ldy, stream);
     }
@@ -912,7 +588,7 @@ static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2,
         // 96 output channels (the data gradients that flow into layer0 / layer1, whose inputs have 96 channels) as TWO 64-wide uniform
         // tiles, the second half empty (a third more MFMA work, on tiles that are twice as fast as the bordered 128 x 32 ones).  Only
         // where the caller allows it - the backward: the forward keeps its tiles, and with them its bits (pad64)
-        const bool pad64 = defer && defer->pad64 && cp % 64 == 32 && cp > 64 && !x2 && !a.wb3 && a.nbatch <= 1 &&
+        const bool pad64 = defer && defer->pad64 && cp % 64 == 32 && cp > 64 && !x2 && a.nbatch <= 1 &&
                            ((d->ksize > 1 && d->n >= 64 && d->n % 64 == 0 && conv_variant() != 99) || (d->ksize == 1 && M % 64 == 0)) &&
                            M * (int64_t)d->cin * 4 < ((int64_t)1 << 32) && (int64_t)cp * a.Ktot * 4 < ((int64_t)1 << 32) &&
                            getenv("BE_NO_UNI_TILES") == nullptr && getenv("BE_NO_PAD64") == nullptr;      // = every condition of `uni` below
@@ -935,7 +611,7 @@ static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2,
         // uniform 64 x 64 tiles (be_igemm_body.h, UNI): the pixel-major tiles of whole 64-image groups, and 1x1 convolutions /
         // linears whose row count is a multiple of 64 - no border test, addresses = per-thread constant + uniform offset
         static const bool no_uni = getenv("BE_NO_UNI_TILES") != nullptr;              // A/B knob
-        const bool uni = t64 && !no_uni && !x2 && !a.wb3 && a.nbatch <= 1 && M * (int64_t)d->cin * 4 < ((int64_t)1 << 32) &&
+        const bool uni = t64 && !no_uni && !x2 && a.nbatch <= 1 && M * (int64_t)d->cin * 4 < ((int64_t)1 << 32) &&
                          (int64_t)cp * a.Ktot * 4 < ((int64_t)1 << 32) && (a.pixmaj == 2 || (d->ksize == 1 && M % 64 == 0));
         // split-K when the caller lent scratch: a few hundred workgroups each walking the whole K loop leave most of
         // the chip idle (batch-64 training: 144-216 tiles, up to 216 chunks each); S slices make S times the
@@ -974,10 +650,10 @@ static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2,
                      : launch_conv<4, 1, 1, 1, MODE_TAPS, 16, 0>(a, s, BE_KERNEL_CONV_SMALL);
     }
     // 1x1 convolutions / linears of large batches are plain row GEMMs: the LDS-DMA kernel of be_wino.hip (bit-identical)
-    if (d->ksize == 1 && !x2 && cp % 128 == 0 && M >= 4096 && a.nbatch <= 1 && !a.wb3 && !no_rows && d->cin % 16 == 0)
+    if (d->ksize == 1 && !x2 && cp % 128 == 0 && M >= 4096 && a.nbatch <= 1 && !no_rows && d->cin % 16 == 0)
         return be::gemm_rows(x, M, d->cin, pw, d->cout, pb, res, d->act, y, ldy, stream);
     // large batches of small images, 3x3: the pixel-major LDS-DMA kernel (be_conv_pm.hip; bit-identical)
-    if (d->ksize == 3 && d->n >= 512 && !res && a.nbatch <= 1 && !a.wb3 && conv_variant() == 0 && be::aligned16(y) && ldy % 4 == 0) {
+    if (d->ksize == 3 && d->n >= 512 && !res && a.nbatch <= 1 && conv_variant() == 0 && be::aligned16(y) && ldy % 4 == 0) {
         const int rc = be::conv_pm(d, x, d->w, x2, cin2, pw, pb, y, ldy, a.Ktot, stream);
         if (rc != 1) return rc;
     }
@@ -994,7 +670,6 @@ static int conv_dispatch(const be_conv_desc* d, const float* x, const float* x2,
     }
     if (cp % 128 == 0) {
         a.n_tiles = cp / 128;
-        if (a.wb3 && a.nbatch <= 1) return launch_conv_b3(a, s);      // opt-in split-bf16 mode
         // K-chunk 16 (40 KB of LDS, three workgroups per CU) measured 8 % faster than 32 (two per CU); 8 is slower
         // again (barrier per 16 MFMAs); s_setprio around the MFMA phase and a 4th workgroup per CU change nothing.
         if (conv_variant() == 32) return launch_conv<2, 2, 2, 2, MODE_TAPS, 32, 0>(a, s, BE_KERNEL_CONV_128x128);

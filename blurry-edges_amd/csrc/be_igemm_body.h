@@ -26,8 +26,6 @@ struct ConvArgs {
     float* partial;
     int nbatch;
     int64_t xb, wb, yb;   // batched launches (blockIdx.z = batch index): element strides of x, w, y between batches
-    const unsigned short* wb3;   // experimental split-bf16 mode: the packed weights as three bf16 planes (hi, mid, lo),
-    size_t plane;                //   each laid out exactly like `w`; plane = elements per plane
 };
 
 // __launch_bounds__(256, w): w = workgroups per CU the LDS admits (= waves per SIMD), so the register allocator may

@@ -152,11 +152,7 @@ int block(const float* packed, int l0, const float* x, float* t, float* o, int n
 
 // The same block on a 6x6 map with both 3x3 convolutions in Winograd F(3x3,3x3) form (be_wino.hip): 2.56x fewer multiplies
 // than the direct form; the 1x1 downsample runs as its own convolution into `r` and joins in the output transform of conv2.
-// chain: 0 = stand-alone block; 1 = x's input transform is already in the first transform buffer (the block before wrote it);
-// 2 = also write the NEXT block's input transform (into that first buffer again: it is dead after conv1).  Large sub-batches
-// only (be::wino_pair_chained returns 1 otherwise and the block runs stand-alone).
-int block_wino(const float* packed, int l0, const float* x, float* t, float* o, float* r, float* w, int n, void* stream,
-               int pool2 = 0, int chain_in = 0, int chain_out = 0, bool* chained = nullptr) {
+int block_wino(const float* packed, int l0, const float* x, float* t, float* o, float* r, float* w, int n, void* stream, int pool2 = 0) {
     const PackedLayout& L = layout();
     const int c = kLayers[l0].cout;
     (void)t;                                          // conv1's 6x6 result only ever exists in registers (k_wino_out_in)
@@ -170,16 +166,6 @@ int block_wino(const float* packed, int l0, const float* x, float* t, float* o, 
             d.n = n; d.h = 6; d.w = 6; d.cin = kLayers[l0 + 2].cin; d.cout = c; d.ksize = 1; d.act = 0;
             if ((rc = be_conv_nhwc_f32(&d, x, packed + L.dw_off[l0 + 2], packed + L.zero_off, nullptr, r, c, stream))) return rc;
         }
-    }
-    {
-        float* va = w;                                // two transform-domain buffers of 100 x 384 floats per patch each
-        float* vb = w + (size_t)n * 100 * 384;
-        const int rc = be::wino_pair_chained(chain_in ? nullptr : x, packed + L.uw_off[l0], packed + L.ub_off[l0], 1,
-                                             packed + L.uw_off[l0 + 1], packed + L.ub_off[l0 + 1], r, 1, o, n, kLayers[l0].cin, c, c,
-                                             va, vb, chain_out ? va : nullptr, stream, pool2);
-        if (chained) *chained = rc == 0 && chain_out;
-        if (rc <= 0) return rc;                       // done (0) or a real error (< 0); 1 = not a fused shape
-        if (chain_in) return be::fail(BE_EINVAL, "block_wino: chained input but the block cannot run fused");
     }
     return be::wino_pair(x, packed + L.uw_off[l0], packed + L.ub_off[l0], 1, packed + L.uw_off[l0 + 1], packed + L.ub_off[l0 + 1], r,
                          1, o, n, kLayers[l0].cin, c, c, w, (size_t)n * RW, stream, pool2);
@@ -210,8 +196,7 @@ int forward_impl(const float* packed, const float* x, const be_patch_view* view,
         float* rc_ = rb + (size_t)nb * RB;
         float* rw = rc_ + (size_t)nb * RC;                // Winograd transform-domain buffers
         float* rr = rw + (size_t)nb * RW;                 // downsample branch of the current block
-        const bool b3 = be_conv_b3_active(packed) != 0;   // this packed buffer runs the split-bf16 experiment: direct convolutions
-        const bool wino = g_wino && !b3;
+        const bool wino = g_wino != 0;
         int rc;
         // x4 -> RB ; conv1 -> RA ; pool -> RB(after x4 is dead: RB is big enough to hold both side by side)
         float* x4 = rb;                                   // nb*1764
@@ -219,7 +204,7 @@ int forward_impl(const float* packed, const float* x, const be_patch_view* view,
         // large sub-batches: conv1 on the pixel-major LDS-DMA kernel, which reads a staging with 28 pixels per row (3 zero
         // pixels left, 4 right; 2352 floats per patch, still in front of p1)
         static const bool no_pm = getenv("BE_NO_CONV_PM") != nullptr;
-        if (nb >= 512 && !no_pm && !b3) {
+        if (nb >= 512 && !no_pm) {
             if (x) rc = be_nchw3_to_nhwc4p_f32(x + first * 3 * BE_NPIX, x4, nb, BE_R, BE_R, 28, stream);
             else rc = be_view_to_nhwc4p_f32(view, P, first, x4, nb, 28, stream);
             if (rc) return rc;
@@ -238,18 +223,16 @@ int forward_impl(const float* packed, const float* x, const be_patch_view* view,
         if ((rc = block(packed, 1, p1, ra, rc_, nb, 11, stream))) return rc;
         float* p2 = rb;                                   // nb*3456
         if ((rc = be_maxpool_nhwc_f32(rc_, p2, nb, 11, 11, 96, 3, 2, 1, stream))) return rc;
-        // layer1: in RB, t RA, out RC.  Large sub-batches (fused Winograd kernels): every block's conv2 also writes the next
-        // block's input transform from its epilogue (ch1 / ch2), so k_wino_in runs for layer1 only
-        bool ch1 = false, ch2 = false;
-        if ((rc = wino ? block_wino(packed, 4, p2, ra, rc_, rr, rw, nb, stream, 0, 0, 1, &ch1) : block(packed, 4, p2, ra, rc_, nb, 6, stream))) return rc;
+        // layer1: in RB, t RA, out RC
+        if ((rc = wino ? block_wino(packed, 4, p2, ra, rc_, rr, rw, nb, stream) : block(packed, 4, p2, ra, rc_, nb, 6, stream))) return rc;
         // layer2: in RC, t RA, out RB
-        if ((rc = wino ? block_wino(packed, 7, rc_, ra, rb, rr, rw, nb, stream, 0, ch1, 1, &ch2) : block(packed, 7, rc_, ra, rb, nb, 6, stream))) return rc;
+        if ((rc = wino ? block_wino(packed, 7, rc_, ra, rb, rr, rw, nb, stream) : block(packed, 7, rc_, ra, rb, nb, 6, stream))) return rc;
         // layer3: in RB, t RA, out RC; then maxpool(2,2) -> p3 [nb,3,3,256] = the (H,W,C) flatten.  Winograd path: the
         // output transform pools in registers and writes p3 directly (into RC: RB is still the block's input)
         float* p3;
         if (wino) {
             p3 = rc_;
-            if ((rc = block_wino(packed, 10, rb, ra, p3, rr, rw, nb, stream, 1, ch2, 0))) return rc;
+            if ((rc = block_wino(packed, 10, rb, ra, p3, rr, rw, nb, stream, 1))) return rc;
         } else {
             if ((rc = block(packed, 10, rb, ra, rc_, nb, 6, stream))) return rc;
             p3 = rb;                                      // nb*2304

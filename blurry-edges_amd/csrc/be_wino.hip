@@ -774,11 +774,6 @@ extern "C" int be_wino_conv3x3_6x6_f32(const float* x, const float* packed_w, co
     hipStream_t s = be::as_stream(stream);
     float* V = workspace;
     float* M = workspace + (size_t)100 * n * cin;
-    if (be::wino_fused_ok(n, cin, cout)) {              // large batches: output transform in the GEMM's epilogue, no M
-        BE_WINO_LAUNCH(k_wino_in, dim3(grid_cap(n * 4 * (cin / 4), 256)), dim3(256), 0, s, x, V, n, cin / 4, 1);
-        if (int rc = be::check_launch("be_wino_conv3x3_6x6_f32(in)")) return rc;
-        return be::wino_fused(V, packed_w, packed_bias, residual, act, y, nullptr, n, cin, cout, 1, stream);
-    }
     const int tm = wino_large(n, cout);
     BE_WINO_LAUNCH(k_wino_in, dim3(grid_cap(n * 4 * (cin / 4), 256)), dim3(256), 0, s, x, V, n, cin / 4, tm);
     if (int rc = be::check_launch("be_wino_conv3x3_6x6_f32(in)")) return rc;
@@ -809,14 +804,6 @@ int be::wino_pair(const float* x, const float* packed_w1, const float* packed_bi
     const size_t big = (size_t)(cin > cmid ? cin : cmid);
     float* V = workspace;
     float* M = workspace + (size_t)100 * n * big;
-    if (be::wino_fused_ok(n, cin, cmid) && be::wino_fused_ok(n, cmid, cout)) {
-        // large batches (be_wino_fused.hip): conv1's GEMM writes conv2's transform-domain input straight from its epilogue,
-        // conv2's GEMM writes the block's output (or its 2x2 max-pool); no M buffer, no separate output transforms
-        BE_WINO_LAUNCH(k_wino_in, dim3(grid_cap(n * 4 * (cin / 4), 256)), dim3(256), 0, s, x, V, n, cin / 4, 1);
-        if (int rc = be::check_launch("be_wino_conv3x3_pair_6x6_f32(in)")) return rc;
-        if (int rc = be::wino_fused(V, packed_w1, packed_bias1, nullptr, act1, nullptr, M, n, cin, cmid, 2, stream)) return rc;
-        return be::wino_fused(M, packed_w2, packed_bias2, residual, act2, y, nullptr, n, cmid, cout, pool2 ? 4 : 1, stream);
-    }
     const int tm1 = wino_large(n, cmid), tm2 = wino_large(n, cout);
     {
         be::ProfileScope prof(s, BE_KERNEL_WINO_TRANSFORM, 0.0, 4.0 * n * cin * (36.0 + 100.0), 0.0);
@@ -841,21 +828,6 @@ int be::wino_pair(const float* x, const float* packed_w1, const float* packed_bi
                                cout / 4, act2, tm2);
     }
     return be::check_launch("be_wino_conv3x3_pair_6x6_f32(out)");
-}
-
-int be::wino_pair_chained(const float* x, const float* packed_w1, const float* packed_bias1, int act1, const float* packed_w2,
-                          const float* packed_bias2, const float* residual, int act2, float* y, int64_t n, int cin, int cmid, int cout,
-                          float* v_in, float* v_mid, float* v_next, void* stream, int pool2) {
-    if (!be::wino_fused_ok(n, cin, cmid) || !be::wino_fused_ok(n, cmid, cout)) return 1;
-    BE_REQUIRE(packed_w1 && packed_bias1 && packed_w2 && packed_bias2 && y && v_in && v_mid, "wino_pair_chained: null pointer");
-    BE_REQUIRE(!(pool2 && v_next), "wino_pair_chained: the pooled block is the last one");
-    hipStream_t s = be::as_stream(stream);
-    if (x) {
-        BE_WINO_LAUNCH(k_wino_in, dim3(grid_cap(n * 4 * (cin / 4), 256)), dim3(256), 0, s, x, v_in, n, cin / 4, 1);
-        if (int rc = be::check_launch("wino_pair_chained(in)")) return rc;
-    }
-    if (int rc = be::wino_fused(v_in, packed_w1, packed_bias1, nullptr, act1, nullptr, v_mid, n, cin, cmid, 2, stream)) return rc;
-    return be::wino_fused(v_mid, packed_w2, packed_bias2, residual, act2, y, v_next, n, cmid, cout, pool2 ? 4 : (v_next ? 3 : 1), stream);
 }
 
 extern "C" int be_wino_conv3x3_pair_6x6_f32(const float* x, const float* packed_w1, const float* packed_bias1, int act1,

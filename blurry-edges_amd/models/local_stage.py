@@ -95,10 +95,8 @@ class LocalStage(nn.Module):
                     fc4.weight, fc4.bias])
         return out
 
-    # "f32" (default): exact fp32 MFMA.  "bf16x3" (EXPERIMENTAL, opt-in; also BE_CONV_PRECISION=bf16x3): the 128x128-tile
-    # convolutions of layers 1-3 and fc.1 split every fp32 operand exactly into three bf16 pieces and take six bf16 MFMAs
-    # per product with fp32 accumulation (include/blurry_edges_hip.h, be_conv_use_b3).
-    conv_precision = os.environ.get("BE_CONV_PRECISION", "f32")
+    # the arithmetic of every convolution: exact fp32 MFMA products, fp32 accumulation (bench.py reports it as `dtype`)
+    conv_precision = "f32"
     # True (default): the 3x3 convolutions on the 6x6 maps run as Winograd F(3x3,3x3) (2.56x fewer multiplies, exact fp32
     # products; be_wino.hip).  False: direct implicit-GEMM convolutions everywhere.  A per-call option of the C ABI
     # (be_local_stage_opts): instances with different settings coexist in one process.
@@ -107,19 +105,11 @@ class LocalStage(nn.Module):
     chunk = 0
     # 2 (default): an eval batch of 8192 patches and more (or an image pair with 4096+ patch positions) runs as two halves
     # on two side streams - patches are independent, the halves' kernels fill each other's tails and let HBM-bound transform
-    # kernels overlap matrix-bound ones: 14.0 -> 13.5 ms per 8192 patches, results bit-identical (tools/exp_two_streams.py,
+    # kernels overlap matrix-bound ones: 14.0 -> 13.5 ms per 8192 patches, results bit-identical (profiles/HISTORY.md,
     # DESIGN 3.1f).  1: one stream (what the per-kernel roofline measurements use: a kernel's duration means something only
     # when nothing else shares the chip).
     streams = int(os.environ.get("BE_LOCAL_STREAMS", "2"))
     _side = None
-
-    def __del__(self):
-        # a split-bf16 registration is keyed by the packed buffer's address: take it back before the buffer is freed
-        try:
-            if getattr(self, "_b3_planes", None) is not None and self._packed is not None:
-                native.conv_use_b3(self._packed, on=False)
-        except Exception:
-            pass
 
     def invalidate_packed(self):
         """Drop the cached BN-folded weight pack.  Needed whenever parameters or running statistics change on the device
@@ -135,14 +125,9 @@ class LocalStage(nn.Module):
 
     def _packed_weights(self):
         tensors = [t.detach() for t in self._tensor_list()]
-        key = tuple((t.data_ptr(), t._version) for t in tensors) + (self.conv_precision,)
+        key = tuple((t.data_ptr(), t._version) for t in tensors)
         if self._packed is None or key != self._packed_key:
-            if self.conv_precision not in ("f32", "bf16x3"):
-                raise ValueError(f"LocalStage.conv_precision must be 'f32' or 'bf16x3', got {self.conv_precision!r}")
-            if self._packed is not None:
-                native.conv_use_b3(self._packed, on=False)              # the old buffer's registration (if any) goes with it
             self._packed = native.local_stage_pack(tensors, eps=self.conv1[1].eps)
-            self._b3_planes = native.conv_use_b3(self._packed, on=self.conv_precision == "bf16x3")
             self._packed_key = key
         return self._packed
 

@@ -192,7 +192,7 @@ class _GlobalLossFn(torch.autograd.Function):
         img_fit, img_gt = img_fit.contiguous(), img_gt.contiguous()
         # the CURRENT folded image / boundary (the reference detaches them before the consistency terms)
         recs = torch.stack([native.render_full(opts, dcal.consts, 0.0, False, native.global_denorm(e[b]),
-                                               native.view_image_pair_nhwc(img_fit[b], st))[0] for b in range(B)])
+                                               native.view_image_pair_nhwc(img_fit[b], st), pixels=img_fit)[0] for b in range(B)])
         m = native.fold_records_batch(opts, recs, hp, wp, H, W, st, False, want=("image", "bndry"))     # one launch for the batch
         G, Gb = m["image"], m["bndry"]
         Gd = helper.get_image_derivative(G.view(B * 2, 3, H, W)).view(B, 2, 3, H - 2, W - 2)

@@ -349,17 +349,6 @@ int be_wino_conv3x3_pair_6x6_f32(const float* x, const float* packed_w1, const f
                                  const float* packed_w2, const float* packed_bias2, const float* residual, int act2, float* y,
                                  int64_t n, int cin, int cmid, int cout, float* workspace, size_t workspace_floats, void* stream);
 
-/* EXPERIMENTAL, opt-in: split-bf16 arithmetic for the 128x128-tile convolutions.  Every fp32 operand is split exactly
- * into three bf16 pieces (x = hi + mid + lo) and a product is six bf16 MFMAs accumulated in fp32 (the three dropped
- * cross terms are <= 2^-24 relative, the size of one fp32 rounding).  be_conv_split_b3_f32 turns a packed weight
- * buffer of n floats into planes [3][n] bf16; be_conv_use_b3(packed, planes, n) makes every later convolution whose
- * packed weights lie inside that buffer use them: the registration belongs to THAT buffer (up to 8 at a time, mutex-guarded), so
- * models with and without the mode coexist; (packed, NULL, 0) takes the buffer back to exact fp32, (NULL, NULL, 0) forgets all.
- * Default is off: exact fp32 MFMA. */
-int be_conv_split_b3_f32(const float* packed, size_t n, void* planes, void* stream);
-int be_conv_use_b3(const float* packed, const void* planes, size_t n);
-int be_conv_b3_active(const float* packed);     /* 1 while planes are registered for the buffer `packed` points into */
-
 /* nn.MaxPool2d(k, stride, pad) on NHWC (models/local_stage.py:42-43). */
 int be_maxpool_nhwc_f32(const float* x, float* y, int n, int h, int w, int c, int k, int stride, int pad,
                         void* stream);

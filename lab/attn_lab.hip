@@ -1,7 +1,6 @@
 // Kernel-level bench for the GlobalStage attention kernels (be_attn.hip), without Python: the source file is included, so the
 // kernels in its anonymous namespace can be launched and timed one by one with hipEvents.
-//   cd blurry-edges_amd/csrc && hipcc --offload-arch=gfx950 -O3 -std=c++17 -mllvm -amdgpu-mfma-vgpr-form -I../../include \
-//        ../../tools/attn_lab.hip -o ../../tools/bin/attn_lab        (then: tools/bin/attn_lab [B] [reps])
+//   make -C lab        (then: lab/bin/attn_lab [B] [reps])
 // B x 8 heads x 4096 tokens.  This is where the round-2 rewrite of the three kernels was developed (variants lived here and were
 // compared with the then-product kernels before they replaced them; numbers in profiles/r02_attention_rewrite.md).
 #include "../blurry-edges_amd/csrc/be_attn.hip"

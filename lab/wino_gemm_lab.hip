@@ -1,5 +1,5 @@
 // Lab bench for the 25 transform-domain GEMMs of the Winograd layers (be_wino.hip: k_wino_gemm).  Stand-alone program:
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/wino_gemm_lab.hip -o gpurun_out/wino_gemm_lab && ./wino_gemm_lab
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 lab/wino_gemm_lab.hip -o lab/bin/wino_gemm_lab   (or: make -C lab) && ./wino_gemm_lab
 // Variants are timed with hipEvents on M = 32768 rows (8192 patches) and checked against variant 0 (the product kernel's
 // text).  Knock-outs (wrong results by construction, timing only) are marked KO.
 #include <hip/hip_runtime.h>

@@ -354,3 +354,59 @@ def test_adjoint_kernels_same_results_through_both_bindings(env, monkeypatch):
     assert len(via_ops) == len(via_ctypes) == 22
     for i, (x, y) in enumerate(zip(via_ops, via_ctypes)):
         assert torch.equal(x, y), i
+
+
+def test_pass_b_folds_losses_and_attention_same_results_through_both_bindings(env, monkeypatch):
+    """render_full, fold_records (single and batched), local_loss (+ finish), global_loss and the attention forward /
+    training forward / backward are torch.ops.be.* operators as well; the product classes go through them (native.ops()), and
+    BE_TORCH_OPS=0 (ctypes over the same C symbols) gives the same bits."""
+    native, synth, utils = env["native"], env["synth"], env["utils"]
+    from be_hip import train_global_stage as tgs
+    from oracle import global_loss as ogl
+    for name in ("render_full", "fold_records", "local_loss", "local_loss_finish", "global_loss", "attention", "attention_train_fwd", "attention_bwd",
+                 "etas2depth", "depth2sigma"):
+        assert hasattr(native.ops(), name), name
+    a = utils.get_args("global_train", argv=[])
+    a.batch_size = 1
+    hg = utils.PostProcessGlobalBase(a, DEV)
+    hl = utils.PostProcessLocalBase(utils.get_args("local_train", argv=[]), DEV)
+    dc = utils.DepthEtas(a, DEV)
+    img = T(synth.synthetic_image_pair(147, 147)[0]).to(DEV)
+    p12 = T(synth.plausible_params12(4096, name="bind12")).to(DEV)
+    smp = {k: torch.from_numpy(v)[None].to(DEV) for k, v in synth.synthetic_global_sample(147, 147).items()}
+    est = torch.from_numpy(synth.plausible_global_output(4096))[None].to(DEV)
+    B_, S = 64, 5
+    lest = T(synth.plausible_params10(B_, name="bindl")).to(DEV)
+    limg = T(synth.f32(synth.hash_uniform(S, "b_img", (B_, 21, 21, 3)))).to(DEV)
+    lbd = T(synth.f32(synth.hash_uniform(S, "b_bd", (B_, 21, 21)))).to(DEV)
+    lde = T(synth.f32(synth.hash_uniform(S, "b_de", (B_, 19, 19, 3)))).to(DEV)
+    qkv = (T(synth.f32(synth.hash_normal(S, "b_qkv", (2 * 256, 3 * 8 * 16)))) * 0.5).to(DEV)
+    dout = T(synth.f32(synth.hash_normal(S, "b_dout", (2 * 256, 8 * 16)))).to(DEV)
+
+    def both():
+        opts = hg.render_opts(False)
+        rec, ex = native.render_full(opts, dc.consts, 10.39, False, p12, native.view_image_pair(img), want=("patches", "depth_mask", "boundary"),
+                                     pixels=img)
+        out = [rec, ex["patches"], ex["depth_mask"], ex["boundary"]]
+        out += list(native.fold_records(opts, rec, 64, 64, 147, 147).values())
+        out += list(native.fold_records_batch(opts, torch.stack([rec, rec]), 64, 64, 147, 147, want=("image", "conf")).values())
+        partial, grad, _ = native.local_loss(hl.render_opts(False), lest, limg, limg, lbd, lde, 1e-3, 5e-4)
+        out += [partial, grad, native.local_loss_finish(partial, 1e-3, 5e-4).reshape(1)]
+        e = est.clone().requires_grad_(True)
+        loss = utils.global_loss(hg, dc, e, smp["img_gt"], smp["img_gt"], smp["bndry_dist"], smp["deri"], smp["bndry_depth"], ogl.GAMMA_FINAL)
+        loss.backward()
+        out += [loss.detach().reshape(1), e.grad]
+        o, _ = native.attention(qkv, 2, 256, 8)
+        of, lse, ws = tgs.attention_train_fwd(qkv, 2, 256, 8, 0.1, 1234)
+        dq, _ = tgs.attention_bwd(qkv, of, lse, dout, 2, 256, 8, 0.1, 1234, ws=ws, operands_ready=True)
+        out += [o, of, lse, dq]
+        return [t.clone() for t in out]
+
+    assert native.ops() is not None
+    via_ops = both()
+    monkeypatch.setattr(native, "_ops", False)
+    assert native.ops() is None
+    via_ctypes = both()
+    assert len(via_ops) == len(via_ctypes)
+    for i, (x, y) in enumerate(zip(via_ops, via_ctypes)):
+        assert x.shape == y.shape and torch.equal(x, y), i

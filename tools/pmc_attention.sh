@@ -1,6 +1,6 @@
-# PMC passes over the attention kernels (tools/bin/attn_lab, batch 8): MFMA-busy, wave cycles, instruction mix
+# PMC passes over the attention kernels (lab/bin/attn_lab, batch 8): MFMA-busy, wave cycles, instruction mix
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/pmc_attn
-run() { name=$1; shift; timeout -k 10 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/pmc_attn/$name -- tools/bin/attn_lab 8 3 > gpurun_out/pmc_attn/$name.log 2>&1 || echo "FAILED $name"; }
+run() { name=$1; shift; timeout -k 10 200 rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d gpurun_out/pmc_attn/$name -- lab/bin/attn_lab 8 3 > gpurun_out/pmc_attn/$name.log 2>&1 || echo "FAILED $name"; }
 run sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE &&
 run sq2 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VALU SQ_INSTS_SALU SQ_ACTIVE_INST_VALU
 ls gpurun_out/pmc_attn/*/* | head
