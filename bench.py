@@ -19,7 +19,7 @@ with the input already resident in HBM.  Prints ONE JSON line (rank 0).
                  each with its own clock and dominant kernel
   dp             the data-parallel training step (configs[4]): at N > 1 K steps of be_hip.train_local.train_step(world=N)
                  with the bucketed RCCL gradient all-reduce (four buckets) overlapped with the backward; at N = 1 the same code, world 1
-  cpu_baseline   the oracle on the host cores, 1024 pairs x 3 runs, median (rank 0, N = 1 only)
+  cpu_baseline   the oracle on the host cores, the whole 4096-pair workload x 3 runs, median (rank 0, N = 1 only)
 
 Multi-GPU: patch pairs are independent, so every rank runs its own shard of 4096 pairs with NO data-path
 collective (weak scaling); RCCL carries the barrier, the MAX of the elapsed time - and, in the dp leg, the gradients.
@@ -45,8 +45,8 @@ FLOP_PER_PATCH = 387.716e6            # SURVEY.md A.2 (2*MAC, convs + linears)
 FLOP_PER_PAIR = 2 * FLOP_PER_PATCH    # 775.43 MFLOP, SURVEY.md 8d
 PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: dense fp32 matrix peak
 PEAK_HBM_TBPS = 8.0                   # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s is what a float4 copy reaches)
-CPU_SAMPLE_PAIRS = 1024               # bounded sample, 3 repeats, median (~2 s per run on 16 threads)
-CPU_REPEATS = 3
+CPU_SAMPLE_PAIRS = 4096               # the WHOLE configs[1] workload (not a quarter of it): ~8 s per run on 16 threads,
+CPU_REPEATS = 3                       # 3 repeats, median: ~25 s of CPU work (the task's bound for this leg: 10-30 s)
 # kernel id 6 = the 25 transform-domain GEMMs of one Winograd layer: the hooks count the 25 x 2 x 4n x cin x cout FLOPs they
 # execute; the same layer as a direct 3x3 convolution on a 6x6 map is 2 x 36 x 9 x n x cin x cout
 ALGO_OVER_HOOK = {6: (2.0 * 36 * 9) / (25.0 * 2 * 4)}
@@ -265,7 +265,8 @@ def leg_global_training(dev, steps=12):
     for p in model.parameters():
         if p.dim() > 1:
             torch.nn.init.xavier_normal_(p)
-    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, fused=dp.fused_adamw())
+    from be_hip.optim import ClipAdamW
+    opt = ClipAdamW(model.parameters(), lr=1e-4, gather=True)
     gamma = train_global.GammaSchedule(args).final()
     batch = {k: torch.stack([d[k] for d in data]) for k in ("pm", "img_gt", "bndry_dist", "deri", "bndry_depth")}
     model.train()

@@ -614,6 +614,20 @@ def nchw3_to_nhwc4(x):
     return y
 
 
+def patches_to_nhwc4(x):
+    """x: logical [N,3,h,w] patches -> the NHWC4 staging [N,h,w,4] conv1 reads.  A contiguous NCHW tensor takes
+    be_nchw3_to_nhwc4_f32; a PERMUTED VIEW of a channels-last tensor - what `img.permute(0,3,1,2)` makes of the dataset's
+    [N,h,w,3] batches (local_training.py:103) - is read in place through a patch view (be_view_to_nhwc4_f32): no NCHW copy first."""
+    n, c, h, w = x.shape
+    if c == 3 and (h, w) == (BE_R, BE_R) and x.dtype == torch.float32 and n > 0 and x.stride() == (h * w * 3, 1, w * 3, 3):
+        dptr(x.permute(0, 2, 3, 1), "x")                     # contiguous [N,h,w,3] on the GPU, else this raises
+        view = PatchView(x.data_ptr(), 0, 1, w * 3, 3, 0, h * w * 3, n)
+        y = torch.empty(n, h, w, 4, dtype=torch.float32, device=x.device)
+        check(lib().be_view_to_nhwc4_f32(C.byref(view), n, 0, dptr(y), n, stream_ptr(x.device)), "be_view_to_nhwc4_f32")
+        return y
+    return nchw3_to_nhwc4(x.to(torch.float32).contiguous())
+
+
 def nchw3_to_nhwc4p(x, wrow=28):
     """[N,3,h,w] -> [N,h,wrow,4]: image column c at padded column c + 3, zeros elsewhere (staging of conv1 for large batches)."""
     n, c, h, w = x.shape

@@ -11,7 +11,8 @@ eager `clip_and_step` therefore bumps their version counters (`torch.autograd.gr
 caches keyed on `_version` - LocalStage's BN-folded weight pack - see the update; a replayed hipGraph cannot do that, which is
 why GraphedStep / SegmentedGraphStep call `model.invalidate_packed()` themselves.  `step()`
 alone is AdamW without clipping; `clip_and_step(max_norm)` is the fused tail of the training step and returns the gradient norm
-before clipping (a device scalar).  Gradients that are not one flat buffer in parameter order are refused (no silent fallback)."""
+before clipping (a device scalar).  Gradients that are not one flat buffer in parameter order are refused (no silent fallback)
+unless the optimizer was built with `gather=True` (the GlobalStage loops: one multi-tensor copy gathers them first)."""
 from __future__ import annotations
 
 import ctypes as C
@@ -23,7 +24,7 @@ from .native import check, dptr, lib, stream_ptr
 
 
 class ClipAdamW(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, write_back=True):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, write_back=True, gather=False):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         if len(self.param_groups) != 1:
             raise ValueError("ClipAdamW: one parameter group (the training scripts of the reference use one)")
@@ -37,6 +38,7 @@ class ClipAdamW(torch.optim.Optimizer):
         self._step = torch.zeros(1, dtype=torch.float32, device=dev)
         self._norm = torch.zeros(1, dtype=torch.float32, device=dev)
         self.write_back = bool(write_back)
+        self.gather, self._gbuf, self._gviews = bool(gather), None, None
         chunk = lib().be_adam_chunk()
         self._partial = torch.empty((self._n + chunk - 1) // chunk, dtype=torch.float64, device=dev)
         entries, self._offsets, off = [], [], 0
@@ -62,11 +64,25 @@ class ClipAdamW(torch.optim.Optimizer):
         if g0 is None:
             raise RuntimeError("ClipAdamW: no gradients (call backward first)")
         base = g0.data_ptr()
-        for p, off in zip(ps, self._offsets):
-            if p.grad is None or p.grad.data_ptr() != base + 4 * off or not p.grad.is_contiguous():
-                raise RuntimeError("ClipAdamW: gradients must be consecutive slices of one flat buffer in parameter order "
-                                   "(be_hip.train.backward_train writes them that way); use torch.optim.AdamW otherwise")
-        return base
+        flat = all(p.grad is not None and p.grad.data_ptr() == base + 4 * off and p.grad.is_contiguous() for p, off in zip(ps, self._offsets))
+        if flat:
+            return base
+        if not self.gather:
+            raise RuntimeError("ClipAdamW: gradients must be consecutive slices of one flat buffer in parameter order "
+                               "(be_hip.train.backward_train writes them that way); build the optimizer with gather=True for a "
+                               "backward that allocates them one by one, or use torch.optim.AdamW")
+        # gather mode (GlobalStage: its backward returns one tensor per parameter): one multi-tensor copy into the optimizer's own
+        # flat buffer, and .grad re-pointed at the views - so the clipped gradient is what .grad shows afterwards, as with
+        # clip_grad_norm_
+        if any(p.grad is None for p in ps):
+            raise RuntimeError("ClipAdamW: a parameter has no gradient")
+        if self._gbuf is None:
+            self._gbuf = torch.empty(self._n, dtype=torch.float32, device=self._m.device)
+            self._gviews = [self._gbuf[off:off + p.numel()].view_as(p) for p, off in zip(ps, self._offsets)]
+        torch._foreach_copy_(self._gviews, [p.grad for p in ps])
+        for p, v in zip(ps, self._gviews):
+            p.grad = v
+        return self._gbuf.data_ptr()
 
     @torch.no_grad()
     def clip_and_step(self, max_norm=1.0, grad_scale=1.0):

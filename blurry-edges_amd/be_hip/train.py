@@ -300,7 +300,7 @@ def forward_train(x, t):
         S[name] = (xin, saved)
         return out
 
-    x4 = native.nchw3_to_nhwc4(x)
+    x4 = native.patches_to_nhwc4(x)                       # NCHW, or the dataset's channels-last batch seen through permute(0,3,1,2)
     a1 = unit("conv1", 0, x4)
     p1, S["pool1"] = _pool_fwd_idx(a1, 3, 2, 1)
 
@@ -419,7 +419,7 @@ class LocalStageTrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, *tensors):
         t = [v.detach() for v in tensors]
-        out, S = forward_train(x.detach().to(torch.float32).contiguous(), t)
+        out, S = forward_train(x.detach().to(torch.float32), t)
         ctx.S, ctx.t = S, t
         return out
 

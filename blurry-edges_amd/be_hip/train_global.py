@@ -78,8 +78,11 @@ def train_step(model, helper, dcal, opt, batch, gamma, flat=None, world=1, clip=
     loss.backward()
     if flat is not None:
         dp.allreduce_mean_(dp.grads_as_flat(list(model.parameters()), flat), world)      # zero-copy when the backward wrote one buffer
-    torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=clip, norm_type=2)
-    opt.step()
+    if hasattr(opt, "clip_and_step"):    # be_hip.optim.ClipAdamW(gather=True): norm + clip + AdamW in two launches (+ one gathering copy)
+        opt.clip_and_step(clip)
+    else:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=clip, norm_type=2)
+        opt.step()
     return loss.detach()
 
 
@@ -111,7 +114,8 @@ def main(argv=None):
     for p in model.parameters():
         if p.dim() > 1:
             torch.nn.init.xavier_normal_(p)
-    opt = torch.optim.AdamW(model.parameters(), lr=a.lr, fused=dp.fused_adamw())
+    from .optim import ClipAdamW
+    opt = ClipAdamW(model.parameters(), lr=a.lr, gather=True)     # clip_grad_norm_ + AdamW of global_training.py:213-214, fused
     flat = dp.flat_grad_buffer(model.parameters()) if world > 1 else None
     sched = GammaSchedule(args)
     gamma = sched.final()

@@ -41,20 +41,24 @@ def train_step(model, helper, opt, batch, beta_b, beta_s, flat=None, world=1, cl
     all-reduced on a side stream as soon as the backward has finished their slice (overlap); without one, `flat` selects
     the older path - one bucketed all-reduce after the whole backward.
     stats: optional dict that receives `grad_norm` (the total norm clip_grad_norm_ measured, a device scalar)."""
-    import utils
-    from . import train
+    from . import native, train
     est = model(batch["img_ny"].permute(0, 3, 1, 2))
     opt.zero_grad(set_to_none=True)      # backward then SETS .grad (no fill, no accumulate launch per parameter)
-    loss = utils.local_loss(helper, est, batch["img_gt"], batch["img_gt"], batch["bndry_dist"], batch["deri"], beta_b, beta_s, write_back=False)
+    # LocalLoss forward + analytic backward in one launch (what utils.local_loss wraps in an autograd.Function; called directly
+    # here: `loss.backward()` through the Function costs a ones-fill and a `1 * grad` launch per step, and the loss kernel wraps
+    # the raw angles itself in float64 - no write-back into est).  local_training.py:105 passes the clean image as both images.
+    partial, dloss_dest, _ = native.local_loss(helper.render_opts(False), est.detach(), batch["img_gt"].contiguous(), batch["img_gt"].contiguous(),
+                                               batch["bndry_dist"].contiguous(), batch["deri"].contiguous(), beta_b, beta_s, want_grad=True)
+    loss = native.local_loss_finish(partial, beta_b, beta_s)
     if sync is not None and (world > 1 or sync.always):
         train.set_grad_hook(sync.bucket_ready, sync.groups)
         try:
-            loss.backward()
+            est.backward(dloss_dest)
         finally:
             train.set_grad_hook(None)
         sync.finish()                    # the compute stream waits for the last bucket; .grad now holds the mean
     else:
-        loss.backward()
+        est.backward(dloss_dest)
         if flat is not None and world > 1:
             dp.allreduce_mean_(dp.grads_as_flat(list(model.parameters()), flat), world)      # zero-copy when the backward wrote one buffer
     if hasattr(opt, "clip_and_step"):    # be_hip.optim.ClipAdamW: norm + clip + AdamW over the flat gradient buffer, two launches

@@ -203,7 +203,8 @@ def global_train(args, quiet=False):
         # every rank seeds torch identically (same shuffle, same initial weights); the dropout masks must NOT be identical across
         # the replicas of one global batch, so each rank salts the seed GlobalStage draws per step
         model.dropout_seed_salt = (rank * 0x9E3779B1) & 0x7FFFFFFF
-    opt = torch.optim.AdamW(model.parameters(), lr=args.learning_rate, fused=dp.fused_adamw())
+    from .optim import ClipAdamW
+    opt = ClipAdamW(model.parameters(), lr=args.learning_rate, gather=True)      # AdamW defaults of global_training.py:196, fused with the clipping
     helper = utils.PostProcessGlobalBase(args, dev)
     dcal = utils.DepthEtas(args, dev)
     gamma = GammaSchedule(args)

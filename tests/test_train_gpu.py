@@ -381,6 +381,26 @@ def test_global_training_loop_runs_and_descends():
     losses = [float(train_global.train_step(model, helper, dcal, opt, batch, ogl.GAMMA_FINAL)) for _ in range(8)]
     print("global loss", ["%.5f" % v for v in losses])
     assert all(np.isfinite(losses)) and losses[-1] < losses[0]
+    # round 4: the loops use be_hip.optim.ClipAdamW(gather=True) - the backward returns one gradient tensor per parameter, one
+    # multi-tensor copy gathers them into the optimizer's flat buffer - and must follow clip_grad_norm_ + torch.optim.AdamW
+    from be_hip.optim import ClipAdamW
+    torch.manual_seed(0)
+    model2 = models.GlobalStage(device=DEV).to(DEV)
+    for lyr in model2.encoder.layers:
+        lyr.dropout.p = lyr.dropout1.p = lyr.dropout2.p = 0.0
+        lyr.self_attn.dropout = 0.0
+    opt2 = ClipAdamW(model2.parameters(), lr=1e-4, gather=True)
+    model2.train()
+    losses2 = [float(train_global.train_step(model2, helper, dcal, opt2, batch, ogl.GAMMA_FINAL)) for _ in range(8)]
+    print("global loss (ClipAdamW)", ["%.5f" % v for v in losses2])
+    assert max(abs(a - b) / abs(a) for a, b in zip(losses, losses2)) <= 1e-4
+    p0 = next(model2.parameters())
+    assert p0.grad.data_ptr() == opt2._gbuf.data_ptr()               # .grad shows the clipped gradient, as after clip_grad_norm_
+    with pytest.raises(RuntimeError):                                # without gather=True scattered gradients are refused
+        o3 = ClipAdamW(model.parameters(), lr=1e-4)
+        for q in model.parameters():
+            q.grad = torch.zeros_like(q)
+        o3.clip_and_step(1.0)
     sched = train_global.GammaSchedule(args)
     g0 = sched.step()
     assert abs(g0["color"] - 1.0) < 1e-12 and abs(sched.final()["depth"] - 0.5) < 1e-12
@@ -1045,3 +1065,27 @@ def test_global_stage_dropout_seed_salt_decorrelates_identically_seeded_replicas
         with torch.no_grad():
             outs.append(m(x).clone())
     assert torch.equal(outs[0], outs[1]) and not torch.equal(outs[0], outs[2])
+
+
+def test_train_forward_reads_a_channels_last_batch_in_place():
+    """local_training.py:103 feeds `img_ny.permute(0,3,1,2)` - a view of the dataset's [B,21,21,3] batch.  The training forward
+    stages such a view straight into conv1's NHWC4 input (be_view_to_nhwc4_f32) instead of making an NCHW copy first: same bits."""
+    if not torch.cuda.is_available():
+        pytest.fail("gpu-marked test run without a GPU")
+    from be_hip import native
+    img = torch.from_numpy(synth.f32(synth.hash_uniform(9, "cl_batch", (64, 21, 21, 3)))).to(DEV)
+    view = img.permute(0, 3, 1, 2)
+    assert not view.is_contiguous()
+    a = native.patches_to_nhwc4(view)
+    b = native.nchw3_to_nhwc4(view.contiguous())
+    assert torch.equal(a, b) and a.data_ptr() != b.data_ptr()
+    assert torch.equal(native.patches_to_nhwc4(view.contiguous()), b)                 # a plain NCHW batch keeps its path
+    import models
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in synth.local_stage_state_dict().items()}
+    outs = []
+    for x in (view, view.contiguous()):
+        m = models.LocalStage()
+        m.load_state_dict(sd)
+        m = m.to(DEV).train()
+        outs.append(m(x))
+    assert torch.equal(outs[0], outs[1])
