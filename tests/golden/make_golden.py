@@ -672,7 +672,43 @@ def G17():
     save("g17_big_image", **out)
 
 
-GROUPS = dict(G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G8=G8, G9=G9, G10=G10, G11=G11, G12=G12, G13=G13, G14=G14, G15=G15, G16=G16, G17=G17)
+def G18():
+    """The reference's local training loop, free-running: local_training.py:99-108 for 20 steps at batch 64 (LocalStage in train mode with
+    batch statistics, LocalLoss at the final betas, clip_grad_norm_(1), AdamW(lr 6e-5)) on the portable synthetic training patches,
+    float32 and float64 runs: loss and total gradient norm of every step, final parameters (subsampled) and running statistics."""
+    B, STEPS = 64, 20
+    data = synth.synthetic_training_patches(B * STEPS, seed=1871)
+    a = ref_args("local_train")
+    out = {}
+    for tag, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        torch.manual_seed(0)
+        m = load_local_stage().to(dt).train()
+        crit = _local_helper(dt, B)
+        crit.final_beta()
+        opt = torch.optim.AdamW(m.parameters(), lr=a.learning_rate)
+        losses, norms = [], []
+        for it in range(STEPS):
+            b = {k: torch.from_numpy(v[it * B:(it + 1) * B]).to(dt) for k, v in data.items()}
+            est = m(b["img_ny"].permute(0, 3, 1, 2))
+            opt.zero_grad()
+            loss = crit(est, b["img_gt"], b["img_gt"], b["bndry_dist"], b["deri"])       # local_training.py:105 passes the clean image twice
+            loss.backward()
+            norms.append(float(torch.nn.utils.clip_grad_norm_(m.parameters(), max_norm=1, norm_type=2)))
+            opt.step()
+            losses.append(float(loss))
+            print(tag, it, losses[-1], norms[-1], flush=True)
+        sd = m.state_dict()
+        out[tag + "_loss"] = np.asarray(losses)
+        out[tag + "_grad_norm"] = np.asarray(norms)
+        for k in ("conv1.0.weight", "fc.4.weight", "fc.4.bias", "conv1.1.running_mean", "conv1.1.running_var", "fc.2.running_mean",
+                  "fc.2.running_var", "layer0.0.conv2.1.weight"):
+            out[f"{tag}_final_{k}"] = n(sd[k])
+        for k in ("layer2.0.conv2.0.weight", "fc.1.weight"):
+            out[f"{tag}_finalsub_{k}"] = n(sd[k].flatten()[::997])
+    save("g18_local_training_trajectory", **out)
+
+
+GROUPS = dict(G1=G1, G2=G2, G3=G3, G4=G4, G5=G5, G6=G6, G7=G7, G8=G8, G9=G9, G10=G10, G11=G11, G12=G12, G13=G13, G14=G14, G15=G15, G16=G16, G17=G17, G18=G18)
 
 if __name__ == "__main__":
     todo = sys.argv[1:] or list(GROUPS)
