@@ -406,3 +406,22 @@ def test_g17_big_image_band_matches_the_reference_run():
     assert int((dc > 1e-4).sum()) <= 2 and float(dc.max()) <= 3 / 100, dc.max()
     dd = (thr[band].sum(-1) - T(g["depth_map_rowsum"][220:279], torch.float64)).abs()
     assert int((dd > 1e-3).sum()) <= 2, dd.max()
+
+
+def test_oracle_training_step_vs_the_reference_trajectory_g18():
+    """g18 = the reference's own training loop (local_training.py:99-108) run free for 20 steps.  Step 0 of the float64 run pins the
+    oracle's TRAINING path end to end - train-mode forward with batch statistics, LocalLoss, autograd through both - by its loss
+    and by the total gradient norm clip_grad_norm_ reported."""
+    from oracle import local_stage as ols, render as orr
+    g = load_golden("g18_local_training_trajectory")
+    B = 64
+    data = synth.synthetic_training_patches(B * 20, seed=1871)
+    b = {k: torch.from_numpy(v[:B]).double() for k, v in data.items()}
+    sd = ols.to_torch_sd(synth.local_stage_state_dict(), torch.float64)
+    params = {k: v.requires_grad_(True) for k, v in sd.items() if v.is_floating_point() and "running" not in k}
+    est = ols.local_stage_forward({**sd, **params}, b["img_ny"].permute(0, 3, 1, 2), training=True)
+    loss = orr.local_loss(est, b["img_gt"], b["img_gt"], b["bndry_dist"], b["deri"], 1e-3, 5e-4)[0]
+    grads = torch.autograd.grad(loss, list(params.values()))
+    norm = float(torch.sqrt(sum((gr ** 2).sum() for gr in grads)))
+    assert abs(float(loss) - float(g["f64_loss"][0])) <= 1e-10 * abs(float(g["f64_loss"][0]))
+    assert abs(norm - float(g["f64_grad_norm"][0])) <= 1e-8 * float(g["f64_grad_norm"][0])
