@@ -37,7 +37,7 @@ def _setup(rank):
     return args, model, helper, batch
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, algorithm="allreduce"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -49,7 +49,7 @@ def _worker(rank, world, port, q):
                 p.add_(0.5)
     dp.broadcast_parameters(model, src=0)                           # ... is aligned with rank 0 first
     opt = torch.optim.SGD(model.parameters(), lr=0.0)               # lr 0: the step leaves the (clipped) means in .grad
-    sync = dp.GradSync(world)
+    sync = dp.GradSync(world, algorithm=algorithm)
     stats = {}
     train_local.train_step(model, helper, opt, batch, args.beta_bndry_loc, args.beta_smthns, world=world, clip=1e9, stats=stats,
                            sync=sync)
@@ -60,13 +60,15 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_processes_on_one_gpu_train_step_world_2_gives_the_mean_gradient():
+@pytest.mark.parametrize("algorithm", ["allreduce", "rs_ag"])
+def test_two_processes_on_one_gpu_train_step_world_2_gives_the_mean_gradient(algorithm):
+    """algorithm "rs_ag" (round 4): every bucket as reduce_scatter + all_gather - the same mean, bit for bit, on two ranks."""
     if not torch.cuda.is_available():
         pytest.fail("gpu-marked test run without a GPU")
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, algorithm)) for r in range(2)]
     for p in procs:
         p.start()
     got = dict()
