@@ -11,9 +11,9 @@ with the input already resident in HBM.  Prints ONE JSON line (rank 0).
 
 `value` is that configuration and nothing else.  The same line also carries (outside the timed region of `value`):
   roofline       the dominant kernel of the step, measured live with hipEvents on the launch stream (SURVEY 8d);
-                 `frac` = the FLOPs of the algorithm that runs (Winograd F(3x3,3x3) on layers 1-3: what the matrix pipe issues)
+                 `frac` = the FLOPs of the algorithm that runs (Winograd tiles on layers 1-3: what the matrix pipe issues)
                  / duration / peak, a utilisation <= 1; `direct_conv_equivalent_frac` = the same time priced in the reference's
-                 direct-convolution FLOPs (324 multiplies where F(3x3,3x3) does 100), which exceeds 1
+                 direct-convolution FLOPs (324 multiplies where the Winograd tiles do 80), which exceeds 1
   extra_configs  configs[2] (local training step as a hipGraph), configs[3] (147x147 and 587x587 image pairs end to end), the global-stage
                  training step at batch 8,
                  each with its own clock and dominant kernel
@@ -47,9 +47,10 @@ PEAK_FP32_MFMA_TFLOPS = 157.3         # MI355X_MICROARCH.md: dense fp32 matrix p
 PEAK_HBM_TBPS = 8.0                   # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s is what a float4 copy reaches)
 CPU_SAMPLE_PAIRS = 4096               # the WHOLE configs[1] workload (not a quarter of it): ~8 s per run on 16 threads,
 CPU_REPEATS = 3                       # 3 repeats, median: ~25 s of CPU work (the task's bound for this leg: 10-30 s)
-# kernel id 6 = the 25 transform-domain GEMMs of one Winograd layer: the hooks count the 25 x 2 x 4n x cin x cout FLOPs they
-# execute; the same layer as a direct 3x3 convolution on a 6x6 map is 2 x 36 x 9 x n x cin x cout
-ALGO_OVER_HOOK = {6: (2.0 * 36 * 9) / (25.0 * 2 * 4)}
+# kernel id 6 = the transform-domain GEMMs of one Winograd layer (one per position): the hooks count the positions x 2 x tiles x cin x
+# cout FLOPs they execute; the same layer as a direct 3x3 convolution on a 6x6 map is 2 x 36 x 9 x n x cin x cout.
+# positions x tiles per map = 40 x 2 (8x5 tiles, be_wino_tile_rows() = 6) or 25 x 4 (5x5 tiles): filled in main()
+ALGO_OVER_HOOK = {}
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
 
 
@@ -443,6 +444,9 @@ def main():
     from be_hip import native, synth
     import models, utils
     native.lib()                                   # fails loudly if the HIP library is missing
+    wino_rows = native.lib().be_wino_tile_rows()
+    wino_mults = 5 * (wino_rows + 2) * (12 // wino_rows)          # multiplies per 6x6 map and channel pair: 80 or 100
+    ALGO_OVER_HOOK[6] = (2.0 * 36 * 9) / (2.0 * wino_mults)
 
     # ---- synthetic workload, resident in HBM before the timed region (each rank: its own shard)
     x_np, z_gt = synth.synthetic_patch_pairs(PAIRS, seed=synth.SEED_DEFAULT + rank)
@@ -506,7 +510,7 @@ def main():
                 print(f"{i:4d}  {rr[0][0]:5d}  {rr[0][1] / 1e9:8.2f}  {ms_i:7.4f}  {rr[0][1] / ms_i / 1e9:8.2f}", file=sys.stderr)
         if prof:
             executed_per_pair = sum(r[4] for r in recs) / args.steps / PAIRS
-            # achieved / frac = the FLOPs of the algorithm that RUNS (Winograd F(3x3,3x3): the 25 transform-domain GEMMs) over the
+            # achieved / frac = the FLOPs of the algorithm that RUNS (the transform-domain GEMMs of the Winograd tiles) over the
             # launch duration: a utilisation, <= 1.  The same time priced in the reference's direct-convolution FLOPs
             # (SURVEY 8d's per-unit figure) is kept next to it under an explicit name; it exceeds 1 by the arithmetic saving.
             roof = dict(bound="mfma", kernel=prof["kernel"], achieved=prof["executed_tflops"], peak=round(peak, 1), unit="TFLOP/s",
@@ -527,13 +531,14 @@ def main():
                         schedule="this pass: one stream (model.streams = 1), so that every launch has the chip to itself; the timed region "
                                  f"of `value`: {timed_streams} stream(s) (two half-batches of 4096 patches on two side streams fill each "
                                  "other's tails: DESIGN 3.1f)",
-                        definitions="achieved / frac (= executed_*): the FLOPs of the algorithm this kernel runs - the 25 transform-domain "
-                                    "GEMMs of a Winograd F(3x3,3x3) layer, 25*2*4n*cin*cout, tile padding included; equal to what the MFMA "
+                        definitions="achieved / frac (= executed_*): the FLOPs of the algorithm this kernel runs - the transform-domain "
+                                    f"GEMMs of a Winograd layer ({wino_mults} multiplies per 6x6 map and channel pair: "
+                                    f"{2 * wino_mults}*n*cin*cout FLOPs), tile padding included; equal to what the MFMA "
                                     "pipe issued (PMC SQ_INSTS_VALU_MFMA_MOPS_F32 x 512) - / its average launch duration (hipEvents on the "
                                     "launch stream, this run) / the dense fp32 matrix peak: the utilisation of the matrix pipe, <= 1; "
                                     "end_to_end_frac prices the whole step that way.  direct_conv_equivalent_*: the same durations priced in "
                                     "the reference's direct-convolution FLOPs (SURVEY 8d: 2*MAC incl. zero-padding taps, 324 multiplies per "
-                                    "map and channel pair where F(3x3,3x3) does 100): exceeds 1 by the arithmetic saving, not by skipped work")
+                                    f"map and channel pair where the Winograd tiles do {wino_mults}): exceeds 1 by the arithmetic saving, not by skipped work")
             # HBM bytes per launch come from separate rocprofv3 --pmc passes (profiles/), never from this run.  The record names
             # the kernel sources it was measured on (sha256): while those are byte-identical to the sources of the library that
             # is running, the counters describe the running kernel and `traffic` is filled; otherwise only `traffic_recorded`

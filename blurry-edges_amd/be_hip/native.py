@@ -91,6 +91,7 @@ _SIGNATURES = {
     "be_conv_nhwc_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, C.c_int, _P]),
     "be_conv_nhwc_splitk_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, _P, C.c_int, _P, C.c_size_t, _P]),
     "be_conv_nhwc_batched_f32": (C.c_int, [C.POINTER(ConvDesc), _P, _P, _P, _P, C.c_int, C.c_int, C.c_int64, C.c_int64, C.c_int64, _P]),
+    "be_wino_tile_rows": (C.c_int, []),
     "be_wino_packed_floats": (C.c_size_t, [C.c_int, C.c_int]),
     "be_wino_pack_f32": (C.c_int, [_P] * 6 + [C.c_float, C.c_int, C.c_int, _P, _P, _P]),
     "be_wino_workspace_floats": (C.c_size_t, [C.c_int64, C.c_int, C.c_int]),
@@ -747,7 +748,7 @@ def local_stage_forward_view(packed, view, patches_per_image: int, n: int, devic
 KERNEL_NAMES = {0: "k_conv_igemm<2,2,2,2,TAPS> (128x128)", 1: "k_conv_igemm<4,1,1,3,TAPS> (128x96)",
                 2: "k_conv_igemm<4,1,1,2,TAPS> (128x64)", 3: "k_conv_igemm<4,1,1,1,TAPS> (128x32)",
                 4: "k_conv_igemm<4,1,1,2,ROW8> (conv1)", 5: "k_conv_igemm small-M tiles (64x64 / 128x32)",
-                6: "k_wino_gemm_ws / k_wino_gemm (128x128 tiles, the 25 Winograd transform-domain GEMMs of a layer per launch; weight-stationary form for K = 96 / 256 / 384 and full tiles)",
+                6: "k_wino_gemm_ws / k_wino_gemm (128x128 tiles, the Winograd transform-domain GEMMs of a layer - one per position: 40 for the 8x5 tiles - per launch; weight-stationary form for K = 96 / 256 / 384 and full tiles)",
                 7: "k_wino_gemm as a row GEMM (1x1 convolutions / linears of large batches)",
                 8: "k_wino_in / k_wino_out_in / k_wino_out / k_wino_out_pool2 (Winograd transforms)", 9: "k_maxpool_nhwc",
                 10: "k_render_colors (pass A)", 11: "conv1 input staging",

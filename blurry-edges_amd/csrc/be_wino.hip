@@ -22,18 +22,12 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+// tile shape (be_wino_math.h): TH x 3 outputs per tile from an NR x 5 window; TPI tiles per 6x6 map; NPOS positions = GEMMs
+constexpr int TH = be::WINO_TH, NR = be::WINO_NR, TY = be::WINO_TY, TPI = be::WINO_TPI, NPOS = be::WINO_NPOS, NOUT = be::WINO_OUT;
+
 inline unsigned grid_cap(int64_t total, int block, int64_t limit = 65535) {
     int64_t g = (total + block - 1) / block;
     return (unsigned)(g < 1 ? 1 : (g > limit ? limit : g));
-}
-
-// G (5x3): rows 1/2 [1 0 0], -1/2 [1 1 1], -1/6 [1 -1 1], 1/6 [1 2 4], [0 0 1]
-__device__ __forceinline__ void g_rows(const float a, const float b, const float c, float out[5]) {
-    out[0] = 0.5f * a;
-    out[1] = -0.5f * (a + b + c);
-    out[2] = -(a - b + c) * (1.0f / 6.0f);
-    out[3] = (a + 2.0f * b + 4.0f * c) * (1.0f / 6.0f);
-    out[4] = c;
 }
 
 __global__ void k_wino_pack(const float* __restrict__ w, const float* __restrict__ b, const float* __restrict__ gamma,
@@ -43,28 +37,28 @@ __global__ void k_wino_pack(const float* __restrict__ w, const float* __restrict
     const int64_t gs = (int64_t)gridDim.x * blockDim.x;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gs) {
         const int co = (int)(idx / cin), ci = (int)(idx % cin);
-        float u[5][5];
+        float u[NR][5];
         if (co < cout) {
             const float scale = gamma ? gamma[co] / sqrtf(var[co] + eps) : 1.0f;
             const float* g = w + ((size_t)co * cin + ci) * 9;
-            float t[5][3];                                  // G g
+            float t[NR][3];                                 // G_rows g: the kernel's three rows -> NR transform rows, column by column
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                float col[5];
-                g_rows(g[c] * scale, g[3 + c] * scale, g[6 + c] * scale, col);
+                float col[NR];
+                be::wino_g_rows(g[c] * scale, g[3 + c] * scale, g[6 + c] * scale, col);
 #pragma unroll
-                for (int r = 0; r < 5; ++r) t[r][c] = col[r];
+                for (int r = 0; r < NR; ++r) t[r][c] = col[r];
             }
 #pragma unroll
-            for (int r = 0; r < 5; ++r) g_rows(t[r][0], t[r][1], t[r][2], u[r]);     // (G g) G^T
+            for (int r = 0; r < NR; ++r) be::wino_g5(t[r][0], t[r][1], t[r][2], u[r]);     // (G_rows g) G^T
         } else {
 #pragma unroll
-            for (int r = 0; r < 5; ++r)
+            for (int r = 0; r < NR; ++r)
 #pragma unroll
                 for (int c = 0; c < 5; ++c) u[r][c] = 0.0f;
         }
 #pragma unroll
-        for (int r = 0; r < 5; ++r)
+        for (int r = 0; r < NR; ++r)
 #pragma unroll
             for (int c = 0; c < 5; ++c) U[(size_t)(5 * r + c) * total + idx] = u[r][c];
     }
@@ -86,34 +80,34 @@ template <int NT> __device__ __forceinline__ void st_s(f32x4* p, f32x4 v) {
     if constexpr (NT & 2) __builtin_nontemporal_store(v, p); else *p = v;
 }
 
-// one thread = one tile (patch, ty, tx) x one channel quad; arithmetic: be_wino_math.h (shared with the fused GEMM epilogue)
+// one thread = one tile (patch, ty, tx) x one channel quad; arithmetic: be_wino_math.h
 template <int NT>
 __global__ __launch_bounds__(256)
 void k_wino_in(const float* __restrict__ x, float* __restrict__ V, int64_t n, int c4, int tm) {
-    const int64_t total = n * 4 * c4;
+    const int64_t total = n * TPI * c4;
     const int64_t gs = (int64_t)gridDim.x * blockDim.x;
-    // float4 elements between transform positions / between tiles: plane-major V [25][4n][C] (small batches) or
-    // tile-major V [4n][25][C] (large batches: a tile's 25 x C block is one contiguous piece of HBM for this kernel)
-    const int64_t plane = tm ? c4 : n * 4 * c4, ts = tm ? 25 * c4 : c4;
+    // float4 elements between transform positions / between tiles: plane-major V [NPOS][TPI n][C] (small batches) or
+    // tile-major V [TPI n][NPOS][C] (large batches: a tile's NPOS x C block is one contiguous piece of HBM for this kernel)
+    const int64_t plane = tm ? c4 : n * TPI * c4, ts = tm ? NPOS * c4 : c4;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gs) {
         const int cq = (int)(idx % c4);
         const int64_t tile = idx / c4;
-        const int64_t img = tile >> 2;
-        const int ty = (int)(tile >> 1) & 1, tx = (int)tile & 1;
+        const int64_t img = tile / TPI;
+        const int tt = (int)(tile - img * TPI), ty = tt >> 1, tx = tt & 1;
         const f32x4* src = reinterpret_cast<const f32x4*>(x) + img * 36 * c4 + cq;
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-        f32x4 d[5][5], v[25];
+        f32x4 d[NR][5], v[NPOS];
 #pragma unroll
-        for (int r = 0; r < 5; ++r)
+        for (int r = 0; r < NR; ++r)
 #pragma unroll
             for (int c = 0; c < 5; ++c) {
-                const int yy = 3 * ty - 1 + r, xx = 3 * tx - 1 + c;
+                const int yy = TH * ty - 1 + r, xx = 3 * tx - 1 + c;
                 d[r][c] = ((unsigned)xx < 6u && (unsigned)yy < 6u) ? ld_s<NT>(src + (size_t)(yy * 6 + xx) * c4) : zero;
             }
-        be::wino_in25(d, v);
+        be::wino_in(d, v);
         f32x4* dst = reinterpret_cast<f32x4*>(V) + tile * ts + cq;
 #pragma unroll
-        for (int z = 0; z < 25; ++z) st_s<NT>(dst + (size_t)z * plane, v[z]);
+        for (int z = 0; z < NPOS; ++z) st_s<NT>(dst + (size_t)z * plane, v[z]);
     }
 }
 
@@ -127,34 +121,34 @@ template <int NT>
 __global__ __launch_bounds__(256)
 void k_wino_out(const float* __restrict__ M, const float* __restrict__ bias, const float* __restrict__ res,
                 float* __restrict__ y, int64_t n, int c4, int act, int tm) {
-    const int64_t total = n * 4 * c4;
+    const int64_t total = n * TPI * c4;
     const int64_t gs = (int64_t)gridDim.x * blockDim.x;
-    const int64_t plane = tm ? c4 : n * 4 * c4, ts = tm ? 25 * c4 : c4;
+    const int64_t plane = tm ? c4 : n * TPI * c4, ts = tm ? NPOS * c4 : c4;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gs) {
         const int cq = (int)(idx % c4);
         const int64_t tile = idx / c4;
-        const int64_t img = tile >> 2;
-        const int ty = (int)(tile >> 1) & 1, tx = (int)tile & 1;
+        const int64_t img = tile / TPI;
+        const int tt = (int)(tile - img * TPI), ty = tt >> 1, tx = tt & 1;
         const f32x4* src = reinterpret_cast<const f32x4*>(M) + tile * ts + cq;
-        f32x4 m[25], o[9], rv[9];
+        f32x4 m[NPOS], o[NOUT], rv[NOUT];
 #pragma unroll
-        for (int z = 0; z < 25; ++z) m[z] = ld_s<NT>(src + (size_t)z * plane);
-        // the residual's nine values are fetched with the 25 transform-domain ones (inside the store loop each was a round trip of
+        for (int z = 0; z < NPOS; ++z) m[z] = ld_s<NT>(src + (size_t)z * plane);
+        // the residual's values are fetched with the transform-domain ones (inside the store loop each was a round trip of
         // its own: the kernel sat 58 % of its wave cycles in s_waitcnt)
         if (res) {
 #pragma unroll
-            for (int r = 0; r < 3; ++r)
+            for (int r = 0; r < TH; ++r)
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    rv[3 * r + c] = ld_s<NT>(reinterpret_cast<const f32x4*>(res) + ((size_t)img * 36 + (3 * ty + r) * 6 + 3 * tx + c) * c4 + cq);
+                    rv[3 * r + c] = ld_s<NT>(reinterpret_cast<const f32x4*>(res) + ((size_t)img * 36 + (TH * ty + r) * 6 + 3 * tx + c) * c4 + cq);
         }
-        be::wino_out9(m, o);
+        be::wino_out(m, o);
         const f32x4 bv = reinterpret_cast<const f32x4*>(bias)[cq];
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+        for (int r = 0; r < TH; ++r)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
-                const size_t e = ((size_t)img * 36 + (3 * ty + r) * 6 + 3 * tx + c) * c4 + cq;
+                const size_t e = ((size_t)img * 36 + (TH * ty + r) * 6 + 3 * tx + c) * c4 + cq;
                 f32x4 v = o[3 * r + c] + bv;
                 if (res) v += rv[3 * r + c];
                 st_s<NT>(reinterpret_cast<f32x4*>(y) + e, wino_act(v, act));
@@ -163,52 +157,52 @@ void k_wino_out(const float* __restrict__ M, const float* __restrict__ bias, con
 }
 
 // conv1 -> conv2 of a residual block without the intermediate map in HBM: one thread = one image x one channel quad reads the
-// 100 transform-domain values of conv1's result, forms the 6x6 map (+ bias, Smish) in registers and writes the 100
-// transform-domain values conv2's GEMMs read.  Saves the 36 values written and re-read (4x, tile overlap) per channel.
+// TPI x NPOS transform-domain values of conv1's result, forms the 6x6 map (+ bias, Smish) in registers and writes the TPI x NPOS
+// transform-domain values conv2's GEMMs read.  Saves the 36 values written and re-read (tile overlap) per channel.
 template <int NT>
 __global__ __launch_bounds__(256, 1)
 void k_wino_out_in(const float* __restrict__ M, const float* __restrict__ bias, float* __restrict__ V, int64_t n, int c4, int act,
                    int tm_in, int tm_out) {
     const int64_t total = n * c4;
     const int64_t gs = (int64_t)gridDim.x * blockDim.x;
-    const int64_t plane = tm_in ? c4 : n * 4 * c4, ts = tm_in ? 25 * c4 : c4;          // M as conv1's GEMMs wrote it
-    const int64_t plane_o = tm_out ? c4 : n * 4 * c4, ts_o = tm_out ? 25 * c4 : c4;    // V as conv2's GEMMs read it
+    const int64_t plane = tm_in ? c4 : n * TPI * c4, ts = tm_in ? NPOS * c4 : c4;          // M as conv1's GEMMs wrote it
+    const int64_t plane_o = tm_out ? c4 : n * TPI * c4, ts_o = tm_out ? NPOS * c4 : c4;    // V as conv2's GEMMs read it
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gs) {
         const int cq = (int)(idx % c4);
         const int64_t img = idx / c4;
         const f32x4 bv = reinterpret_cast<const f32x4*>(bias)[cq];
         f32x4 y[6][6];
 #pragma unroll
-        for (int ty = 0; ty < 2; ++ty)
+        for (int ty = 0; ty < TY; ++ty)
 #pragma unroll
             for (int tx = 0; tx < 2; ++tx) {
-                const f32x4* src = reinterpret_cast<const f32x4*>(M) + (img * 4 + ty * 2 + tx) * ts + cq;
-                f32x4 m[25], o[9];
+                const f32x4* src = reinterpret_cast<const f32x4*>(M) + (img * TPI + ty * 2 + tx) * ts + cq;
+                f32x4 m[NPOS], o[NOUT];
 #pragma unroll
-                for (int z = 0; z < 25; ++z) m[z] = ld_s<NT>(src + (size_t)z * plane);
-                be::wino_out9(m, o);
+                for (int z = 0; z < NPOS; ++z) m[z] = ld_s<NT>(src + (size_t)z * plane);
+                be::wino_out(m, o);
 #pragma unroll
-                for (int r = 0; r < 3; ++r)
+                for (int r = 0; r < TH; ++r)
 #pragma unroll
-                    for (int c = 0; c < 3; ++c) y[3 * ty + r][3 * tx + c] = wino_act(o[3 * r + c] + bv, act);
+                    for (int c = 0; c < 3; ++c) y[TH * ty + r][3 * tx + c] = wino_act(o[3 * r + c] + bv, act);
             }
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ty = 0; ty < 2; ++ty)
+        for (int ty = 0; ty < TY; ++ty)
 #pragma unroll
             for (int tx = 0; tx < 2; ++tx) {
-                f32x4 d[5][5], v[25];
+                f32x4 d[NR][5], v[NPOS];
 #pragma unroll
-                for (int r = 0; r < 5; ++r)
+                for (int r = 0; r < NR; ++r)
 #pragma unroll
                     for (int c = 0; c < 5; ++c) {
-                        const int yy = 3 * ty - 1 + r, xx = 3 * tx - 1 + c;
+                        const int yy = TH * ty - 1 + r, xx = 3 * tx - 1 + c;
                         d[r][c] = (xx >= 0 && xx < 6 && yy >= 0 && yy < 6) ? y[yy < 0 ? 0 : (yy > 5 ? 5 : yy)][xx < 0 ? 0 : (xx > 5 ? 5 : xx)] : zero;
                     }
-                be::wino_in25(d, v);
-                f32x4* dst = reinterpret_cast<f32x4*>(V) + (img * 4 + ty * 2 + tx) * ts_o + cq;
+                be::wino_in(d, v);
+                f32x4* dst = reinterpret_cast<f32x4*>(V) + (img * TPI + ty * 2 + tx) * ts_o + cq;
 #pragma unroll
-                for (int z = 0; z < 25; ++z) st_s<NT>(dst + (size_t)z * plane_o, v[z]);
+                for (int z = 0; z < NPOS; ++z) st_s<NT>(dst + (size_t)z * plane_o, v[z]);
             }
     }
 }
@@ -222,35 +216,35 @@ void k_wino_out_pool2(const float* __restrict__ M, const float* __restrict__ bia
                       float* __restrict__ y, int64_t n, int c4, int act, int tm) {
     const int64_t total = n * c4;
     const int64_t gs = (int64_t)gridDim.x * blockDim.x;
-    const int64_t plane = tm ? c4 : n * 4 * c4, ts = tm ? 25 * c4 : c4;
+    const int64_t plane = tm ? c4 : n * TPI * c4, ts = tm ? NPOS * c4 : c4;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gs) {
         const int cq = (int)(idx % c4);
         const int64_t img = idx / c4;
         const f32x4 bv = reinterpret_cast<const f32x4*>(bias)[cq];
         f32x4 v[6][6];
 #pragma unroll
-        for (int ty = 0; ty < 2; ++ty)
+        for (int ty = 0; ty < TY; ++ty)
 #pragma unroll
             for (int tx = 0; tx < 2; ++tx) {
-                const f32x4* src = reinterpret_cast<const f32x4*>(M) + (img * 4 + ty * 2 + tx) * ts + cq;
-                f32x4 m[25], o[9], rv[9];
+                const f32x4* src = reinterpret_cast<const f32x4*>(M) + (img * TPI + ty * 2 + tx) * ts + cq;
+                f32x4 m[NPOS], o[NOUT], rv[NOUT];
 #pragma unroll
-                for (int z = 0; z < 25; ++z) m[z] = ld_s<NT>(src + (size_t)z * plane);
-                if (res) {                                   // with the tile's 25 loads, not one by one behind the transform
+                for (int z = 0; z < NPOS; ++z) m[z] = ld_s<NT>(src + (size_t)z * plane);
+                if (res) {                                   // with the tile's loads, not one by one behind the transform
 #pragma unroll
-                    for (int r = 0; r < 3; ++r)
+                    for (int r = 0; r < TH; ++r)
 #pragma unroll
                         for (int c = 0; c < 3; ++c)
-                            rv[3 * r + c] = ld_s<NT>(reinterpret_cast<const f32x4*>(res) + ((size_t)img * 36 + (3 * ty + r) * 6 + 3 * tx + c) * c4 + cq);
+                            rv[3 * r + c] = ld_s<NT>(reinterpret_cast<const f32x4*>(res) + ((size_t)img * 36 + (TH * ty + r) * 6 + 3 * tx + c) * c4 + cq);
                 }
-                be::wino_out9(m, o);
+                be::wino_out(m, o);
 #pragma unroll
-                for (int r = 0; r < 3; ++r)
+                for (int r = 0; r < TH; ++r)
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
                         f32x4 w = o[3 * r + c] + bv;
                         if (res) w += rv[3 * r + c];
-                        v[3 * ty + r][3 * tx + c] = wino_act(w, act);
+                        v[TH * ty + r][3 * tx + c] = wino_act(w, act);
                     }
             }
 #pragma unroll
@@ -610,22 +604,30 @@ int launch_ws(const GemmArgs& g, hipStream_t s, int64_t n, int cin, int cout, in
     static be::DeviceFlags attr_set{};                      // dynamic-LDS cap raised once per device (thread-safe)
     if (int rc_ = be::ensure_dynamic_lds(reinterpret_cast<const void*>(&k_wino_gemm_ws<KCH, KIND>), lds, attr_set)) return rc_;
     const int cus = be::device_cu_count();
-    // R rounds of ONE workgroup per CU (the kernel takes the whole register file of a CU).  Workgroup ids go round-robin over the
-    // 8 XCDs, so the count that has to fit is per XCD: ceil(units / 8) * n_tiles <= R * (CUs per XCD) - one workgroup too many
-    // on an XCD is a whole extra round for everybody.  At least 8 M ranges per problem when there is that much work.
+    // ONE workgroup per CU at a time (the kernel takes the whole register file of a CU).  Workgroup ids go round-robin over the 8
+    // XCDs, so what has to fit is per XCD: ceil(units / 8) * n_tiles workgroups in rounds of (CUs per XCD).  mgroups = M ranges per
+    // problem: the launch lasts rounds x (tiles per range + the register fill, ~0.3 of a tile's time).  Searched, not guessed
+    // (round 4): with 40 problems x 128 row tiles and N = 256 the old rule (first round count that gives >= 8 ranges) chose 9 ranges =
+    // 3 rounds of 15 tiles where 16 ranges are exactly 5 rounds of 8 (ideal: 40 tile times per CU; 45 -> 41).
     const int per_xcd = cus / 8 > 0 ? cus / 8 : 1;
     int mgroups = 1;
-    for (int rounds = 1; rounds <= 16; ++rounds) {
-        const int units_max = 8 * (per_xcd * rounds / g.n_tiles);
-        mgroups = units_max / g.nb;
-        if (mgroups >= 8 || mgroups >= g.m_tiles / 4) break;
+    {
+        const int mg_max = g.m_tiles / 4 > 0 ? g.m_tiles / 4 : 1;                   // >= 4 tiles per register fill
+        double best = 1e30;
+        for (int mg = 1; mg <= mg_max; ++mg) {
+            const int tiles_per = (g.m_tiles + mg - 1) / mg;
+            const int ranges = (g.m_tiles + tiles_per - 1) / tiles_per;             // ranges that really have tiles
+            if (ranges != mg) continue;
+            const int wg_xcd = ((g.nb * mg + 7) / 8) * g.n_tiles;
+            const int rounds = (wg_xcd + per_xcd - 1) / per_xcd;
+            const double cost = rounds * (tiles_per + 0.3);
+            if (cost < best - 1e-9) { best = cost; mgroups = mg; }
+        }
     }
-    if (mgroups < 1) mgroups = 1;
-    if (mgroups > g.m_tiles / 4) mgroups = g.m_tiles / 4 > 0 ? g.m_tiles / 4 : 1;     // >= 4 tiles per register fill
     const int units = g.nb * mgroups;
     const unsigned grid = (unsigned)(8 * ((units + 7) / 8) * g.n_tiles);
     {
-        const double rows = kid == BE_KERNEL_WINO_GEMM ? 4.0 * n : (double)n, probs = g.nb;
+        const double rows = kid == BE_KERNEL_WINO_GEMM ? (double)TPI * n : (double)n, probs = g.nb;
         be::ProfileScope prof(s, kid, probs * 2.0 * rows * cin * cout,
                               probs * 4.0 * (rows * cin + (double)cin * cout + rows * cout),
                               probs * 2.0 * g.m_tiles * g.n_tiles * 128.0 * 128.0 * cin);
@@ -636,9 +638,11 @@ int launch_ws(const GemmArgs& g, hipStream_t s, int64_t n, int cin, int cout, in
 
 }  // namespace
 
+extern "C" int be_wino_tile_rows(void) { return TH; }
+
 extern "C" size_t be_wino_packed_floats(int cout, int cin) {
     if (cout <= 0 || cin <= 0 || cin % 32) return 0;
-    return (size_t)25 * ((cout + 31) / 32 * 32) * cin;
+    return (size_t)NPOS * ((cout + 31) / 32 * 32) * cin;
 }
 
 extern "C" int be_wino_pack_f32(const float* w, const float* b, const float* gamma, const float* beta, const float* mean,
@@ -656,7 +660,7 @@ extern "C" int be_wino_pack_f32(const float* w, const float* b, const float* gam
 
 extern "C" size_t be_wino_workspace_floats(int64_t n, int cin, int cout) {
     if (n <= 0) return 0;
-    return (size_t)100 * n * ((size_t)cin + cout);              // V [25][4n][cin] + M [25][4n][cout]
+    return (size_t)100 * n * ((size_t)cin + cout);              // room for V + M of either tile shape (NPOS x TPI = 100 or 80 values per channel)
 }
 
 namespace {
@@ -664,7 +668,7 @@ namespace {
 // large batches take k_wino_gemm and the tile-major buffers, small ones the batched k_conv_igemm launch and plane-major buffers
 bool wino_large(int64_t n, int cout) {
     static const bool no_persist = getenv("BE_WINO_NO_PERSIST") != nullptr;        // A/B knob
-    return ((cout + 31) / 32 * 32) % 128 == 0 && 4 * n >= 4096 && !no_persist && 100 * n * (int64_t)cout < ((int64_t)1 << 31);
+    return ((cout + 31) / 32 * 32) % 128 == 0 && n >= 1024 && !no_persist && (int64_t)NPOS * TPI * n * (int64_t)cout < ((int64_t)1 << 31);
 }
 
 int wino_gemms(const float* V, const float* packed_w, float* M, int64_t n, int cin, int cout, hipStream_t s, void* stream) {
@@ -675,29 +679,31 @@ int wino_gemms(const float* V, const float* packed_w, float* M, int64_t n, int c
         static be::DeviceFlags attr_set{};                      // dynamic-LDS cap raised once per device (thread-safe)
         if (int rc_ = be::ensure_dynamic_lds(reinterpret_cast<const void*>(&k_wino_gemm<0>), lds, attr_set)) return rc_;
         // tile-major V [4n][25][cin] and M [4n][25][cout]: problem z = column block z of a row
-        GemmArgs g{V, packed_w, M, (int)(4 * n), cin, cout, 25 * cout, 25, (int)((4 * n + 127) / 128), cp / 128,
-                   (int64_t)cin, (int64_t)cp * cin, (int64_t)cout, 25 * cin, 128, 0, nullptr, nullptr, 0};
+        const int64_t rows = (int64_t)TPI * n;
+        GemmArgs g{V, packed_w, M, (int)rows, cin, cout, NPOS * cout, NPOS, (int)((rows + 127) / 128), cp / 128,
+                   (int64_t)cin, (int64_t)cp * cin, (int64_t)cout, NPOS * cin, 128, 0, nullptr, nullptr, 0};
         // weight-stationary form: full tiles only, enough M tiles to amortise the register fill, cout a multiple of 128
         static const bool no_ws = getenv("BE_WINO_NO_WS") != nullptr;               // A/B knob
-        static const int ws_min_tiles = getenv("BE_WINO_WS_MIN_TILES") ? atoi(getenv("BE_WINO_WS_MIN_TILES")) : 128;   // A/B knob
-        if (!no_ws && (4 * n) % 128 == 0 && g.m_tiles >= ws_min_tiles && cout % 128 == 0) {
+        // (>= 64 row tiles: a 4096-patch half of the two-stream schedule has 2 x 4096 rows per position with the 8x5 tiles)
+        static const int ws_min_tiles = getenv("BE_WINO_WS_MIN_TILES") ? atoi(getenv("BE_WINO_WS_MIN_TILES")) : (TPI == 2 ? 64 : 128);   // A/B knob
+        if (!no_ws && rows % 128 == 0 && g.m_tiles >= ws_min_tiles && cout % 128 == 0) {
             if (cin == 96) return launch_ws<6>(g, s, n, cin, cout);
             if (cin == 256) return launch_ws<16>(g, s, n, cin, cout);
             if (cin == 384) return launch_ws<24>(g, s, n, cin, cout);
         }
         const unsigned grid = (unsigned)(8 * ((g.m_tiles + 7) / 8) * g.n_tiles);
         {
-            be::ProfileScope prof(s, BE_KERNEL_WINO_GEMM, 25.0 * 2.0 * 4 * n * cin * cout,
-                                  25.0 * 4.0 * (4.0 * n * cin + (double)cin * cout + 4.0 * n * cout),
-                                  25.0 * 2.0 * g.m_tiles * g.n_tiles * 128.0 * 128.0 * cin);
+            be::ProfileScope prof(s, BE_KERNEL_WINO_GEMM, (double)NPOS * 2.0 * rows * cin * cout,
+                                  (double)NPOS * 4.0 * ((double)rows * cin + (double)cin * cout + (double)rows * cout),
+                                  (double)NPOS * 2.0 * g.m_tiles * g.n_tiles * 128.0 * 128.0 * cin);
             hipLaunchKernelGGL(k_wino_gemm<0>, dim3(grid), dim3(256), lds, s, g);
         }
         return be::check_launch("be_wino_conv3x3_6x6_f32(gemm)");
     }
     be_conv_desc d;
-    d.n = (int)(4 * n); d.h = 1; d.w = 1; d.cin = cin; d.cout = cout; d.ksize = 1; d.act = 0;
-    return be_conv_nhwc_batched_f32(&d, V, packed_w, nullptr, M, cout, 25, (int64_t)4 * n * cin, (int64_t)cp * cin,
-                                    (int64_t)4 * n * cout, stream);
+    d.n = (int)(TPI * n); d.h = 1; d.w = 1; d.cin = cin; d.cout = cout; d.ksize = 1; d.act = 0;
+    return be_conv_nhwc_batched_f32(&d, V, packed_w, nullptr, M, cout, NPOS, (int64_t)TPI * n * cin, (int64_t)cp * cin,
+                                    (int64_t)TPI * n * cout, stream);
 }
 
 int wino_args_ok(const char* who, int64_t n, int cin, int cout) {
@@ -775,10 +781,10 @@ extern "C" int be_wino_conv3x3_6x6_f32(const float* x, const float* packed_w, co
     float* V = workspace;
     float* M = workspace + (size_t)100 * n * cin;
     const int tm = wino_large(n, cout);
-    BE_WINO_LAUNCH(k_wino_in, dim3(grid_cap(n * 4 * (cin / 4), 256)), dim3(256), 0, s, x, V, n, cin / 4, tm);
+    BE_WINO_LAUNCH(k_wino_in, dim3(grid_cap(n * TPI * (cin / 4), 256)), dim3(256), 0, s, x, V, n, cin / 4, tm);
     if (int rc = be::check_launch("be_wino_conv3x3_6x6_f32(in)")) return rc;
     if (int rc = wino_gemms(V, packed_w, M, n, cin, cout, s, stream)) return rc;
-    BE_WINO_LAUNCH(k_wino_out, dim3(grid_cap(n * 4 * (cout / 4), 256)), dim3(256), 0, s, M, packed_bias, residual, y, n, cout / 4,
+    BE_WINO_LAUNCH(k_wino_out, dim3(grid_cap(n * TPI * (cout / 4), 256)), dim3(256), 0, s, M, packed_bias, residual, y, n, cout / 4,
                        act, tm);
     return be::check_launch("be_wino_conv3x3_6x6_f32(out)");
 }
@@ -806,25 +812,25 @@ int be::wino_pair(const float* x, const float* packed_w1, const float* packed_bi
     float* M = workspace + (size_t)100 * n * big;
     const int tm1 = wino_large(n, cmid), tm2 = wino_large(n, cout);
     {
-        be::ProfileScope prof(s, BE_KERNEL_WINO_TRANSFORM, 0.0, 4.0 * n * cin * (36.0 + 100.0), 0.0);
-        BE_WINO_LAUNCH(k_wino_in, dim3(grid_cap(n * 4 * (cin / 4), 256)), dim3(256), 0, s, x, V, n, cin / 4, tm1);
+        be::ProfileScope prof(s, BE_KERNEL_WINO_TRANSFORM, 0.0, 4.0 * n * cin * (36.0 + (double)(NPOS * TPI)), 0.0);
+        BE_WINO_LAUNCH(k_wino_in, dim3(grid_cap(n * TPI * (cin / 4), 256)), dim3(256), 0, s, x, V, n, cin / 4, tm1);
     }
     if (int rc = be::check_launch("be_wino_conv3x3_pair_6x6_f32(in)")) return rc;
     if (int rc = wino_gemms(V, packed_w1, M, n, cin, cmid, s, stream)) return rc;
     {
-        be::ProfileScope prof(s, BE_KERNEL_WINO_TRANSFORM, 0.0, 4.0 * n * cmid * (100.0 + 100.0), 0.0);
+        be::ProfileScope prof(s, BE_KERNEL_WINO_TRANSFORM, 0.0, 4.0 * n * cmid * (2.0 * NPOS * TPI), 0.0);
         BE_WINO_LAUNCH(k_wino_out_in, dim3(grid_cap(n * (cmid / 4), 256)), dim3(256), 0, s, M, packed_bias1, V, n, cmid / 4, act1,
                            tm1, tm2);
     }
     if (int rc = be::check_launch("be_wino_conv3x3_pair_6x6_f32(out_in)")) return rc;
     if (int rc = wino_gemms(V, packed_w2, M, n, cmid, cout, s, stream)) return rc;
     {
-        be::ProfileScope prof(s, BE_KERNEL_WINO_TRANSFORM, 0.0, 4.0 * n * cout * (100.0 + (residual ? 36.0 : 0.0) + (pool2 ? 9.0 : 36.0)), 0.0);
+        be::ProfileScope prof(s, BE_KERNEL_WINO_TRANSFORM, 0.0, 4.0 * n * cout * ((double)(NPOS * TPI) + (residual ? 36.0 : 0.0) + (pool2 ? 9.0 : 36.0)), 0.0);
         if (pool2)
             BE_WINO_LAUNCH(k_wino_out_pool2, dim3(grid_cap(n * (cout / 4), 256)), dim3(256), 0, s, M, packed_bias2, residual, y, n,
                                cout / 4, act2, tm2);
         else
-            BE_WINO_LAUNCH(k_wino_out, dim3(grid_cap(n * 4 * (cout / 4), 256)), dim3(256), 0, s, M, packed_bias2, residual, y, n,
+            BE_WINO_LAUNCH(k_wino_out, dim3(grid_cap(n * TPI * (cout / 4), 256)), dim3(256), 0, s, M, packed_bias2, residual, y, n,
                                cout / 4, act2, tm2);
     }
     return be::check_launch("be_wino_conv3x3_pair_6x6_f32(out)");

@@ -255,7 +255,7 @@ int be_local_stage_pack_f32(const float* const* tensors_host /* [86] device ptrs
 
 /* Per-call options of the forward (NULL = the defaults).  They travel with the call - no process-wide state, so two models
  * with different settings, or two host threads, do not interfere.
- *   winograd  1 (default): the 3x3 convolutions on the 6x6 maps (layers 1-3) run in Winograd F(3x3,3x3) form; 0: direct
+ *   winograd  1 (default): the 3x3 convolutions on the 6x6 maps (layers 1-3) run in Winograd form (be_wino_tile_rows()); 0: direct
  *             implicit GEMM (the form the split-bf16 experiment and A/B runs use).  Both read the same packed buffer.
  *   chunk     the batch is walked in sub-batches of this many patches (0 = default 8192) so that the workspace stays bounded
  *             whatever N is; the same value must be given to be_local_stage_workspace_bytes(). */
@@ -326,15 +326,18 @@ int be_conv_nhwc_fused2_f32(const be_conv_desc* desc_host, const float* x, const
                             const float* packed_w, const float* packed_bias, float* y, int ldy, void* stream);
 /* nbatch independent problems of the same shape in one launch (grid.z): batch b reads x + b*x_stride, packed_w +
  * b*w_stride and writes y + b*y_stride (strides in floats, multiples of 4).  packed_bias may be NULL (no bias) - here
- * and in be_conv_nhwc_f32.  Used for the 25 GEMMs of the Winograd convolutions below. */
+ * and in be_conv_nhwc_f32.  Used for the per-position GEMMs of the Winograd convolutions below. */
 int be_conv_nhwc_batched_f32(const be_conv_desc* d, const float* x, const float* packed_w, const float* packed_bias, float* y,
                              int ldy, int nbatch, int64_t x_stride, int64_t w_stride, int64_t y_stride, void* stream);
 
-/* Winograd F(3x3,3x3) for 3x3 'same' convolutions on 6x6 maps (LocalStage layers 1-3): exact fp32 arithmetic with 2.56x
- * fewer multiplies than the direct form.  be_wino_pack_f32 folds an optional eval BatchNorm like be_conv_pack_f32 and
- * writes U [25][cout_pad32][cin] + bias [cout_pad32]; be_wino_conv3x3_6x6_f32 runs input transform, 25 batched GEMMs and
- * output transform (+ bias, + residual [N,6,6,cout] if not NULL, + act 0 none | 1 Smish | 2 ReLU).  x, y NHWC.
+/* Winograd form of the 3x3 'same' convolutions on 6x6 maps (LocalStage layers 1-3): exact fp32 products and accumulation with
+ * fewer multiplies than the direct form.  Tile shape (compile-time, be_wino_tile_rows()): 6 = F(6,3) along the rows x F(3,3) along
+ * the columns - two 8x5 tiles per map, 40 transform positions, 80 multiplies per map and channel pair instead of 324 (the default
+ * since round 4); 3 = F(3,3) x F(3,3) - four 5x5 tiles, 25 positions, 100 multiplies (rounds 1-3).  be_wino_pack_f32 folds an
+ * optional eval BatchNorm like be_conv_pack_f32 and writes U [positions][cout_pad32][cin] + bias [cout_pad32];
+ * be_wino_conv3x3_6x6_f32 runs input transform, `positions` batched GEMMs and output transform (+ bias, residual, activation).
  * workspace: be_wino_workspace_floats(n, cin, cout) floats.  cin %% 32 == 0, cout %% 4 == 0. */
+int be_wino_tile_rows(void);      /* 6 or 3: output rows per Winograd tile; positions = 5 (rows + 2), tiles per map = 12 / rows */
 size_t be_wino_packed_floats(int cout, int cin);
 int be_wino_pack_f32(const float* w_oihw, const float* bias, const float* bn_gamma, const float* bn_beta, const float* bn_mean,
                      const float* bn_var, float bn_eps, int cout, int cin, float* packed_w, float* packed_bias, void* stream);
@@ -613,7 +616,7 @@ int be_datagen_crop_f64(const double* const* in6, const double* bloc, const doub
 #define BE_KERNEL_CONV_128x32       3   /* fc.4                                                                */
 #define BE_KERNEL_CONV_ROW8_128x64  4   /* conv1 (7x7 row-gather)                                              */
 #define BE_KERNEL_CONV_SMALL        5   /* 64x64 / 128x32 tiles for small M (training batches)                 */
-#define BE_KERNEL_WINO_GEMM         6   /* k_wino_gemm_ws / k_wino_gemm: the 25 transform-domain GEMMs of a Winograd layer */
+#define BE_KERNEL_WINO_GEMM         6   /* k_wino_gemm_ws / k_wino_gemm: the transform-domain GEMMs (one per position) of a Winograd layer */
 #define BE_KERNEL_GEMM_ROWS         7   /* k_wino_gemm as a row GEMM: 1x1 convolutions / linears, large batches */
 /* HBM-bound kernels: `bytes` = the algorithmic bytes the launch has to move, `flops` = 0 */
 #define BE_KERNEL_WINO_TRANSFORM    8   /* k_wino_in / k_wino_out / k_wino_out_in / k_wino_out_pool2 */

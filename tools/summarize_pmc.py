@@ -71,8 +71,9 @@ if "FETCH_SIZE" in dom and "WRITE_SIZE" in dom:
     # bench.py reports this under roofline.traffic_recorded only while kernel_id still names its dominant kernel
     json.dump({"kernel": "k_wino_gemm_ws<6|16|24> (be_wino.hip)" if wino else "k_conv_igemm<2,2,2,2,TAPS>", "kernel_id": 6 if wino else 0,
                "bytes_per_launch": rd + wr, "read_bytes": rd, "write_bytes": wr,
-               # 25 x 4 B x (4n x cin + cin x cout + 4n x cout) averaged over the six launches of a step, n = 8192
-               "algo_bytes_per_launch": 1878289066.67 if wino else None, "git_head": head,
+               # positions x 4 B x (tiles x cin + cin x cout + tiles x cout) averaged over the six launches of a step, n = 8192:
+               # 40 positions x 2 n tiles (8x5 Winograd tiles, round 4); 25 x 4 n gave 1878289066.67
+               "algo_bytes_per_launch": 1509294080.0 if wino else None, "git_head": head,
                # bench.py fills roofline.traffic from this record only while these sources are byte-identical to the running library's
                "kernel_sources": SOURCES, "kernel_source_sha": source_sha(SOURCES),
                "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/pmc_passes.sh); FETCH_SIZE x2 (gfx950), KiB -> B; "
