@@ -73,12 +73,20 @@ __global__ void k_wino_pack(const float* __restrict__ w, const float* __restrict
 }
 
 // streaming accesses of the transform kernels: NT bit 0 = non-temporal loads, bit 1 = non-temporal stores (A/B: BE_WINO_NT)
-template <int NT> __device__ __forceinline__ f32x4 ld_s(const f32x4* p) {
+template <int NT, class V> __device__ __forceinline__ V ld_s(const V* p) {
     if constexpr (NT & 1) return __builtin_nontemporal_load(p); else return *p;
 }
-template <int NT> __device__ __forceinline__ void st_s(f32x4* p, f32x4 v) {
+template <int NT, class V> __device__ __forceinline__ void st_s(V* p, V v) {
     if constexpr (NT & 2) __builtin_nontemporal_store(v, p); else *p = v;
 }
+// channels per thread of the output-side transform kernels: with the 8x5 tiles a thread holding a channel QUAD needs 40 + 18 + 18
+// float4 values live (304 registers: the compiler parked 64-130 of them in AGPRs and the kernels fell to 4.9 TB/s); a channel
+// PAIR per thread needs half and runs two waves per SIMD.  Per-channel arithmetic: the width changes no bit.
+constexpr int VW_OUT = TH == 6 ? 2 : 4;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+template <int W> struct VecOf;
+template <> struct VecOf<4> { typedef f32x4 type; };
+template <> struct VecOf<2> { typedef f32x2 type; };
 
 // one thread = one tile (patch, ty, tx) x one channel quad; arithmetic: be_wino_math.h
 template <int NT>
@@ -111,16 +119,24 @@ void k_wino_in(const float* __restrict__ x, float* __restrict__ V, int64_t n, in
     }
 }
 
-__device__ __forceinline__ f32x4 wino_act(f32x4 v, int act) {
-    if (act == 1) { v[0] = be::smish(v[0]); v[1] = be::smish(v[1]); v[2] = be::smish(v[2]); v[3] = be::smish(v[3]); }
-    else if (act == 2) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+template <class V>
+__device__ __forceinline__ V wino_act(V v, int act) {
+    constexpr int W = (int)(sizeof(V) / sizeof(float));
+    if (act == 1) {
+#pragma unroll
+        for (int k = 0; k < W; ++k) v[k] = be::smish(v[k]);
+    } else if (act == 2) {
+#pragma unroll
+        for (int k = 0; k < W; ++k) v[k] = fmaxf(v[k], 0.f);
+    }
     return v;
 }
 
-template <int NT>
+template <int NT, int VW = VW_OUT>
 __global__ __launch_bounds__(256)
 void k_wino_out(const float* __restrict__ M, const float* __restrict__ bias, const float* __restrict__ res,
                 float* __restrict__ y, int64_t n, int c4, int act, int tm) {
+    typedef typename VecOf<VW>::type vec;
     const int64_t total = n * TPI * c4;
     const int64_t gs = (int64_t)gridDim.x * blockDim.x;
     const int64_t plane = tm ? c4 : n * TPI * c4, ts = tm ? NPOS * c4 : c4;
@@ -129,8 +145,8 @@ void k_wino_out(const float* __restrict__ M, const float* __restrict__ bias, con
         const int64_t tile = idx / c4;
         const int64_t img = tile / TPI;
         const int tt = (int)(tile - img * TPI), ty = tt >> 1, tx = tt & 1;
-        const f32x4* src = reinterpret_cast<const f32x4*>(M) + tile * ts + cq;
-        f32x4 m[NPOS], o[NOUT], rv[NOUT];
+        const vec* src = reinterpret_cast<const vec*>(M) + tile * ts + cq;
+        vec m[NPOS], o[NOUT], rv[NOUT];
 #pragma unroll
         for (int z = 0; z < NPOS; ++z) m[z] = ld_s<NT>(src + (size_t)z * plane);
         // the residual's values are fetched with the transform-domain ones (inside the store loop each was a round trip of
@@ -140,18 +156,18 @@ void k_wino_out(const float* __restrict__ M, const float* __restrict__ bias, con
             for (int r = 0; r < TH; ++r)
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    rv[3 * r + c] = ld_s<NT>(reinterpret_cast<const f32x4*>(res) + ((size_t)img * 36 + (TH * ty + r) * 6 + 3 * tx + c) * c4 + cq);
+                    rv[3 * r + c] = ld_s<NT>(reinterpret_cast<const vec*>(res) + ((size_t)img * 36 + (TH * ty + r) * 6 + 3 * tx + c) * c4 + cq);
         }
         be::wino_out(m, o);
-        const f32x4 bv = reinterpret_cast<const f32x4*>(bias)[cq];
+        const vec bv = reinterpret_cast<const vec*>(bias)[cq];
 #pragma unroll
         for (int r = 0; r < TH; ++r)
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const size_t e = ((size_t)img * 36 + (TH * ty + r) * 6 + 3 * tx + c) * c4 + cq;
-                f32x4 v = o[3 * r + c] + bv;
+                vec v = o[3 * r + c] + bv;
                 if (res) v += rv[3 * r + c];
-                st_s<NT>(reinterpret_cast<f32x4*>(y) + e, wino_act(v, act));
+                st_s<NT>(reinterpret_cast<vec*>(y) + e, wino_act(v, act));
             }
     }
 }
@@ -159,10 +175,11 @@ void k_wino_out(const float* __restrict__ M, const float* __restrict__ bias, con
 // conv1 -> conv2 of a residual block without the intermediate map in HBM: one thread = one image x one channel quad reads the
 // TPI x NPOS transform-domain values of conv1's result, forms the 6x6 map (+ bias, Smish) in registers and writes the TPI x NPOS
 // transform-domain values conv2's GEMMs read.  Saves the 36 values written and re-read (tile overlap) per channel.
-template <int NT>
-__global__ __launch_bounds__(256, 1)
+template <int NT, int VW = VW_OUT>
+__global__ __launch_bounds__(256, VW_OUT == 2 ? 2 : 1)
 void k_wino_out_in(const float* __restrict__ M, const float* __restrict__ bias, float* __restrict__ V, int64_t n, int c4, int act,
                    int tm_in, int tm_out) {
+    typedef typename VecOf<VW>::type vec;
     const int64_t total = n * c4;
     const int64_t gs = (int64_t)gridDim.x * blockDim.x;
     const int64_t plane = tm_in ? c4 : n * TPI * c4, ts = tm_in ? NPOS * c4 : c4;          // M as conv1's GEMMs wrote it
@@ -170,14 +187,14 @@ void k_wino_out_in(const float* __restrict__ M, const float* __restrict__ bias, 
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gs) {
         const int cq = (int)(idx % c4);
         const int64_t img = idx / c4;
-        const f32x4 bv = reinterpret_cast<const f32x4*>(bias)[cq];
-        f32x4 y[6][6];
+        const vec bv = reinterpret_cast<const vec*>(bias)[cq];
+        vec y[6][6];
 #pragma unroll
         for (int ty = 0; ty < TY; ++ty)
 #pragma unroll
             for (int tx = 0; tx < 2; ++tx) {
-                const f32x4* src = reinterpret_cast<const f32x4*>(M) + (img * TPI + ty * 2 + tx) * ts + cq;
-                f32x4 m[NPOS], o[NOUT];
+                const vec* src = reinterpret_cast<const vec*>(M) + (img * TPI + ty * 2 + tx) * ts + cq;
+                vec m[NPOS], o[NOUT];
 #pragma unroll
                 for (int z = 0; z < NPOS; ++z) m[z] = ld_s<NT>(src + (size_t)z * plane);
                 be::wino_out(m, o);
@@ -186,12 +203,12 @@ void k_wino_out_in(const float* __restrict__ M, const float* __restrict__ bias, 
 #pragma unroll
                     for (int c = 0; c < 3; ++c) y[TH * ty + r][3 * tx + c] = wino_act(o[3 * r + c] + bv, act);
             }
-        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+        const vec zero = vec(0.f);
 #pragma unroll
         for (int ty = 0; ty < TY; ++ty)
 #pragma unroll
             for (int tx = 0; tx < 2; ++tx) {
-                f32x4 d[NR][5], v[NPOS];
+                vec d[NR][5], v[NPOS];
 #pragma unroll
                 for (int r = 0; r < NR; ++r)
 #pragma unroll
@@ -200,7 +217,7 @@ void k_wino_out_in(const float* __restrict__ M, const float* __restrict__ bias, 
                         d[r][c] = (xx >= 0 && xx < 6 && yy >= 0 && yy < 6) ? y[yy < 0 ? 0 : (yy > 5 ? 5 : yy)][xx < 0 ? 0 : (xx > 5 ? 5 : xx)] : zero;
                     }
                 be::wino_in(d, v);
-                f32x4* dst = reinterpret_cast<f32x4*>(V) + (img * TPI + ty * 2 + tx) * ts_o + cq;
+                vec* dst = reinterpret_cast<vec*>(V) + (img * TPI + ty * 2 + tx) * ts_o + cq;
 #pragma unroll
                 for (int z = 0; z < NPOS; ++z) st_s<NT>(dst + (size_t)z * plane_o, v[z]);
             }
@@ -210,24 +227,25 @@ void k_wino_out_in(const float* __restrict__ M, const float* __restrict__ bias, 
 // Last block of LocalStage: output transform + bias + residual + activation + the 2x2 max-pool that follows it
 // (models/local_stage.py:42,67: maxpool after layer3), one thread per image and channel quad: the 6x6 map exists only in
 // registers, [N,3,3,C] is written (saves the map's round trip through HBM and the pooling launch).
-template <int NT>
-__global__ __launch_bounds__(256, 1)
+template <int NT, int VW = VW_OUT>
+__global__ __launch_bounds__(256, VW_OUT == 2 ? 2 : 1)
 void k_wino_out_pool2(const float* __restrict__ M, const float* __restrict__ bias, const float* __restrict__ res,
                       float* __restrict__ y, int64_t n, int c4, int act, int tm) {
+    typedef typename VecOf<VW>::type vec;
     const int64_t total = n * c4;
     const int64_t gs = (int64_t)gridDim.x * blockDim.x;
     const int64_t plane = tm ? c4 : n * TPI * c4, ts = tm ? NPOS * c4 : c4;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gs) {
         const int cq = (int)(idx % c4);
         const int64_t img = idx / c4;
-        const f32x4 bv = reinterpret_cast<const f32x4*>(bias)[cq];
-        f32x4 v[6][6];
+        const vec bv = reinterpret_cast<const vec*>(bias)[cq];
+        vec v[6][6];
 #pragma unroll
         for (int ty = 0; ty < TY; ++ty)
 #pragma unroll
             for (int tx = 0; tx < 2; ++tx) {
-                const f32x4* src = reinterpret_cast<const f32x4*>(M) + (img * TPI + ty * 2 + tx) * ts + cq;
-                f32x4 m[NPOS], o[NOUT], rv[NOUT];
+                const vec* src = reinterpret_cast<const vec*>(M) + (img * TPI + ty * 2 + tx) * ts + cq;
+                vec m[NPOS], o[NOUT], rv[NOUT];
 #pragma unroll
                 for (int z = 0; z < NPOS; ++z) m[z] = ld_s<NT>(src + (size_t)z * plane);
                 if (res) {                                   // with the tile's loads, not one by one behind the transform
@@ -235,14 +253,14 @@ void k_wino_out_pool2(const float* __restrict__ M, const float* __restrict__ bia
                     for (int r = 0; r < TH; ++r)
 #pragma unroll
                         for (int c = 0; c < 3; ++c)
-                            rv[3 * r + c] = ld_s<NT>(reinterpret_cast<const f32x4*>(res) + ((size_t)img * 36 + (TH * ty + r) * 6 + 3 * tx + c) * c4 + cq);
+                            rv[3 * r + c] = ld_s<NT>(reinterpret_cast<const vec*>(res) + ((size_t)img * 36 + (TH * ty + r) * 6 + 3 * tx + c) * c4 + cq);
                 }
                 be::wino_out(m, o);
 #pragma unroll
                 for (int r = 0; r < TH; ++r)
 #pragma unroll
                     for (int c = 0; c < 3; ++c) {
-                        f32x4 w = o[3 * r + c] + bv;
+                        vec w = o[3 * r + c] + bv;
                         if (res) w += rv[3 * r + c];
                         v[TH * ty + r][3 * tx + c] = wino_act(w, act);
                     }
@@ -251,11 +269,11 @@ void k_wino_out_pool2(const float* __restrict__ M, const float* __restrict__ bia
         for (int py = 0; py < 3; ++py)
 #pragma unroll
             for (int px = 0; px < 3; ++px) {
-                f32x4 m;
+                vec m;
 #pragma unroll
-                for (int k = 0; k < 4; ++k)
+                for (int k = 0; k < VW; ++k)
                     m[k] = fmaxf(fmaxf(v[2 * py][2 * px][k], v[2 * py][2 * px + 1][k]), fmaxf(v[2 * py + 1][2 * px][k], v[2 * py + 1][2 * px + 1][k]));
-                st_s<NT>(reinterpret_cast<f32x4*>(y) + ((size_t)img * 9 + py * 3 + px) * c4 + cq, m);
+                st_s<NT>(reinterpret_cast<vec*>(y) + ((size_t)img * 9 + py * 3 + px) * c4 + cq, m);
             }
     }
 }
@@ -606,7 +624,7 @@ int launch_ws(const GemmArgs& g, hipStream_t s, int64_t n, int cin, int cout, in
     const int cus = be::device_cu_count();
     // ONE workgroup per CU at a time (the kernel takes the whole register file of a CU).  Workgroup ids go round-robin over the 8
     // XCDs, so what has to fit is per XCD: ceil(units / 8) * n_tiles workgroups in rounds of (CUs per XCD).  mgroups = M ranges per
-    // problem: the launch lasts rounds x (tiles per range + the register fill, ~0.3 of a tile's time).  Searched, not guessed
+    // problem: the launch lasts rounds x (tiles per range + the register fill, ~0.5 of a tile's time).  Searched, not guessed
     // (round 4): with 40 problems x 128 row tiles and N = 256 the old rule (first round count that gives >= 8 ranges) chose 9 ranges =
     // 3 rounds of 15 tiles where 16 ranges are exactly 5 rounds of 8 (ideal: 40 tile times per CU; 45 -> 41).
     const int per_xcd = cus / 8 > 0 ? cus / 8 : 1;
@@ -620,7 +638,7 @@ int launch_ws(const GemmArgs& g, hipStream_t s, int64_t n, int cin, int cout, in
             if (ranges != mg) continue;
             const int wg_xcd = ((g.nb * mg + 7) / 8) * g.n_tiles;
             const int rounds = (wg_xcd + per_xcd - 1) / per_xcd;
-            const double cost = rounds * (tiles_per + 0.3);
+            const double cost = rounds * (tiles_per + 0.5);
             if (cost < best - 1e-9) { best = cost; mgroups = mg; }
         }
     }
@@ -784,7 +802,7 @@ extern "C" int be_wino_conv3x3_6x6_f32(const float* x, const float* packed_w, co
     BE_WINO_LAUNCH(k_wino_in, dim3(grid_cap(n * TPI * (cin / 4), 256)), dim3(256), 0, s, x, V, n, cin / 4, tm);
     if (int rc = be::check_launch("be_wino_conv3x3_6x6_f32(in)")) return rc;
     if (int rc = wino_gemms(V, packed_w, M, n, cin, cout, s, stream)) return rc;
-    BE_WINO_LAUNCH(k_wino_out, dim3(grid_cap(n * TPI * (cout / 4), 256)), dim3(256), 0, s, M, packed_bias, residual, y, n, cout / 4,
+    BE_WINO_LAUNCH(k_wino_out, dim3(grid_cap(n * TPI * (cout / VW_OUT), 256)), dim3(256), 0, s, M, packed_bias, residual, y, n, cout / VW_OUT,
                        act, tm);
     return be::check_launch("be_wino_conv3x3_6x6_f32(out)");
 }
@@ -819,7 +837,7 @@ int be::wino_pair(const float* x, const float* packed_w1, const float* packed_bi
     if (int rc = wino_gemms(V, packed_w1, M, n, cin, cmid, s, stream)) return rc;
     {
         be::ProfileScope prof(s, BE_KERNEL_WINO_TRANSFORM, 0.0, 4.0 * n * cmid * (2.0 * NPOS * TPI), 0.0);
-        BE_WINO_LAUNCH(k_wino_out_in, dim3(grid_cap(n * (cmid / 4), 256)), dim3(256), 0, s, M, packed_bias1, V, n, cmid / 4, act1,
+        BE_WINO_LAUNCH(k_wino_out_in, dim3(grid_cap(n * (cmid / VW_OUT), 256)), dim3(256), 0, s, M, packed_bias1, V, n, cmid / VW_OUT, act1,
                            tm1, tm2);
     }
     if (int rc = be::check_launch("be_wino_conv3x3_pair_6x6_f32(out_in)")) return rc;
@@ -827,11 +845,11 @@ int be::wino_pair(const float* x, const float* packed_w1, const float* packed_bi
     {
         be::ProfileScope prof(s, BE_KERNEL_WINO_TRANSFORM, 0.0, 4.0 * n * cout * ((double)(NPOS * TPI) + (residual ? 36.0 : 0.0) + (pool2 ? 9.0 : 36.0)), 0.0);
         if (pool2)
-            BE_WINO_LAUNCH(k_wino_out_pool2, dim3(grid_cap(n * (cout / 4), 256)), dim3(256), 0, s, M, packed_bias2, residual, y, n,
-                               cout / 4, act2, tm2);
+            BE_WINO_LAUNCH(k_wino_out_pool2, dim3(grid_cap(n * (cout / VW_OUT), 256)), dim3(256), 0, s, M, packed_bias2, residual, y, n,
+                               cout / VW_OUT, act2, tm2);
         else
-            BE_WINO_LAUNCH(k_wino_out, dim3(grid_cap(n * TPI * (cout / 4), 256)), dim3(256), 0, s, M, packed_bias2, residual, y, n,
-                               cout / 4, act2, tm2);
+            BE_WINO_LAUNCH(k_wino_out, dim3(grid_cap(n * TPI * (cout / VW_OUT), 256)), dim3(256), 0, s, M, packed_bias2, residual, y, n,
+                               cout / VW_OUT, act2, tm2);
     }
     return be::check_launch("be_wino_conv3x3_pair_6x6_f32(out)");
 }

@@ -71,9 +71,11 @@ __device__ __forceinline__ void wino_bt_rows(const float d[WINO_NR], float o[WIN
 
 // Input transform of one NR x 5 window d[row][col] -> v[5 r + c] = (B_r^T d B_c)[r][c]: columns first (the vertical transform of
 // each of the five columns), then rows (the 5-point transform of each transform row).
-__device__ __forceinline__ void wino_in(const wf32x4 d[WINO_NR][5], wf32x4 v[WINO_NPOS]) {
+// V = a float vector type (4 or 2 channels per thread: the arithmetic is per channel, so the width changes no bit)
+template <class V>
+__device__ __forceinline__ void wino_in(const V d[WINO_NR][5], V v[WINO_NPOS]) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < (int)(sizeof(V) / sizeof(float)); ++k) {
         float t[WINO_NR][5];
 #pragma unroll
         for (int c = 0; c < 5; ++c) {
@@ -143,9 +145,10 @@ __device__ __forceinline__ void wino_at8(const float m[8], float o[6]) {
 }
 
 // the NPOS transform-domain values of one tile -> its TH x 3 output block, y[3 r + c] (vector form: one channel quad per thread)
-__device__ __forceinline__ void wino_out(const wf32x4 m[WINO_NPOS], wf32x4 y[WINO_OUT]) {
+template <class V>
+__device__ __forceinline__ void wino_out(const V m[WINO_NPOS], V y[WINO_OUT]) {
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < (int)(sizeof(V) / sizeof(float)); ++k) {
         if constexpr (WINO_TH == 3) {
             float mm[25], Y[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
