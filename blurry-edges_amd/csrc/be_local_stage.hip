@@ -4,7 +4,7 @@
 // Activations are NHWC in a caller-provided workspace; the batch is walked in sub-batches (default 8192 patches,
 // measured best) so the workspace stays bounded whatever N is.  Per sub-batch: staging, conv1, 2-3 pools, layer0 as two direct
 // launches (conv1; conv2 with the downsample fused in), layers 1-3 each as a 1x1 downsample launch + the Winograd pair
-// (input transform, 25 GEMMs, output+input transform, 25 GEMMs, output transform - layer3's with the 2x2 max-pool in it;
+// (input transform, 40 GEMMs, output+input transform, 40 GEMMs, output transform - layer3's with the 2x2 max-pool in it;
 // be_wino.hip), fc.1, fc.4.  Sub-batches of 512 patches and more take the LDS-DMA kernels (be_conv_pm.hip for conv1 on a
 // row-padded staging and for layer0, the row GEMM of be_wino.hip for the 1x1s and fc.1); smaller ones k_conv_igemm - same
 // results bit for bit.  No allocation, no synchronisation, no process-wide state: graph-capturable, re-entrant.  opts->winograd = 0
@@ -30,7 +30,7 @@ inline size_t cout_pad(int c) { return (size_t)((c + 31) / 32 * 32); }
 
 struct PackedLayout {
     size_t w_off[15], b_off[15], total;
-    size_t uw_off[15], ub_off[15];     // Winograd F(3x3,3x3) form of the 3x3 convs on the 6x6 maps (layers 4,5,7,8,10,11)
+    size_t uw_off[15], ub_off[15];     // Winograd form (be_wino_math.h: 8x5 tiles) of the 3x3 convs on the 6x6 maps (layers 4,5,7,8,10,11)
     size_t dw_off[15], db_off[15];     // their blocks' 1x1 downsample convs as stand-alone convs (layers 6, 9, 12)
     PackedLayout() {
         size_t o = 0;
@@ -64,7 +64,7 @@ const PackedLayout& layout() { static PackedLayout l; return l; }
 // workspace regions, floats per patch (lifetimes: see be_local_stage_forward_f32; RA holds conv1's output, then
 // each block's intermediate t)
 constexpr size_t RA = 28224, RB = 13824, RC = 13824;
-// Winograd path: RW = transform-domain input + output of the widest layer (100 values per channel: 25 positions x 4 tiles,
+// Winograd path: RW = transform-domain input + output of the widest layer (room for 100 values per channel: 25 positions x 4 tiles; the 8x5 tiles use 80,
 // 384 + 384 channels), RR = the block's downsample branch [6,6,384]
 constexpr size_t RW = 100 * (384 + 384), RR = 13824;
 constexpr size_t WS_FLOATS_PER_PATCH = RA + RB + RC + RW + RR;

@@ -51,7 +51,7 @@ for k, cs in out.items():
         cs.setdefault("derived", {})["l2_hit_rate"] = h / (h + m)
 json.dump(out, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
 head = sys.argv[3] if len(sys.argv) > 3 else None
-SOURCES = ["be_wino.hip"]
+SOURCES = ["be_wino.hip", "be_wino_math.h"]
 
 
 def source_sha(files):
