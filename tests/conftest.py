@@ -14,8 +14,26 @@ for p in (ROOT, PKG):
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+_CONFIG = None
+
+
 def pytest_configure(config):
+    global _CONFIG
+    _CONFIG = config
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.hookimpl(trylast=True)
+def pytest_runtest_logreport(report):
+    """Flush the progress output after every test: with stdout on a pipe or a file the dots sit in an 8 KB buffer, and a runner that
+    watches for output (the GPU box kills a command that has been silent for 7 minutes) sees a suite with one 3-minute test as hung."""
+    tr = _CONFIG.pluginmanager.get_plugin("terminalreporter") if _CONFIG is not None else None
+    if tr is not None:
+        try:
+            tr._tw.flush()
+        except Exception:
+            pass
+    sys.stdout.flush()
 
 
 def load_golden(name):
