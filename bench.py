@@ -6,8 +6,11 @@ a batch of 4096 synthetic 21x21 two-aperture patch pairs (8192 CNN patches) per 
   LocalStage CNN (fp32-MFMA implicit GEMM)  ->  wedge renderer pass A (colours, ridge solve)  ->  DfD depth solve
 with the input already resident in HBM.  Prints ONE JSON line (rank 0).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+  python bench.py [--gpus N] [--steps K] [--warmup W]          N > 1: this process only spawns the N ranks (children of the same
+                                                               script, started before any GPU call) and relays their exit codes
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W      (the same ranks under a launcher)
+The line's `launch` object says who ran: launcher, backend, rccl_ranks (world size under backend nccl), RCCL version, every rank's
+device / pid / own clock, and value / world.
 
 `value` is that configuration and nothing else.  The same line also carries (outside the timed region of `value`):
   roofline       the dominant kernel of the step, measured live with hipEvents on the launch stream (SURVEY 8d);
@@ -403,6 +406,40 @@ def leg_dp(dev, native, dist, rank, world, steps, algorithm="allreduce"):
     return res
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as child processes of this script - RANK /
+    LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT in their environment, exactly what torch.distributed.run would set - from
+    a parent that never touches the GPU, relay their output (rank 0 prints the one JSON line), and return the worst exit code.  A
+    rank that dies takes the others with it (by PID) after a grace period, so that a failed run ends instead of hanging in a collective."""
+    import socket
+    if "BE_LOCAL_DEVICE" not in os.environ and torch.cuda.device_count() < n:      # device_count() does not initialise the GPU
+        print(f"bench.py: --gpus {n} but {torch.cuda.device_count()} device(s) visible", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=os.environ.get("MASTER_PORT", str(port)), HSA_ENABLE_IPC_MODE_LEGACY="0", BE_BENCH_LAUNCHER="self")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    codes = [None] * n
+    deadline = None
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        if deadline is None and any(c not in (None, 0) for c in codes):
+            deadline = time.monotonic() + 30.0              # a rank failed: the rest get 30 s to print what they have and leave
+        if deadline is not None and time.monotonic() > deadline:
+            for i, p in enumerate(procs):
+                if codes[i] is None:
+                    p.kill()
+                    codes[i] = p.wait()
+        time.sleep(0.2)
+    return max(abs(c) for c in codes)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -421,9 +458,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # the plain command `python bench.py --gpus N`: this process becomes the launcher.  It has made no GPU call (importing torch
+        # makes none) and makes none: the N ranks are CHILD processes of the same script, one per GPU, over RCCL
+        raise SystemExit(spawn_ranks(args.gpus))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if local_rank >= torch.cuda.device_count() >= 1:
         local_rank = 0                             # the launcher masked the devices: each rank sees only its own GPU
     dist = None
@@ -484,7 +524,7 @@ def main():
     for _ in range(args.steps):
         est = step()
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = own_elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -558,6 +598,24 @@ def main():
             except Exception:
                 roof["traffic_recorded"] = None
 
+    # ---- what lets a reader verify the run: who ran, on which device, over which library
+    prop = torch.cuda.get_device_properties(dev)
+    me = dict(rank=rank, local_rank=local_rank, device=f"cuda:{local_rank}", name=prop.name, pid=os.getpid(),
+              pci_bus_id=getattr(prop, "pci_bus_id", None), visible=os.environ.get("HIP_VISIBLE_DEVICES", os.environ.get("CUDA_VISIBLE_DEVICES")),
+              ms_per_step=round(own_elapsed / args.steps * 1e3, 3))
+    ranks_info = [me]
+    if dist is not None:
+        ranks_info = [None] * world
+        dist.all_gather_object(ranks_info, me)
+    backend = dist.get_backend() if dist is not None else None
+    try:
+        rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception:
+        rccl_version = None
+    launch = dict(launcher=os.environ.get("BE_BENCH_LAUNCHER", "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "none"),
+                  backend=backend, rccl_ranks=(dist.get_world_size() if backend == "nccl" else 0), rccl_version=rccl_version,
+                  ranks=ranks_info, value_per_gpu=round(pairs_per_s / world, 1))
+
     # ---- the other configurations, each on its own clock (never part of `value`)
     extra, dp_leg = None, None
     head = git_head()
@@ -573,7 +631,7 @@ def main():
                                    "(8192 CNN patches): LocalStage inference + pass-A colour solve + depth solve",
                        "pairs_per_gpu": PAIRS, "streams": model.streams, "weights": "portable-generator random init (no checkpoint offline)",
                        "sharding": "independent pairs per rank, no data-path collective"},
-            "roofline": roof, "cpu_baseline": cpu, "extra_configs": extra, "dp": dp_result, "git_head": head,
+            "roofline": roof, "cpu_baseline": cpu, "launch": launch, "extra_configs": extra, "dp": dp_result, "git_head": head,
         }
         out.update(more or {})
         return out

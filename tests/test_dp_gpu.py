@@ -223,17 +223,26 @@ def test_workflow_local_and_global_training_data_parallel_two_ranks(tmp_path):
     assert os.path.exists(os.path.join(logs, "exp_local_stage_training.txt"))
 
 
-def test_bench_two_rank_rehearsal_on_one_gpu(tmp_path):
-    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), rehearsed on ONE GPU over gloo
-    (BE_DIST_BACKEND=gloo BE_LOCAL_DEVICE=0): the N > 1 branch - barriers, MAX over ranks, rank-0-only legs, the dp leg with the
-    real gradient exchange and the segmented-graph step, the watchdog plumbing - must produce ONE well-formed JSON line."""
+@pytest.mark.parametrize("launcher", ["plain", "torchrun"])
+def test_bench_two_rank_rehearsal_on_one_gpu(tmp_path, launcher):
+    """`python bench.py --gpus 2` - the PLAIN command, as the driver's N = 1 record is launched: bench.py spawns its two ranks itself
+    as child processes before any GPU call - rehearsed on ONE GPU over gloo (BE_DIST_BACKEND=gloo BE_LOCAL_DEVICE=0): the N > 1
+    branch - barriers, MAX over ranks, rank-0-only legs, the dp leg with the real gradient exchange and the segmented-graph step,
+    the watchdog plumbing - must produce ONE well-formed JSON line that says who ran where.  "torchrun": the same through
+    torch.distributed.run (headline only)."""
     if not torch.cuda.is_available():
         pytest.fail("gpu-marked test run without a GPU")
     import json
     import subprocess
     env = dict(os.environ, BE_DIST_BACKEND="gloo", BE_LOCAL_DEVICE="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"]
+    if launcher == "plain":
+        cmd = [sys.executable] + tail
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+               "--master-port", str(_free_port())] + tail + ["--no-extra"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -241,8 +250,16 @@ def test_bench_two_rank_rehearsal_on_one_gpu(tmp_path):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak" and d["value"] > 0 and d["cpu_baseline"] is None
     assert d["value"] == pytest.approx(2 * 4096 * 3 / (d["ms_per_step"] * 3e-3), rel=1e-3)          # whole-job aggregate
+    la = d["launch"]
+    assert la["launcher"] == ("self" if launcher == "plain" else "torch.distributed.run") and la["backend"] == "gloo"
+    assert la["rccl_ranks"] == 0                                           # gloo rehearsal: no rank talked RCCL, and the line says so
+    assert [x["rank"] for x in la["ranks"]] == [0, 1] and len({x["pid"] for x in la["ranks"]}) == 2
+    assert la["value_per_gpu"] == pytest.approx(d["value"] / 2, rel=1e-3) and la["rccl_version"]
+    assert d["roofline"]["executed_frac"] > 0.5
+    if launcher == "torchrun":
+        return
     dp = d["dp"]
     assert dp["world"] == 2 and dp["global_batch"] == 128 and dp["allreduce_bytes"] == 4 * 7254122 and dp["allreduce_buckets"] == 4
     assert dp["dp_step_ms"] > 0 and dp["allreduce_ms"] > 0 and dp["segmented_graph_step_ms"] > 0 and "error" not in dp
-    assert d["roofline"]["executed_frac"] > 0.5 and len(d["extra_configs"]) == 4 and all("error" not in e for e in d["extra_configs"])
+    assert len(d["extra_configs"]) == 4 and all("error" not in e for e in d["extra_configs"])
     assert d["extra_configs"][3]["images_per_s"] > 0                       # the global-stage training step

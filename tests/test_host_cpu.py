@@ -329,3 +329,41 @@ def test_drawing_helpers_keep_the_reference_names(tmp_path, monkeypatch):
     sheet = v.visualize(rgb, rgb, rgb, rgb, rgb, rgb, np.ones((8, 8)), np.zeros((8, 8)), np.full((8, 8), 0.9), np.full((8, 8), 0.9))
     assert sheet.dtype == np.uint8 and sheet.shape == v.canvas_blank.shape
     assert (sheet[40:56, 0:16] == 127).all() and (sheet[40:56, (3 * 13) * 2:(3 * 13) * 2 + 16] == 255).all()   # input panel, confidence panel
+
+
+def test_bench_plain_command_spawns_one_child_per_rank_before_any_gpu_call(monkeypatch):
+    """`python bench.py --gpus N` (the driver's plain command, no launcher): the parent starts N children of the same script with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, never initialises the GPU itself, and returns the worst exit code; without
+    enough devices it refuses with code 2 instead of hanging in a rendezvous."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    started = []
+
+    class FakeProc:
+        def __init__(self, cmd, env=None):
+            started.append((cmd, env))
+            self.rc = 0 if env["RANK"] == "0" else 3
+
+        def poll(self):
+            return self.rc
+
+        def wait(self):
+            return self.rc
+
+        def kill(self):
+            pass
+    monkeypatch.setattr(bench.subprocess, "Popen", FakeProc)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "2", "--steps", "3"])
+    monkeypatch.setenv("BE_LOCAL_DEVICE", "0")
+    assert bench.spawn_ranks(2) == 3                                # the worst child's code
+    assert len(started) == 2 and not torch.cuda.is_initialized()
+    for r, (cmd, env) in enumerate(started):
+        assert cmd[0] == sys.executable and cmd[1].endswith("bench.py") and cmd[2:] == ["--gpus", "2", "--steps", "3"]
+        assert (env["RANK"], env["LOCAL_RANK"], env["WORLD_SIZE"], env["MASTER_ADDR"]) == (str(r), str(r), "2", "127.0.0.1")
+        assert env["MASTER_PORT"] == started[0][1]["MASTER_PORT"] and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    monkeypatch.delenv("BE_LOCAL_DEVICE")
+    started.clear()
+    assert bench.spawn_ranks(2) == 2 and not started               # no GPU here: refused, nothing spawned
