@@ -4,7 +4,9 @@ Same constructor signature, module tree and state-dict layout (100 entries, incl
 as the reference's models/local_stage.py:30-62, so checkpoints written by either load into the other with
 strict=True.  What differs is what runs: forward() hands the raw parameter tensors to libblurry_edges_hip
 (BatchNorm folded, fp32-MFMA implicit-GEMM convs with fused Smish / residual epilogues, NHWC activations)
-through the C ABI in include/blurry_edges_hip.h.  There is no eager / CPU path.
+through the C ABI in include/blurry_edges_hip.h.  A GPU tensor runs on the HIP kernels or raises - there is no eager fallback;
+a CPU tensor (BASELINE configs[0]: "PyTorch-CPU, plumbing, no GPU") runs the module tree itself, as GlobalStage and
+DepthCompletion do: that tree is the reference's network, layer for layer.
 """
 from __future__ import annotations
 
@@ -47,7 +49,13 @@ class ResidualBlock(nn.Module):
         self.activation = Smish()
 
     def forward(self, x):
-        raise RuntimeError("ResidualBlock runs only as part of LocalStage.forward (fused HIP kernels)")
+        """CPU tensors only (BASELINE configs[0]): the module tree as it stands, i.e. the reference's own computation
+        (models/local_stage.py:20-28).  On the GPU a block never runs alone: LocalStage.forward hands the whole stack to the HIP
+        kernels, and a GPU tensor arriving here is refused rather than served by stock PyTorch ops."""
+        if x.is_cuda:
+            raise RuntimeError("ResidualBlock runs only as part of LocalStage.forward on the GPU (fused HIP kernels)")
+        shortcut = x if self.downsample is None else self.downsample(x)
+        return self.activation(self.conv2(self.conv1(x)) + shortcut)
 
 
 class LocalStage(nn.Module):
@@ -97,8 +105,8 @@ class LocalStage(nn.Module):
 
     # the arithmetic of every convolution: exact fp32 MFMA products, fp32 accumulation (bench.py reports it as `dtype`)
     conv_precision = "f32"
-    # True (default): the 3x3 convolutions on the 6x6 maps run as Winograd F(3x3,3x3) (2.56x fewer multiplies, exact fp32
-    # products; be_wino.hip).  False: direct implicit-GEMM convolutions everywhere.  A per-call option of the C ABI
+    # True (default): the 3x3 convolutions on the 6x6 maps run as Winograd F(6,3) x F(3,3) on 8x5 tiles (80 multiplies per map and
+    # channel pair instead of 324, exact fp32 products; be_wino.hip, be_wino_math.h).  False: direct implicit-GEMM convolutions everywhere.  A per-call option of the C ABI
     # (be_local_stage_opts): instances with different settings coexist in one process.
     winograd = os.environ.get("BE_WINOGRAD", "1") != "0"
     # sub-batch (patches) the forward walks a large batch in; 0 = the library default (8192)
@@ -131,13 +139,22 @@ class LocalStage(nn.Module):
             self._packed_key = key
         return self._packed
 
+    def _forward_module_tree(self, x):
+        """CPU tensors: BASELINE configs[0] ("PyTorch-CPU, plumbing, no GPU") - the module tree this class owns for the
+        state-dict contract IS the reference's network, so running it is the reference's computation (models/local_stage.py:63-73):
+        stock PyTorch in eval and train mode, autograd included.  Not a fallback of the GPU path: a GPU tensor never gets here."""
+        x = self.maxpool1(self.conv1(x))
+        x = self.maxpool1(self.layer0(x))
+        x = self.layer3(self.layer2(self.layer1(x)))
+        return self.fc(self.maxpool2(x))
+
     def forward(self, x):
+        if not x.is_cuda:
+            return self._forward_module_tree(x)
         if self.training:
             # batch-statistics BatchNorm + full backward on the HIP training kernels (be_hip/train.py);
             # running statistics and num_batches_tracked are updated in place, as nn.BatchNorm does.
             from be_hip.train import LocalStageTrainFn
-            if not x.is_cuda:
-                raise RuntimeError("LocalStage: expected a tensor on the GPU; the HIP path has no CPU fallback")
             out = LocalStageTrainFn.apply(x, *self._tensor_list())
             self._packed_key = None          # running statistics changed under the packed (BN-folded) weights
             # one multi-tensor launch for the 14 counters (a `+= 1` each was 14 launches of a 270-launch step)

@@ -42,7 +42,26 @@ class DepthEtas:
         return self._consts
 
     def etas2depth(self, eta1, eta2):
+        if not (eta1.is_cuda or eta2.is_cuda):
+            return self._etas2depth_cpu(eta1, eta2)
         return ag.Etas2Depth.apply(eta1, eta2, self._consts)            # differentiable (global_training.py:91-92)
 
     def depth2sigma(self, depth, rho_prime):
+        if not depth.is_cuda:
+            return torch.abs((1 / depth - rho_prime) * self.s + 1) / self.denominator_factor_root
         return ag.Depth2Sigma.apply(depth, self._consts, rho_prime)
+
+    def _etas2depth_cpu(self, e1, e2):
+        """CPU tensors (BASELINE configs[0], "PyTorch-CPU, plumbing"): the same solve as a torch expression, with the reference's
+        operation order (utils/depth_etas.py:23-34) so that fp32 results are the reference's bit for bit (golden g5).  The point
+        (e1, e2) is projected orthogonally onto the segment of the valid locus {e2 - e1 = I, e1 + e2 = I, e1 - e2 = I} that the three
+        half-plane tests select; a point beyond all three keeps its raw values."""
+        c = self._consts
+        I = self.intercept.to(e1.device)
+        above = -c.sin_w * e1 + c.cos_w * (e2 - I) > 0                  # beyond the upper wing  e2 - e1 = I
+        middle = -c.sin_m * (e1 - I) + c.cos_m * e2 > 0                 # below the middle piece e1 + e2 = I
+        below = -c.sin_w * (e1 - I) + c.cos_w * e2 < 0                  # beyond the lower wing  e1 - e2 = I
+        half_sum = (e1 + e2 - I) / 2
+        p1 = torch.where(above, half_sum, torch.where(middle, I + (e1 - e2 - I) / 2, torch.where(below, I + half_sum, e1)))
+        p2 = torch.where(above, I + half_sum, torch.where(middle, (e2 - e1 + I) / 2, torch.where(below, half_sum, e2)))
+        return self.numerator / (self.denominator_factor * (p1 ** 2 - p2 ** 2) + self.denominator_constant)

@@ -60,6 +60,8 @@ class PostProcessBase(nn.Module, ABC):
         return t.view(b, hp, wp, t.shape[1], t.shape[2], t.shape[3]).permute(0, 3, 4, 5, 1, 2)
 
     def params2etas(self, params):
+        if not params.is_cuda:                                  # BASELINE configs[0] (PyTorch-CPU plumbing): eta = 10^(2 erf(p) - 2)
+            return torch.pow(10, torch.erf(params) * 2 - 2)
         return ag.Params2Etas.apply(params)
 
     def params2dists(self, params):

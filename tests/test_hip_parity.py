@@ -337,12 +337,19 @@ def test_forward_of_a_large_batch_is_run_to_run_bit_identical(native):
             assert torch.equal(m(x), ref)
 
 
-def test_product_path_refuses_cpu_tensors(native):
+def test_gpu_model_never_serves_a_cpu_tensor_and_native_entry_points_refuse_them(native):
+    """A model on the GPU fed a CPU tensor fails (no silent CPU service on a GPU box); the native entry points refuse CPU tensors.
+    (A CPU model on a CPU tensor is BASELINE configs[0] and runs the module tree: tests/test_host_cpu.py.)"""
     import models
-    m = models.LocalStage().eval()
+    m = models.LocalStage().to(DEV).eval()
     with pytest.raises(RuntimeError):
         with torch.no_grad():
             m(torch.zeros(2, 3, 21, 21))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        native.local_stage_forward(m._packed_weights(), torch.zeros(2, 3, 21, 21))
+    blk = m.layer1[0]
+    with pytest.raises(RuntimeError, match="fused HIP kernels"):
+        blk(torch.zeros(1, 96, 6, 6, device=DEV))
 
 
 # ------------------------------------------------------------------------------------------ training loss

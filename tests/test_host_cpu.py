@@ -148,8 +148,66 @@ def test_local_stage_state_dict_layout_matches_the_reference():
     m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in ref.items()}, strict=True)
     assert sum(p.numel() for p in m.parameters()) == 7254122
     assert len(m._tensor_list()) == 86
-    with pytest.raises(RuntimeError):
-        m.eval()(torch.zeros(1, 3, 21, 21))                           # CPU tensor: refused, no fallback
+
+
+def test_configs0_single_pair_on_pytorch_cpu_through_models_and_utils_matches_the_reference_goldens():
+    """BASELINE configs[0]: "single 21x21 two-aperture patch pair, local_stage forward + depth_etas on PyTorch-CPU (plumbing, no
+    GPU)".  On CPU tensors models.LocalStage runs its own module tree (the reference's network, models/local_stage.py:63-73) and
+    utils.DepthEtas / params2etas evaluate as torch expressions: logits within 1e-6 of what the real reference produced (g1, fp32 and
+    fp64), the depth solve bit-exact against g5, autograd through the CPU forward works (local_training.py:103-106 on a CPU device)."""
+    import models, utils
+    from conftest import relmax
+    g = load_golden("g1_local_stage_eval")
+    m = models.LocalStage()
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.local_stage_state_dict().items()}, strict=True)
+    m.eval()
+    x = torch.from_numpy(synth.uniform_patches(16))
+    with torch.no_grad():
+        assert relmax(m(x).numpy(), g["logits"]) <= 1e-6
+        xs, _ = synth.synthetic_patch_pairs(8)
+        est = m(torch.from_numpy(xs))
+        assert relmax(est.numpy(), g["logits_synth_pairs"]) <= 1e-6
+        assert relmax(m.double()(x.double()).numpy(), g["logits_fp64"]) <= 1e-12
+    m.float()
+    # one pair: [2,3,21,21] -> [2,10] -> eta -> depth of both wedges (SURVEY 8d config 1)
+    a = utils.get_args("eval", argv=[])
+    d = utils.DepthEtas(a, "cpu")
+    helper = utils.PostProcessLocalBase(utils.get_args("local_train", argv=[]), "cpu")
+    with torch.no_grad():
+        pair = torch.stack([torch.from_numpy(xs[0]), torch.from_numpy(xs[8])])
+        e = m(pair)
+        assert torch.equal(e, est[[0, 8]]) or relmax(e.numpy(), est[[0, 8]].numpy()) <= 1e-6
+        eta = helper.params2etas(e[:, 8:])                               # [2 apertures, 2 wedges]
+        assert torch.equal(eta, 10 ** (torch.erf(e[:, 8:]) * 2 - 2))
+        z = d.etas2depth(eta[0], eta[1])
+        assert z.shape == (2,) and bool(torch.isfinite(z).all())
+    g5 = load_golden("g5_depth")
+    lin = torch.linspace(1e-4, 1.0, 64)
+    e1, e2 = torch.meshgrid(lin, lin, indexing="ij")
+    assert np.array_equal(d.etas2depth(e1, e2).numpy(), g5["z_lin"])                     # bit-exact, all four branches
+    lg = torch.logspace(-4, 0, 48)
+    l1, l2 = torch.meshgrid(lg, lg, indexing="ij")
+    assert np.array_equal(d.etas2depth(l1, l2).numpy(), g5["z_log"])
+    depth = torch.linspace(0.6, 2.3, 257)
+    assert np.array_equal(d.depth2sigma(depth, 10.39).numpy(), g5["sigma_rho_prime"])
+    assert np.array_equal(d.depth2sigma(depth, 10.0).numpy(), g5["sigma_rho_1"])
+    assert relmax(d.etas2depth(e1.double(), e2.double()).numpy(), g5["z_lin_f64"]) <= 1e-7
+    # train mode on the CPU: batch statistics + autograd, against what the reference produced (g2)
+    g2 = load_golden("g2_local_stage_train")
+    m.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.local_stage_state_dict().items()}, strict=True)
+    m.train()
+    xt = torch.from_numpy(synth.uniform_patches(64, name="train_patches"))
+    ct = torch.from_numpy(synth.f32(synth.hash_normal(synth.SEED_DEFAULT, "train_cotangent", (64, 10))))
+    y = m(xt)
+    (y * ct).sum().backward()
+    assert relmax(y.detach().numpy(), g2["logits"]) <= 2e-5
+    named = dict(m.named_parameters())
+    checked = 0
+    for k in g2:
+        if k.startswith("grad_") and k != "grad_x_sub":
+            assert relmax(named[k[len("grad_"):]].grad.numpy(), g2[k]) <= 2e-4, k
+            checked += 1
+    assert checked >= 4
 
 
 def test_args_defaults_and_depth_constants():
