@@ -54,7 +54,7 @@ CPU_REPEATS = 3                       # 3 repeats, median: ~25 s of CPU work (th
 # cout FLOPs they execute; the same layer as a direct 3x3 convolution on a 6x6 map is 2 x 36 x 9 x n x cin x cout.
 # positions x tiles per map = 40 x 2 (8x5 tiles, be_wino_tile_rows() = 6) or 25 x 4 (5x5 tiles): filled in main()
 ALGO_OVER_HOOK = {}
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_traffic.json")
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
 
 
 def cpu_baseline(x_np, sd_np):
@@ -164,14 +164,12 @@ def git_head():
         return None
 
 
-def kernel_source_sha(files):
-    """sha256 over the named kernel sources (relative to csrc/): what a recorded counter measurement is valid for"""
-    import hashlib
-    h = hashlib.sha256()
-    for f in files:
-        with open(os.path.join(ROOT, "blurry-edges_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
-    return h.hexdigest()[:16]
+def build_info():
+    """lib/BUILD_INFO.json: what build() recorded about the sources the loaded libraries were compiled from ({} if absent)"""
+    try:
+        return json.load(open(os.path.join(ROOT, "blurry-edges_amd", "lib", "BUILD_INFO.json")))
+    except Exception:
+        return {}
 
 
 def leg_local_training(dev, native, peak, steps=60):
@@ -590,7 +588,10 @@ def main():
                                                 kernel_sources=tr.get("kernel_sources"), kernel_source_sha=tr.get("kernel_source_sha"))
                 if tr.get("kernel_id") != prof["kernel_id"]:
                     roof["traffic_note"] = f"{os.path.relpath(TRAFFIC_FILE, ROOT)} describes kernel id {tr.get('kernel_id')}, not the dominant one"
-                elif tr.get("kernel_sources") and kernel_source_sha(tr["kernel_sources"]) == tr.get("kernel_source_sha"):
+                elif (tr.get("kernel_source_sha") and tr["kernel_source_sha"] == build_info().get("kernel_source_sha")
+                      and tr.get("wino_tile_rows") == wino_rows):
+                    # the record and the RUNNING library were built from the same kernel sources (lib/BUILD_INFO.json, written by
+                    # build() at compile time) with the same tile shape: the counters describe the running kernel
                     roof["traffic"] = tr["bytes_per_launch"]
                     roof["traffic_over_algorithmic"] = round(tr["bytes_per_launch"] / tr["algo_bytes_per_launch"], 3)
                 else:

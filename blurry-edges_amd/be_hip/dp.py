@@ -182,7 +182,7 @@ class GradSync:
             ev.record()                                               # behind the last kernel that wrote flat[lo:hi]
             with torch.cuda.stream(self.side):
                 self.side.wait_event(ev)
-                hs = self._issue(piece, dist)
+                hs = self._issue(piece, dist, (lo, hi))
                 if self.timing:
                     for h in hs:
                         h.wait()                                      # the SIDE stream waits for the collective(s) ...
@@ -194,22 +194,26 @@ class GradSync:
                     self.handles.extend(hs)
         elif piece.is_cuda:
             host = piece.cpu()
-            for h in self._issue(host, dist):
+            for h in self._issue(host, dist, (lo, hi)):
                 h.wait()
             piece.copy_(host)
         else:
-            self.handles.extend(self._issue(piece, dist))
+            self.handles.extend(self._issue(piece, dist, (lo, hi)))
 
-    def _issue(self, piece, dist):
-        """the bucket's sum over the ranks, in place, as asynchronous collective(s) in issue order -> their handles"""
+    def _issue(self, piece, dist, bucket):
+        """the bucket's sum over the ranks, in place, as asynchronous collective(s) in issue order -> their handles.
+        bucket = (lo, hi) of the piece in the flat buffer: names the scratch shard of the rs_ag form."""
         w = dist.get_world_size(self.group)
         if self.algorithm == "allreduce" or w == 1 or piece.numel() < w:
             return [dist.all_reduce(piece, op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
         r = dist.get_rank(self.group)
         s = piece.numel() // w                                        # shard length; [w * s, n) is the remainder
         main = piece[:w * s]
-        key = (piece.device, s)
-        shard = self._shards.get(key)                                 # one scratch shard per bucket size, reused every step
+        # one scratch shard PER BUCKET, reused every step.  Not per shard length (ADVICE r4): two equal-sized buckets of one step
+        # would share it, and only the RCCL path orders bucket A's gather (which reads the shard) before bucket B's scatter (which
+        # writes it) - on the gloo path the gather may still be running on a worker thread
+        key = (piece.device, bucket, s)
+        shard = self._shards.get(key)
         if shard is None:
             shard = self._shards[key] = torch.empty(s, dtype=piece.dtype, device=piece.device)
         hs = [dist.reduce_scatter_tensor(shard, main, op=dist.ReduceOp.SUM, group=self.group, async_op=True)]

@@ -12,7 +12,10 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libblurry_edges_hip.so")
+# BE_LIB_DIR: another build of the SAME C ABI (e.g. lib/wino3 from `make -C csrc wino3`, the 5x5-tile Winograd A/B library); the torch
+# extension links against the default library, so an alternative directory runs on the ctypes binding
+_ALT_DIR = os.environ.get("BE_LIB_DIR")
+LIB_PATH = os.path.join(_ALT_DIR or os.path.join(os.path.dirname(_HERE), "lib"), "libblurry_edges_hip.so")
 
 BE_R = 21
 NPIX = 441
@@ -219,7 +222,7 @@ def ops():
     same C symbols; a missing extension file is an error (build() makes both), not a reason to fall back silently."""
     global _ops
     if _ops is None:
-        if os.environ.get("BE_TORCH_OPS", "1") == "0":
+        if os.environ.get("BE_TORCH_OPS", "1") == "0" or _ALT_DIR:
             _ops = False
         else:
             lib()                                      # the C-ABI library first: the extension links against it

@@ -212,9 +212,31 @@ def global_train(args, quiet=False):
     curve = np.zeros((args.epoch_num,), dtype=float)
     best, best_epoch = np.inf, 0
     feats = lambda p: p.permute(0, 2, 1, 3).flatten(2, 3).contiguous()          # [B,2,P,19] -> [B,P,38]
-    with open(f'{args.log_path}/exp_global_stage_training.txt' if rank == 0 else os.devnull, 'wt') as f:
-        _log_header(f, args)
-        for epoch in range(args.epoch_num):
+    # --resume (not in the reference): everything the loop carries from one epoch to the next is in {model_path}/global_resume.ckpt -
+    # weights, AdamW moments, both schedules, the shuffling generator and torch's RNG (the dropout seeds come from it), the curve and
+    # the best checkpoint - so a resumed run takes exactly the steps the uninterrupted one would have taken
+    resume_path = f'{args.model_path}/global_resume.ckpt'
+    first_epoch = 0
+    resumed = bool(getattr(args, "resume", False)) and os.path.exists(resume_path)
+    if resumed:
+        ck = torch.load(resume_path, map_location=dev, weights_only=False)
+        model.load_state_dict(ck["model"])
+        opt.load_state_dict(ck["opt"])
+        sched.load_state_dict(ck["sched"])
+        gamma.idx = ck["gamma_idx"]
+        sampler.set_state(ck["sampler"])
+        torch.set_rng_state(ck["torch_rng"])
+        first_epoch, best, best_epoch = ck["epoch"], ck["best"], ck["best_epoch"]
+        curve[:first_epoch] = ck["curve"][:first_epoch]
+        if rank == 0 and ck.get("best_model") is not None:
+            torch.save(ck["best_model"], f'{args.model_path}/best_run_exp_global_stage.pth')
+    t_start = time.perf_counter()
+    budget = float(getattr(args, "time_budget", 0.0) or 0.0)
+    stopped_early = False
+    with open(f'{args.log_path}/exp_global_stage_training.txt' if rank == 0 else os.devnull, 'at' if resumed else 'wt') as f:
+        if not resumed:
+            _log_header(f, args)
+        for epoch in range(first_epoch, args.epoch_num):
             g = gamma.step()
             model.train()
             for param, _, img_gt, bndry_dist, deri, bndry_depth in tr.batches(args.batch_size, shuffle=True, drop_last=True,
@@ -237,8 +259,26 @@ def global_train(args, quiet=False):
             if epoch >= args.dynamic_epoch[1]:
                 sched.step(curve[epoch])
             if not quiet and rank == 0:
-                print(f'epoch {epoch + 1}: validation loss {curve[epoch]:.6f}')
-        print(f'\n-- Best epoch is the {best_epoch + 1:d}th, with average loss of {best:.10f}.', file=f, flush=True)
+                print(f'epoch {epoch + 1}: validation loss {curve[epoch]:.6f}', flush=True)
+            if rank == 0 and (getattr(args, "resume", False) or budget > 0):
+                bm = f'{args.model_path}/best_run_exp_global_stage.pth'
+                torch.save(dict(model=model.state_dict(), opt=opt.state_dict(), sched=sched.state_dict(), gamma_idx=gamma.idx,
+                                sampler=sampler.get_state(), torch_rng=torch.get_rng_state(), epoch=epoch + 1, best=best,
+                                best_epoch=best_epoch, curve=curve.copy(),
+                                best_model=torch.load(bm, map_location="cpu") if os.path.exists(bm) else None), resume_path + ".tmp")
+                os.replace(resume_path + ".tmp", resume_path)
+            if budget > 0 and epoch + 1 < args.epoch_num:
+                stopped_early = time.perf_counter() - t_start > budget
+                if dist is not None:                                   # rank 0's clock decides for everyone (collectives pair up)
+                    flag = torch.tensor([int(stopped_early)], device=dev if dist.get_backend() == "nccl" else "cpu")
+                    dist.broadcast(flag, 0)
+                    stopped_early = bool(flag.item())
+                if stopped_early:
+                    if rank == 0:
+                        print(f'-- time budget reached after epoch {epoch + 1} of {args.epoch_num}: continue with --resume', flush=True)
+                    break
+        if not stopped_early:
+            print(f'\n-- Best epoch is the {best_epoch + 1:d}th, with average loss of {best:.10f}.', file=f, flush=True)
     if rank == 0:
         np.save(f'{args.log_path}/loss_curve_exp_global_stage.npy', curve)
         utils.showCurve(args, curve, 'loss_curve_exp_global_stage')

@@ -543,7 +543,7 @@ TORCH_LIBRARY(be, m) {
     m.def("local_loss_finish(Tensor partial, float beta_b, float beta_s) -> Tensor");
     m.def("global_loss(Tensor opts, Tensor consts, Tensor est, Tensor img_fit, Tensor img_gt, Tensor G, Tensor Gd, Tensor Gb, Tensor bdist, Tensor deri, "
           "Tensor bdepth, float[] gamma6, int hp, int wp, int stride) -> (Tensor, Tensor, Tensor)");
-    m.def("attention(Tensor qkv, int B, int L, int l_valid, int H, Tensor? workspace) -> (Tensor, Tensor)");
+    m.def("attention(Tensor qkv, int B, int L, int l_valid, int H, Tensor(a!)? workspace) -> (Tensor, Tensor(a!))");
     m.def("attention_train_fwd(Tensor qkv, Tensor(a!) workspace, int B, int L, int l_valid, int H, float p, int seed) -> (Tensor, Tensor)");
     m.def("attention_bwd(Tensor qkv, Tensor out, Tensor lse, Tensor dout, Tensor(a!) workspace, Tensor(b!) scratch, bool operands_ready, int B, int L, "
           "int l_valid, int H, float p, int seed) -> Tensor");

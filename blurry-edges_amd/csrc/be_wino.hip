@@ -1,18 +1,22 @@
-// Winograd F(3x3, 3x3) for the 3x3 convolutions on the 6x6 maps of LocalStage layers 1-3 (models/local_stage.py:20-28,
-// 39-41).  A 6x6 output is four 3x3 tiles; each tile needs a 5x5 input window (stride 3, one pixel of zero padding), and
+// Winograd convolution for the 3x3 layers on the 6x6 maps of LocalStage layers 1-3 (models/local_stage.py:20-28, 39-41).
+// Tile shape (be_wino_math.h, BE_WINO_TH = 6, the default since round 4): F(6,3) along the rows x F(3,3) along the columns.  A 6x6
+// output is TWO tiles of 6x3 outputs; each needs an 8x5 input window (one pixel of zero padding), and
 //     Y = A^T [ (G g G^T) o (B^T d B) ] A      summed over the input channels
-// turns the convolution into 25 independent GEMMs [tiles x Cin] x [Cin x Cout] (one per position of the 5x5 transform
-// domain): 100 multiplies per (cin, cout) pair and map instead of the 324 of the direct form (256 once the taps that
-// fall into the zero padding are skipped) - 2.56x less work for the matrix pipe, in exact fp32 arithmetic.
-// Interpolation points 0, 1, -1, 2, inf; the transforms are small integer / sixth combinations.  Accuracy measured on the
-// whole network against the fp64 oracle: logits 2.0e-6 (direct fp32 convolutions: 2.3e-6), see DESIGN.md 3.1c.
+// turns the convolution into NPOS = 40 independent GEMMs [2N tiles x Cin] x [Cin x Cout] (one per position of the 8x5 transform
+// domain): 80 multiplies per (cin, cout) pair and map instead of the 324 of the direct form - 4.05x less work for the matrix
+// pipe, in exact fp32 products.  Interpolation points: rows 0, +-1, +-2, +-1/2, inf; columns 0, +-1, 2, inf.
+// -DBE_WINO_TH=3 builds rounds 1-3's F(3x3,3x3): four 5x5 tiles per map, 25 GEMMs, 100 multiplies (an A/B target, `make wino3`).
+// Accuracy on the whole network against the fp64 oracle: logits 0.9-4.9e-6 over random, trained and stressed weights (5x5 tiles:
+// 1.8-3.0e-6; direct fp32 convolutions 1.1-3.3e-6), tolerance 1e-5 - DESIGN.md 3.1 / 4.
 //
-//   k_wino_pack   weights [Cout,Cin,3,3] (+ folded BatchNorm) -> U [25][Cout_pad][Cin] in the 1x1 layout of k_conv_igemm
-//   k_wino_in     x [N,6,6,C] NHWC -> V [25][4N][C]            (HBM-bound: reads 36, writes 100 values per channel)
-//   k_wino_gemm   M[xi] = V[xi] U[xi]^T for the 25 positions xi: one workgroup per 128x128 tile walks all 25 (large batches;
-//                 small ones go through be_conv_nhwc_batched_f32 on k_conv_igemm, same arithmetic per output element)
-//   k_wino_out    M [25][4N][Cout] -> y [N,6,6,Cout] + bias (+ residual) (+ Smish)
-//   k_wino_out_in conv1 -> conv2 of a residual block: output transform + Smish + input transform, the map stays in registers
+//   k_wino_pack    weights [Cout,Cin,3,3] (+ folded BatchNorm) -> U [NPOS][Cout_pad][Cin] in the 1x1 layout of k_conv_igemm
+//   k_wino_in      x [N,6,6,C] NHWC -> V: tile-major [TPI N][NPOS][C] for large batches, plane-major [NPOS][TPI N][C] for small ones
+//                  (HBM-bound: reads 36, writes TPI * NPOS = 80 values per channel)
+//   k_wino_gemm    M[xi] = V[xi] U[xi]^T for the NPOS positions xi: one workgroup per 128x128 tile walks all of them (large
+//                  batches; small ones go through be_conv_nhwc_batched_f32 on k_conv_igemm, same arithmetic per output element)
+//   k_wino_gemm_ws the same GEMMs weight-stationary (B tile in registers, A streamed through LDS by DMA): batches of >= 4096 maps
+//   k_wino_out     M -> y [N,6,6,Cout] + bias (+ residual) (+ Smish)
+//   k_wino_out_in  conv1 -> conv2 of a residual block: output transform + Smish + input transform, the map stays in registers
 #include <cstdlib>
 #include "be_common.h"
 #include "be_device_math.h"

@@ -58,6 +58,10 @@ _GROUPS = {
         ('--dynamic_epoch', dict(type=int, nargs=3, default=[30, 100, 200])),
         ('--input_size', dict(type=int, default=38)),
         ('--output_size', dict(type=int, default=12)),
+        # not in the reference: continue a run from {model_path}/global_resume.ckpt (written after every epoch), and stop cleanly
+        # after the epoch that passes this many seconds (0 = no limit) - a 350-epoch schedule in bounded jobs
+        ('--resume', dict(action='store_true')),
+        ('--time_budget', dict(type=float, default=0.0)),
     ],
     'data_gen_test': [
         ('--data_path', dict(type=str, default='./data/data_test')),

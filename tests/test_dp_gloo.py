@@ -119,6 +119,18 @@ def _sync_worker(rank, world, port, q, groups, algorithm="allreduce"):
     s2.bucket_ready(odd, 0, 1001)
     s2.finish()
     assert torch.equal(odd, torch.arange(1001, dtype=torch.float32) * 1.5)
+    # two EQUAL-sized buckets in one step: each has its own scratch shard - sharing one by shard length would let
+    # bucket A's all_gather (still on a gloo worker thread) read what bucket B's reduce_scatter is writing
+    eq = torch.from_numpy(synth.f32(synth.hash_normal(300 + rank, "dp_eq", (400000,))))
+    s3 = dp.GradSync(world, algorithm=algorithm)
+    for _ in range(3):
+        e = eq.clone()
+        s3.bucket_ready(e, 200000, 400000)
+        s3.bucket_ready(e, 0, 200000)
+        s3.finish()
+        want = (synth.f32(synth.hash_normal(300, "dp_eq", (400000,))) + synth.f32(synth.hash_normal(301, "dp_eq", (400000,)))) / np.float32(2)
+        assert np.array_equal(e.numpy(), want)
+    assert algorithm != "rs_ag" or len(s3._shards) == 2
     # replicas are aligned from rank 0, and rank 0's BatchNorm statistics reach everyone before a checkpoint
     with torch.no_grad():
         for prm in m.parameters():

@@ -207,6 +207,9 @@ def test_local_stage_logits_vs_golden_and_oracle(native):
     assert y.shape == (16, 10)
     assert relmax(y.cpu(), g["logits"]) <= 1e-5          # vs the fp32 reference
     assert relmax(y.cpu(), g["logits_fp64"]) <= 1e-5     # vs the fp64 reference
+    e64 = relmax(y.cpu(), g["logits_fp64"])
+    print(f"logits vs the fp64 reference at random-init weights: {e64:.2e}")
+    assert e64 <= 6e-6                                   # explicit margin under the 1e-5 tolerance (measured ~2e-6 with the 8x5 tiles)
     xs, _ = synth.synthetic_patch_pairs(8)
     with torch.no_grad():
         ys = m(T(xs).to(DEV))
@@ -605,7 +608,7 @@ def test_winograd_conv_matches_the_direct_convolution(n, cin, cout):
     """be_wino_conv3x3_6x6_f32 (Winograd tiles - round 4: F(6,3) x F(3,3), two 8x5 tiles per map - input transform, one batched GEMM
     per transform position, output transform) against the direct implicit-GEMM convolution and the float64 oracle, with folded
     BatchNorm, residual and Smish.  Measured per layer on this random data: 8x5 tiles 5-10e-6, 5x5 tiles (rounds 1-3) 2-6e-6, direct
-    1-2e-6; bound 2e-5 (the whole-network logit tolerance is 1e-5 and is held with a margin of 2 - see the trained / stressed tests)."""
+    1-2e-6; bound 1.5e-5 (the whole-network logit tolerance is 1e-5 and is held with a margin of 2 - see the trained / stressed tests)."""
     assert native_mod().lib().be_wino_tile_rows() in (3, 6)
     from be_hip import native
     x = T(synth.hash_normal(31, "w_x", (n, 6, 6, cin)).astype(np.float32)).to(DEV)
@@ -626,7 +629,7 @@ def test_winograd_conv_matches_the_direct_convolution(n, cin, cout):
     ref = (y * torch.tanh(torch.log(1 + torch.sigmoid(y)))).permute(0, 2, 3, 1)
     e_d, e_w = relmax(direct.cpu(), ref), relmax(wino.cpu(), ref)
     print(f"n={n} {cin}->{cout}: direct {e_d:.2e}  winograd {e_w:.2e}")
-    assert e_d <= 4e-6 and e_w <= 2e-5
+    assert e_d <= 4e-6 and e_w <= 1.5e-5            # measured 5-10e-6: a 2x drift of the Winograd transforms fails here, not at 1e-5 on the logits
     # chained pair with the intermediate map in registers == two single convolutions
     w2 = T((synth.hash_normal(39, "w_w2", (cout, cout, 3, 3)) * np.sqrt(2.0 / (9 * cout))).astype(np.float32)).to(DEV)
     uw2, ub2 = native.wino_pack(w2, b)
@@ -635,7 +638,7 @@ def test_winograd_conv_matches_the_direct_convolution(n, cin, cout):
     pair, _ = native.wino_conv3x3_pair(x, uw, ub, cout, uw2, ub2, cout, residual=res)
     assert torch.equal(pair, two)
     plain, _ = native.wino_conv3x3(x, uw, ub, cout)                     # no residual, no activation
-    assert relmax(plain.cpu(), (y - res.cpu().double().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)) <= 2e-5
+    assert relmax(plain.cpu(), (y - res.cpu().double().permute(0, 3, 1, 2)).permute(0, 2, 3, 1)) <= 1.5e-5
 
 
 _TWO_THREADS = r'''
@@ -689,6 +692,8 @@ def test_torch_operator_binding_and_ctypes_binding_give_identical_results(native
     """torch.ops.be.* (csrc/be_torch_ops.cpp) and the ctypes binding call the same C symbols: LocalStage eval forward, pass-A
     colours and the depth solve must be bit-identical through either, and the operators are what the product path uses."""
     import models, utils
+    if os.environ.get("BE_TORCH_OPS", "1") == "0" or os.environ.get("BE_LIB_DIR"):
+        pytest.skip("compares the two bindings: the torch-operator binding is switched off in this environment")
     assert native.ops() is not None, "the torch extension did not load"
     sd = {k: T(v) for k, v in synth.local_stage_state_dict().items()}
     x = T(synth.uniform_patches(192, name="opsbind")).to(DEV)
@@ -714,6 +719,51 @@ def test_torch_operator_binding_and_ctypes_binding_give_identical_results(native
             native._ops = saved
     for a, b in zip(*res):
         assert torch.equal(a, b)
+
+
+def test_per_call_options_winograd_and_chunk_across_coexisting_instances(native):
+    """The per-call options of the C ABI (be_local_stage_opts: winograd, chunk) on two LocalStage instances that coexist in one
+    process: Winograd is on by default; off gives different bits, both within 1e-5 of the oracle;
+    toggling back reproduces the first bits; a second instance with winograd=False, chunk=1000 interleaved with the first repeats
+    bit-identically; and sub-batches that land on each side of the kernel-family thresholds (n >= 1024: tile-major buffers +
+    k_wino_gemm; rows % 128 == 0 and >= 64 row tiles, i.e. n % 64 == 0 and n >= 4096: the weight-stationary k_wino_gemm_ws) leave
+    every logit unchanged."""
+    import models
+    from oracle import local_stage as ols
+    sd_np = synth.local_stage_state_dict()
+    sd = {k: torch.from_numpy(np.asarray(v)) for k, v in sd_np.items()}
+    a, b = models.LocalStage(), models.LocalStage()
+    for m in (a, b):
+        m.load_state_dict(sd)
+        m.to(DEV).eval()
+        m.streams = 1
+    assert a.winograd is True and a.chunk == 0
+    b.winograd, b.chunk = False, 1000
+    N = 9000
+    x = T(synth.uniform_patches(N, name="opts")).to(DEV)
+    with torch.no_grad():
+        ya, yb = a(x).clone(), b(x).clone()
+        assert not torch.equal(ya, yb)                                   # two algorithms: different roundings ...
+        idx = torch.arange(0, N, 173)
+        ref = ols.local_stage_forward(ols.to_torch_sd(sd_np, torch.float64), x[idx].cpu().double())
+        ea, eb = relmax(ya[idx].cpu(), ref), relmax(yb[idx].cpu(), ref)
+        print(f"winograd {ea:.2e}  direct (chunk 1000) {eb:.2e}")
+        assert ea <= 1e-5 and eb <= 1e-5                                 # ... of the same function
+        for _ in range(2):                                               # interleaved: no option leaks from one instance to the other
+            assert torch.equal(a(x), ya) and torch.equal(b(x), yb)
+        a.winograd = False
+        assert torch.equal(a(x), yb)                                     # direct, one 8192 + 808 split == direct in nine sub-batches
+        a.winograd = True
+        assert torch.equal(a(x), ya)
+        # Winograd sub-batches on each side of the thresholds: 1000 (small: plane-major + batched igemm), 1024 (large, 16 row tiles),
+        # 4096 (weight-stationary) + an 808 tail, 4160 = 65 * 64 (weight-stationary, ragged range search) + 680, 5000 + 4000 (large,
+        # rows % 128 != 0)
+        for chunk in (1000, 1024, 4096, 4160, 5000):
+            a.chunk = chunk
+            assert torch.equal(a(x), ya), chunk
+        a.chunk = 0
+        b.winograd = True                                                # and the other instance follows when ITS option changes
+        assert torch.equal(b(x), ya)
 
 
 # ------------------------------------------------------------------------------------------ trained and stressed weights

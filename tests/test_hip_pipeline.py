@@ -559,6 +559,22 @@ def test_workflow_datagen_train_precalc_train_eval_end_to_end(env, tmp_path):
                                                       "--batch_size", "2"])
     gcurve = wf.global_train(a, quiet=True)
     assert np.isfinite(gcurve).all() and (models_dir / "best_run_exp_global_stage.pth").exists()
+    # --resume / --time_budget (not in the reference: a 350-epoch schedule in bounded jobs): three epochs in one go against the same
+    # three epochs as three jobs that each stop after one epoch and continue from global_resume.ckpt - identical validation curves,
+    # identical best checkpoint (weights, AdamW moments, both schedules, the shuffle generator and the dropout seeds all carry over)
+    runs = {}
+    for tag, extra, calls in (("straight", [], 1), ("resumed", ["--resume", "--time_budget", "1e-9"], 3)):
+        md, lg = tmp_path / f"w_{tag}", tmp_path / f"logs_{tag}"
+        a = utils.get_args("global_train", argv=["--model_path", str(md), "--cuda", DEV, "--data_path", str(root), "--log_path", str(lg),
+                                                 "--epoch_num", "3", "--batch_size", "2", "--dynamic_epoch", "2", "2", "5"] + extra)
+        for _ in range(calls):
+            c = wf.global_train(a, quiet=True)
+        runs[tag] = (c, torch.load(md / "best_run_exp_global_stage.pth", map_location="cpu"), (lg / "exp_global_stage_training.txt").read_text())
+    assert np.isfinite(runs["straight"][0]).all() and np.array_equal(runs["straight"][0], runs["resumed"][0])
+    for k, v in runs["straight"][1].items():
+        assert torch.equal(v, runs["resumed"][1][k]), k
+    assert runs["resumed"][2].count("Best epoch") == 1 and runs["resumed"][2].count("Training:") == 1
+    assert [ln.split()[0] for ln in runs["resumed"][2].splitlines() if ln[:1].isdigit()] == ["1", "2", "3"]
     # a test set in TestDataset's format made of the validation images (depth_maps = the generator's image depths)
     test_dir = tmp_path / "test"
     test_dir.mkdir()

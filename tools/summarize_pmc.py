@@ -51,16 +51,12 @@ for k, cs in out.items():
         cs.setdefault("derived", {})["l2_hit_rate"] = h / (h + m)
 json.dump(out, open(f"profiles/{tag}_pmc_summary.json", "w"), indent=1)
 head = sys.argv[3] if len(sys.argv) > 3 else None
-SOURCES = ["be_wino.hip", "be_wino_math.h"]
-
-
-def source_sha(files):
-    import hashlib, os
-    h = hashlib.sha256()
-    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "blurry-edges_amd", "csrc")
-    for f in files:
-        h.update(open(os.path.join(root, f), "rb").read())
-    return h.hexdigest()[:16]
+# the sources and tile shape the measured library was built from: recorded by build() in lib/BUILD_INFO.json (travels to the GPU box
+# with the libraries); bench.py fills roofline.traffic from this record only while the RUNNING library's BUILD_INFO names the same
+import os
+_info_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "blurry-edges_amd", "lib", "BUILD_INFO.json")
+INFO = json.load(open(_info_path)) if os.path.exists(_info_path) else {}
+head = head or INFO.get("git_head")
 
 
 dom = out.get("wino_gemm") or out.get("conv128x128", {})
@@ -75,7 +71,8 @@ if "FETCH_SIZE" in dom and "WRITE_SIZE" in dom:
                # 40 positions x 2 n tiles (8x5 Winograd tiles, round 4); 25 x 4 n gave 1878289066.67
                "algo_bytes_per_launch": 1509294080.0 if wino else None, "git_head": head,
                # bench.py fills roofline.traffic from this record only while these sources are byte-identical to the running library's
-               "kernel_sources": SOURCES, "kernel_source_sha": source_sha(SOURCES),
+               "kernel_sources": INFO.get("kernel_sources"), "kernel_source_sha": INFO.get("kernel_source_sha"),
+               "wino_tile_rows": INFO.get("wino_tile_rows"),
                "method": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes (tools/pmc_passes.sh); FETCH_SIZE x2 (gfx950), KiB -> B; "
                          "counts L2 misses, i.e. Infinity-Cache hits too",
                "launches_averaged": dom["FETCH_SIZE"]["launches"]}, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
