@@ -12,11 +12,14 @@ Split of the work:
           truncation) -- `draw_scenes`.
   GPU   : everything per pixel (be_datagen.hip through the C ABI): rasterisation, dilations, separable PSF blur +
           compositing in float64, distance transforms, Sobel, noise, patch cropping.
-Rasterisation rule (the reference uses cv2 drawing, which is not available offline and not specified bit-for-bit):
-a pixel is INSIDE a polygon with integer vertices when all edge functions have one sign (zero counts) and it lies in
-the vertex bounding box; inside a circle when dx^2 + dy^2 <= r^2; the 1-pixel OUTLINE is the inside pixels with a
-4-neighbour outside (evaluated analytically, also beyond the image border).  Everything downstream of the masks follows
-the reference exactly and is pinned against it (golden g14).
+Rasterisation rule: the reference draws with cv2.circle / cv2.drawContours (thickness -1 and 1, default LINE_8, shift 0;
+train_val_data_generator.py:58-76).  cv2 is not available offline, so `be_datagen_raster_u32` follows the ALGORITHMS those calls
+run in OpenCV 4.x modules/imgproc/src/drawing.cpp: Circle() - the midpoint walk over one octant, filled rows or the eight
+symmetric points; Line() - clipLine() to the image, then the 8-connected LineIterator started from the left end point;
+CollectPolyEdges() + FillEdgeCollection() - every edge drawn with Line(), the non-horizontal ones kept in 16.16 fixed point,
+active for y0 <= y < y1, runs from ceil(x_left) to floor(x_right).  One workgroup per object leaves a FILL and a RING bit plane;
+oracle/datagen.py holds the same rules in numpy and known answers worked by hand pin both (tests/test_host_cpu.py).  Everything
+downstream of the masks follows the reference exactly and is pinned against it (golden g14).
 """
 from __future__ import annotations
 
@@ -107,6 +110,19 @@ def _t(a, dev, dt):
     return torch.from_numpy(np.ascontiguousarray(a)).to(dt).to(dev)
 
 
+def rasterize(shape, nobj, dev, H=147, W=147):
+    """The FILL / RING masks of be_datagen_raster_u32, unpacked: shape [n,MAXO,10] int32, nobj [n] -> bool [n,MAXO,2,H,W]
+    (what cv2.circle / cv2.drawContours with thickness -1 / 1 paint; objects >= nobj[i] are empty)."""
+    shape_t, nobj_t = _t(np.asarray(shape), dev, torch.int32), _t(np.asarray(nobj), dev, torch.int32)
+    n = int(nobj_t.shape[0])
+    rw = (W + 31) // 32
+    planes = torch.empty(lib().be_datagen_raster_words(n, H, W, MAXO), dtype=torch.int32, device=dev)
+    check(lib().be_datagen_raster_u32(dptr(shape_t), dptr(nobj_t), n, H, W, MAXO, dptr(planes), stream_ptr(dev)), "be_datagen_raster_u32")
+    words = planes.view(n, MAXO, 2, H, rw, 1)
+    bits = (words >> torch.arange(32, device=planes.device, dtype=torch.int32)) & 1          # [..., rw, 32], bit x & 31 of word x >> 5
+    return bits.reshape(n, MAXO, 2, H, rw * 32)[..., :W].bool()
+
+
 def generate(scenes, dev, alpha_range=(180.0, 200.0), sigma_read=2.0, seed=synth.SEED_DEFAULT, cam=None, z_far=1.18):
     """Run the GPU generator on `draw_scenes` output.  Returns float64 GPU tensors with the reference's layouts:
     images [n,2,H,W,3] (clean, 0..255, rounded), images_aif [n,H,W,3] (/255), boundary_locations [n,H,W] (0/255),
@@ -125,11 +141,13 @@ def generate(scenes, dev, alpha_range=(180.0, 200.0), sigma_read=2.0, seed=synth
                image_depths=new(n, H, W), boundary_depths=new(n, H, W), boundary_distances=new(n, H, W),
                derivative_maps=new(n, 2, H, W, 3), images_gt=new(n, 2, H, W, 3), images_ny=new(n, 2, H, W, 3))
     st = stream_ptr(dev)
-    check(lib().be_datagen_scene_f64(dptr(shape), dptr(prop), dptr(nobj), dptr(bg), n, H, W, MAXO, float(z_far),
+    planes = torch.empty(lib().be_datagen_raster_words(n, H, W, MAXO), dtype=torch.int32, device=dev)   # FILL / RING bit planes
+    check(lib().be_datagen_raster_u32(dptr(shape), dptr(nobj), n, H, W, MAXO, dptr(planes), st), "be_datagen_raster_u32")
+    check(lib().be_datagen_scene_f64(dptr(planes), dptr(prop), dptr(nobj), dptr(bg), n, H, W, MAXO, float(z_far),
                                      dptr(out["images_aif"]), dptr(out["boundary_locations"]), dptr(out["image_depths"]),
                                      dptr(out["boundary_depths"]), st), "be_datagen_scene_f64")
     scratch = torch.empty(lib().be_datagen_blur_scratch_bytes(n, H, W), dtype=torch.uint8, device=dev)
-    check(lib().be_datagen_blur_composite_f64(dptr(shape), dptr(prop), dptr(nobj), dptr(bg), dptr(sig), n, H, W, MAXO,
+    check(lib().be_datagen_blur_composite_f64(dptr(planes), dptr(prop), dptr(nobj), dptr(bg), dptr(sig), n, H, W, MAXO,
                                               int(scenes["nobj"].max()), dptr(out["images"]), dptr(scratch), scratch.numel(), st),
           "be_datagen_blur_composite_f64")
     check(lib().be_datagen_finish_f64(dptr(out["images"]), dptr(out["boundary_locations"]), dptr(out["boundary_distances"]),

@@ -110,6 +110,8 @@ _SIGNATURES = {
     "be_maxpool_nhwc_ld_f32": (C.c_int, [_P, C.c_int, _P] + [C.c_int] * 7 + [_P]),
     "be_nchw_to_nhwc_pad_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int64, C.c_int, _P]),
     "be_upconv2x2_scatter_f32": (C.c_int, [_P, _P, C.c_int64] + [C.c_int] * 9 + [_P]),
+    "be_datagen_raster_words": (C.c_size_t, [C.c_int] * 4),
+    "be_datagen_raster_u32": (C.c_int, [_P, _P] + [C.c_int] * 4 + [_P, _P]),
     "be_datagen_scene_f64": (C.c_int, [_P, _P, _P, _P] + [C.c_int] * 4 + [C.c_double] + [_P] * 5),
     "be_datagen_blur_scratch_bytes": (C.c_size_t, [C.c_int] * 3),
     "be_datagen_blur_composite_f64": (C.c_int, [_P] * 5 + [C.c_int] * 5 + [_P, _P, C.c_size_t, _P]),

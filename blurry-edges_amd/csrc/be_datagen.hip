@@ -1,9 +1,10 @@
 // Synthetic-shape training data on the GPU: per-pixel work of train_val_data_generator.py:31-275.
-// All arithmetic the reference does in numpy float64 is float64 here; rasterisation is exact integer arithmetic.
+// All arithmetic the reference does in numpy float64 is float64 here; rasterisation follows OpenCV's integer algorithms.
 // HBM-bound streaming kernels over [N,H,W] images, one thread per pixel (or per element); nothing here is GEMM-shaped.
 //
+//   k_raster           per object: the FILL and RING bit planes under OpenCV's scan-conversion rules (cv2.circle / cv2.drawContours, :58-76)
 //   k_scene            objects far -> near: all-in-focus colour, boundary locations, image depth, boundary depth
-//                      (3x3 dilations of the analytic inside / outline tests, :77-85,100-103)
+//                      (3x3 dilations of the two planes, :77-85,100-103)
 //   k_mask / k_blur_h / k_blur_v_composite   per object: binary mask, separable Gaussian PSF of its depth per aperture
 //                      (scipy.ndimage.convolve(mode='reflect') of the (2k+1)^2 kernel, k = ceil(3 sigma), :87-94),
 //                      alpha-composite onto the two aperture images
@@ -19,28 +20,181 @@ constexpr int SHAPE_INTS = 10;     // kind, nv, x0,y0 .. x3,y3   (circle: x0,y0 
 constexpr int PROP_F64 = 4;        // z, c0, c1, c2
 constexpr int MAXO_LDS = 32;
 
-__device__ __forceinline__ bool inside(const int* s, int x, int y) {
-    if (s[0] == 0) {
-        const int64_t dx = x - s[2], dy = y - s[3];
-        return dx * dx + dy * dy <= (int64_t)s[4] * s[4];
+// ---- rasterisation: OpenCV's scan-conversion rules (round 5) --------------------------------------------------------------
+// The reference draws every object with cv2.circle / cv2.drawContours (train_val_data_generator.py:58-76; default LINE_8, shift 0).
+// k_raster follows the algorithms those calls run in OpenCV 4.x modules/imgproc/src/drawing.cpp - Circle() (midpoint walk, filled
+// rows / eight symmetric points), Line() = clipLine() + the 8-connected LineIterator started from the left end point,
+// CollectPolyEdges() + FillEdgeCollection() (16.16 fixed-point edges, active for y0 <= y < y1, runs from ceil(x_left) to
+// floor(x_right)) - and leaves two bit planes per object, FILL and RING (the thickness-1 outline), [N][maxo][2][H][ceil(W/32)]
+// words; every later kernel reads bits.  One workgroup per (object, image).  oracle/datagen.py restates the same rules in numpy.
+constexpr int XY_SHIFT = 16;
+__host__ __device__ __forceinline__ int raster_row_words(int W) { return (W + 31) >> 5; }
+
+__device__ __forceinline__ bool plane_bit(const uint32_t* __restrict__ plane, int rw, int x, int y) {
+    return (plane[(size_t)y * rw + (x >> 5)] >> (x & 31)) & 1u;
+}
+__device__ __forceinline__ void set_px(uint32_t* plane, int rw, int H, int W, int x, int y) {
+    if ((unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H) atomicOr(&plane[(size_t)y * rw + (x >> 5)], 1u << (x & 31));
+}
+// pixels x1..x2 (inclusive) of row y, clipped to the image
+__device__ __forceinline__ void set_run(uint32_t* plane, int rw, int H, int W, int y, int x1, int x2) {
+    if ((unsigned)y >= (unsigned)H) return;
+    x1 = max(x1, 0); x2 = min(x2, W - 1);
+    if (x1 > x2) return;
+    for (int w = x1 >> 5; w <= (x2 >> 5); ++w) {
+        const int lo = max(x1 - 32 * w, 0), hi = min(x2 - 32 * w, 31);
+        const uint32_t m = (hi == 31 ? 0xffffffffu : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+        atomicOr(&plane[(size_t)y * rw + w], m);
     }
-    const int nv = s[1];
-    bool pos = true, neg = true;
-    int xmin = s[2], xmax = s[2], ymin = s[3], ymax = s[3];
-    for (int k = 0; k < nv; ++k) {
-        const int x0 = s[2 + 2 * k], y0 = s[3 + 2 * k];
-        const int kn = k + 1 == nv ? 0 : k + 1;
-        const int x1 = s[2 + 2 * kn], y1 = s[3 + 2 * kn];
-        const int64_t c = (int64_t)(x1 - x0) * (y - y0) - (int64_t)(y1 - y0) * (x - x0);
-        pos = pos && c >= 0;
-        neg = neg && c <= 0;
-        xmin = min(xmin, x0); xmax = max(xmax, x0); ymin = min(ymin, y0); ymax = max(ymax, y0);
-    }
-    return (pos || neg) && x >= xmin && x <= xmax && y >= ymin && y <= ymax;
 }
 
-__device__ __forceinline__ bool outline(const int* s, int x, int y) {
-    return inside(s, x, y) && !(inside(s, x - 1, y) && inside(s, x + 1, y) && inside(s, x, y - 1) && inside(s, x, y + 1));
+// clipLine(Size(W, H), p1, p2): false when nothing of the segment is inside
+__device__ __forceinline__ bool clip_line(int W, int H, long long& x1, long long& y1, long long& x2, long long& y2) {
+    const long long right = W - 1, bottom = H - 1;
+    int c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8;
+    int c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8;
+    if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+        long long a;
+        if (c1 & 12) {
+            a = c1 < 8 ? 0 : bottom;
+            x1 += (long long)((double)(a - y1) * (double)(x2 - x1) / (double)(y2 - y1));
+            y1 = a;
+            c1 = (x1 < 0) + (x1 > right) * 2;
+        }
+        if (c2 & 12) {
+            a = c2 < 8 ? 0 : bottom;
+            x2 += (long long)((double)(a - y2) * (double)(x2 - x1) / (double)(y2 - y1));
+            y2 = a;
+            c2 = (x2 < 0) + (x2 > right) * 2;
+        }
+        if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+            if (c1) {
+                a = c1 == 1 ? 0 : right;
+                y1 += (long long)((double)(a - x1) * (double)(y2 - y1) / (double)(x2 - x1));
+                x1 = a;
+                c1 = 0;
+            }
+            if (c2) {
+                a = c2 == 1 ? 0 : right;
+                y2 += (long long)((double)(a - x2) * (double)(y2 - y1) / (double)(x2 - x1));
+                x2 = a;
+                c2 = 0;
+            }
+        }
+    }
+    return (c1 | c2) == 0;
+}
+
+// Line(img, p1, p2, color, 8): LineIterator(leftToRight = true) on the clipped segment
+__device__ void draw_line(uint32_t* plane, int rw, int H, int W, int ax, int ay, int bx, int by) {
+    long long x1 = ax, y1 = ay, x2 = bx, y2 = by;
+    if ((unsigned long long)x1 >= (unsigned long long)W || (unsigned long long)x2 >= (unsigned long long)W ||
+        (unsigned long long)y1 >= (unsigned long long)H || (unsigned long long)y2 >= (unsigned long long)H) {
+        if (!clip_line(W, H, x1, y1, x2, y2)) return;
+    }
+    int dx = (int)(x2 - x1), dy = (int)(y2 - y1), sy = 1;
+    if (dx < 0) { dx = -dx; dy = -dy; x1 = x2; y1 = y2; }
+    if (dy < 0) { dy = -dy; sy = -1; }
+    const bool vert = dy > dx;
+    if (vert) { const int t = dx; dx = dy; dy = t; }
+    int err = dx - 2 * dy;
+    const int plus = 2 * dx, minus = -2 * dy;
+    int x = (int)x1, y = (int)y1;
+    for (int i = 0; i <= dx; ++i) {
+        set_px(plane, rw, H, W, x, y);
+        const bool m = err < 0;
+        err += minus + (m ? plus : 0);
+        if (vert) { y += sy; x += m ? 1 : 0; }
+        else { x += 1; y += m ? sy : 0; }
+    }
+}
+
+constexpr int RASTER_MAX_PAIRS = 2048;     // octant steps of the midpoint walk kept in LDS: radius < ~2800
+
+__global__ __launch_bounds__(256)
+void k_raster(const int* __restrict__ shape, const int* __restrict__ nobj, int H, int W, int maxo, uint32_t* __restrict__ masks) {
+    const int img = blockIdx.y, o = blockIdx.x;
+    const int rw = raster_row_words(W);
+    uint32_t* fill = masks + ((size_t)img * maxo + o) * 2 * H * rw;
+    uint32_t* ring = fill + (size_t)H * rw;
+    for (int i = threadIdx.x; i < 2 * H * rw; i += blockDim.x) fill[i] = 0u;
+    if (o >= nobj[img]) return;
+    __shared__ int s[SHAPE_INTS];
+    __shared__ short pair_dx[RASTER_MAX_PAIRS], pair_dy[RASTER_MAX_PAIRS];
+    __shared__ int npairs;
+    __shared__ long long ex[4], edx[4];
+    __shared__ int ey0[4], ey1[4], nedge;
+    if (threadIdx.x < SHAPE_INTS) s[threadIdx.x] = shape[((size_t)img * maxo + o) * SHAPE_INTS + threadIdx.x];
+    __syncthreads();
+    if (s[0] == 0) {
+        // Circle(): the octant walk is sequential and short; thread 0 records it, then every (step, row pair) is painted in parallel
+        const int cx = s[2], cy = s[3], r = s[4];
+        if (threadIdx.x == 0) {
+            int err = 0, dx = r, dy = 0, plus = 1, minus = (r << 1) - 1, n = 0;
+            while (dx >= dy && n < RASTER_MAX_PAIRS) {
+                pair_dx[n] = (short)dx; pair_dy[n] = (short)dy; ++n;
+                ++dy; err += plus; plus += 2;
+                if (err > 0) { err -= minus; --dx; minus -= 2; }        // mask = (err <= 0) - 1
+            }
+            npairs = n;
+        }
+        __syncthreads();
+        for (int it = threadIdx.x; it < 4 * npairs; it += blockDim.x) {
+            const int k = it >> 2, which = it & 3;
+            const int dx = pair_dx[k], dy = pair_dy[k];
+            const int yy = which == 0 ? cy - dy : which == 1 ? cy + dy : which == 2 ? cy - dx : cy + dx;
+            const int hw = which < 2 ? dx : dy;
+            set_run(fill, rw, H, W, yy, cx - hw, cx + hw);
+            set_px(ring, rw, H, W, cx - hw, yy);
+            set_px(ring, rw, H, W, cx + hw, yy);
+        }
+        return;
+    }
+    const int nv = s[1];
+    if (threadIdx.x == 0) {
+        // CollectPolyEdges(): the non-horizontal edges, x in 16.16 at the upper end point, dx per scan line (C++ integer division)
+        int n = 0;
+        int px = s[2 + 2 * (nv - 1)], py = s[3 + 2 * (nv - 1)];
+        for (int i = 0; i < nv; ++i) {
+            const int qx = s[2 + 2 * i], qy = s[3 + 2 * i];
+            if (py != qy) {
+                const bool down = py < qy;
+                ey0[n] = down ? py : qy; ey1[n] = down ? qy : py;
+                ex[n] = (long long)(down ? px : qx) << XY_SHIFT;
+                edx[n] = (((long long)qx - px) << XY_SHIFT) / ((long long)qy - py);
+                ++n;
+            }
+            px = qx; py = qy;
+        }
+        nedge = n;
+    }
+    if ((int)threadIdx.x < nv) {                  // the outline: one Line() per edge, on both planes (the fill draws it too)
+        const int i = threadIdx.x, j = i == 0 ? nv - 1 : i - 1;
+        draw_line(ring, rw, H, W, s[2 + 2 * j], s[3 + 2 * j], s[2 + 2 * i], s[3 + 2 * i]);
+        draw_line(fill, rw, H, W, s[2 + 2 * j], s[3 + 2 * j], s[2 + 2 * i], s[3 + 2 * i]);
+    }
+    __syncthreads();
+    // FillEdgeCollection(): per scan line the active edges in ascending x, consecutive pairs bound a run
+    for (int y = threadIdx.x; y < H; y += blockDim.x) {
+        long long ax[4], adx[4];
+        int na = 0;
+        for (int e = 0; e < nedge; ++e)
+            if (ey0[e] <= y && y < ey1[e]) { ax[na] = ex[e] + (long long)(y - ey0[e]) * edx[e]; adx[na] = edx[e]; ++na; }
+        for (int i = 1; i < na; ++i)              // insertion sort by (x, dx)
+            for (int j = i; j > 0 && (ax[j] < ax[j - 1] || (ax[j] == ax[j - 1] && adx[j] < adx[j - 1])); --j) {
+                const long long t = ax[j]; ax[j] = ax[j - 1]; ax[j - 1] = t;
+                const long long u = adx[j]; adx[j] = adx[j - 1]; adx[j - 1] = u;
+            }
+        for (int k = 0; k + 1 < na; k += 2) {
+            const long long x1 = (ax[k] + (1LL << XY_SHIFT) - 1) >> XY_SHIFT, x2 = ax[k + 1] >> XY_SHIFT;
+            if (x1 < W && x2 >= 0) set_run(fill, rw, H, W, y, (int)max(x1, 0LL), (int)min(x2, (long long)W - 1));
+        }
+    }
+}
+
+// the two planes of object o of image img
+__device__ __forceinline__ const uint32_t* fill_plane(const uint32_t* masks, int img, int o, int maxo, int H, int rw) {
+    return masks + ((size_t)img * maxo + o) * 2 * H * rw;
 }
 
 __device__ __forceinline__ int reflect(int i, int n) {            // scipy 'reflect': (d c b a | a b c d | d c b a)
@@ -50,38 +204,37 @@ __device__ __forceinline__ int reflect(int i, int n) {            // scipy 'refl
 }
 
 __global__ __launch_bounds__(256)
-void k_scene(const int* __restrict__ shape, const double* __restrict__ prop, const int* __restrict__ nobj,
+void k_scene(const uint32_t* __restrict__ masks, const double* __restrict__ prop, const int* __restrict__ nobj,
              const double* __restrict__ bg, int H, int W, int maxo, double z_far, double* __restrict__ aif,
              double* __restrict__ bloc, double* __restrict__ idep, double* __restrict__ bdep) {
-    __shared__ int sh[MAXO_LDS * SHAPE_INTS];
     __shared__ double pr[MAXO_LDS * PROP_F64];
     const int img = blockIdx.y;
     const int no = nobj[img];
-    for (int i = threadIdx.x; i < no * SHAPE_INTS; i += blockDim.x) sh[i] = shape[(size_t)img * maxo * SHAPE_INTS + i];
     for (int i = threadIdx.x; i < no * PROP_F64; i += blockDim.x) pr[i] = prop[(size_t)img * maxo * PROP_F64 + i];
     __syncthreads();
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= H * W) return;
     const int y = p / W, x = p - y * W;
+    const int rw = raster_row_words(W);
     double c0 = bg[img * 3], c1 = bg[img * 3 + 1], c2 = bg[img * 3 + 2];
     double bl = 0.0, dep = z_far, bd = 0.0;
     for (int o = 0; o < no; ++o) {
-        const int* s = sh + o * SHAPE_INTS;
+        const uint32_t* fill = fill_plane(masks, img, o, maxo, H, rw);
+        const uint32_t* ring = fill + (size_t)H * rw;
         const double z = pr[o * PROP_F64];
+        // 3x3 dilations of the filled mask and of the outline (:77-78); boundary depth where the dilated fill is (:84-85)
         bool fill_d = false, ol_d = false;
         for (int dy = -1; dy <= 1; ++dy)
             for (int dx = -1; dx <= 1; ++dx) {
                 const int xx = x + dx, yy = y + dy;
                 if ((unsigned)xx >= (unsigned)W || (unsigned)yy >= (unsigned)H) continue;
-                if (inside(s, xx, yy)) {
-                    fill_d = true;
-                    if (!ol_d && outline(s, xx, yy)) ol_d = true;
-                }
+                fill_d = fill_d || plane_bit(fill, rw, xx, yy);
+                ol_d = ol_d || plane_bit(ring, rw, xx, yy);
             }
         if (fill_d) bd = ol_d ? z : 0.0;
-        if (inside(s, x, y)) {
+        if (plane_bit(fill, rw, x, y)) {
             dep = z;
-            bl = outline(s, x, y) ? 255.0 : 0.0;
+            bl = plane_bit(ring, rw, x, y) ? 255.0 : 0.0;
             c0 = pr[o * PROP_F64 + 1]; c1 = pr[o * PROP_F64 + 2]; c2 = pr[o * PROP_F64 + 3];
         }
     }
@@ -95,13 +248,14 @@ __global__ void k_fill_bg(const double* __restrict__ bg, double* __restrict__ im
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gs) imgs[i] = bg[(i / per_img) * 3 + i % 3];
 }
 
-__global__ void k_mask(const int* __restrict__ shape, const int* __restrict__ nobj, int o, int H, int W, int maxo,
+__global__ void k_mask(const uint32_t* __restrict__ masks, const int* __restrict__ nobj, int o, int H, int W, int maxo,
                        unsigned char* __restrict__ mask) {
     const int img = blockIdx.y;
     const int p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= H * W || o >= nobj[img]) return;
     const int y = p / W, x = p - y * W;
-    mask[(size_t)img * H * W + p] = inside(shape + ((size_t)img * maxo + o) * SHAPE_INTS, x, y) ? 1 : 0;
+    const int rw = raster_row_words(W);
+    mask[(size_t)img * H * W + p] = plane_bit(fill_plane(masks, img, o, maxo, H, rw), rw, x, y) ? 1 : 0;
 }
 
 // tmp[img][a][y][x] = sum_d g(d) mask(y, reflect(x + d)),  g(d) = exp(-d^2 / (2 sigma^2))
@@ -327,12 +481,23 @@ int dims_ok(const char* who, int64_t n, int H, int W, int maxo) {
 
 }  // namespace
 
-extern "C" int be_datagen_scene_f64(const int* shape, const double* prop, const int* nobj, const double* bg, int n, int H,
+extern "C" size_t be_datagen_raster_words(int n, int H, int W, int maxo) {
+    return (size_t)n * maxo * 2 * H * raster_row_words(W);
+}
+
+extern "C" int be_datagen_raster_u32(const int* shape, const int* nobj, int n, int H, int W, int maxo, uint32_t* masks, void* stream) {
+    BE_REQUIRE(shape && nobj && masks, "be_datagen_raster_u32: null pointer");
+    if (int rc = dims_ok("be_datagen_raster_u32", n, H, W, maxo)) return rc;
+    hipLaunchKernelGGL(k_raster, dim3(maxo, n), dim3(256), 0, be::as_stream(stream), shape, nobj, H, W, maxo, masks);
+    return be::check_launch("be_datagen_raster_u32");
+}
+
+extern "C" int be_datagen_scene_f64(const uint32_t* masks, const double* prop, const int* nobj, const double* bg, int n, int H,
                                     int W, int maxo, double z_far, double* aif, double* bloc, double* idep, double* bdep,
                                     void* stream) {
-    BE_REQUIRE(shape && prop && nobj && bg && aif && bloc && idep && bdep, "be_datagen_scene_f64: null pointer");
+    BE_REQUIRE(masks && prop && nobj && bg && aif && bloc && idep && bdep, "be_datagen_scene_f64: null pointer");
     if (int rc = dims_ok("be_datagen_scene_f64", n, H, W, maxo)) return rc;
-    hipLaunchKernelGGL(k_scene, dim3((H * W + 255) / 256, n), dim3(256), 0, be::as_stream(stream), shape, prop, nobj, bg, H, W,
+    hipLaunchKernelGGL(k_scene, dim3((H * W + 255) / 256, n), dim3(256), 0, be::as_stream(stream), masks, prop, nobj, bg, H, W,
                        maxo, z_far, aif, bloc, idep, bdep);
     return be::check_launch("be_datagen_scene_f64");
 }
@@ -342,10 +507,10 @@ extern "C" size_t be_datagen_blur_scratch_bytes(int n, int H, int W) {
     return ((px + 255) / 256) * 256 + px * 2 * sizeof(double);      // mask bytes | tmp f64 [n,2,H,W] (also reused as int32 [n,H,W])
 }
 
-extern "C" int be_datagen_blur_composite_f64(const int* shape, const double* prop, const int* nobj, const double* bg,
+extern "C" int be_datagen_blur_composite_f64(const uint32_t* masks, const double* prop, const int* nobj, const double* bg,
                                              const double* sig, int n, int H, int W, int maxo, int max_nobj, double* imgs,
                                              void* scratch, size_t scratch_bytes, void* stream) {
-    BE_REQUIRE(shape && prop && nobj && bg && sig && imgs && scratch, "be_datagen_blur_composite_f64: null pointer");
+    BE_REQUIRE(masks && prop && nobj && bg && sig && imgs && scratch, "be_datagen_blur_composite_f64: null pointer");
     if (int rc = dims_ok("be_datagen_blur_composite_f64", n, H, W, maxo)) return rc;
     BE_REQUIRE(max_nobj >= 0 && max_nobj <= maxo, "be_datagen_blur_composite_f64: max_nobj outside [0, maxo]");
     BE_REQUIRE(scratch_bytes >= be_datagen_blur_scratch_bytes(n, H, W), "be_datagen_blur_composite_f64: scratch too small");
@@ -357,7 +522,7 @@ extern "C" int be_datagen_blur_composite_f64(const int* shape, const double* pro
     hipLaunchKernelGGL(k_fill_bg, dim3(cap(total, 256)), dim3(256), 0, s, bg, imgs, (int64_t)2 * H * W * 3, total);
     const dim3 grid((H * W + 255) / 256, n);
     for (int o = 0; o < max_nobj; ++o) {
-        hipLaunchKernelGGL(k_mask, grid, dim3(256), 0, s, shape, nobj, o, H, W, maxo, mask);
+        hipLaunchKernelGGL(k_mask, grid, dim3(256), 0, s, masks, nobj, o, H, W, maxo, mask);
         hipLaunchKernelGGL(k_blur_h, grid, dim3(256), 0, s, mask, sig, nobj, o, H, W, maxo, tmp);
         hipLaunchKernelGGL(k_blur_v_composite, grid, dim3(256), 0, s, tmp, sig, prop, nobj, o, H, W, maxo, imgs);
     }

@@ -580,12 +580,20 @@ int be_layernorm_bwd_f32(const float* dy, const float* v, const float* gamma, fl
  * nobj [N], bg [N,3], sig [N,maxo,2] PSF radius in pixels per aperture (utils/data_generator.py:16-17).
  * N < 65536, maxo <= 32.
  * ------------------------------------------------------------------------------------------------- */
-/* aif [N,H,W,3] (colour / 255, as images_aif is stored, :137), bloc [N,H,W] (0/255), idep, bdep [N,H,W]  (:36-41,77-85,100-103). */
-int be_datagen_scene_f64(const int* shape, const double* prop, const int* nobj, const double* bg, int n, int H, int W,
+/* Rasterisation (cv2.circle / cv2.drawContours of train_val_data_generator.py:58-76, thickness -1 and 1): two bit planes per
+ * object, FILL and RING, masks [N][maxo][2][H][ceil(W/32)] uint32 (be_datagen_raster_words of them; bit x & 31 of word x >> 5).
+ * The planes follow the algorithms those calls run in OpenCV 4.x modules/imgproc/src/drawing.cpp: Circle() (midpoint walk),
+ * Line() = clipLine() + the 8-connected LineIterator from the left end point, CollectPolyEdges() + FillEdgeCollection() (16.16
+ * fixed-point edges, active for y0 <= y < y1, runs from ceil(x_left) to floor(x_right)).  Objects >= nobj[i] get empty planes. */
+size_t be_datagen_raster_words(int n, int H, int W, int maxo);
+int be_datagen_raster_u32(const int* shape, const int* nobj, int n, int H, int W, int maxo, uint32_t* masks, void* stream);
+/* aif [N,H,W,3] (colour / 255, as images_aif is stored, :137), bloc [N,H,W] (0/255), idep, bdep [N,H,W]  (:36-41,77-85,100-103);
+ * masks: the planes be_datagen_raster_u32 wrote. */
+int be_datagen_scene_f64(const uint32_t* masks, const double* prop, const int* nobj, const double* bg, int n, int H, int W,
                          int maxo, double z_far, double* aif, double* bloc, double* idep, double* bdep, void* stream);
-/* imgs [N,2,H,W,3]: background, then every object blurred with its PSF per aperture and alpha-composited (:87-94). */
+/* imgs [N,2,H,W,3]: background, then every object (its FILL plane) blurred with its PSF per aperture and alpha-composited (:87-94). */
 size_t be_datagen_blur_scratch_bytes(int n, int H, int W);
-int be_datagen_blur_composite_f64(const int* shape, const double* prop, const int* nobj, const double* bg, const double* sig,
+int be_datagen_blur_composite_f64(const uint32_t* masks, const double* prop, const int* nobj, const double* bg, const double* sig,
                                   int n, int H, int W, int maxo, int max_nobj, double* imgs, void* scratch,
                                   size_t scratch_bytes, void* stream);
 /* imgs <- round(imgs); bdist [N,H,W] city-block distance to the nearest bloc > 0 pixel (ones when there is none);

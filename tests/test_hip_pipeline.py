@@ -500,6 +500,48 @@ def test_datagen_on_gpu_vs_oracle_and_reference_golden(env):
         assert float(pt["alphas"][p_]) == float(d2["alphas"][im])
 
 
+def test_rasteriser_planes_vs_the_opencv_rules_of_the_oracle(env):
+    """be_datagen_raster_u32 (one workgroup per object: Circle / Line + clipLine / CollectPolyEdges + FillEdgeCollection of OpenCV's
+    drawing.cpp, cv2.circle / cv2.drawContours of train_val_data_generator.py:58-76) against oracle.datagen.cv_masks, bit for bit:
+    the generator's own scenes, and hand-built edge cases - radius 0 and 1, a circle around a corner, shapes entirely outside,
+    zero-area and collinear polygons, horizontal and vertical edges, vertices far outside the image, a non-square image."""
+    from be_hip import datagen as dg
+    from oracle import datagen as odg
+    sc = dg.draw_scenes(4, seed=4242, name="raster")
+    got = dg.rasterize(sc["shape"], sc["nobj"], DEV).cpu().numpy()
+    seen = set()
+    for i in range(4):
+        for o in range(dg.MAXO):
+            if o >= sc["nobj"][i]:
+                assert not got[i, o].any()
+                continue
+            kind, pts = odg.shape_points(sc["shape"][i, o])
+            fill, ring = odg.cv_masks(kind, pts, 147, 147)
+            assert np.array_equal(got[i, o, 0], fill) and np.array_equal(got[i, o, 1], ring), (i, o, kind)
+            seen.add(kind)
+    assert seen == {0, 1, 2}
+    H, W = 40, 70
+    cases = [(0, 0, 10, 10, 0), (0, 0, 10, 10, 1), (0, 0, 0, 0, 12), (0, 0, 69, 39, 30), (0, 0, -50, -50, 8), (0, 0, 35, 20, 300),
+             (1, 4, 5, 5, 5, 5, 5, 5, 5, 5), (1, 4, 3, 3, 30, 3, 30, 20, 3, 20), (1, 4, -20, 10, 35, -15, 90, 10, 35, 35),
+             (1, 4, 10, 5, 40, 5, 40, 5, 10, 5), (2, 3, 2, 2, 8, 5, 14, 8), (2, 3, -100, -100, 200, 10, -30, 150),
+             (2, 3, 0, 0, 69, 0, 0, 39), (2, 3, 69, 39, 69, 0, 0, 39), (2, 3, 5, 30, 60, 30, 33, 31), (2, 3, 80, 5, 90, 20, 75, 30),
+             (1, 4, 10, 10, 50, 30, 50, 10, 10, 30)]                      # the last one is a bow-tie: four active edges per scan line
+    rng = np.random.RandomState(9)
+    for _ in range(15):
+        nv = int(rng.choice([3, 4]))
+        cases.append((1 if nv == 4 else 2, nv, *rng.randint(-40, 110, size=2 * nv).tolist()))
+    shape = np.zeros((1, dg.MAXO, 10), dtype=np.int32)
+    for k, c in enumerate(cases):
+        shape[0, k, :len(c)] = c
+    got = dg.rasterize(shape, np.array([len(cases)], dtype=np.int32), DEV, H, W).cpu().numpy()
+    for k in range(len(cases)):
+        kind, pts = odg.shape_points(shape[0, k])
+        fill, ring = odg.cv_masks(kind, pts, H, W)
+        assert np.array_equal(got[0, k, 0], fill), (k, cases[k])
+        assert np.array_equal(got[0, k, 1], ring), (k, cases[k])
+    assert not got[0, len(cases):].any()
+
+
 def test_datagen_files_feed_the_local_training_dataset(env, tmp_path):
     """generate -> crop -> save -> data.ShapeDataset: the .npy wire format either side of training."""
     import data

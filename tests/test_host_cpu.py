@@ -425,3 +425,73 @@ def test_bench_plain_command_spawns_one_child_per_rank_before_any_gpu_call(monke
     monkeypatch.delenv("BE_LOCAL_DEVICE")
     started.clear()
     assert bench.spawn_ranks(2) == 2 and not started               # no GPU here: refused, nothing spawned
+
+
+def test_opencv_scan_conversion_rules_known_answers():
+    """oracle.datagen restates the algorithms cv2.circle / cv2.drawContours run (OpenCV drawing.cpp: Circle, Line = clipLine +
+    LineIterator, CollectPolyEdges + FillEdgeCollection; train_val_data_generator.py:58-76).  cv2 is absent offline, so the
+    restatement is held to known answers worked BY HAND from those algorithms, and to the invariants they imply."""
+    from oracle import datagen as od
+
+    def rows(mask):
+        return ["".join("#" if v else "." for v in r) for r in mask]
+    # Circle(): radius 0 is one pixel; radius 1 a plus (err > 0 after the first step: dx drops to 0); radius 2: rows of half-width
+    # 0,1,2,1,0; radius 3: 0,2,2,3,2,2,0 - worked from err = dx^2 + dy^2 - r^2 with one decrement per step
+    for r, half in ((0, [0]), (1, [0, 1, 0]), (2, [0, 1, 2, 1, 0]), (3, [0, 2, 2, 3, 2, 2, 0]), (4, [0, 2, 3, 3, 4, 3, 3, 2, 0])):
+        fill, ring = od.cv_circle_masks(6, 6, r, 13, 13)
+        assert [int(fill[6 - r + i].sum()) for i in range(2 * r + 1)] == [2 * h + 1 for h in half], r
+        assert fill.sum() == sum(2 * h + 1 for h in half) and (ring & ~fill).sum() == 0
+        for i, h in enumerate(half):                                  # each row is the run [cx - h, cx + h]; its ends are on the ring
+            assert fill[6 - r + i, 6 - h] and fill[6 - r + i, 6 + h] and ring[6 - r + i, 6 - h] and ring[6 - r + i, 6 + h]
+        assert np.array_equal(fill, fill[::-1]) and np.array_equal(fill, fill[:, ::-1]) and np.array_equal(fill, fill.T)
+    # the ring of radius 3: the eight symmetric points of the octant walk (dx,dy) = (3,0), (2,1), (2,2)
+    _, ring3 = od.cv_circle_masks(4, 4, 3, 9, 9)
+    assert rows(ring3) == [".........", "....#....", "..##.##..", "..#...#..", ".#.....#.", "..#...#..", "..##.##..", "....#....", "........."]
+    # a circle hanging over the border is the same circle cropped (Circle() clips rows and points, nothing else changes)
+    big, _ = od.cv_circle_masks(30, 30, 17, 61, 61)
+    cut, _ = od.cv_circle_masks(30 - 22, 30 - 25, 17, 20, 18)
+    assert np.array_equal(cut, big[25:45, 22:40])
+    # Line(): (0,0) -> (5,2): err = 5 - 4 = 1, minus = -4, plus = 10: y steps when err < 0 BEFORE the update -> y = 0,0,1,1,2,2
+    img = np.zeros((4, 7), dtype=bool)
+    od.cv_line(img, (0, 0), (5, 2))
+    assert rows(img) == ["##.....", "..##...", "....##.", "......."]
+    rev = np.zeros((4, 7), dtype=bool)
+    od.cv_line(rev, (5, 2), (0, 0))                                    # leftToRight: the same pixels from either end
+    assert np.array_equal(img, rev)
+    steep = np.zeros((7, 4), dtype=bool)
+    od.cv_line(steep, (0, 0), (2, 5))
+    assert np.array_equal(steep, img.T)
+    # clipLine(): (-4,1) -> (8,7) on a 6 x 6 image: x1 < 0 -> y1 += (0 - -4) * 6 / 12 = 2 -> (0,3); y2 > 5 -> x2 += (5 - 7) * 8 / 4
+    # (formed with the ALREADY clipped first point: x2 - x1 = 8, y2 - y1 = 4) = -4 -> (4,5)
+    assert od.cv_clip_line(6, 6, -4, 1, 8, 7) == (True, 0, 3, 4, 5)
+    assert od.cv_clip_line(6, 6, -4, -1, -1, 9)[0] is False           # entirely to the left
+    assert od.cv_clip_line(6, 6, 1, 2, 4, 3) == (True, 1, 2, 4, 3)
+    # FillEdgeCollection(): the triangle (1,1), (9,1), (1,9): the horizontal edge is not collected; left edge x = 1, the
+    # hypotenuse x = 9 - (y - 1) (dx = -65536 exactly); active for 1 <= y < 9, runs [1, 10 - y]; row 9 comes from Line() only
+    fill, ring = od.cv_poly_masks([(1, 1), (9, 1), (1, 9)], 11, 11)
+    assert [int(fill[y].sum()) for y in range(11)] == [0, 9, 8, 7, 6, 5, 4, 3, 2, 1, 0]
+    assert all(fill[y, 1:11 - y].all() for y in range(1, 9)) and fill[9, 1] and (ring & ~fill).sum() == 0
+    assert int(ring.sum()) == 9 + 8 + 7                                # three edges of 9 pixels sharing their three corners
+    # fixed point: the edge (0,0) -> (3,7) has dx = trunc(3 * 65536 / 7) = 28086, so the scan-line runs of the triangle (0,0), (3,7),
+    # (0,7) end at floor(y * 28086 / 65536) = 0,0,0,1,1,2,2 for y = 0..6; the edge's own Line() pixels are x = 0,0,1,1,2,2,3,3
+    # (the steep walk steps x after every second row): the union has 1,1,2,2,3,3,4 pixels, row 7 is the horizontal edge (4)
+    f2, r2 = od.cv_poly_masks([(0, 0), (3, 7), (0, 7)], 9, 6)
+    assert od._trunc_div(3 << 16, 7) == 28086 and od._trunc_div(-(3 << 16), 7) == -28086
+    assert [int(np.nonzero(r2[y])[0].max()) for y in range(8)] == [0, 0, 1, 1, 2, 2, 3, 3]
+    assert [int(f2[y].sum()) for y in range(9)] == [1, 1, 2, 2, 3, 3, 4, 4, 0]
+    # invariants over many random polygons that cross the border: the outline is inside the fill, rotating the vertex
+    # list changes nothing, a degenerate (collinear) polygon is its outline
+    rng = np.random.RandomState(5)
+    for _ in range(60):
+        nv = int(rng.choice([3, 4]))
+        pts = rng.randint(-30, 70, size=(nv, 2))
+        fill, ring = od.cv_poly_masks(pts, 40, 44)
+        assert (ring & ~fill).sum() == 0
+        f_rot, r_rot = od.cv_poly_masks(np.roll(pts, 1, axis=0), 40, 44)
+        assert np.array_equal(fill, f_rot) and np.array_equal(ring, r_rot)
+        # (REVERSING the list is not an invariant: clipLine() clips the first end point with the unclipped second and the second
+        #  with the clipped first, so a clipped edge walked the other way can differ by a pixel - only the interior is the same)
+        f_rev, r_rev = od.cv_poly_masks(pts[::-1], 40, 44)
+        assert np.array_equal(fill & ~(ring | r_rev), f_rev & ~(ring | r_rev))
+    fl, rl = od.cv_poly_masks([(2, 2), (8, 5), (14, 8)], 12, 18)
+    assert np.array_equal(fl, rl) and rl.sum() == 13

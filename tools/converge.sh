@@ -7,11 +7,16 @@
 #                 from ckpt/global_resume.ckpt when present)
 #   STAGE=eval    held-out synthetic set (seed shifted) -> HIP pipeline metrics, oracle pipeline metrics on the same checkpoint + images
 set -e
-cd $GRAFT_REPO_ROOT/blurry-edges_amd
+# ckpt/frozen/ (git-ignored, travels with the snapshot): a copy of the tree + built libraries at the commit the run STARTED on, so
+# that all stages of one training run execute the same code while the working tree moves on (FROZEN=0: the working tree)
+R=$GRAFT_REPO_ROOT
+T=$R; [ "${FROZEN:-1}" = 1 ] && [ -d $R/ckpt/frozen/blurry-edges_amd/lib ] && T=$R/ckpt/frozen
+echo "code tree: $T"
+cd $T/blurry-edges_amd
 STAGE=${STAGE:-local}
 df -h /tmp | tail -n 1; free -g | sed -n 2p
-D=/tmp/be_conv; mkdir -p $D ../gpurun_out/r05_converged
-O=$(cd ../gpurun_out/r05_converged && pwd)
+D=/tmp/be_conv; mkdir -p $D $R/gpurun_out/r05_converged
+O=$R/gpurun_out/r05_converged
 NT=${NT:-8000}; NV=${NV:-2000}
 t() { date +%s.%N; }
 if [ ! -f $D/data/images_ny_val.npy ]; then
@@ -31,14 +36,14 @@ local)
   tail -n 4 $O/local_train_epochs.txt
   ;;
 global)
-  cp ../ckpt/pretrained_local_stage.pth $D/w/
+  cp $R/ckpt/pretrained_local_stage.pth $D/w/
   EG=${GLOBAL_EPOCHS:-40}
   T2=$(t)
   if [ ! -f $D/data/params_src_val.npy ]; then
     python -m be_hip.workflow global_pre --data_path $D/data --model_path $D/w > $O/global_pre.log 2>&1
     echo "global_pre: $(python -c "print(f'{$(t) - $T2:.1f}')") s" | tee -a $O/${STAGE}_times.txt
   fi
-  [ -f ../ckpt/global_resume.ckpt ] && cp ../ckpt/global_resume.ckpt $D/w/
+  [ -f $R/ckpt/global_resume.ckpt ] && cp $R/ckpt/global_resume.ckpt $D/w/
   T3=$(t)
   python -m be_hip.workflow global_train --data_path $D/data --model_path $D/w --log_path $D/logs --epoch_num $EG \
       ${GLOBAL_DYN:+--dynamic_epoch $GLOBAL_DYN} --resume --time_budget ${GLOBAL_BUDGET:-900} >> $O/global_train.log 2>&1
@@ -49,8 +54,8 @@ global)
   tail -n 3 $D/logs/exp_global_stage_training.txt
   ;;
 eval)
-  cp ../ckpt/pretrained_local_stage.pth ../ckpt/pretrained_global_stage.pth $D/w/
+  cp $R/ckpt/pretrained_local_stage.pth $R/ckpt/pretrained_global_stage.pth $D/w/
   cp $D/w/pretrained_global_stage.pth $D/w/pretrained_global_stage_w.pth
-  python ../tests/converged_eval.py --data $D/data --weights $D/w --out $O ${EVAL_N:+--n $EVAL_N} ${ORACLE_N:+--oracle-n $ORACLE_N} 2>&1 | tee $O/eval.log
+  python $T/tests/converged_eval.py --data $D/data --weights $D/w --out $O ${EVAL_N:+--n $EVAL_N} ${ORACLE_N:+--oracle-n $ORACLE_N} 2>&1 | tee $O/eval.log
   ;;
 esac
