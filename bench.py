@@ -282,7 +282,7 @@ def leg_global_training(dev, steps=12):
                 images_per_s=round(B / ms * 1e3, 1), steps=steps, first_loss=float(losses[0]), last_loss=float(losses[-1]))
 
 
-def leg_dp(dev, native, dist, rank, world, steps, algorithm="allreduce"):
+def leg_dp(dev, native, dist, rank, world, steps, algorithm="allreduce", buckets=4):
     """configs[4], local half: `steps` data-parallel training steps, per-GPU batch 64, gradients averaged by the bucketed
     all-reduce that overlaps the backward (be_hip.dp.GradSync over RCCL); plus the same step without the exchange and the
     exchange alone, so that the exposed communication can be read off.  world = 1 runs the identical code without a group."""
@@ -308,7 +308,7 @@ def leg_dp(dev, native, dist, rank, world, steps, algorithm="allreduce"):
             port = sk.getsockname()[1]
         dist1.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
         own_group = True
-    sync = dp.GradSync(world, always=own_group, algorithm=algorithm) if (world > 1 or own_group) else None
+    sync = dp.GradSync(world, always=own_group, algorithm=algorithm, groups=dp.GROUPS_BY_COUNT[buckets]) if (world > 1 or own_group) else None
     if world > 1 or own_group:
         dp.broadcast_parameters(model, src=0)
     it = [0]
@@ -341,7 +341,7 @@ def leg_dp(dev, native, dist, rank, world, steps, algorithm="allreduce"):
     local = []
     ms = clock(step, steps)
     res = dict(config="configs[4] (LocalStage half): data-parallel local training, per-GPU batch 64, eager launches, "
-                      "gradient buckets (fc | layer3 | layer2 | layer1 + layer0 + conv1) all-reduced on a side stream while the backward runs",
+                      f"{buckets} gradient buckets (be_hip.dp.GROUPS_BY_COUNT) all-reduced on a side stream while the backward runs",
                world=world, global_batch=B * world, steps=steps, dp_step_ms=round(ms, 4),
                patches_per_s=round(B * world / ms * 1e3, 1), allreduce_bytes=4 * sum(p.numel() for p in model.parameters()),
                allreduce_buckets=len(sync.groups) if sync is not None else 0, algorithm=algorithm)
@@ -450,6 +450,9 @@ def main():
                                                            "(default), 1 = one stream (what profiles/ are taken with)")
     ap.add_argument("--dp-algorithm", default=os.environ.get("BE_DP_ALGORITHM", "allreduce"), choices=("allreduce", "rs_ag"),
                     help="gradient exchange of the dp leg: one all_reduce per bucket, or reduce_scatter + all_gather (be_hip.dp.GradSync)")
+    ap.add_argument("--dp-buckets", type=int, default=int(os.environ.get("BE_DP_BUCKETS", "4")), choices=(2, 4, 5),
+                    help="gradient buckets of the dp leg (be_hip.dp.GROUPS_BY_COUNT): 4 (default), 2 or 5")
+    ap.add_argument("--only-dp", action="store_true", help="run the dp leg alone (A/B runs of the exchange): no extra_configs, no cpu baseline")
     ap.add_argument("--layers", action="store_true", help="print the per-launch conv timing table to stderr")
     args = ap.parse_args()
 
@@ -638,7 +641,7 @@ def main():
         return out
 
     if not args.no_extra:
-        if rank == 0:
+        if rank == 0 and not args.only_dp:
             extra = []
             for leg in (lambda: [leg_local_training(dev, native, peak)], lambda: leg_image_pairs(dev, native, peak),
                         lambda: [leg_global_training(dev)]):
@@ -665,7 +668,7 @@ def main():
             watchdog.daemon = True
             watchdog.start()
         try:
-            dp_leg = leg_dp(dev, native, dist, rank, world, max(10, args.steps), algorithm=args.dp_algorithm)
+            dp_leg = leg_dp(dev, native, dist, rank, world, max(10, args.steps), algorithm=args.dp_algorithm, buckets=args.dp_buckets)
         except Exception as e:
             dp_leg = dict(error=f"{type(e).__name__}: {e}")
             print(f"[bench rank {rank}] dp leg failed: {dp_leg['error']}", file=sys.stderr, flush=True)
@@ -678,7 +681,7 @@ def main():
 
     cpu = None
     more = {}
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.only_dp:
         cpu, (est_o, col_o, z_o) = cpu_baseline(x_np, sd_np)
         p = CPU_SAMPLE_PAIRS
         with torch.no_grad():

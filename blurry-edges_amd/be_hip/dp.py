@@ -99,6 +99,10 @@ def grads_as_flat(params, fallback: torch.Tensor | None = None):
 GRAD_POINTS = ((78, 86), (60, 78), (42, 60), (24, 42), (0, 24))
 # buckets = unions of consecutive completion points.  Round 3 default: the head (0.6 MB) is merged into layer1's bucket.
 DEFAULT_GROUPS = ((78, 86), (60, 78), (42, 60), (0, 42))
+# two buckets (round 5 A/B: fewer hipGraph segments in SegmentedGraphStep, fewer collectives; the exposed one is 13.2 MB):
+# fc + layer3 (15.8 MB) | layer2 + layer1 + layer0 + conv1 (13.2 MB)
+TWO_GROUPS = ((60, 86), (0, 60))
+GROUPS_BY_COUNT = {2: TWO_GROUPS, 4: DEFAULT_GROUPS, 5: GRAD_POINTS}
 
 
 def check_groups(groups):

@@ -43,14 +43,16 @@ global)
     python -m be_hip.workflow global_pre --data_path $D/data --model_path $D/w > $O/global_pre.log 2>&1
     echo "global_pre: $(python -c "print(f'{$(t) - $T2:.1f}')") s" | tee -a $O/${STAGE}_times.txt
   fi
-  [ -f $R/ckpt/global_resume.ckpt ] && cp $R/ckpt/global_resume.ckpt $D/w/
+  # the checkpoints live under gpurun_out/ (merged back even when the call is cut at its limit): weights + resume state, ~25 MB
+  mkdir -p $O/gw
+  [ -f $R/ckpt/global_resume.ckpt ] && cp $R/ckpt/global_resume.ckpt $O/gw/
   T3=$(t)
-  python -m be_hip.workflow global_train --data_path $D/data --model_path $D/w --log_path $D/logs --epoch_num $EG \
-      ${GLOBAL_DYN:+--dynamic_epoch $GLOBAL_DYN} --resume --time_budget ${GLOBAL_BUDGET:-900} >> $O/global_train.log 2>&1
+  python -m be_hip.workflow global_train --data_path $D/data --model_path $O/gw --log_path $D/logs --epoch_num $EG \
+      ${GLOBAL_DYN:+--dynamic_epoch $GLOBAL_DYN} --resume --time_budget ${GLOBAL_BUDGET:-780} >> $O/global_train.log 2>&1
   echo "global_train (to epoch budget): $(python -c "print(f'{$(t) - $T3:.1f}')") s" | tee -a $O/${STAGE}_times.txt
   cp $D/logs/exp_global_stage_training.txt $O/global_train_epochs_$(date +%s).txt
-  cp $D/w/best_run_exp_global_stage.pth $O/pretrained_global_stage.pth
-  cp $D/w/global_resume.ckpt $O/global_resume.ckpt
+  cp $O/gw/best_run_exp_global_stage.pth $O/pretrained_global_stage.pth
+  cp $O/gw/global_resume.ckpt $O/global_resume.ckpt
   tail -n 3 $D/logs/exp_global_stage_training.txt
   ;;
 eval)
