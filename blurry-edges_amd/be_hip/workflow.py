@@ -224,8 +224,8 @@ def global_train(args, quiet=False):
         opt.load_state_dict(ck["opt"])
         sched.load_state_dict(ck["sched"])
         gamma.idx = ck["gamma_idx"]
-        sampler.set_state(ck["sampler"])
-        torch.set_rng_state(ck["torch_rng"])
+        sampler.set_state(ck["sampler"].cpu())                       # generator states are CPU byte tensors (map_location moved them)
+        torch.set_rng_state(ck["torch_rng"].cpu())
         first_epoch, best, best_epoch = ck["epoch"], ck["best"], ck["best_epoch"]
         curve[:first_epoch] = ck["curve"][:first_epoch]
         if rank == 0 and ck.get("best_model") is not None:
