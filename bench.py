@@ -438,6 +438,18 @@ def spawn_ranks(n):
     return max(abs(c) for c in codes)
 
 
+_JSON_FD = None
+
+
+def emit(line):
+    """the ONE JSON line, on the process's real stdout"""
+    sys.stdout.flush()
+    if _JSON_FD is None:
+        print(line, flush=True)
+    else:
+        os.write(_JSON_FD, (line + "\n").encode())
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -465,6 +477,13 @@ def main():
         raise SystemExit(spawn_ranks(args.gpus))
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+    # stdout carries the JSON line and nothing else: native libraries write there too (RCCL prints a five-line version banner
+    # to stdout when its first communicator comes up), so file descriptor 1 is pointed at stderr for the rest of the run and
+    # the line goes to a private copy of the real stdout
+    global _JSON_FD
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
     if local_rank >= torch.cuda.device_count() >= 1:
         local_rank = 0                             # the launcher masked the devices: each rank sees only its own GPU
     dist = None
@@ -662,7 +681,7 @@ def main():
                 msg = "dp leg did not finish within 180 s (watchdog)"
                 print(f"[bench rank {rank}] {msg}", file=sys.stderr, flush=True)
                 if rank == 0:
-                    print(json.dumps(headline(dict(error=msg))), flush=True)
+                    emit(json.dumps(headline(dict(error=msg))))
                 os._exit(3)                               # the headline is out; a hung collective is NOT a clean run
             watchdog = threading.Timer(180.0, bail)
             watchdog.daemon = True
@@ -674,7 +693,7 @@ def main():
             print(f"[bench rank {rank}] dp leg failed: {dp_leg['error']}", file=sys.stderr, flush=True)
             if world > 1:                                 # the other ranks may be waiting inside a collective: do not join them
                 if rank == 0:
-                    print(json.dumps(headline(dp_leg)), flush=True)
+                    emit(json.dumps(headline(dp_leg)))
                 os._exit(3)                               # headline printed, exit code says the dp leg failed
         if watchdog is not None:
             watchdog.cancel()
@@ -697,7 +716,7 @@ def main():
                                                   / est_o.abs().max()))
 
     if rank == 0:
-        print(json.dumps(headline(dp_leg, cpu, more)), flush=True)
+        emit(json.dumps(headline(dp_leg, cpu, more)))
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
