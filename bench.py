@@ -390,6 +390,20 @@ def leg_dp(dev, native, dist, rank, world, steps, algorithm="allreduce", buckets
         res["segmented_graph_step_ms"] = round(clock(seg_step, steps), 4)
         mine["segmented_graph_step_ms"] = local[-1]
         res["segmented_graph_patches_per_s"] = round(B * world / res["segmented_graph_step_ms"] * 1e3, 1)
+        # the same step as ONE hipGraph with the bucket collectives captured inside it (SegmentedGraphStep(capture_collectives=True));
+        # a failure here (a stack that cannot capture RCCL calls) is recorded, not fatal
+        if os.environ.get("BE_BENCH_NO_CAPTURED_DP") is None:
+            try:
+                cap = train_local.SegmentedGraphStep(model, helper, opt, sync, world=world, capture_collectives=True)
+
+                def cap_step():
+                    lo = (it[0] % 8) * B
+                    it[0] += 1
+                    return cap({k: v[lo:lo + B] for k, v in data.items()}, args.beta_bndry_loc, args.beta_smthns)
+                res["captured_graph_step_ms"] = round(clock(cap_step, steps), 4)
+                mine["captured_graph_step_ms"] = local[-1]
+            except Exception as e:
+                res["captured_graph_step_error"] = f"{type(e).__name__}: {e}"[:300]
     # every rank reports its OWN clocks (rank 0 alone hides a straggler): one line per rank on stderr, and the
     # list of all ranks in rank 0's JSON line.  The `*_ms` figures above are the MAX over ranks of the same clocks.
     print(f"[bench rank {rank}] dp: {json.dumps(mine)}", file=sys.stderr, flush=True)

@@ -120,8 +120,15 @@ class SegmentedGraphStep:
     engine would run the backward - and the hook that ends and begins captures - on another thread than the one that began the
     capture.  Same kernels, same order, same results as train_step (tests/test_dp_gpu.py)."""
 
-    def __init__(self, model, helper, opt, sync, world=1, clip=1.0):
+    def __init__(self, model, helper, opt, sync, world=1, clip=1.0, capture_collectives=None):
+        """capture_collectives (round 5; default: environment BE_DP_CAPTURE, "0"): capture the bucket all-reduces INTO the graph -
+        the whole data-parallel step is then ONE hipGraph: the backward's bucket hook issues the collective on GradSync's side stream
+        behind an event, all of it recorded by the capture (cross-stream dependencies become graph edges), and a replay is one host
+        call.  PyTorch's ProcessGroupNCCL supports capture; lab/rccl_capture_probe.py checks it on this stack."""
         self.model, self.helper, self.opt, self.sync, self.world, self.clip = model, helper, opt, sync, world, clip
+        if capture_collectives is None:
+            capture_collectives = os.environ.get("BE_DP_CAPTURE", "0") == "1"
+        self.capture_collectives = bool(capture_collectives) and sync is not None
         self.key = self.graphs = self.static = self.loss = self.flat = self.ranges = None
         self.warm = 0
         self.stream = None
@@ -176,6 +183,10 @@ class SegmentedGraphStep:
         else:
             for k in self.static:
                 self.static[k].copy_(batch[k])
+        if self.capture_collectives:
+            self.graphs[0].replay()                      # forward, loss, backward, the bucket collectives, division, clip, AdamW
+            self.model.invalidate_packed()
+            return self.loss.clone()
         nb = len(self.graphs) - 1
         for k in range(nb):
             self.graphs[k].replay()
@@ -192,6 +203,30 @@ class SegmentedGraphStep:
     def _capture(self, batch, beta_b, beta_s):
         self.static = {k: v.clone() for k, v in batch.items()}
         torch.cuda.synchronize()
+        if self.capture_collectives:
+            g = torch.cuda.CUDAGraph()
+            seen = []
+
+            def hook_c(flat, lo, hi):                    # bucket final: its collective goes onto the side stream, inside the capture
+                seen.append((flat, lo, hi))
+                self.sync.bucket_ready(flat, lo, hi)
+            if self.stream is None:
+                self.stream = torch.cuda.Stream()
+            self.stream.wait_stream(torch.cuda.current_stream())
+            timing, self.sync.timing = self.sync.timing, False           # timed events cannot be captured
+            with torch.cuda.stream(self.stream):
+                with torch.cuda.graph(g, stream=self.stream, capture_error_mode="thread_local"):
+                    self.loss = self._step(self.static, beta_b, beta_s, hook_c)
+                    self.sync.wait()                     # the capturing stream joins the side stream: every collective is an ancestor
+                    flat = seen[0][0]
+                    self.sync.flat = None
+                    if self.world > 1 or self.sync.always:
+                        flat.div_(self.world)
+                    self._clip_step()
+            self.sync.timing = timing
+            torch.cuda.current_stream().wait_stream(self.stream)
+            self.graphs, self.flat, self.ranges = [g], flat, [(lo, hi) for _, lo, hi in seen]
+            return
         from .dp import DEFAULT_GROUPS
         nb = len(self.sync.groups if self.sync is not None else DEFAULT_GROUPS)
         graphs = [torch.cuda.CUDAGraph() for _ in range(nb + 1)]

@@ -119,13 +119,14 @@ def _nccl_worker(port, q):
     import models
     data = {k: torch.from_numpy(v).to(DEV) for k, v in synth.synthetic_training_patches(64 * 4, seed=77).items()}
     finals = []
-    for mode in ("eager", "segmented"):
+    for mode in ("eager", "segmented", "captured"):
         mm = models.LocalStage().to(DEV)
         mm.load_state_dict({k: torch.from_numpy(np.asarray(v)) for k, v in synth.local_stage_state_dict().items()})
         mm.train()
         opt = torch.optim.AdamW(mm.parameters(), lr=1e-3, capturable=True, fused=dp.fused_adamw())
         sync = dp.GradSync(1, always=True)
-        seg = train_local.SegmentedGraphStep(mm, helper, opt, sync, world=1) if mode == "segmented" else None
+        # "captured" (round 5): the bucket all-reduces recorded INTO one hipGraph (capture_collectives=True)
+        seg = train_local.SegmentedGraphStep(mm, helper, opt, sync, world=1, capture_collectives=(mode == "captured")) if mode != "eager" else None
         losses = []
         for it in range(8):
             b = {k: v[(it % 4) * 64:(it % 4 + 1) * 64] for k, v in data.items()}
@@ -134,7 +135,8 @@ def _nccl_worker(port, q):
             else:
                 losses.append(float(train_local.train_step(mm, helper, opt, b, args.beta_bndry_loc, args.beta_smthns, sync=sync)))
         torch.cuda.synchronize()
-        finals.append((losses, {k: v.detach().cpu().numpy().copy() for k, v in mm.state_dict().items()}, seg is not None and seg.graphs is not None))
+        finals.append((losses, {k: v.detach().cpu().numpy().copy() for k, v in mm.state_dict().items()},
+                       seg is not None and seg.graphs is not None and len(seg.graphs) == (1 if mode == "captured" else len(sync.groups) + 1)))
     res.append(finals)
     q.put(res)
     dist.destroy_process_group()
@@ -154,10 +156,14 @@ def test_gradsync_over_rccl_one_rank_group_leaves_the_gradients_untouched():
     p.join(timeout=120)
     assert p.exitcode == 0
     assert np.array_equal(g0, g1) and np.isfinite(g0).all() and nbytes == 3 * 4 * 7254122
-    (l_e, sd_e, _), (l_s, sd_s, captured) = finals
+    (l_e, sd_e, _), (l_s, sd_s, captured), (l_c, sd_c, one_graph) = finals
     assert captured and l_e == l_s and np.isfinite(l_e).all()
     for k in sd_e:
         assert np.array_equal(sd_e[k], sd_s[k]), k
+    # the whole step as ONE hipGraph with the RCCL calls captured inside it: same bits again
+    assert one_graph and l_e == l_c
+    for k in sd_e:
+        assert np.array_equal(sd_e[k], sd_c[k]), k
 
 
 def _workflow_worker(rank, world, port, root, models_dir, logs, q):
