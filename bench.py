@@ -392,7 +392,9 @@ def leg_dp(dev, native, dist, rank, world, steps, algorithm="allreduce", buckets
         res["segmented_graph_patches_per_s"] = round(B * world / res["segmented_graph_step_ms"] * 1e3, 1)
         # the same step as ONE hipGraph with the bucket collectives captured inside it (SegmentedGraphStep(capture_collectives=True));
         # a failure here (a stack that cannot capture RCCL calls) is recorded, not fatal
-        if os.environ.get("BE_BENCH_NO_CAPTURED_DP") is None:
+        # (N > 1: opt-in with BE_BENCH_CAPTURED_DP=1 - unproven between real ranks, and a capture that fails on one rank only
+        #  would leave the others waiting inside a collective)
+        if os.environ.get("BE_BENCH_NO_CAPTURED_DP") is None and (world == 1 or os.environ.get("BE_BENCH_CAPTURED_DP") == "1"):
             try:
                 cap = train_local.SegmentedGraphStep(model, helper, opt, sync, world=world, capture_collectives=True)
 
