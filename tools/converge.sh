@@ -19,11 +19,11 @@ D=/tmp/be_conv; mkdir -p $D $R/gpurun_out/r05_converged
 O=$R/gpurun_out/r05_converged
 NT=${NT:-8000}; NV=${NV:-2000}
 t() { date +%s.%N; }
-if [ ! -f $D/data/images_ny_val.npy ]; then
+if [ $STAGE != eval ] && [ ! -f $D/data/images_ny_val.npy ]; then
   T0=$(t); python -m be_hip.datagen --data_path $D/data --num_sample_train $NT --num_sample_val $NV > $O/${STAGE}_1_datagen.log 2>&1
   echo "datagen $NT + $NV: $(python -c "print(f'{$(t) - $T0:.1f}')") s" | tee -a $O/${STAGE}_times.txt
 fi
-mkdir -p $D/w
+mkdir -p $D/w $D/data
 case $STAGE in
 local)
   EL=${LOCAL_EPOCHS:-1000}; DYN=${LOCAL_DYN:-200}
