@@ -92,6 +92,51 @@ def cpu_baseline(x_np, sd_np):
                        f"({', '.join('%.2f' % t for t in times)} s), torch {torch.__version__} CPU, {ncores} threads"), (est, col, z)
 
 
+CHECKPOINT_DIR = os.path.join(ROOT, "checkpoints")
+CONVERGED_RECORD = os.path.join(ROOT, "profiles", "r05_converged", "converged_eval.json")
+
+
+def converged_leg(dev, native, x, x_np, pairs=512):
+    """Accuracy keys from a CONVERGED model: checkpoints/pretrained_local_stage.pth is the LocalStage trained here at
+    the reference's full schedule (utils/args.py:29-36; tools/converge.sh, profiles/r05_converged/).  Live: the hot path with those
+    weights on the bench's own pairs against the oracle with the same weights (logits, depth RMSE over non-flipped pairs, branch
+    flips) - parity at trained weights.  Recorded: the end-to-end depth metrics of the HIP and the oracle pipelines on a held-out
+    set (tests/converged_eval.py on the GPU box; the oracle pipeline takes 11 s per image pair, too long for this line)."""
+    import models, utils
+    from oracle import local_stage as ols, render as orr, depth as od
+    path = os.path.join(CHECKPOINT_DIR, "pretrained_local_stage.pth")
+    if not os.path.exists(path):
+        return None
+    sd = torch.load(path, map_location="cpu")
+    m = models.LocalStage()
+    m.load_state_dict(sd)
+    m = m.to(dev).eval()
+    dcal = utils.DepthEtas(utils.get_args("eval", argv=[]), dev)
+    with torch.no_grad():
+        est = m(x)
+        depth = native.local_depth(dcal.consts, est)
+    torch.cuda.synchronize()
+    p = pairs
+    xs = torch.from_numpy(np.concatenate([x_np[:p], x_np[PAIRS:PAIRS + p]]))
+    with torch.no_grad():
+        est_o = ols.local_stage_forward({k: v for k, v in sd.items()}, xs)
+        z_o = orr.local_depth(od.depth_consts(), est_o[:p], est_o[p:])
+    eh = torch.cat([est[:p], est[PAIRS:PAIRS + p]]).cpu()
+    d = depth[:p].cpu() - z_o
+    keep = d.abs() / z_o.abs() <= 1e-3
+    out = dict(checkpoint="checkpoints/pretrained_local_stage.pth (LocalStage, 1000 epochs x 250 steps of batch 64 on 16 000 synthetic patches)",
+               sample_pairs=p, logits_relmax_vs_oracle=float((eh - est_o).abs().max() / est_o.abs().max()),
+               depth_rmse_vs_oracle_m=float(torch.sqrt((d[keep] ** 2).mean())), depth_branch_flip_frac=float((~keep).float().mean()))
+    try:
+        rec = json.load(open(CONVERGED_RECORD))
+        out["recorded_end_to_end"] = dict(source=os.path.relpath(CONVERGED_RECORD, ROOT),
+                                          **{k: rec[k] for k in ("n_pairs", "oracle_pairs", "hip_pipeline_vs_boundary_depth", "hip_pipeline_vs_image_depth",
+                                                                 "same_pairs", "depth_build_minus_oracle") if k in rec})
+    except Exception:
+        out["recorded_end_to_end"] = None
+    return out
+
+
 def conv_profile(native, fn, iters, peak, per_iter=320):
     """Run fn() `iters` times with a hipEvent pair around every matrix-kernel launch (on the launch stream); returns the
     dominant kernel (most time) with its algorithmic and executed rates, and the list of records.  per_iter: upper bound of
@@ -726,7 +771,11 @@ def main():
         d = (zh - z_o)
         rel = d.abs() / z_o.abs()
         keep = rel <= 1e-3                                       # branch-flipped pairs are counted, not averaged
-        more = dict(depth_rmse_vs_oracle_m=float(torch.sqrt((d[keep] ** 2).mean())),
+        try:
+            conv = converged_leg(dev, native, x, x_np)
+        except Exception as e:
+            conv = dict(error=f"{type(e).__name__}: {e}"[:300])
+        more = dict(converged=conv, depth_rmse_vs_oracle_m=float(torch.sqrt((d[keep] ** 2).mean())),
                     depth_branch_flip_frac=float((~keep).float().mean()),
                     logits_relmax_vs_oracle=float((torch.cat([est[:p], est[PAIRS:PAIRS + p]]).cpu() - est_o).abs().max()
                                                   / est_o.abs().max()))
