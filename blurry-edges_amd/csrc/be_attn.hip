@@ -590,7 +590,15 @@ __global__ void k_attn_dq_finish(const float* __restrict__ part, float* __restri
         const int64_t bh = row / L, l = row % L;
         f32x4v acc = {0.f, 0.f, 0.f, 0.f};
         if (l < rows_done)
-            for (int gq = 0; gq < ngroups; ++gq) acc += *reinterpret_cast<const f32x4v*>(part + (((size_t)gq * BH + bh) * L + l) * DH + 4 * dq4);
+            for (int g0 = 0; g0 < ngroups; g0 += 8) {           // eight partials in flight (one load per add left the sum latency-bound: 103 us
+                f32x4v p[8];                                    // for 268 MB), added in group order
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (g0 + j < ngroups) p[j] = *reinterpret_cast<const f32x4v*>(part + (((size_t)(g0 + j) * BH + bh) * L + l) * DH + 4 * dq4);
+#pragma unroll
+                for (int j = 0; j < 8; ++j)
+                    if (g0 + j < ngroups) acc += p[j];
+            }
         const int64_t b = bh / H, hd = bh % H;
         *reinterpret_cast<f32x4v*>(dqkv + ((size_t)b * L + l) * 3 * H * DH + hd * DH + 4 * dq4) = acc * scale;
     }

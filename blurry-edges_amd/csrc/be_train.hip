@@ -962,6 +962,32 @@ __device__ __forceinline__ void post_job(const PostJob& a, const int b) {
             }
             return;
         }
+        if (a.wtaps == 1 && a.wS >= 32) {
+            // MANY slices of a small matrix (GlobalStage's linears over 8 x 4096 tokens: up to 128 slices of 49 152 - 98 304 floats).
+            // One thread per element walked all of them in 16 dependent rounds of 8 loads (101 us per call, 32 calls per step = 12 %
+            // of the global training step).  Here a workgroup takes 64 positions x 4 slice groups: group g sums the slices g, g + 4,
+            // g + 8, ... (8 loads in flight, added in that order), the four partial sums meet in LDS in a fixed order.
+            __shared__ float red4[4][64];
+            const int64_t plane = a.wsize;
+            const int pos = threadIdx.x & 63, grp = threadIdx.x >> 6;
+            for (int64_t i0 = (int64_t)b * 64; i0 < plane; i0 += (int64_t)a.nb_w * 64) {
+                const int64_t i = i0 + pos;
+                float s = 0.f;
+                if (i < plane)
+                    for (int k0 = grp; k0 < a.wS; k0 += 32) {
+                        float p[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) p[j] = k0 + 4 * j < a.wS ? a.wpart[(int64_t)(k0 + 4 * j) * plane + i] : 0.f;
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) if (k0 + 4 * j < a.wS) s += p[j];
+                    }
+                red4[grp][pos] = s;
+                __syncthreads();
+                if (grp == 0 && i < plane) a.dw[i] = (red4[0][pos] + red4[1][pos]) + (red4[2][pos] + red4[3][pos]);
+                __syncthreads();
+            }
+            return;
+        }
         if (a.wtaps) {                                      // k_wgrad128's slices [S][tap][cout*cin] -> dW[cout][cin][tap]
             // a workgroup sums 256 consecutive (cout, cin) positions for every tap (coalesced reads of each slice plane), parks
             // the 256 x taps results in LDS and writes them out as ONE contiguous run (the transposed stores straight from
@@ -1801,7 +1827,7 @@ extern "C" int be_linear_param_grads_f32(const float* x, const float* dy, float*
     pa.nj = 1;
     PostJob& pj = pa.j[0];
     pj.wpart = wpart; pj.dw = dw; pj.wsize = wsize; pj.wS = S; pj.wtaps = 1; pj.cout1 = cout;
-    pj.nb_w = (int)cap_grid(wsize, 256, 1024);
+    pj.nb_w = S >= 32 ? (int)cap_grid(wsize, 64, 2048) : (int)cap_grid(wsize, 256, 1024);      // S >= 32: 64 positions per workgroup (post_job)
     pj.dbpart = dbpart; pj.db = db; pj.nb_rows = rb.n; pj.C = cout; pj.nb_b = cout / 32;
     hipLaunchKernelGGL(k_bwd_post, dim3(pj.nb_w + pj.nb_b), dim3(256), 0, s, pa);
     return be::check_launch("be_linear_param_grads_f32");
