@@ -364,6 +364,8 @@ def test_pass_b_folds_losses_and_attention_same_results_through_both_bindings(en
     """render_full, fold_records (single and batched), local_loss (+ finish), global_loss and the attention forward /
     training forward / backward are torch.ops.be.* operators as well; the product classes go through them (native.ops()), and
     BE_TORCH_OPS=0 (ctypes over the same C symbols) gives the same bits."""
+    if os.environ.get("BE_TORCH_OPS", "1") == "0" or os.environ.get("BE_LIB_DIR"):
+        pytest.skip("compares the two bindings: the torch-operator binding is switched off in this environment")
     native, synth, utils = env["native"], env["synth"], env["utils"]
     from be_hip import train_global_stage as tgs
     from oracle import global_loss as ogl
