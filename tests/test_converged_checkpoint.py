@@ -89,7 +89,9 @@ def test_hip_path_at_the_converged_checkpoints_vs_the_fp64_oracle():
     col_o = orr.render_pass_a(orr.wrap_angles10(est.cpu()).double(), x.double())["colors"]
     assert relmax(colors.cpu().numpy(), col_o.numpy()) <= 1e-4
     z_o = orr.local_depth(od.depth_consts(), est.cpu()[:48], est.cpu()[48:])
-    assert np.array_equal(depth.cpu().numpy(), z_o.numpy())            # the depth solve is bit-exact at any weights
+    # eta = 10^(2 erf(p) - 2) goes through the device's erff / powf here and through torch's on the oracle side (an ulp apart); the
+    # solve behind it is bit-exact for equal eta (test_etas2depth_bit_exact_vs_oracle_and_golden)
+    assert relmax(depth.cpu().numpy(), z_o.numpy()) <= 2e-6
     # GlobalStage at its trained weights: eval forward of one 4096-token sequence against the fp64 oracle
     gm = models.GlobalStage(device=DEV)
     gm.load_state_dict(sg)
