@@ -136,6 +136,7 @@ _SIGNATURES = {
     "be_nchw3_to_nhwc4p_f32": (C.c_int, [_P, _P, C.c_int64, C.c_int, C.c_int, C.c_int, _P]),
     "be_view_to_nhwc4p_f32": (C.c_int, [_P, C.c_int64, C.c_int64, _P, C.c_int64, C.c_int, _P]),
     "be_conv7x7_nhwc4p_f32": (C.c_int, [C.POINTER(ConvDesc), _P, C.c_int, _P, _P, _P, C.c_int, _P]),
+    "be_conv7x7_pool_nhwc4p_f32": (C.c_int, [_P, C.c_int64, _P, _P, _P, _P]),
     "be_render_full_f32": (C.c_int, [C.POINTER(RenderOpts), C.POINTER(DepthConsts), C.c_float, C.c_int, _P,
                                      C.POINTER(PatchView), _P, _P, _P, _P, _P, _P, _P, C.c_int64, _P]),
     "be_fold_records_f32": (C.c_int, [C.POINTER(RenderOpts), _P] + [C.c_int] * 6 + [_P] * 6 + [_P]),
@@ -651,6 +652,17 @@ def conv7x7_nhwc4p(xp, w_img, pw, pb, cout, act):
     d = ConvDesc(n, h, w_img, 4, cout, 7, int(act))
     check(lib().be_conv7x7_nhwc4p_f32(C.byref(d), dptr(xp, "x"), wrow, dptr(pw), dptr(pb), dptr(y), cout, stream_ptr(xp.device)),
           "be_conv7x7_nhwc4p_f32")
+    return y
+
+
+def conv7x7_pool_nhwc4p(xp, pw, pb):
+    """conv1 + Smish + MaxPool2d(3, 2, 1) in one launch on the padded staging xp [N,21,28,4] -> [N,11,11,64]."""
+    n, h, wrow, c4 = xp.shape
+    if (h, wrow, c4) != (21, 28, 4):
+        raise RuntimeError(f"conv7x7_pool_nhwc4p: expected [N,21,28,4], got {tuple(xp.shape)}")
+    y = torch.empty(n, 11, 11, 64, dtype=torch.float32, device=xp.device)
+    check(lib().be_conv7x7_pool_nhwc4p_f32(dptr(xp, "x"), n, dptr(pw), dptr(pb), dptr(y), stream_ptr(xp.device)),
+          "be_conv7x7_pool_nhwc4p_f32")
     return y
 
 

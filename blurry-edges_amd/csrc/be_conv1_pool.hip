@@ -1,0 +1,162 @@
+// LocalStage's head for LARGE batches in ONE kernel: conv1 (7x7, 3 -> 64, padding 3) + folded BatchNorm + Smish + MaxPool(3, 2, 1),
+// models/local_stage.py:34-37,42,64-65 - image-major (round 5).
+//
+// The pixel-major conv1 (be_conv_pm.hip, ROW8) writes its 21 x 21 x 64 map to HBM (925 MB per 8192 patches) only for
+// k_maxpool_nhwc to read it back and keep a quarter: 0.79 + 0.25 ms of a 12 ms step.  A pixel-major tile cannot pool (a 3 x 3
+// window spans nine tiles).  Here a workgroup owns WHOLE images, one after the other:
+//   - the image's padded staging (21 rows x 28 pixels x 4 channels, be_nchw3_to_nhwc4p_f32) sits in LDS between three zero rows
+//     above and below: every tap of every output pixel is an in-bounds 16-byte LDS read, no im2col copy exists anywhere;
+//   - the weights are STATIONARY in registers: a wave owns 32 output channels and keeps their 7 x 8 x 4 packed taps (28 quads per
+//     lane, 112 VGPRs) for the whole launch; 14 row tiles of 32 pixels x 2 channel tiles per image, two row tiles in flight per wave;
+//   - the epilogue (bias, Smish) lands in an LDS plane [441][64]; after a barrier the workgroup takes the 3 x 3 / stride 2 maxima
+//     from it and writes the 11 x 11 x 64 pooled map - the only HBM write (31 KB per image instead of 113 + 31).
+// Arithmetic: the same fp32 MFMA chain per output element as k_conv_igemm / k_conv_pm in ROW8 mode - kernel rows top to bottom,
+// pixel pairs left to right, channels 0, 1, 2, lane half = pixel of the pair - with the rows above / below the image multiplied by
+// zeros instead of skipped (x + 0 * w = x), the same bias + Smish, the same maximum: bit-identical to conv1 followed by the pool
+// kernel (tests/test_hip_parity.py holds it to that).
+#include "be_common.h"
+#include "be_device_math.h"
+#include <cstdlib>
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int R = 21, HW = R * R, WROW = 28, PADR = R + 6, COUT = 64, KTOT = 224, OR_ = 11;
+constexpr int IMG_FLOATS = PADR * WROW * 4;            // 3024: padded staging of one image
+constexpr int IMG_QUADS = R * WROW;                    // 588 float4 of real rows
+constexpr int PLANE_FLOATS = HW * COUT;                // 28224
+constexpr size_t LDS_BYTES = (size_t)(2 * IMG_FLOATS + PLANE_FLOATS) * sizeof(float);      // 137 088
+
+__global__ __launch_bounds__(256, 1)
+void k_conv1_pool(const float* __restrict__ x4p, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
+                  int64_t n) {
+    extern __shared__ __attribute__((aligned(16))) float smem_c1[];
+    float* img_lds = smem_c1;                          // [2][PADR][WROW][4]
+    float* plane = smem_c1 + 2 * IMG_FLOATS;           // [HW][COUT]
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
+    const int ntile = wave & 1, mpar = wave >> 1;
+    const int cout = ntile * 32 + li;
+
+    // zero rows above and below both image buffers (never written again)
+    for (int i = tid; i < 2 * 2 * 3 * WROW; i += 256) {
+        const int buf = i / (2 * 3 * WROW), r = i % (2 * 3 * WROW);
+        const int row = r < 3 * WROW ? r / WROW : (R + 3) + (r - 3 * WROW) / WROW, col = r % WROW;
+        reinterpret_cast<f32x4*>(img_lds + buf * IMG_FLOATS)[row * WROW + col] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    // the wave's weights: quad (kh, g) of lane (li, lh) = taps of pixel 2 g + lh of kernel row kh, channels 0..3, for its channel
+    f32x4 bw[7][4];
+#pragma unroll
+    for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bw[kh][g] = *reinterpret_cast<const f32x4*>(w + (size_t)cout * KTOT + kh * 32 + (2 * g + lh) * 4);
+    const float bs = bias ? bias[cout] : 0.0f;
+
+    // first image of this workgroup into buffer 0
+    int64_t img = blockIdx.x;
+    f32x4 pre[3];
+    auto fetch = [&](int64_t im) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(x4p + im * (int64_t)(R * WROW * 4));
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int q = tid + 256 * j;
+            pre[j] = q < IMG_QUADS ? src[q] : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto stash = [&](int buf) {
+        f32x4* dst = reinterpret_cast<f32x4*>(img_lds + buf * IMG_FLOATS) + 3 * WROW;
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int q = tid + 256 * j;
+            if (q < IMG_QUADS) dst[q] = pre[j];
+        }
+    };
+    if (img < n) { fetch(img); stash(0); }
+    __syncthreads();
+
+    int buf = 0;
+    for (; img < n; img += gridDim.x, buf ^= 1) {
+        const int64_t nxt = img + gridDim.x;
+        if (nxt < n) fetch(nxt);                       // the next image's loads fly under this image's MFMAs
+        const float* im = img_lds + buf * IMG_FLOATS;
+        // ---- this wave's 7 row tiles, two at a time: t = mpar + 2 s
+#pragma unroll 1
+        for (int s = 0; s < 7; s += 2) {
+            const int t0 = mpar + 2 * s, t1 = t0 + 2;
+            const bool two = s + 1 < 7;
+            const int p0 = min(t0 * 32 + li, HW - 1), p1 = min((two ? t1 : t0) * 32 + li, HW - 1);
+            const float* a0 = im + ((p0 / R) * WROW + p0 % R + lh) * 4;
+            const float* a1 = im + ((p1 / R) * WROW + p1 % R + lh) * 4;
+            f32x16 acc0, acc1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+#pragma unroll
+            for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 f0 = *reinterpret_cast<const f32x4*>(a0 + kh * WROW * 4 + g * 8);
+                    const f32x4 f1 = *reinterpret_cast<const f32x4*>(a1 + kh * WROW * 4 + g * 8);
+                    const f32x4 b = bw[kh][g];
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(f0.x, b.x, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f1.x, b.x, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(f0.y, b.y, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f1.y, b.y, acc1, 0, 0, 0);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(f0.z, b.z, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f1.z, b.z, acc1, 0, 0, 0);
+                }
+            // D[row][col]: col = lane & 31 (the channel), row = (r & 3) + 8 (r >> 2) + 4 lh (the pixel of the tile)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int q0 = t0 * 32 + rr;
+                if (q0 < HW) plane[q0 * COUT + cout] = be::smish(acc0[r] + bs);
+                const int q1 = t1 * 32 + rr;
+                if (two && q1 < HW) plane[q1 * COUT + cout] = be::smish(acc1[r] + bs);
+            }
+        }
+        if (nxt < n) stash(buf ^ 1);
+        __syncthreads();
+        // ---- MaxPool(3, 2, 1) of the plane -> y [img][11][11][64]; a tap outside the image re-reads the nearest one inside
+        float* yo = y + img * (int64_t)(OR_ * OR_ * COUT);
+        for (int it = tid; it < OR_ * OR_ * (COUT / 4); it += 256) {
+            const int q = it & 15, op = it >> 4, oy = op / OR_, ox = op - oy * OR_;
+            f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int yy = min(max(2 * oy - 1 + dy, 0), R - 1);
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int xx = min(max(2 * ox - 1 + dx, 0), R - 1);
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(plane + (yy * R + xx) * COUT + 4 * q);
+                    m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
+                }
+            }
+            *reinterpret_cast<f32x4*>(yo + op * COUT + 4 * q) = m;
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" int be_conv7x7_pool_nhwc4p_f32(const float* x4p, int64_t n, const float* packed_w, const float* packed_bias, float* y,
+                                          void* stream) {
+    BE_REQUIRE(x4p && packed_w && y, "be_conv7x7_pool_nhwc4p_f32: null pointer");
+    BE_REQUIRE(n > 0 && n < ((int64_t)1 << 31), "be_conv7x7_pool_nhwc4p_f32: n outside (0, 2^31)");
+    BE_REQUIRE(be::aligned16(x4p) && be::aligned16(packed_w) && be::aligned16(y), "be_conv7x7_pool_nhwc4p_f32: 16-byte alignment");
+    static be::DeviceFlags attr_set{};
+    if (int rc_ = be::ensure_dynamic_lds(reinterpret_cast<const void*>(&k_conv1_pool), LDS_BYTES, attr_set)) return rc_;
+    hipStream_t s = be::as_stream(stream);
+    const int cus = be::device_cu_count();
+    const unsigned grid = (unsigned)(n < cus ? n : cus);              // one workgroup per CU (137 KB of LDS), images dealt round-robin
+    {
+        // algorithmic: 2 * M * 147 * 64; executed: 14 row tiles x 2 channel tiles x 84 MFMAs of 4096 FLOP per image
+        const double M = (double)n * HW;
+        be::ProfileScope prof(s, BE_KERNEL_CONV_ROW8_128x64, 2.0 * M * 147.0 * COUT, 4.0 * (M * 3.0 + 147.0 * COUT + (double)n * OR_ * OR_ * COUT),
+                              (double)n * 14.0 * 2.0 * 84.0 * 4096.0);
+        hipLaunchKernelGGL(k_conv1_pool, dim3(grid), dim3(256), LDS_BYTES, s, x4p, packed_w, packed_bias, y, n);
+    }
+    return be::check_launch("be_conv7x7_pool_nhwc4p_f32");
+}

@@ -204,21 +204,30 @@ int forward_impl(const float* packed, const float* x, const be_patch_view* view,
         // large sub-batches: conv1 on the pixel-major LDS-DMA kernel, which reads a staging with 28 pixels per row (3 zero
         // pixels left, 4 right; 2352 floats per patch, still in front of p1)
         static const bool no_pm = getenv("BE_NO_CONV_PM") != nullptr;
+        bool pooled = false;
         if (nb >= 512 && !no_pm) {
             if (x) rc = be_nchw3_to_nhwc4p_f32(x + first * 3 * BE_NPIX, x4, nb, BE_R, BE_R, 28, stream);
             else rc = be_view_to_nhwc4p_f32(view, P, first, x4, nb, 28, stream);
             if (rc) return rc;
-            be_conv_desc d;
-            d.n = nb; d.h = 21; d.w = 21; d.cin = 4; d.cout = 64; d.ksize = 7; d.act = 1;
             const PackedLayout& L = layout();
-            if ((rc = be_conv7x7_nhwc4p_f32(&d, x4, 28, packed + L.w_off[0], packed + L.b_off[0], ra, 64, stream))) return rc;
+            // conv1 + Smish + the first max-pool in one image-major launch (be_conv1_pool.hip): the 21 x 21 x 64 map never reaches
+            // HBM; bit-identical to the pixel-major conv1 followed by the pool kernel (BE_NO_CONV1_POOL=1: that pair, for A/B runs)
+            static const bool no_c1p = getenv("BE_NO_CONV1_POOL") != nullptr;
+            if (!no_c1p) {
+                if ((rc = be_conv7x7_pool_nhwc4p_f32(x4, nb, packed + L.w_off[0], packed + L.b_off[0], p1, stream))) return rc;
+                pooled = true;
+            } else {
+                be_conv_desc d;
+                d.n = nb; d.h = 21; d.w = 21; d.cin = 4; d.cout = 64; d.ksize = 7; d.act = 1;
+                if ((rc = be_conv7x7_nhwc4p_f32(&d, x4, 28, packed + L.w_off[0], packed + L.b_off[0], ra, 64, stream))) return rc;
+            }
         } else {
             if (x) rc = be_nchw3_to_nhwc4_f32(x + first * 3 * BE_NPIX, x4, nb, BE_NPIX, stream);
             else rc = be_view_to_nhwc4_f32(view, P, first, x4, nb, stream);
             if (rc) return rc;
             if ((rc = conv(packed, 0, x4, nullptr, ra, nb, 21, 1, 64, stream))) return rc;
         }
-        if ((rc = be_maxpool_nhwc_f32(ra, p1, nb, 21, 21, 64, 3, 2, 1, stream))) return rc;
+        if (!pooled && (rc = be_maxpool_nhwc_f32(ra, p1, nb, 21, 21, 64, 3, 2, 1, stream))) return rc;
         // layer0 @11x11: t in RA, out in RC
         if ((rc = block(packed, 1, p1, ra, rc_, nb, 11, stream))) return rc;
         float* p2 = rb;                                   // nb*3456

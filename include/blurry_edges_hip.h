@@ -370,6 +370,11 @@ int be_view_to_nhwc4p_f32(const be_patch_view* view_host, int64_t patches_per_im
  * by be_conv_pack_f32(ksize 7).  Bit-identical to be_conv_nhwc_f32 on the unpadded staging. */
 int be_conv7x7_nhwc4p_f32(const be_conv_desc* d, const float* x, int wrow, const float* packed_w, const float* packed_bias,
                           float* y, int ldy, void* stream);
+/* conv1 + folded BatchNorm + Smish + MaxPool2d(3, 2, 1) of LocalStage's head (models/local_stage.py:34-37,42,64-65) in ONE launch,
+ * image-major: x4p [n,21,28,4] (the padded staging of be_nchw3_to_nhwc4p_f32 / be_view_to_nhwc4p_f32, wrow = 28), packed_w / bias =
+ * the 7x7 pack of be_conv_pack_f32 (cout 64, K = 224), y [n,11,11,64].  A workgroup keeps whole images in LDS, the weights in
+ * registers, and writes only the pooled map.  Bit-identical to be_conv7x7_nhwc4p_f32 (act 1) followed by be_maxpool_nhwc_f32(3,2,1). */
+int be_conv7x7_pool_nhwc4p_f32(const float* x4p, int64_t n, const float* packed_w, const float* packed_bias, float* y, void* stream);
 /* Patches [first, first+n) of a view -> [n,21,21,4] (the staging be_local_stage_forward_view_f32 uses). */
 int be_view_to_nhwc4_f32(const be_patch_view* view_host, int64_t patches_per_image, int64_t first, float* y,
                          int64_t n, void* stream);

@@ -313,6 +313,35 @@ def test_large_batch_kernels_are_bit_identical_to_the_small_batch_kernels(native
     assert torch.equal(f_new, f_old)
 
 
+@pytest.mark.parametrize("n", [1, 3, 255, 600, 1031])
+def test_conv1_pool_fused_kernel_is_bit_identical_to_conv1_then_pool(native, n):
+    """be_conv7x7_pool_nhwc4p_f32 (image-major: whole images in LDS, weights in registers, conv1 + folded BatchNorm + Smish + the
+    3 / 2 / 1 max-pool in one launch, only the pooled map written) against the pixel-major conv1 on the same staging followed by the
+    pool kernel, and against k_conv_igemm's row mode on the unpadded staging: every pooled value identical bit for bit - fewer
+    images than workgroups, more than one image per workgroup, a ragged count; images with large negative values (Smish's floor)."""
+    g = torch.Generator().manual_seed(100 + n)
+    x = ((torch.rand(n, 3, 21, 21, generator=g) - 0.3) * 3.0).to(DEV)
+    w = ((torch.rand(64, 3, 7, 7, generator=g) - 0.5) * 0.4).to(DEV)
+    b = (torch.rand(64, generator=g) - 0.5).to(DEV)
+    bn = tuple(t.to(DEV) for t in (0.5 + torch.rand(64, generator=g), torch.rand(64, generator=g) - 0.5, torch.rand(64, generator=g) - 0.5,
+                                   0.5 + torch.rand(64, generator=g)))
+    pw, pb = native.conv_pack(w, b, bn=bn)
+    xp = native.nchw3_to_nhwc4p(x)
+    fused = native.conv7x7_pool_nhwc4p(xp, pw, pb)
+    two = native.maxpool_nhwc(native.conv7x7_nhwc4p(xp, 21, pw, pb, 64, act=1), 3, 2, 1)
+    assert fused.shape == (n, 11, 11, 64) and torch.equal(fused, two)
+    old = native.maxpool_nhwc(native.conv_nhwc(native.nchw3_to_nhwc4(x[:200].contiguous()), pw, pb, 64, 7, act=1), 3, 2, 1)
+    assert torch.equal(fused[:200], old[:n])
+    # against PyTorch in float64: Conv2d + BatchNorm (eval) + Smish + MaxPool2d
+    k = min(n, 8)
+    y = torch.nn.functional.conv2d(x[:k].cpu().double(), w.cpu().double(), b.cpu().double(), padding=3)
+    ga, be_, mu, var = (t.cpu().double()[None, :, None, None] for t in bn)
+    y = (y - mu) / torch.sqrt(var + 1e-5) * ga + be_
+    y = y * torch.tanh(torch.log(1 + torch.sigmoid(y)))
+    ref = torch.nn.functional.max_pool2d(y, 3, 2, 1).permute(0, 2, 3, 1)
+    assert relmax(fused[:k].cpu(), ref) <= 3e-6
+
+
 @pytest.mark.parametrize("n,h,w,cin,cout", [(512, 7, 7, 32, 96), (700, 5, 9, 64, 192), (1031, 3, 3, 32, 96)])
 def test_pixel_major_kernel_shapes(native, n, h, w, cin, cout):
     """be_conv_pm.hip away from LocalStage's shapes: exactly two / a ragged number of 256-image groups, non-square and 3x3
