@@ -8,8 +8,10 @@
 //     above and below: every tap of every output pixel is an in-bounds 16-byte LDS read, no im2col copy exists anywhere;
 //   - the weights are STATIONARY in registers: a wave owns 32 output channels and keeps their 7 x 8 x 4 packed taps (28 quads per
 //     lane, 112 VGPRs) for the whole launch; 14 row tiles of 32 pixels x 2 channel tiles per image, two row tiles in flight per wave;
-//   - the epilogue (bias, Smish) lands in an LDS plane [441][64]; after a barrier the workgroup takes the 3 x 3 / stride 2 maxima
-//     from it and writes the 11 x 11 x 64 pooled map - the only HBM write (31 KB per image instead of 113 + 31).
+//   - the epilogue (bias, Smish) takes the 3 x 3 / stride 2 maxima on the fly: every value goes to the one, two or four pooled
+//     cells whose window holds its pixel with an LDS float maximum (ds_max_f32) - the 21 x 21 x 64 map exists nowhere; after a
+//     barrier the workgroup writes the 11 x 11 x 64 pooled map (31 KB per image instead of 113 + 31 of HBM writes) and resets the
+//     cells.  55 KB of LDS per workgroup: two workgroups per CU, one's epilogue and barriers under the other's MFMAs.
 // Arithmetic: the same fp32 MFMA chain per output element as k_conv_igemm / k_conv_pm in ROW8 mode - kernel rows top to bottom,
 // pixel pairs left to right, channels 0, 1, 2, lane half = pixel of the pair - with the rows above / below the image multiplied by
 // zeros instead of skipped (x + 0 * w = x), the same bias + Smish, the same maximum: bit-identical to conv1 followed by the pool
@@ -26,15 +28,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int R = 21, HW = R * R, WROW = 28, PADR = R + 6, COUT = 64, KTOT = 224, OR_ = 11;
 constexpr int IMG_FLOATS = PADR * WROW * 4;            // 3024: padded staging of one image
 constexpr int IMG_QUADS = R * WROW;                    // 588 float4 of real rows
-constexpr int PLANE_FLOATS = HW * COUT;                // 28224
-constexpr size_t LDS_BYTES = (size_t)(2 * IMG_FLOATS + PLANE_FLOATS) * sizeof(float);      // 137 088
+constexpr int POOL_FLOATS = OR_ * OR_ * COUT;          // 7744: the pooled map
+constexpr size_t LDS_BYTES = (size_t)(2 * IMG_FLOATS + POOL_FLOATS) * sizeof(float);       // 55 168: two workgroups per CU
 
-__global__ __launch_bounds__(256, 1)
+__device__ __forceinline__ void lds_fmax(float* p, float v) {
+    __builtin_amdgcn_ds_fmaxf((__attribute__((address_space(3))) float*)p, v, __ATOMIC_RELAXED, __MEMORY_SCOPE_WRKGRP, false);
+}
+
+__global__ __launch_bounds__(256, 2)
 void k_conv1_pool(const float* __restrict__ x4p, const float* __restrict__ w, const float* __restrict__ bias, float* __restrict__ y,
                   int64_t n) {
     extern __shared__ __attribute__((aligned(16))) float smem_c1[];
     float* img_lds = smem_c1;                          // [2][PADR][WROW][4]
-    float* plane = smem_c1 + 2 * IMG_FLOATS;           // [HW][COUT]
+    float* pool = smem_c1 + 2 * IMG_FLOATS;            // [11][11][COUT]: running maxima of the image in flight
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int ntile = wave & 1, mpar = wave >> 1;
@@ -53,6 +59,7 @@ void k_conv1_pool(const float* __restrict__ x4p, const float* __restrict__ w, co
 #pragma unroll
         for (int g = 0; g < 4; ++g) bw[kh][g] = *reinterpret_cast<const f32x4*>(w + (size_t)cout * KTOT + kh * 32 + (2 * g + lh) * 4);
     const float bs = bias ? bias[cout] : 0.0f;
+    for (int i = tid; i < POOL_FLOATS / 4; i += 256) reinterpret_cast<f32x4*>(pool)[i] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 
     // first image of this workgroup into buffer 0
     int64_t img = blockIdx.x;
@@ -106,34 +113,34 @@ void k_conv1_pool(const float* __restrict__ x4p, const float* __restrict__ w, co
                     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(f0.z, b.z, acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f1.z, b.z, acc1, 0, 0, 0);
                 }
-            // D[row][col]: col = lane & 31 (the channel), row = (r & 3) + 8 (r >> 2) + 4 lh (the pixel of the tile)
+            // D[row][col]: col = lane & 31 (the channel), row = (r & 3) + 8 (r >> 2) + 4 lh (the pixel of the tile).  Pixel (py, px)
+            // lies in the windows of the pooled rows py >> 1 and, for odd py, (py >> 1) + 1 (likewise the columns)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const int q0 = t0 * 32 + rr;
-                if (q0 < HW) plane[q0 * COUT + cout] = be::smish(acc0[r] + bs);
-                const int q1 = t1 * 32 + rr;
-                if (two && q1 < HW) plane[q1 * COUT + cout] = be::smish(acc1[r] + bs);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int q = (h ? t1 : t0) * 32 + rr;
+                    if ((h && !two) || q >= HW) continue;
+                    const float v = be::smish((h ? acc1[r] : acc0[r]) + bs);
+                    const int py = (q * 3121) >> 16, px = q - py * R;             // q / 21 for q < 441
+                    float* c = pool + ((py >> 1) * OR_ + (px >> 1)) * COUT + cout;
+                    lds_fmax(c, v);
+                    if (px & 1) lds_fmax(c + COUT, v);
+                    if (py & 1) {
+                        lds_fmax(c + OR_ * COUT, v);
+                        if (px & 1) lds_fmax(c + (OR_ + 1) * COUT, v);
+                    }
+                }
             }
         }
         if (nxt < n) stash(buf ^ 1);
         __syncthreads();
-        // ---- MaxPool(3, 2, 1) of the plane -> y [img][11][11][64]; a tap outside the image re-reads the nearest one inside
-        float* yo = y + img * (int64_t)(OR_ * OR_ * COUT);
-        for (int it = tid; it < OR_ * OR_ * (COUT / 4); it += 256) {
-            const int q = it & 15, op = it >> 4, oy = op / OR_, ox = op - oy * OR_;
-            f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy) {
-                const int yy = min(max(2 * oy - 1 + dy, 0), R - 1);
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const int xx = min(max(2 * ox - 1 + dx, 0), R - 1);
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(plane + (yy * R + xx) * COUT + 4 * q);
-                    m[0] = fmaxf(m[0], v[0]); m[1] = fmaxf(m[1], v[1]); m[2] = fmaxf(m[2], v[2]); m[3] = fmaxf(m[3], v[3]);
-                }
-            }
-            *reinterpret_cast<f32x4*>(yo + op * COUT + 4 * q) = m;
+        // ---- the pooled map -> y [img][11][11][64]; the cells go back to -inf for the next image
+        float* yo = y + img * (int64_t)POOL_FLOATS;
+        for (int i = tid; i < POOL_FLOATS / 4; i += 256) {
+            reinterpret_cast<f32x4*>(yo)[i] = reinterpret_cast<const f32x4*>(pool)[i];
+            reinterpret_cast<f32x4*>(pool)[i] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         }
         __syncthreads();
     }
@@ -150,7 +157,7 @@ extern "C" int be_conv7x7_pool_nhwc4p_f32(const float* x4p, int64_t n, const flo
     if (int rc_ = be::ensure_dynamic_lds(reinterpret_cast<const void*>(&k_conv1_pool), LDS_BYTES, attr_set)) return rc_;
     hipStream_t s = be::as_stream(stream);
     const int cus = be::device_cu_count();
-    const unsigned grid = (unsigned)(n < cus ? n : cus);              // one workgroup per CU (137 KB of LDS), images dealt round-robin
+    const unsigned grid = (unsigned)(n < 2 * cus ? n : 2 * cus);      // two workgroups per CU (55 KB of LDS each), images dealt round-robin
     {
         // algorithmic: 2 * M * 147 * 64; executed: 14 row tiles x 2 channel tiles x 84 MFMAs of 4096 FLOP per image
         const double M = (double)n * HW;
