@@ -2,7 +2,7 @@
 # behind roofline.traffic (tools/pmc_passes.sh -> tools/summarize_pmc.py, which stamps the record with lib/BUILD_INFO.json's
 # kernel-source sha and tile shape), the local-training launch census, the end-to-end workflow demo.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT && mkdir -p gpurun_out/r5v
-timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r5v/prof -- python bench.py --no-cpu-baseline --no-extra --streams 1 --steps 20 --warmup 5 > gpurun_out/r5v/rocprof.log 2>&1; echo "rocprof rc=$?"
+timeout -k 10 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/r5v/prof -- python bench.py --no-cpu-baseline --no-extra --streams 1 --steps 20 --warmup 5 --soak-seconds 0 > gpurun_out/r5v/rocprof.log 2>&1; echo "rocprof rc=$?"
 bash tools/pmc_passes.sh > gpurun_out/r5v/pmc_passes.log 2>&1; echo "pmc rc=$?"
 python3 tools/summarize_pmc.py gpurun_out/pmc r05 > gpurun_out/r5v/pmc_summary.log 2>&1; echo "summary rc=$?"; mkdir -p gpurun_out/r5v/profiles && cp profiles/r05_pmc_summary.json profiles/r05_pmc_traffic.json gpurun_out/r5v/profiles/ 2>/dev/null
 timeout -k 10 300 python bench.py --no-cpu-baseline --no-extra --streams 1 --steps 50 --warmup 5 > gpurun_out/r5v/bench_one_stream.json 2>/dev/null; echo "bench1 rc=$?"
