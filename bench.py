@@ -89,21 +89,21 @@ def cpu_baseline(x_np, sd_np):
     dt = float(np.median(times))
     return dict(value=p / dt, unit="patch-pairs/s", cores=ncores, kind="port",
                 sample=f"{p} pairs ({2 * p} CNN patches) of the same synthetic workload, median of {CPU_REPEATS} runs "
-                       f"({', '.join('%.2f' % t for t in times)} s), torch {torch.__version__} CPU, {ncores} threads"), (est, col, z)
+                       f"({', '.join('%.2f' % t for t in times)} s), torch {torch.__version__} CPU, {ncores} threads"), (est, col, z), (ols, orr, od)
 
 
 CHECKPOINT_DIR = os.path.join(ROOT, "checkpoints")
 CONVERGED_RECORD = os.path.join(ROOT, "profiles", "r05_converged", "converged_eval.json")
 
 
-def converged_leg(dev, native, x, x_np, pairs=512):
-    """Accuracy keys from a CONVERGED model: checkpoints/pretrained_local_stage.pth is the LocalStage trained here at
+def converged_leg(dev, native, x, x_np, oracle_mods, pairs=512):
+    """Part of the cpu_baseline leg (the oracle as CHECKER).  Accuracy keys from a CONVERGED model: checkpoints/pretrained_local_stage.pth is the LocalStage trained here at
     the reference's full schedule (utils/args.py:29-36; tools/converge.sh, profiles/r05_converged/).  Live: the hot path with those
     weights on the bench's own pairs against the oracle with the same weights (logits, depth RMSE over non-flipped pairs, branch
     flips) - parity at trained weights.  Recorded: the end-to-end depth metrics of the HIP and the oracle pipelines on a held-out
     set (tests/converged_eval.py on the GPU box; the oracle pipeline takes 11 s per image pair, too long for this line)."""
     import models, utils
-    from oracle import local_stage as ols, render as orr, depth as od
+    ols, orr, od = oracle_mods                          # handed over by cpu_baseline(): the one leg of this file that imports oracle/
     path = os.path.join(CHECKPOINT_DIR, "pretrained_local_stage.pth")
     if not os.path.exists(path):
         return None
@@ -781,7 +781,7 @@ def main():
     cpu = None
     more = {}
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not args.only_dp:
-        cpu, (est_o, col_o, z_o) = cpu_baseline(x_np, sd_np)
+        cpu, (est_o, col_o, z_o), oracle_mods = cpu_baseline(x_np, sd_np)
         p = CPU_SAMPLE_PAIRS
         with torch.no_grad():
             est = step()
@@ -791,7 +791,7 @@ def main():
         rel = d.abs() / z_o.abs()
         keep = rel <= 1e-3                                       # branch-flipped pairs are counted, not averaged
         try:
-            conv = converged_leg(dev, native, x, x_np)
+            conv = converged_leg(dev, native, x, x_np, oracle_mods)
         except Exception as e:
             conv = dict(error=f"{type(e).__name__}: {e}"[:300])
         more = dict(converged=conv, depth_rmse_vs_oracle_m=float(torch.sqrt((d[keep] ** 2).mean())),
