@@ -52,6 +52,7 @@ def main():
     ap.add_argument("--out", required=True)
     ap.add_argument("--n", type=int, default=200)
     ap.add_argument("--oracle-n", type=int, default=12)
+    ap.add_argument("--big", type=int, default=0, help="also score this many held-out 587 x 587 pairs through DepthPipeline.run_big")
     a = ap.parse_args()
     import models, utils
     from be_hip import datagen as dg, workflow as wf
@@ -171,6 +172,27 @@ def main():
         o32 = ols.local_stage_forward(sd_l, x)
         errs["oracle_fp32"] = float((o32.double() - ref).abs().max() / ref.abs().max())
     res["logits_relmax_vs_fp64_oracle"] = errs
+    # ---- the big-image path (blurry_edges_test_big.py: 587 x 587, 36 blocks of 147 x 147 with margin patches dropped) with the trained
+    #      checkpoints, on held-out generated 587 x 587 scenes (the same object count on 16x the area: large flat shapes)
+    if a.big > 0:
+        sc = dg.draw_scenes(a.big, seed=880001, img_size=(587, 587), num_shape=tuple(ga.num_shape), z_range=tuple(ga.Z_range), name="scenes.heldout_big")
+        d = dg.generate(sc, dev, alpha_range=tuple(ga.alpha), sigma_read=ga.sigma, seed=880001, z_far=ga.Z_range[1],
+                        cam=dict(s=ga.cam_params['s'], rho=(ga.cam_params['rho_1'], ga.cam_params['rho_2']),
+                                 sigma_cam=ga.cam_params['sigma_cam'], pixel_pitch=ga.cam_params['pixel_pitch'], mag=ga.mag))
+        tb, ti, secs = np.zeros(5), np.zeros(5), 0.0
+        with torch.no_grad():
+            for j in range(a.big):
+                img = (d["images_ny"][j] / d["alphas"][j]).float().permute(0, 3, 1, 2).contiguous()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                maps = pipe.run_big(img, n_margin=10)
+                torch.cuda.synchronize()
+                secs += time.perf_counter() - t0
+                dm = maps["depth_map"].cpu().numpy().astype(np.float64)
+                tb += score_boundary(dm, d["boundary_depths"][j].cpu().numpy())[0]
+                ti += np.array(utils.eval_depth(dm[None], d["image_depths"][j].cpu().numpy()[None], dm[None] > 0, crop=ea.crop))
+        res["big_587"] = dict(pairs=a.big, seconds_per_pair=secs / a.big, vs_boundary_depth=dict(zip(names, (tb / a.big).tolist())),
+                              vs_image_depth=dict(zip(names, (ti / a.big).tolist())))
     os.makedirs(a.out, exist_ok=True)
     with open(os.path.join(a.out, "converged_eval.json"), "w") as f:
         json.dump(res, f, indent=1)

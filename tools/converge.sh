@@ -58,6 +58,6 @@ global)
 eval)
   cp $R/ckpt/pretrained_local_stage.pth $R/ckpt/pretrained_global_stage.pth $D/w/
   cp $D/w/pretrained_global_stage.pth $D/w/pretrained_global_stage_w.pth
-  python $T/tests/converged_eval.py --data $D/data --weights $D/w --out $O ${EVAL_N:+--n $EVAL_N} ${ORACLE_N:+--oracle-n $ORACLE_N} 2>&1 | tee $O/eval.log
+  python $T/tests/converged_eval.py --data $D/data --weights $D/w --out $O ${EVAL_N:+--n $EVAL_N} ${ORACLE_N:+--oracle-n $ORACLE_N} ${EVAL_BIG:+--big $EVAL_BIG} 2>&1 | tee $O/eval.log
   ;;
 esac
