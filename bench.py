@@ -471,7 +471,7 @@ def spawn_ranks(n):
     a parent that never touches the GPU, relay their output (rank 0 prints the one JSON line), and return the worst exit code.  A
     rank that dies takes the others with it (by PID) after a grace period, so that a failed run ends instead of hanging in a collective."""
     import socket
-    if "BE_LOCAL_DEVICE" not in os.environ and torch.cuda.device_count() < n:      # device_count() does not initialise the GPU
+    if "BE_LOCAL_DEVICE" not in os.environ and os.environ.get("BE_BENCH_DRYRUN") != "1" and torch.cuda.device_count() < n:      # device_count() does not initialise the GPU
         print(f"bench.py: --gpus {n} but {torch.cuda.device_count()} device(s) visible", file=sys.stderr)
         return 2
     with socket.socket() as sk:
@@ -489,7 +489,7 @@ def spawn_ranks(n):
             if codes[i] is None:
                 codes[i] = p.poll()
         if deadline is None and any(c not in (None, 0) for c in codes):
-            deadline = time.monotonic() + 30.0              # a rank failed: the rest get 30 s to print what they have and leave
+            deadline = time.monotonic() + float(os.environ.get("BE_BENCH_GRACE", "30"))   # a rank failed: the rest get 30 s to print what they have and leave
         if deadline is not None and time.monotonic() > deadline:
             for i, p in enumerate(procs):
                 if codes[i] is None:
@@ -497,6 +497,45 @@ def spawn_ranks(n):
                     codes[i] = p.wait()
         time.sleep(0.2)
     return max(abs(c) for c in codes)
+
+
+def dryrun(args, rank, world):
+    """BE_BENCH_DRYRUN=1: the launch path WITHOUT a GPU (a CPU test of what the driver's plain `python bench.py --gpus N` sets in motion):
+    rendezvous over gloo, barrier, K trivial timed steps with the MAX over ranks, the `launch` record gathered from every rank, ONE
+    JSON line from rank 0, clean teardown.  BE_BENCH_DRYRUN_FAIL_RANK=r makes rank r die before the rendezvous (exit code 5)."""
+    if os.environ.get("BE_BENCH_DRYRUN_FAIL_RANK") == str(rank):
+        os._exit(5)
+    dist = None
+    if world > 1:
+        import datetime
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=120))
+        dist.barrier()
+    t0 = time.perf_counter()
+    acc = torch.zeros(1)
+    for _ in range(args.steps):
+        acc += 1
+    if dist is not None:
+        dist.barrier()
+    elapsed = own = time.perf_counter() - t0
+    me = dict(rank=rank, local_rank=int(os.environ.get("LOCAL_RANK", "0")), pid=os.getpid(), ms_per_step=round(own / max(args.steps, 1) * 1e3, 6))
+    ranks = [me]
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        ranks = [None] * world
+        dist.all_gather_object(ranks, me)
+    if rank == 0:
+        emit(json.dumps({"dryrun": True, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                         "ms_per_step": round(elapsed / max(args.steps, 1) * 1e3, 6),
+                         "launch": dict(launcher=os.environ.get("BE_BENCH_LAUNCHER", "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ else "none"),
+                                        backend="gloo" if dist is not None else None, rccl_ranks=0, ranks=ranks)}))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
 
 
 _JSON_FD = None
@@ -541,12 +580,14 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     # stdout carries the JSON line and nothing else: native libraries write there too (RCCL prints a five-line version banner
-    # to stdout when its first communicator comes up), so file descriptor 1 is pointed at stderr for the rest of the run and
+    # to stdout when its first communicator comes up, gloo a line per rank), so file descriptor 1 is pointed at stderr for the rest of the run and
     # the line goes to a private copy of the real stdout
     global _JSON_FD
     sys.stdout.flush()
     _JSON_FD = os.dup(1)
     os.dup2(2, 1)
+    if os.environ.get("BE_BENCH_DRYRUN") == "1":
+        return dryrun(args, rank, world)
     if local_rank >= torch.cuda.device_count() >= 1:
         local_rank = 0                             # the launcher masked the devices: each rank sees only its own GPU
     dist = None

@@ -185,3 +185,29 @@ def test_bucketed_gradient_sync_on_the_real_local_stage_buffer(five, algorithm):
     ref = (a + b) / np.float32(2)
     assert np.array_equal(sub, ref[::1009]) and abs(total - float(ref.astype(np.float64).sum())) < 1e-6 * n ** 0.5
     assert ok
+
+
+def test_bench_plain_command_launch_path_dry_run_on_the_cpu():
+    """`python bench.py --gpus 2` - the plain command - with BE_BENCH_DRYRUN=1 (no GPU work): the parent spawns two ranks, they
+    rendezvous over gloo on 127.0.0.1, barrier, time K steps with the MAX over ranks, gather the `launch` record and rank 0 prints
+    ONE JSON line; exit code 0.  With a rank that dies before the rendezvous the parent gives the others their grace period, ends
+    them and reports failure instead of hanging (what the driver would see as rc != 0)."""
+    import json
+    import subprocess
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(BE_BENCH_DRYRUN="1", BE_BENCH_GRACE="3")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["dryrun"] and d["n_gpus"] == 2 and d["steps"] == 5
+    la = d["launch"]
+    assert la["launcher"] == "self" and la["backend"] == "gloo" and [x["rank"] for x in la["ranks"]] == [0, 1]
+    assert len({x["pid"] for x in la["ranks"]}) == 2
+    t0 = time.monotonic()
+    r = subprocess.run(cmd, env=dict(env, BE_BENCH_DRYRUN_FAIL_RANK="1"), capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and time.monotonic() - t0 < 120
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]            # no line: rank 0 never got past the rendezvous
