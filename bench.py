@@ -30,6 +30,7 @@ collective (weak scaling); RCCL carries the barrier, the MAX of the elapsed time
 import argparse
 import json
 import os
+import signal
 import subprocess
 import sys
 import time
@@ -477,34 +478,84 @@ def spawn_ranks(n):
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
+    # Children must never outlive this process: each one starts in its OWN session (one process group per rank, so
+    # its helpers go with it), asks the kernel for SIGKILL when the parent dies (PR_SET_PDEATHSIG - covers a parent that is
+    # SIGKILLed itself, which no handler sees), and SIGTERM / SIGINT / SIGHUP to the parent are relayed: terminate, a short grace, kill.
+    def _child_setup():
+        os.setsid()
+        try:
+            import ctypes
+            ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGKILL, 0, 0, 0)      # PR_SET_PDEATHSIG = 1
+        except Exception:
+            pass
+
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=os.environ.get("MASTER_PORT", str(port)), HSA_ENABLE_IPC_MODE_LEGACY="0", BE_BENCH_LAUNCHER="self")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+
+    def _stop_all(sig):
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    os.killpg(p.pid, sig)
+                except (ProcessLookupError, PermissionError):
+                    pass
+
+    got = {"sig": None}
+
+    def _on_signal(signum, _frame):
+        got["sig"] = signum
+
+    old_handlers = {sg: signal.signal(sg, _on_signal) for sg in (signal.SIGTERM, signal.SIGINT, signal.SIGHUP)}
     codes = [None] * n
-    deadline = None
-    while any(c is None for c in codes):
-        for i, p in enumerate(procs):
-            if codes[i] is None:
-                codes[i] = p.poll()
-        if deadline is None and any(c not in (None, 0) for c in codes):
-            deadline = time.monotonic() + float(os.environ.get("BE_BENCH_GRACE", "30"))   # a rank failed: the rest get 30 s to print what they have and leave
-        if deadline is not None and time.monotonic() > deadline:
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=os.environ.get("MASTER_PORT", str(port)), HSA_ENABLE_IPC_MODE_LEGACY="0", BE_BENCH_LAUNCHER="self")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, preexec_fn=_child_setup))
+        deadline = None
+        while any(c is None for c in codes):
             for i, p in enumerate(procs):
                 if codes[i] is None:
-                    p.kill()
-                    codes[i] = p.wait()
-        time.sleep(0.2)
-    return max(abs(c) for c in codes)
+                    codes[i] = p.poll()
+            if got["sig"] is not None and deadline is None:
+                print(f"bench.py: signal {got['sig']} received - stopping {sum(c is None for c in codes)} rank(s)", file=sys.stderr, flush=True)
+                _stop_all(signal.SIGTERM)
+                deadline = time.monotonic() + float(os.environ.get("BE_BENCH_TERM_GRACE", "5"))
+            if deadline is None and any(c not in (None, 0) for c in codes):
+                deadline = time.monotonic() + float(os.environ.get("BE_BENCH_GRACE", "30"))   # a rank failed: the rest get 30 s to print what they have and leave
+            if deadline is not None and time.monotonic() > deadline:
+                _stop_all(signal.SIGKILL)
+                for i, p in enumerate(procs):
+                    if codes[i] is None:
+                        codes[i] = p.wait()
+            time.sleep(0.2)
+    finally:
+        # whatever ended the loop (an exception included): no rank process group survives this function
+        _stop_all(signal.SIGKILL)
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except Exception:
+                pass
+        for sg, h in old_handlers.items():
+            signal.signal(sg, h)
+    if got["sig"] is not None:
+        return 128 + got["sig"]
+    return max(abs(c) for c in codes if c is not None) if any(c is not None for c in codes) else 1
 
 
 def dryrun(args, rank, world):
     """BE_BENCH_DRYRUN=1: the launch path WITHOUT a GPU (a CPU test of what the driver's plain `python bench.py --gpus N` sets in motion):
     rendezvous over gloo, barrier, K trivial timed steps with the MAX over ranks, the `launch` record gathered from every rank, ONE
-    JSON line from rank 0, clean teardown.  BE_BENCH_DRYRUN_FAIL_RANK=r makes rank r die before the rendezvous (exit code 5)."""
+    JSON line from rank 0, clean teardown.  BE_BENCH_DRYRUN_FAIL_RANK=r makes rank r die before the rendezvous (exit code 5);
+    BE_BENCH_DRYRUN_HANG_DIR=d makes every rank write d/rank<r>.pid, ignore SIGTERM and sleep (the dying-parent test)."""
     if os.environ.get("BE_BENCH_DRYRUN_FAIL_RANK") == str(rank):
         os._exit(5)
+    if os.environ.get("BE_BENCH_DRYRUN_HANG_DIR"):              # a rank that never finishes (what a stuck collective looks like to the parent)
+        with open(os.path.join(os.environ["BE_BENCH_DRYRUN_HANG_DIR"], f"rank{rank}.pid"), "w") as f:
+            f.write(str(os.getpid()))
+        signal.signal(signal.SIGTERM, signal.SIG_IGN)             # ... and ignores the polite request: the parent has to kill it
+        time.sleep(600)
+        os._exit(6)
     dist = None
     if world > 1:
         import datetime

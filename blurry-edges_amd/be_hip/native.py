@@ -163,6 +163,7 @@ _SIGNATURES = {
     "be_train_unit_bwd_f32": (C.c_int, [_P] * 11 + [C.c_int] + [_P] * 8 + [C.c_size_t, _P]),
     "be_train_unit_pair_fwd_f32": (C.c_int, [C.POINTER(TrainUnitFwd), C.POINTER(TrainUnitFwd), C.c_float, C.c_float, _P, C.c_size_t, _P]),
     "be_train_unit_pair_bwd_f32": (C.c_int, [C.POINTER(TrainUnitBwd), C.POINTER(TrainUnitBwd), _P, C.c_size_t, _P]),
+    "be_train_sk_plan_debug": (C.c_int, [C.c_int] * 7 + [C.c_double, C.POINTER(C.c_int), C.c_int]),
     "be_linear_param_grads_f32": (C.c_int, [_P, _P, _P, _P, C.c_int, C.c_int, C.c_int, _P, C.c_size_t, _P]),
     "be_linear_small_fwd_f32": (C.c_int, [_P] * 4 + [C.c_int] * 3 + [_P]),
     "be_maxpool_nhwc_fwd_idx_f32": (C.c_int, [_P, _P, _P] + [C.c_int] * 7 + [_P]),

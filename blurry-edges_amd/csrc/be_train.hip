@@ -9,6 +9,7 @@
 #include "be_common.h"
 #include "be_device_math.h"
 #include "be_igemm_body.h"
+#include "be_train_sk.h"
 
 namespace {
 
@@ -941,9 +942,13 @@ struct PostArgs {             // up to two units (a residual block's conv1 and d
     int nj;
     const float* xpart; const float* xadd; float* dx; int64_t xM; int xC, xldp, xS;
     const float* xpart2; int xldp2, xS2;         // the second unit's data-gradient slices (xS2 = 0: none)
+    // round 6 (be_train_sk.h): the slices come from the balanced launch - how many a tile has follows from its place on the axis
+    int sk;
+    be_sk::WGeom wsk[2];
+    be_sk::ConvGeom xsk[2];
 };
 
-__device__ __forceinline__ void post_job(const PostJob& a, const int b) {
+__device__ __forceinline__ void post_job(const PostJob& a, const int b, const be_sk::WGeom* wg) {
     if (b < a.nb_w) {
         if (a.conv1_map) {                                  // dW[co][ci][kh][kw] <- slice[co][kh][kw][ci] of a 224-column row
             const int64_t total = (int64_t)a.cout1 * 147;
@@ -996,18 +1001,24 @@ __device__ __forceinline__ void post_job(const PostJob& a, const int b) {
             const int64_t plane = a.wsize / a.wtaps;        // cout * cin
             for (int64_t i0 = (int64_t)b * 256; i0 < plane; i0 += (int64_t)a.nb_w * 256) {
                 const int64_t i = i0 + threadIdx.x;
-                if (i < plane)
+                if (i < plane) {
+                    // balanced launch: the slices of THIS element's 128 x 128 tile, tap by tap (be_train_sk.h)
+                    int tile_j = 0;
+                    if (wg) { const int cin = wg->cin_tiles * 128, co = (int)(i / cin), ci = (int)(i - (int64_t)co * cin); tile_j = (co >> 7) * wg->cin_tiles + (ci >> 7); }
                     for (int t = 0; t < a.wtaps; ++t) {
+                        int nS = a.wS;
+                        if (wg) { int ts, n; be_sk::w_span(*wg, t, tile_j, ts, n); nS = be_sk::slices_of(ts, n, wg->Q); }
                         float s = 0.f;
-                        for (int k0 = 0; k0 < a.wS; k0 += 8) {          // eight slices in flight, added in slice order
+                        for (int k0 = 0; k0 < nS; k0 += 8) {            // eight slices in flight, added in slice order
                             float p[8];
 #pragma unroll
-                            for (int k = 0; k < 8; ++k) p[k] = k0 + k < a.wS ? a.wpart[((int64_t)(k0 + k) * a.wtaps + t) * plane + i] : 0.f;
+                            for (int k = 0; k < 8; ++k) p[k] = k0 + k < nS ? a.wpart[((int64_t)(k0 + k) * a.wtaps + t) * plane + i] : 0.f;
 #pragma unroll
-                            for (int k = 0; k < 8; ++k) if (k0 + k < a.wS) s += p[k];
+                            for (int k = 0; k < 8; ++k) if (k0 + k < nS) s += p[k];
                         }
                         tbuf[threadIdx.x * a.wtaps + t] = s;
                     }
+                }
                 __syncthreads();
                 const int64_t n_here = (plane - i0 < 256 ? plane - i0 : 256) * a.wtaps;
                 for (int64_t j = threadIdx.x; j < n_here; j += 256) a.dw[i0 * a.wtaps + j] = tbuf[j];
@@ -1057,9 +1068,9 @@ void k_bwd_post(PostArgs g) {
     int b = blockIdx.x;
     const int n_j0 = g.j[0].nb_w + g.j[0].nb_b, n_j1 = g.nj > 1 ? g.j[1].nb_w + g.j[1].nb_b : 0;
     if (b < n_j0) {
-        post_job(g.j[0], b);
+        post_job(g.j[0], b, g.sk ? &g.wsk[0] : nullptr);
     } else if (b < n_j0 + n_j1) {
-        post_job(g.j[1], b - n_j0);
+        post_job(g.j[1], b - n_j0, g.sk ? &g.wsk[1] : nullptr);
     } else {
         const PostArgs& a = g;
         const int bx = b - n_j0 - n_j1, nb_x = gridDim.x - n_j0 - n_j1;
@@ -1068,22 +1079,30 @@ void k_bwd_post(PostArgs g) {
         for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < total; i += (int64_t)nb_x * 256) {
             const int64_t m = i / c4n;
             const int c = (int)(i - m * c4n) * 4;
+            int xS = a.xS, xS2 = a.xS2;
+            if (a.sk) {                                         // balanced launch: the slices of this element's tile (be_train_sk.h)
+                const int HW = a.xsk[0].HW, img = (int)(m / HW), pp = (int)(m - (int64_t)img * HW);
+                int ts, n;
+                be_sk::conv_span(a.xsk[0], img >> 6, pp, c >> 6, ts, n);
+                xS = be_sk::slices_of(ts, n, a.xsk[0].Q);
+                if (a.xS2) { be_sk::conv_span(a.xsk[1], img >> 6, pp, c >> 6, ts, n); xS2 = be_sk::slices_of(ts, n, a.xsk[1].Q); }
+            }
             f32x4 p[8];
 #pragma unroll
             for (int k = 0; k < 8; ++k)
-                if (k < a.xS) p[k] = *reinterpret_cast<const f32x4*>(a.xpart + ((int64_t)k * a.xM + m) * a.xldp + c);
+                if (k < xS) p[k] = *reinterpret_cast<const f32x4*>(a.xpart + ((int64_t)k * a.xM + m) * a.xldp + c);
             f32x4 s = p[0];
 #pragma unroll
-            for (int k = 1; k < 8; ++k) if (k < a.xS) s += p[k];
-            if (a.xS2) {                                        // the second unit's slices: summed on their own in slice order, then
+            for (int k = 1; k < 8; ++k) if (k < xS) s += p[k];
+            if (xS2) {                                          // the second unit's slices: summed on their own in slice order, then
                 f32x4 s2 = {0.f, 0.f, 0.f, 0.f};                // added - the bits of two single-unit calls (dx_add = the second's dx)
-                for (int k0 = 0; k0 < a.xS2; k0 += 4) {         // four loads in flight
+                for (int k0 = 0; k0 < xS2; k0 += 4) {           // four loads in flight
                     f32x4 q[4];
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
-                        if (k0 + k < a.xS2) q[k] = *reinterpret_cast<const f32x4*>(a.xpart2 + ((int64_t)(k0 + k) * a.xM + m) * a.xldp2 + c);
+                        if (k0 + k < xS2) q[k] = *reinterpret_cast<const f32x4*>(a.xpart2 + ((int64_t)(k0 + k) * a.xM + m) * a.xldp2 + c);
 #pragma unroll
-                    for (int k = 0; k < 4; ++k) if (k0 + k < a.xS2) { if (k0 + k == 0) s2 = q[k]; else s2 += q[k]; }
+                    for (int k = 0; k < 4; ++k) if (k0 + k < xS2) { if (k0 + k == 0) s2 = q[k]; else s2 += q[k]; }
                 }
                 s += s2;
             }
@@ -1623,6 +1642,35 @@ int plan_wgrad(const be_train_unit_bwd& u, float* wpart, size_t wpart_bytes, WJo
 }
 inline dim3 wjob_grid(const WJob& w) { return dim3(w.wx, w.wy, w.real / (w.wx * w.wy)); }
 
+// Round 6: the balanced launch (be_train_sk.hip) for the units it takes.  Fills the post kernel's roles for unit j of `pa` (the
+// bias role's partials are the caller's).  The weight-gradient slices are [slice][tap][cout][cin] as k_wgrad128's.
+void sk_post_roles(const be_train_unit_bwd& u, const be::SkUnitIn& in, const be::SkUnitOut& out, PostArgs* pa, int j) {
+    const be_conv_desc* d = &u.desc;
+    const int taps = d->ksize * d->ksize;
+    PostJob& pj = pa->j[j];
+    pj.wpart = in.wpart; pj.dw = u.dw; pj.wsize = (int64_t)d->cout * d->cin * taps; pj.wS = 1; pj.conv1_map = 0; pj.cout1 = d->cout;
+    pj.wtaps = taps;
+    pj.nb_w = (int)cap_grid(pj.wsize / taps, 256, 1024);
+    pa->sk = 1;
+    pa->wsk[j] = out.wg;
+    pa->xsk[j] = out.cg;
+}
+// one unit: true when the balanced launch ran (or failed: *rc), false = "not mine" (the caller takes rounds 3-5's path)
+bool sk_single(const be_train_unit_bwd& u, char* sc, hipStream_t s, PostArgs* pa, const char* who, int* rc) {
+    const be_conv_desc* d = &u.desc;
+    be::SkUnitIn in{&u, reinterpret_cast<float*>(sc + SCR_CONV), SCR_WGRAD - SCR_CONV, reinterpret_cast<float*>(sc + SCR_WGRAD), SCR_TOTAL - SCR_WGRAD};
+    be::SkUnitOut out;
+    be::SkPlan plan;
+    if (be::sk_plan(&in, 1, &out, &plan)) return false;
+    *rc = be::sk_run(&plan, s);
+    if (*rc) return true;
+    sk_post_roles(u, in, out, pa, 0);
+    pa->xpart = in.cpart; pa->xadd = u.dx_add; pa->dx = u.dx; pa->xM = (int64_t)d->n * d->h * d->w; pa->xC = d->cin;
+    pa->xldp = out.ldp; pa->xS = 1;
+    (void)who;
+    return true;
+}
+
 int unit_bwd_one(const be_train_unit_bwd& u, char* sc, void* stream, const char* who) {
     if (int rc = check_bwd_unit(u, who)) return rc;
     const be_conv_desc* d = &u.desc;
@@ -1636,6 +1684,7 @@ int unit_bwd_one(const be_train_unit_bwd& u, char* sc, void* stream, const char*
     PostArgs pa{};
     pa.nj = 1;
     PostJob& pj = pa.j[0];
+    int rc_sk = BE_OK;
     float* wpart = reinterpret_cast<float*>(sc + SCR_WGRAD);
     pj.dbpart = reinterpret_cast<const double*>(sc + SCR_DBPART); pj.db = u.db; pj.nb_rows = nb_rows; pj.C = C; pj.nb_b = C / 32;
     if (d->ksize == 7) {
@@ -1647,6 +1696,8 @@ int unit_bwd_one(const be_train_unit_bwd& u, char* sc, void* stream, const char*
         hipLaunchKernelGGL(k_wgrad_conv1_mfma, dim3(1, 4, S), dim3(256), 0, s, wa);
         pj.wpart = wpart; pj.dw = u.dw; pj.wsize = (int64_t)C * 147; pj.wS = S; pj.conv1_map = 1; pj.cout1 = C;
         pj.nb_w = (C * 147 + 255) / 256;
+    } else if (be::sk_enabled() && be::sk_eligible(u) && sk_single(u, sc, s, &pa, who, &rc_sk)) {
+        if (rc_sk) return rc_sk;
     } else {
         UnitGemmsArgs g{};
         double w_exec = 0.0;
@@ -1720,6 +1771,36 @@ extern "C" int be_train_unit_pair_bwd_f32(const be_train_unit_bwd* a, const be_t
     const be_conv_desc* d = &a->desc;
     const int M = d->n * d->h * d->w, C = d->cout;
     static const bool no_pair = getenv("BE_NO_UNIT_PAIR") != nullptr;             // A/B knob
+    if (!no_pair && be::sk_enabled() && be::sk_eligible(*a) && be::sk_eligible(*b)) {
+        // Round 6: both units' weight gradients and data gradients as ONE balanced launch (be_train_sk.hip).  The slice regions are
+        // split in proportion to what a slice of each unit takes (a 3x3 weight gradient is nine times its block's 1x1 one).
+        const int64_t w0 = (int64_t)a->desc.ksize * a->desc.ksize, w1 = (int64_t)b->desc.ksize * b->desc.ksize;
+        const size_t wreg = SCR_TOTAL - SCR_WGRAD, creg = SCR_WGRAD - SCR_CONV;
+        const size_t wa = (size_t)((double)wreg * w0 / (w0 + w1)) & ~(size_t)255;
+        be::SkUnitIn in[2] = {{a, reinterpret_cast<float*>(sc + SCR_CONV), creg / 2, reinterpret_cast<float*>(sc + SCR_WGRAD), wa},
+                              {b, reinterpret_cast<float*>(sc + SCR_CONV + creg / 2), creg / 2, reinterpret_cast<float*>(sc + SCR_WGRAD + wa), wreg - wa}};
+        be::SkUnitOut out[2];
+        be::SkPlan plan;
+        if (be::sk_plan(in, 2, out, &plan) == BE_OK) {
+            int nb_rows = 0;
+            if (int rc = bwd_bn_launches(u, 2, sc, s, &nb_rows, who)) return rc;
+            if (int rc = be::sk_run(&plan, s)) return rc;
+            PostArgs pa{};
+            pa.nj = 2;
+            for (int j = 0; j < 2; ++j) {
+                const ScrPart sp = scr_part(sc, j, 2);
+                PostJob& pj = pa.j[j];
+                pj.dbpart = reinterpret_cast<const double*>(sp.dbpart); pj.db = u[j]->db; pj.nb_rows = nb_rows; pj.C = C; pj.nb_b = C / 32;
+                sk_post_roles(*u[j], in[j], out[j], &pa, j);
+            }
+            pa.xpart = in[0].cpart; pa.xldp = out[0].ldp; pa.xS = 1;
+            pa.xpart2 = in[1].cpart; pa.xldp2 = out[1].ldp; pa.xS2 = 1;
+            pa.dx = a->dx; pa.xM = M; pa.xC = d->cin;
+            const int nb_x = (int)cap_grid((int64_t)M * (d->cin / 4), 256, 2048);
+            hipLaunchKernelGGL(k_bwd_post, dim3(pa.j[0].nb_w + pa.j[0].nb_b + pa.j[1].nb_w + pa.j[1].nb_b + nb_x), dim3(256), 0, s, pa);
+            return be::check_launch(who);
+        }
+    }
     be::ConvPrep prep[2];
     bool together = !no_pair;
     for (int j = 0; j < 2 && together; ++j) {

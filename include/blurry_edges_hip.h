@@ -464,6 +464,15 @@ int be_train_unit_pair_fwd_f32(const be_train_unit_fwd* a, const be_train_unit_f
                                void* scratch, size_t scratch_bytes, void* stream);
 int be_train_unit_pair_bwd_f32(const be_train_unit_bwd* a, const be_train_unit_bwd* b, void* scratch, size_t scratch_bytes,
                                void* stream);
+/* Round 6: the backward of the units with channel counts that are multiples of 128 on maps of at most 11 x 11 (layers 1-3 of
+ * models/local_stage.py:38-41 at batch 64 k, local_training.py:103-106) runs its weight-gradient GEMM and data-gradient
+ * convolution as ONE persistent, balanced launch (csrc/be_train_sk.h: every problem lays its tiles end to end on an axis of K
+ * chunks, workgroup g takes the chunks [g Q, (g + 1) Q)); BE_NO_TRAIN_SK=1 in the environment selects rounds 3-5's equal-slice
+ * launch instead.  This call is the HOST-ONLY inspection hook of that arithmetic (no GPU, no launch): the plan for one unit
+ * [n,h,w,cin] -> cout, ksize 1 | 3, with `workgroups` slots of which the fraction w_share goes to the weight gradient.  Per
+ * segment six ints are written to seg (at most cap segments): problem (0 weight gradient, 1 convolution), tile, first chunk,
+ * last chunk + 1, slice, slices of that tile.  Returns the segment count, < 0 on bad arguments. */
+int be_train_sk_plan_debug(int n, int h, int w, int cin, int cout, int ksize, int workgroups, double w_share, int* seg, int cap);
 
 /* Parameter gradients of y = x W^T + b over many rows (the linears of GlobalStage in training, global_training.py:207-213 under
  * autograd): dw [cout,cin] = dy^T x and db [cout] = column sums of dy, in two launches (weight-gradient tiles + column-sum

@@ -211,3 +211,51 @@ def test_bench_plain_command_launch_path_dry_run_on_the_cpu():
     r = subprocess.run(cmd, env=dict(env, BE_BENCH_DRYRUN_FAIL_RANK="1"), capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and time.monotonic() - t0 < 120
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]            # no line: rank 0 never got past the rendezvous
+
+
+@pytest.mark.parametrize("how", ["sigterm", "sigkill"])
+def test_bench_plain_command_leaves_no_rank_behind_when_the_parent_dies(how, tmp_path):
+    """a driver that times out kills `python bench.py --gpus N` - the parent of the self-spawned ranks - and nothing else.
+    SIGTERM: the parent relays it, waits BE_BENCH_TERM_GRACE seconds and kills the ranks' process groups (here the ranks IGNORE
+    SIGTERM and sleep, as a rank stuck in a collective would), exit code 128 + 15.  SIGKILL: no handler runs; the ranks asked the
+    kernel for SIGKILL on their parent's death (PR_SET_PDEATHSIG).  Either way no rank pid survives."""
+    import signal
+    import subprocess
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(BE_BENCH_DRYRUN="1", BE_BENCH_DRYRUN_HANG_DIR=str(tmp_path), BE_BENCH_TERM_GRACE="1")
+    parent = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1"], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    try:
+        t0 = time.monotonic()
+        files = [tmp_path / "rank0.pid", tmp_path / "rank1.pid"]
+        while not all(f.exists() and f.read_text().strip() for f in files):
+            assert parent.poll() is None and time.monotonic() - t0 < 240, "the ranks never started"
+            time.sleep(0.2)
+        pids = [int(f.read_text()) for f in files]
+        parent.send_signal(signal.SIGTERM if how == "sigterm" else signal.SIGKILL)
+        rc = parent.wait(timeout=60)
+        assert rc == (-signal.SIGKILL if how == "sigkill" else 128 + signal.SIGTERM), rc
+
+        def alive(pid):
+            try:
+                os.kill(pid, 0)
+            except ProcessLookupError:
+                return False
+            # a zombie whose parent is gone is reaped by init; until then /proc says Z
+            try:
+                return open(f"/proc/{pid}/stat").read().split(")")[-1].split()[0] != "Z"
+            except OSError:
+                return False
+        t1 = time.monotonic()
+        while any(alive(p) for p in pids) and time.monotonic() - t1 < 20:
+            time.sleep(0.2)
+        assert not any(alive(p) for p in pids), pids
+    finally:
+        if parent.poll() is None:
+            parent.kill()
+        for f in tmp_path.glob("rank*.pid"):
+            try:
+                os.kill(int(f.read_text()), signal.SIGKILL)
+            except Exception:
+                pass

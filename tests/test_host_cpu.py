@@ -401,14 +401,17 @@ def test_bench_plain_command_spawns_one_child_per_rank_before_any_gpu_call(monke
     started = []
 
     class FakeProc:
-        def __init__(self, cmd, env=None):
+        pid = 2 ** 22 + 12345                                        # nobody: the parent's closing killpg finds no such group
+
+        def __init__(self, cmd, env=None, preexec_fn=None):
+            assert callable(preexec_fn)                              # own session + PR_SET_PDEATHSIG
             started.append((cmd, env))
             self.rc = 0 if env["RANK"] == "0" else 3
 
         def poll(self):
             return self.rc
 
-        def wait(self):
+        def wait(self, timeout=None):
             return self.rc
 
         def kill(self):
@@ -495,3 +498,55 @@ def test_opencv_scan_conversion_rules_known_answers():
         assert np.array_equal(fill & ~(ring | r_rev), f_rev & ~(ring | r_rev))
     fl, rl = od.cv_poly_masks([(2, 2), (8, 5), (14, 8)], 12, 18)
     assert np.array_equal(fl, rl) and rl.sum() == 13
+
+
+def test_balanced_backward_plan_partitions_every_tile_and_numbers_its_slices():
+    """Round 6 (csrc/be_train_sk.h): the backward GEMMs of a training unit run as ONE persistent launch in which workgroup g of a
+    problem takes the K chunks [g Q, (g + 1) Q) of the problem's tiles laid end to end; a tile's segments write its slices 0, 1, ...
+    and the consumer (k_bwd_post) derives the slice count from the axis alone.  be_train_sk_plan_debug runs that arithmetic on the
+    host (the same inline functions the kernels use): for the shapes of LocalStage's layers 1-3 and some odd ones the segments of every
+    tile partition its chunks exactly, the slice numbers are 0 .. n - 1 in chunk order, and every segment reports the slice count the
+    consumer computes.  Expected tile lengths are worked out here independently (valid taps per pixel, valid pixels per tap)."""
+    import ctypes as C
+    from be_hip import native
+    lib = native.lib()
+
+    def plan(n, h, w, cin, cout, ks, wg, share):
+        cap = 50000
+        seg = (C.c_int * (6 * cap))()
+        ns = lib.be_train_sk_plan_debug(n, h, w, cin, cout, ks, wg, share, seg, cap)
+        assert 0 < ns <= cap, ns
+        return np.frombuffer(seg, dtype=np.int32)[:6 * ns].reshape(ns, 6).copy()
+
+    for (n, h, w, cin, cout, ks, wg, share) in ((64, 6, 6, 384, 384, 3, 768, 0.5), (64, 6, 6, 256, 384, 3, 768, 0.45), (64, 6, 6, 256, 384, 1, 768, 0.5),
+                                                (128, 6, 6, 256, 256, 3, 768, 0.3), (64, 11, 11, 128, 128, 3, 768, 0.5), (64, 3, 3, 128, 256, 3, 64, 0.5),
+                                                (64, 6, 5, 384, 256, 3, 1000, 0.61), (192, 4, 7, 128, 128, 1, 333, 0.2)):
+        s = plan(n, h, w, cin, cout, ks, wg, share)
+        half = ks // 2
+        for prob in (0, 1):
+            tiles = {}
+            for _, t, k0, k1, sl, cnt in s[s[:, 0] == prob]:
+                assert k1 > k0
+                tiles.setdefault(int(t), []).append((int(k0), int(k1), int(sl), int(cnt)))
+            exp = {}
+            if prob == 0:                                         # weight gradient: 128 x 128 tiles per tap, a chunk = one valid pixel of 16 images
+                wx = (cout // 128) * (cin // 128)
+                for t in range(ks * ks):
+                    dy, dx = t // ks - half, t % ks - half
+                    for j in range(wx):
+                        exp[t * wx + j] = (n // 16) * (h - abs(dy)) * (w - abs(dx))
+            else:                                                 # data gradient: a pixel of 64 images x 64 channels, cout / 16 chunks per valid tap
+                nt = cin // 64
+                for g in range(n // 64):
+                    for pp in range(h * w):
+                        py, px = pp // w, pp % w
+                        taps = sum(1 for t in range(ks * ks) if 0 <= py + t // ks - half < h and 0 <= px + t % ks - half < w)
+                        for j in range(nt):
+                            exp[(g * h * w + pp) * nt + j] = taps * (cout // 16)
+            assert set(tiles) == set(exp), (prob, len(tiles), len(exp))
+            for t, segs in tiles.items():
+                segs.sort()
+                assert segs[0][0] == 0 and segs[-1][1] == exp[t], (t, segs, exp[t])
+                assert all(a[1] == b[0] for a, b in zip(segs, segs[1:])), segs
+                assert [x[2] for x in segs] == list(range(len(segs))) and all(x[3] == len(segs) for x in segs), segs
+    assert lib.be_train_sk_plan_debug(63, 6, 6, 128, 128, 3, 768, 0.5, (C.c_int * 6)(), 1) < 0      # a ragged batch is not this launch's

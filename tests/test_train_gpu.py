@@ -929,7 +929,8 @@ def test_unit_pair_launches_equal_two_single_unit_calls_bit_for_bit(binding, mon
     """be_train_unit_pair_fwd_f32 / _bwd_f32 (a residual block's 3x3 convolution and 1x1 downsample in shared launches: one grid for
     the two convolutions, BatchNorm kernels with a grid slice per unit, one closing kernel) against two be_train_unit_*_f32 calls:
     every output and every gradient identical bit for bit, on the four block shapes of LocalStage at batch 64 and on a ragged batch
-    (24 patches: the shapes the merged launch does not take run one after the other inside the call)."""
+    (24 patches: the shapes the merged launch does not take run one after the other inside the call) - except the weight and input
+    gradients of the shapes the balanced launch of round 6 takes, which agree to rounding (see below)."""
     if not torch.cuda.is_available():
         pytest.fail("gpu-marked test run without a GPU")
     from be_hip import native, train
@@ -982,10 +983,20 @@ def test_unit_pair_launches_equal_two_single_unit_calls_bit_for_bit(binding, mon
         assert same(out_a1, out_a2) and same(out_b1, out_b2), (n, cin, cout)
         for s1, s2 in ((sv_a1, sv_a2), (sv_b1, sv_b2)):
             assert all(same(p, q) for p, q in zip(s1, s2)), (n, cin, cout)
+        # Round 6: the units with channel counts that are multiples of 128 run their backward GEMMs as ONE balanced launch
+        # (csrc/be_train_sk.h): where a tile's K loop is cut depends on how the launch's workgroups are shared between the
+        # problems, i.e. on whether one unit or two are in it - the weight gradient and the input gradient of those shapes agree
+        # to the rounding of an fp32 sum regrouped (measured 2-4e-7), everything else stays bit for bit
+        balanced = cin % 128 == 0 and cout % 128 == 0 and n % 64 == 0 and not os.environ.get("BE_NO_TRAIN_SK")
+        close = lambda p, q: float((p - q).norm() / q.norm().clamp_min(1e-30)) <= 2e-6
         for wi in (0, 6):
             assert all(torch.equal(p, q) for p, q in zip(st1[wi], st2[wi])), (n, cin, cout, wi)
-            assert all(torch.equal(p, q) for p, q in zip(g1[wi], g2[wi])), (n, cin, cout, wi)
-        assert torch.equal(ds_a1, ds_a2) and torch.equal(ds_b1, ds_b2) and torch.equal(dx_1, dx_2), (n, cin, cout)
+            dgam1, dbet1, dw1, db1 = g1[wi]
+            dgam2, dbet2, dw2, db2 = g2[wi]
+            assert torch.equal(dgam1, dgam2) and torch.equal(dbet1, dbet2) and torch.equal(db1, db2), (n, cin, cout, wi)
+            assert (close(dw1, dw2) if balanced else torch.equal(dw1, dw2)), (n, cin, cout, wi)
+        assert torch.equal(ds_a1, ds_a2) and torch.equal(ds_b1, ds_b2), (n, cin, cout)
+        assert (close(dx_1, dx_2) if balanced else torch.equal(dx_1, dx_2)), (n, cin, cout)
         if n == 512:
             # ... and the same calls captured into a hipGraph on a side stream: a launch on the null stream would end the capture
             st3, g3 = stats(), grads()

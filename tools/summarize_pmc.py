@@ -19,7 +19,7 @@ NAMES = {"k_conv_igemm<2, 2, 2, 2, 0,": "conv128x128", "k_conv_igemm<4, 1, 1, 3,
          "k_wino_gemm_ws": "wino_gemm", "k_wino_gemm<0>": "wino_gemm", "k_wino_gemm<1>": "gemm_rows", "k_wino_gemm(": "wino_gemm",
          "k_conv1_pool": "conv1_pool_image_major", "k_conv_pm<2, 3, 0>": "conv_pm_256x96", "k_conv_pm<2, 2, 1>": "conv_pm_conv1", "k_maxpool_nhwc": "maxpool",
          # the training step (tools/pmc_train.sh)
-         "k_unit_gemms<0>": "train_unit_gemms_64x64", "k_unit_gemms<1>": "train_unit_gemms_128x32", "k_unit_gemms<2>": "train_unit_gemms_64x64_uniform", "k_conv_igemm<2, 2, 1, 1, 0,": "train_conv_64x64",
+         "k_unit_gemms_sk": "train_unit_gemms_balanced", "k_unit_gemms<0>": "train_unit_gemms_64x64", "k_unit_gemms<1>": "train_unit_gemms_128x32", "k_unit_gemms<2>": "train_unit_gemms_64x64_uniform", "k_conv_igemm<2, 2, 1, 1, 0,": "train_conv_64x64",
          "k_conv_igemm<4, 1, 1, 1, 0,": "train_conv_128x32", "k_bwd_post": "train_bwd_post", "k_bn_stats": "train_bn_stats",
          "k_bn_fwd_apply": "train_bn_fwd_apply", "k_bn_bwd_reduce": "train_bn_bwd_reduce", "k_bn_bwd_apply": "train_bn_bwd_apply",
          "k_local_loss(": "train_local_loss", "k_clip_adamw": "train_clip_adamw", "k_pack_jobs": "train_pack_jobs"}
