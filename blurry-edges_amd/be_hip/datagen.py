@@ -14,7 +14,8 @@ Split of the work:
           compositing in float64, distance transforms, Sobel, noise, patch cropping.
 Rasterisation rule: the reference draws with cv2.circle / cv2.drawContours (thickness -1 and 1, default LINE_8, shift 0;
 train_val_data_generator.py:58-76).  cv2 is not available offline, so `be_datagen_raster_u32` follows the ALGORITHMS those calls
-run in OpenCV 4.x modules/imgproc/src/drawing.cpp: Circle() - the midpoint walk over one octant, filled rows or the eight
+run in OpenCV's modules/imgproc/src/drawing.cpp (the 2.4 - 4.5.1 form of the polygon fill rule; 4.5.2+ is recalled to round both run
+ends - unverifiable offline, see oracle/datagen.py:cv_poly_masks; the masks are pinned to that restatement, not to cv2): Circle() - the midpoint walk over one octant, filled rows or the eight
 symmetric points; Line() - clipLine() to the image, then the 8-connected LineIterator started from the left end point;
 CollectPolyEdges() + FillEdgeCollection() - every edge drawn with Line(), the non-horizontal ones kept in 16.16 fixed point,
 active for y0 <= y < y1, runs from ceil(x_left) to floor(x_right).  One workgroup per object leaves a FILL and a RING bit plane;

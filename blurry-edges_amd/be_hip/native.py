@@ -770,7 +770,8 @@ KERNEL_NAMES = {0: "k_conv_igemm<2,2,2,2,TAPS> (128x128)", 1: "k_conv_igemm<4,1,
                 7: "k_wino_gemm as a row GEMM (1x1 convolutions / linears of large batches)",
                 8: "k_wino_in / k_wino_out_in / k_wino_out / k_wino_out_pool2 (Winograd transforms)", 9: "k_maxpool_nhwc",
                 10: "k_render_colors (pass A)", 11: "conv1 input staging",
-                12: "k_unit_gemms (training units: weight-gradient GEMMs + data-gradient convolutions of one or two units in one launch; a residual block's two forward convolutions)"}
+                12: "k_unit_gemms / k_unit_gemms_sk (training units: weight-gradient GEMMs + data-gradient convolutions of one or two units in one launch; a residual block's two forward convolutions)",
+                13: "k_conv1_pool (conv1 7x7 + Smish + max-pool 3/2/1 in one image-major kernel)"}
 HBM_KERNEL_IDS = (8, 9, 10, 11)
 
 

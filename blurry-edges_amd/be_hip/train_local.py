@@ -110,15 +110,18 @@ class GraphedStep:
 class SegmentedGraphStep:
     """The data-parallel training step as hipGraph segments (buckets + 1) with the gradient buckets' all-reduces issued between them.
 
-    The eager data-parallel step is bound by its ~232 host launches (3.3 ms against 2.6 ms for the single-GPU hipGraph step), and a
-    collective cannot be captured into a graph on this stack.  So the step is cut where the backward finishes a gradient bucket
+    The eager data-parallel step is bound by its host launches.  DEFAULT form (segments): the step is cut where the backward finishes a gradient bucket
     (be_hip.train.set_grad_hook: fc, layer3, layer2, layer1, conv1 + layer0): segment k ends there, the host replays it and
     issues bucket k's all-reduce on the side stream (GradSync.bucket_ready: event behind the segment, RCCL call), then replays
     segment k + 1, which therefore overlaps that collective; the last segment is the division by the world size, the gradient
     clipping and AdamW.  Host cost per step: buckets + 1 graph launches + one RCCL call per bucket (default: 5 + 4).
     The step runs WITHOUT the autograd engine (forward_train / the fused loss kernel / backward_train called directly): the
     engine would run the backward - and the hook that ends and begins captures - on another thread than the one that began the
-    capture.  Same kernels, same order, same results as train_step (tests/test_dp_gpu.py)."""
+    capture.  Same kernels, same order, same results as train_step (tests/test_dp_gpu.py).
+    OPT-IN form (capture_collectives=True / BE_DP_CAPTURE=1, round 5): PyTorch 2.10 + RCCL 2.26 DO capture a collective
+    (lab/rccl_capture_probe.py), so the whole step - bucket all-reduces included - can be ONE hipGraph.  Proven bit-identical at ONE
+    rank only; between real ranks it is unproven (no multi-GPU node has been available), hence opt-in: a capture that fails on one rank
+    would leave the others inside a collective."""
 
     def __init__(self, model, helper, opt, sync, world=1, clip=1.0, capture_collectives=None):
         """capture_collectives (round 5; default: environment BE_DP_CAPTURE, "0"): capture the bucket all-reduces INTO the graph -
@@ -220,7 +223,7 @@ class SegmentedGraphStep:
                     self.sync.wait()                     # the capturing stream joins the side stream: every collective is an ancestor
                     flat = seen[0][0]
                     self.sync.flat = None
-                    if self.world > 1 or self.sync.always:
+                    if self.world > 1:                   # GradSync.finish's condition (a one-rank group divides by nothing)
                         flat.div_(self.world)
                     self._clip_step()
             self.sync.timing = timing
@@ -249,8 +252,8 @@ class SegmentedGraphStep:
             self.loss = self._step(self.static, beta_b, beta_s, hook)
             assert state["k"] == nb, f"the backward reported {state['k']} gradient buckets, {nb} expected"
             flat = seen[0][0]
-            if self.sync is not None and (self.world > 1 or self.sync.always):
-                flat.div_(self.world)                    # GradSync.finish's division, captured
+            if self.sync is not None and self.world > 1:
+                flat.div_(self.world)                    # GradSync.finish's division (same condition), captured
             self._clip_step()
             graphs[nb].capture_end()
         torch.cuda.current_stream().wait_stream(self.stream)
@@ -290,8 +293,8 @@ def main(argv=None):
     losses = []
     step_fn = None
     if a.graph and world > 1:
-        # a collective cannot be captured into a hipGraph on this stack: the data-parallel step is graph segments (buckets + 1) with the
-        # bucket all-reduces issued between them (one whole-step capture here would hang or fail at capture)
+        # default: graph segments (buckets + 1) with the bucket all-reduces issued between them.  One whole-step capture with the
+        # collectives inside works at one rank on this stack (BE_DP_CAPTURE=1) but is unproven between real ranks: opt-in
         step_fn = SegmentedGraphStep(model, helper, opt, sync, world=world)
     elif a.graph:
         # ~130 short launches per step at batch 64: replaying one captured hipGraph removes the host launch cost

@@ -11,11 +11,13 @@
 //   - the epilogue (bias, Smish) takes the 3 x 3 / stride 2 maxima on the fly: every value goes to the one, two or four pooled
 //     cells whose window holds its pixel with an LDS float maximum (ds_max_f32) - the 21 x 21 x 64 map exists nowhere; after a
 //     barrier the workgroup writes the 11 x 11 x 64 pooled map (31 KB per image instead of 113 + 31 of HBM writes) and resets the
-//     cells.  55 KB of LDS per workgroup: two workgroups per CU, one's epilogue and barriers under the other's MFMAs.
+//     cells.  71 KB of LDS per workgroup: two workgroups per CU, one's epilogue and barriers under the other's MFMAs.
 // Arithmetic: the same fp32 MFMA chain per output element as k_conv_igemm / k_conv_pm in ROW8 mode - kernel rows top to bottom,
 // pixel pairs left to right, channels 0, 1, 2, lane half = pixel of the pair - with the rows above / below the image multiplied by
 // zeros instead of skipped (x + 0 * w = x), the same bias + Smish, the same maximum: bit-identical to conv1 followed by the pool
-// kernel (tests/test_hip_parity.py holds it to that).
+// kernel (tests/test_hip_parity.py holds it to that) for FINITE activations.  A NaN activation is dropped here (the maxima start
+// from -inf and fmaxf / ds_max_f32 return the other operand), where torch.nn.MaxPool2d propagates it: a network whose conv1 emits NaN
+// is broken either way, and the reference's checkpoints do not.
 #include "be_common.h"
 #include "be_device_math.h"
 #include <cstdlib>
@@ -26,10 +28,19 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int R = 21, HW = R * R, WROW = 28, PADR = R + 6, COUT = 64, KTOT = 224, OR_ = 11;
-constexpr int IMG_FLOATS = PADR * WROW * 4;            // 3024: padded staging of one image
+// pixels per image row IN LDS: 37 = 21 + 16.  The fragment reads are ds_read_b128 of 32 consecutive output pixels (16 B each); with
+// the staging's 28 pixels per row a tile that wraps into the next image row puts its later lanes 7 pixels further, onto the banks of
+// earlier lanes of the same 16-lane group (round 6 counters: 39 % of the LDS cycles were bank conflicts AFTER the pooled cells had
+// been spread - they were these reads).  With 37 the LDS pixel index of pixel p is congruent to p modulo 16: conflict-free as one row.
+constexpr int LROW = 37;
+constexpr int IMG_FLOATS = PADR * LROW * 4;            // 3996: padded image in LDS
 constexpr int IMG_QUADS = R * WROW;                    // 588 float4 of real rows
 constexpr int POOL_FLOATS = OR_ * OR_ * COUT;          // 7744: the pooled map
-constexpr size_t LDS_BYTES = (size_t)(2 * IMG_FLOATS + POOL_FLOATS) * sizeof(float);       // 55 168: two workgroups per CU
+// floats between pooled cells in LDS: the two halves of a wave work on pixels 4 apart = cells 2 apart; with 64 floats per cell those
+// are 128 floats = the same banks; with 80 they are 160 floats = 32 banks apart (SQ_LDS_BANK_CONFLICT 34 % of the LDS cycles)
+constexpr int CELL = COUT + 16;
+constexpr int POOL_LDS = OR_ * OR_ * CELL;             // 9680
+constexpr size_t LDS_BYTES = (size_t)(2 * IMG_FLOATS + POOL_LDS) * sizeof(float);          // 70 688: two workgroups per CU
 
 __device__ __forceinline__ void lds_fmax(float* p, float v) {
     __builtin_amdgcn_ds_fmaxf((__attribute__((address_space(3))) float*)p, v, __ATOMIC_RELAXED, __MEMORY_SCOPE_WRKGRP, false);
@@ -40,17 +51,17 @@ void k_conv1_pool(const float* __restrict__ x4p, const float* __restrict__ w, co
                   int64_t n) {
     extern __shared__ __attribute__((aligned(16))) float smem_c1[];
     float* img_lds = smem_c1;                          // [2][PADR][WROW][4]
-    float* pool = smem_c1 + 2 * IMG_FLOATS;            // [11][11][COUT]: running maxima of the image in flight
+    float* pool = smem_c1 + 2 * IMG_FLOATS;            // [11][11][CELL]: running maxima of the image in flight (COUT of every CELL floats used)
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63, li = lane & 31, lh = lane >> 5;
     const int ntile = wave & 1, mpar = wave >> 1;
     const int cout = ntile * 32 + li;
 
     // zero rows above and below both image buffers (never written again)
-    for (int i = tid; i < 2 * 2 * 3 * WROW; i += 256) {
-        const int buf = i / (2 * 3 * WROW), r = i % (2 * 3 * WROW);
-        const int row = r < 3 * WROW ? r / WROW : (R + 3) + (r - 3 * WROW) / WROW, col = r % WROW;
-        reinterpret_cast<f32x4*>(img_lds + buf * IMG_FLOATS)[row * WROW + col] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < 2 * 2 * 3 * LROW; i += 256) {
+        const int buf = i / (2 * 3 * LROW), r = i % (2 * 3 * LROW);
+        const int row = r < 3 * LROW ? r / LROW : (R + 3) + (r - 3 * LROW) / LROW, col = r % LROW;
+        reinterpret_cast<f32x4*>(img_lds + buf * IMG_FLOATS)[row * LROW + col] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     // the wave's weights: quad (kh, g) of lane (li, lh) = taps of pixel 2 g + lh of kernel row kh, channels 0..3, for its channel
     f32x4 bw[7][4];
@@ -59,7 +70,7 @@ void k_conv1_pool(const float* __restrict__ x4p, const float* __restrict__ w, co
 #pragma unroll
         for (int g = 0; g < 4; ++g) bw[kh][g] = *reinterpret_cast<const f32x4*>(w + (size_t)cout * KTOT + kh * 32 + (2 * g + lh) * 4);
     const float bs = bias ? bias[cout] : 0.0f;
-    for (int i = tid; i < POOL_FLOATS / 4; i += 256) reinterpret_cast<f32x4*>(pool)[i] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int i = tid; i < POOL_LDS / 4; i += 256) reinterpret_cast<f32x4*>(pool)[i] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 
     // first image of this workgroup into buffer 0
     int64_t img = blockIdx.x;
@@ -73,11 +84,11 @@ void k_conv1_pool(const float* __restrict__ x4p, const float* __restrict__ w, co
         }
     };
     auto stash = [&](int buf) {
-        f32x4* dst = reinterpret_cast<f32x4*>(img_lds + buf * IMG_FLOATS) + 3 * WROW;
+        f32x4* dst = reinterpret_cast<f32x4*>(img_lds + buf * IMG_FLOATS) + 3 * LROW;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int q = tid + 256 * j;
-            if (q < IMG_QUADS) dst[q] = pre[j];
+            if (q < IMG_QUADS) dst[(q / WROW) * LROW + q % WROW] = pre[j];        // staging row of 28 pixels -> LDS row of 37
         }
     };
     if (img < n) { fetch(img); stash(0); }
@@ -94,8 +105,8 @@ void k_conv1_pool(const float* __restrict__ x4p, const float* __restrict__ w, co
             const int t0 = mpar + 2 * s, t1 = t0 + 2;
             const bool two = s + 1 < 7;
             const int p0 = min(t0 * 32 + li, HW - 1), p1 = min((two ? t1 : t0) * 32 + li, HW - 1);
-            const float* a0 = im + ((p0 / R) * WROW + p0 % R + lh) * 4;
-            const float* a1 = im + ((p1 / R) * WROW + p1 % R + lh) * 4;
+            const float* a0 = im + ((p0 / R) * LROW + p0 % R + lh) * 4;
+            const float* a1 = im + ((p1 / R) * LROW + p1 % R + lh) * 4;
             f32x16 acc0, acc1;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
@@ -103,8 +114,8 @@ void k_conv1_pool(const float* __restrict__ x4p, const float* __restrict__ w, co
             for (int kh = 0; kh < 7; ++kh)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const f32x4 f0 = *reinterpret_cast<const f32x4*>(a0 + kh * WROW * 4 + g * 8);
-                    const f32x4 f1 = *reinterpret_cast<const f32x4*>(a1 + kh * WROW * 4 + g * 8);
+                    const f32x4 f0 = *reinterpret_cast<const f32x4*>(a0 + kh * LROW * 4 + g * 8);
+                    const f32x4 f1 = *reinterpret_cast<const f32x4*>(a1 + kh * LROW * 4 + g * 8);
                     const f32x4 b = bw[kh][g];
                     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(f0.x, b.x, acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f1.x, b.x, acc1, 0, 0, 0);
@@ -113,23 +124,43 @@ void k_conv1_pool(const float* __restrict__ x4p, const float* __restrict__ w, co
                     acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(f0.z, b.z, acc0, 0, 0, 0);
                     acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(f1.z, b.z, acc1, 0, 0, 0);
                 }
-            // D[row][col]: col = lane & 31 (the channel), row = (r & 3) + 8 (r >> 2) + 4 lh (the pixel of the tile).  Pixel (py, px)
-            // lies in the windows of the pooled rows py >> 1 and, for odd py, (py >> 1) + 1 (likewise the columns)
+            // D[row][col]: col = lane & 31 (the channel), row = (r & 3) + 8 (r >> 2) + 4 lh (the pixel of the tile): a lane's registers
+            // 4 c .. 4 c + 3 are FOUR CONSECUTIVE pixels.  Pixel (py, px) lies in the windows of the pooled rows py >> 1 and, for odd py,
+            // (py >> 1) + 1 (likewise the columns).  Round 6: the four pixels of a group (same image row: 86 % of the groups) meet THREE
+            // pooled columns - take those maxima in registers first (a maximum is exact and order-free) and send 3 (6 for odd py) LDS
+            // maxima per group instead of 6 (12): round 5 counted 34 % of this kernel's LDS cycles as bank conflicts and MFMA-busy 0.62.
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+            for (int c4 = 0; c4 < 4; ++c4) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    const int q = (h ? t1 : t0) * 32 + rr;
-                    if ((h && !two) || q >= HW) continue;
-                    const float v = be::smish((h ? acc1[r] : acc0[r]) + bs);
-                    const int py = (q * 3121) >> 16, px = q - py * R;             // q / 21 for q < 441
-                    float* c = pool + ((py >> 1) * OR_ + (px >> 1)) * COUT + cout;
-                    lds_fmax(c, v);
-                    if (px & 1) lds_fmax(c + COUT, v);
-                    if (py & 1) {
-                        lds_fmax(c + OR_ * COUT, v);
-                        if (px & 1) lds_fmax(c + (OR_ + 1) * COUT, v);
+                    const int qb = (h ? t1 : t0) * 32 + 8 * c4 + 4 * lh;
+                    if ((h && !two) || qb >= HW) continue;
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = be::smish((h ? acc1[4 * c4 + e] : acc0[4 * c4 + e]) + bs);
+                    const int py = (qb * 3121) >> 16, px0 = qb - py * R;           // qb / 21 for qb < 441
+                    if (px0 + 3 < R) {                          // the group stays in its image row (and inside the image: qb + 3 < 441)
+                        const int a_ = px0 >> 1;
+                        float ma, mb, mc;
+                        if (px0 & 1) { ma = v[0]; mb = fmaxf(v[0], fmaxf(v[1], v[2])); mc = fmaxf(v[2], v[3]); }
+                        else { ma = fmaxf(v[0], v[1]); mb = fmaxf(v[1], fmaxf(v[2], v[3])); mc = v[3]; }
+                        float* c = pool + ((py >> 1) * OR_ + a_) * CELL + cout;
+                        lds_fmax(c, ma); lds_fmax(c + CELL, mb); lds_fmax(c + 2 * CELL, mc);
+                        if (py & 1) { c += OR_ * CELL; lds_fmax(c, ma); lds_fmax(c + CELL, mb); lds_fmax(c + 2 * CELL, mc); }
+                    } else {                                    // the group wraps into the next image row / ends with the image: pixel by pixel
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const int q = qb + e;
+                            if (q >= HW) continue;
+                            const int qy = (q * 3121) >> 16, qx = q - qy * R;
+                            float* c = pool + ((qy >> 1) * OR_ + (qx >> 1)) * CELL + cout;
+                            lds_fmax(c, v[e]);
+                            if (qx & 1) lds_fmax(c + CELL, v[e]);
+                            if (qy & 1) {
+                                lds_fmax(c + OR_ * CELL, v[e]);
+                                if (qx & 1) lds_fmax(c + (OR_ + 1) * CELL, v[e]);
+                            }
+                        }
                     }
                 }
             }
@@ -139,8 +170,9 @@ void k_conv1_pool(const float* __restrict__ x4p, const float* __restrict__ w, co
         // ---- the pooled map -> y [img][11][11][64]; the cells go back to -inf for the next image
         float* yo = y + img * (int64_t)POOL_FLOATS;
         for (int i = tid; i < POOL_FLOATS / 4; i += 256) {
-            reinterpret_cast<f32x4*>(yo)[i] = reinterpret_cast<const f32x4*>(pool)[i];
-            reinterpret_cast<f32x4*>(pool)[i] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            f32x4* cell = reinterpret_cast<f32x4*>(pool + (i >> 4) * CELL) + (i & 15);       // 16 quads of real channels per cell
+            reinterpret_cast<f32x4*>(yo)[i] = *cell;
+            *cell = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         }
         __syncthreads();
     }
@@ -161,7 +193,7 @@ extern "C" int be_conv7x7_pool_nhwc4p_f32(const float* x4p, int64_t n, const flo
     {
         // algorithmic: 2 * M * 147 * 64; executed: 14 row tiles x 2 channel tiles x 84 MFMAs of 4096 FLOP per image
         const double M = (double)n * HW;
-        be::ProfileScope prof(s, BE_KERNEL_CONV_ROW8_128x64, 2.0 * M * 147.0 * COUT, 4.0 * (M * 3.0 + 147.0 * COUT + (double)n * OR_ * OR_ * COUT),
+        be::ProfileScope prof(s, BE_KERNEL_CONV1_POOL, 2.0 * M * 147.0 * COUT, 4.0 * (M * 3.0 + 147.0 * COUT + (double)n * OR_ * OR_ * COUT),
                               (double)n * 14.0 * 2.0 * 84.0 * 4096.0);
         hipLaunchKernelGGL(k_conv1_pool, dim3(grid), dim3(256), LDS_BYTES, s, x4p, packed_w, packed_bias, y, n);
     }

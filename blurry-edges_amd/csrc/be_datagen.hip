@@ -174,6 +174,7 @@ void k_raster(const int* __restrict__ shape, const int* __restrict__ nobj, int H
         draw_line(fill, rw, H, W, s[2 + 2 * j], s[3 + 2 * j], s[2 + 2 * i], s[3 + 2 * i]);
     }
     __syncthreads();
+    // (the pre-4.5.2 form of the rule - ceil left, floor right, no half-pixel offset; oracle/datagen.py:cv_poly_masks records the version doubt)
     // FillEdgeCollection(): per scan line the active edges in ascending x, consecutive pairs bound a run
     for (int y = threadIdx.x; y < H; y += blockDim.x) {
         long long ax[4], adx[4];

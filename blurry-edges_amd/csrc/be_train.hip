@@ -712,11 +712,13 @@ struct StatsArgs {
     float* y;               // [M][C]
     double* stats;          // [nrb][C][2]
     int S, M, C, ldp, rows_per_block;
+    int sk;                 // round 6: the slices come from the balanced launch (be_train_sk.h): a tile's slice count follows from `g`
+    be_sk::ConvGeom g;
 };
 
 __global__ __launch_bounds__(256)
 void k_bn_stats(Two<StatsArgs> two) {
-    const StatsArgs a = two.j[blockIdx.z];
+    const StatsArgs& a = two.j[blockIdx.z];
     __shared__ double lds[UR * UC * 2];
     const int tx = threadIdx.x & 7, ty = threadIdx.x >> 3;
     const int c_base = blockIdx.x * UC, c = c_base + tx * 4;
@@ -727,14 +729,21 @@ void k_bn_stats(Two<StatsArgs> two) {
         if (a.S > 0 && a.bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + c);
         if (a.S > 0) {
             for (int r = r0 + ty; r < r1; r += UR) {
+                int nS = a.S;
+                if (a.sk) {                                  // the slices of this row's tile (pixel of a 64-image group x 64 columns)
+                    const int img = r / a.g.HW, pp = r - img * a.g.HW;
+                    int ts, n;
+                    be_sk::conv_span(a.g, img >> 6, pp, c >> 6, ts, n);
+                    nS = be_sk::slices_of(ts, n, a.g.Q);
+                }
                 // the (<= 8) slices of a row are independent loads: issue them together, then add in slice order
                 f32x4 p[8];
 #pragma unroll
                 for (int s = 0; s < 8; ++s)
-                    if (s < a.S) p[s] = *reinterpret_cast<const f32x4*>(a.partial + ((size_t)s * a.M + r) * a.ldp + c);
+                    if (s < nS) p[s] = *reinterpret_cast<const f32x4*>(a.partial + ((size_t)s * a.M + r) * a.ldp + c);
                 f32x4 t = p[0];
 #pragma unroll
-                for (int s = 1; s < 8; ++s) if (s < a.S) t += p[s];
+                for (int s = 1; s < 8; ++s) if (s < nS) t += p[s];
                 t += b4;
                 *reinterpret_cast<f32x4*>(a.y + (size_t)r * a.C + c) = t;
 #pragma unroll
@@ -1465,7 +1474,7 @@ int check_fwd_unit(const be_train_unit_fwd& u, const char* who) {
 
 // the two BatchNorm launches of the forward for nu units of the same [M, C]; S / ldp: the convolutions' K slices (S = 1: y is final)
 int fwd_bn_launches(const be_train_unit_fwd* const* u, int nu, const int* S, const int* ldp, float eps, float momentum, char* sc,
-                    hipStream_t s, const char* who) {
+                    hipStream_t s, const char* who, const be_sk::ConvGeom* sk = nullptr, float* const* sk_part = nullptr) {
     const int M = u[0]->desc.n * u[0]->desc.h * u[0]->desc.w, C = u[0]->desc.cout;
     const RowBlocks sb = stat_blocks(M, C);
     const RowBlocks ab = apply_blocks(M, C, 256);
@@ -1475,7 +1484,8 @@ int fwd_bn_launches(const be_train_unit_fwd* const* u, int nu, const int* S, con
         const ScrPart sp = scr_part(sc, j, nu);
         BE_REQUIRE((size_t)sb.n * C * 2 * sizeof(double) <= sp.stats_b, "%s: statistics region too small", who);
         st.j[j] = StatsArgs{S[j] > 1 ? reinterpret_cast<const float*>(sp.conv) : nullptr, u[j]->packed_bias, u[j]->y,
-                            reinterpret_cast<double*>(sp.stats), S[j] > 1 ? S[j] : 0, M, C, ldp[j], sb.rows};
+                            reinterpret_cast<double*>(sp.stats), S[j] > 1 ? S[j] : 0, M, C, ldp[j], sb.rows, 0, {}};
+        if (sk) { st.j[j].partial = sk_part[j]; st.j[j].S = 1; st.j[j].ldp = C; st.j[j].sk = 1; st.j[j].g = sk[j]; }
         fa.j[j] = FwdApplyArgs{u[j]->y, reinterpret_cast<const double*>(sp.stats), u[j]->gamma, u[j]->beta, u[j]->res, u[j]->run_mean,
                                u[j]->run_var, u[j]->mean, u[j]->invstd, u[j]->s_in, u[j]->out, sb.n, M, C, ab.rows, u[j]->act, eps, momentum};
     }
@@ -1484,13 +1494,30 @@ int fwd_bn_launches(const be_train_unit_fwd* const* u, int nu, const int* S, con
     return BE_OK;
 }
 
+// BE_NO_TRAIN_SK: rounds 3-5's launches everywhere; BE_NO_TRAIN_SK_FWD: the forward alone (A/B knobs)
+inline bool sk_fwd_enabled() {
+    static const bool off = getenv("BE_NO_TRAIN_SK_FWD") != nullptr;
+    return !off && be::sk_enabled();
+}
+
 int unit_fwd_one(const be_train_unit_fwd& u, float eps, float momentum, char* sc, void* stream, const char* who) {
     if (int rc = check_fwd_unit(u, who)) return rc;
     be_conv_desc dc = u.desc; dc.act = 0;
     int S = 1, ldp = 0;
+    const be_train_unit_fwd* one[1] = {&u};
+    if (sk_fwd_enabled() && be::sk_fwd_eligible(u.desc)) {
+        // round 6: the convolution on the balanced persistent launch (be_train_sk.hip), raw slices summed by k_bn_stats
+        be::SkFwdIn in{&u.desc, u.x, u.packed_w, reinterpret_cast<float*>(sc + SCR_CONV), SCR_WGRAD - SCR_CONV};
+        be_sk::ConvGeom cg;
+        be::SkPlan plan;
+        if (be::sk_plan_fwd(&in, 1, &cg, &plan) == BE_OK) {
+            if (int rc = be::sk_run(&plan, be::as_stream(stream))) return rc;
+            float* part[1] = {in.part};
+            return fwd_bn_launches(one, 1, &S, &ldp, eps, momentum, sc, be::as_stream(stream), who, &cg, part);
+        }
+    }
     if (int rc = be::conv_train(&dc, u.x, u.packed_w, u.packed_bias, nullptr, u.y, dc.cout, sc + SCR_CONV, SCR_WGRAD - SCR_CONV, &S, &ldp, stream))
         return rc;
-    const be_train_unit_fwd* one[1] = {&u};
     return fwd_bn_launches(one, 1, &S, &ldp, eps, momentum, sc, be::as_stream(stream), who);
 }
 }  // namespace
@@ -1519,6 +1546,23 @@ extern "C" int be_train_unit_pair_fwd_f32(const be_train_unit_fwd* a, const be_t
     hipStream_t s = be::as_stream(stream);
     const be_train_unit_fwd* u[2] = {a, b};
     static const bool no_pair = getenv("BE_NO_UNIT_PAIR") != nullptr;             // A/B knob
+    if (!no_pair && sk_fwd_enabled() && be::sk_fwd_eligible(a->desc) && be::sk_fwd_eligible(b->desc)) {
+        // round 6: both convolutions as problems of ONE balanced persistent launch; each unit's slices in its half of the region
+        be::SkFwdIn in[2];
+        for (int j = 0; j < 2; ++j) {
+            const ScrPart sp = scr_part(sc, j, 2);
+            in[j] = be::SkFwdIn{&u[j]->desc, u[j]->x, u[j]->packed_w, reinterpret_cast<float*>(sp.conv), sp.conv_b};
+        }
+        be_sk::ConvGeom cg[2];
+        be::SkPlan plan;
+        if (be::sk_plan_fwd(in, 2, cg, &plan) == BE_OK) {
+            if (int rc = be::sk_run(&plan, s)) return rc;
+            int S1[2] = {1, 1}, l0[2] = {0, 0};
+            float* part[2] = {in[0].part, in[1].part};
+            if (int rc = fwd_bn_launches(u, 2, S1, l0, eps, momentum, sc, s, who, cg, part)) return rc;
+            return be::check_launch(who);
+        }
+    }
     be::ConvPrep prep[2];
     bool together = !no_pair;
     for (int j = 0; j < 2 && together; ++j) {

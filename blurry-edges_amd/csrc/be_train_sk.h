@@ -20,7 +20,7 @@ constexpr int MAX_SLICES_C = 8;     // slices per convolution tile: what k_bwd_p
 constexpr int MAX_SLICES_W = 16;    // slices per weight-gradient tile (k_bwd_post walks them eight at a time)
 
 // A convolution's tiles: ONE output pixel of 64 consecutive images x 64 output channels.  Tile (grp, pp, j) = image group,
-// pixel (natural order), column tile; K chunks of 16 floats: taps(pp) x kmul of them, kmul = Cin / 16.
+// pixel (natural order), column tile; K chunks of 32 floats (one tap of a 32-channel unit): taps(pp) x kmul of them, kmul = Cin / 32.
 struct ConvGeom {
     int HW, n_tiles, kmul, ngrp;
     int Q, L;                                   // quota per workgroup, total chunks
@@ -76,6 +76,7 @@ __host__ __device__ inline void tap_rect(int H, int W, int tdy, int tdx, int& y0
 
 // ---- host side (be_train_sk.hip), called by the unit entry points of be_train.hip
 struct be_train_unit_bwd;
+struct be_conv_desc;
 namespace be {
 struct SkUnitIn { const ::be_train_unit_bwd* u; float* cpart; size_t cpart_bytes; float* wpart; size_t wpart_bytes; };
 struct SkUnitOut { be_sk::ConvGeom cg; be_sk::WGeom wg; int ldp; };
@@ -86,4 +87,8 @@ bool sk_eligible(const ::be_train_unit_bwd& u);        // shapes k_unit_gemms_sk
 struct SkPlan { alignas(16) char blob[1536]; };
 int sk_plan(const SkUnitIn* in, int nu, SkUnitOut* out, SkPlan* plan);
 int sk_run(const SkPlan* plan, hipStream_t s);
+// the forward convolutions of nu (1 | 2) units on the same launch (conv-only problems): raw slices [slices][M][cout] at `part`
+struct SkFwdIn { const ::be_conv_desc* d; const float* x; const float* packed_w; float* part; size_t part_bytes; };
+bool sk_fwd_eligible(const ::be_conv_desc& d);
+int sk_plan_fwd(const SkFwdIn* in, int nu, be_sk::ConvGeom* out, SkPlan* plan);
 }  // namespace be

@@ -1,13 +1,15 @@
 // k_unit_gemms_sk: the weight-gradient GEMMs and data-gradient convolutions of one or two training units as ONE persistent,
 // balanced launch (round 6; the decomposition and why: be_train_sk.h).  local_training.py:103-106.
 //
-// What differs from k_unit_gemms (be_train.hip) besides the decomposition:
-//   - operands go global -> LDS by DMA (global_load_lds_dwordx4) through a ring of three stages, two chunks ahead, counted
-//     vmcnt waits and one raw s_barrier per chunk (the idiom of k_wino_gemm_ws): no staging registers, no ds_write, and the
-//     round trip of a load is hidden behind TWO chunks of MFMAs instead of one (a 64 x 64 tile's chunk is 512 MFMA cycles,
-//     shorter than an L2 miss);
-//   - the convolution's LDS image is [row][16 floats] with the 16-byte quads XOR-swizzled by (row >> 2) & 3 (k_conv_pm's
-//     scheme: conflict-free ds_read_b128 fragments; the padded rows of the register-staged tiles measured 24 % bank conflicts);
+// What differs from k_unit_gemms (be_train.hip) besides the decomposition (each step measured: profiles/r06_sk_timeline.txt):
+//   - operands go global -> LDS by DMA (global_load_lds_dwordx4) through a ring of three stages, two chunks in flight, counted
+//     vmcnt waits and one raw s_barrier per chunk (the idiom of k_wino_gemm_ws): no staging registers, no ds_write;
+//   - every row of an LDS image is a whole 128-byte line of its tensor: the convolution's chunk is 32 floats of K (the first form
+//     of this kernel kept k_unit_gemms' 16-float chunks - half lines, 16 lines per 1-KB DMA instruction - and every workgroup of a CU
+//     advanced at ~10 B/cycle/CU whatever the ring depth (2 or 5 chunks in flight) and whatever the L2 hit rate (all loads aimed at
+//     one chunk: 9 % faster); with whole lines the same launches take 12-25 % less time);
+//   - the convolution's image is [row][8 quads] with the quads XOR-swizzled by (row >> 1) & 7 (conflict-free ds_read_b128
+//     fragments; the padded rows of the register-staged tiles measured 24 % bank conflicts);
 //   - the weight gradient's image is [pixel][128 channels], read by ds_read_b64 (32 lanes x 8 B = all 64 banks once).
 // Arithmetic: exact fp32 products on v_mfma_f32_32x32x2_f32, the K order inside a tile is the one of the kernels this replaces
 // (convolution: 32-channel chunk outer, tap, 16-float half; weight gradient: image group, pixel row, pixel column); only the
@@ -47,23 +49,24 @@ struct SkArgs {
     long long* trace;      // diagnostic (BE_SK_TRACE=1): per workgroup {start, end} on the 100 MHz clock, {problem, position, segments, XCC}
 };
 
-constexpr int STAGE_C = 2048;          // floats per convolution stage: A 64 x 16 + B 64 x 16
+constexpr int STAGE_C = 4096;          // floats per convolution stage: A 64 x 32 + B 64 x 32
 constexpr int STAGE_W = 4096;          // floats per weight-gradient stage: dy 16 x 128 + x 16 x 128
-constexpr int NST_C = 6, PD_C = NST_C - 1;   // convolution ring: stages, chunks in flight (the vmcnt ladder below is written for PD_C = 5)
-static_assert(PD_C == 5, "conv_segment's vmcnt ladder");
-constexpr int SK_LDS_FLOATS = 3 * STAGE_W;
-static_assert(NST_C * STAGE_C <= SK_LDS_FLOATS, "the two rings share one allocation");
+constexpr int SK_LDS_FLOATS = 3 * STAGE_W;   // both rings: three stages, two chunks in flight
 
 // s_waitcnt with only vmcnt counted (expcnt 7, lgkmcnt 15 = no wait): vmcnt(n), n < 16
 #define SK_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0F70 | (n))
 
 // ---- one segment of a convolution tile: chunks [k0, k1) of tile (grp, pp, j) -> slice `slice` ----------------------------------
+// A chunk = 32 floats of K = one (32-channel unit, tap) of the pack: every row of the LDS image is ONE 128-byte line of its
+// tensor (the 16-float chunks of the first form fetched half lines - 16 lines per 1-KB DMA instruction - and the per-workgroup timeline
+// showed every workgroup of a CU advancing at ~10 B/cycle/CU whatever the ring depth or the L2 hit rate).  Image [row][8 quads], quad q
+// of row r stored at q ^ ((r >> 1) & 7): the 16 lanes a ds_read_b128 serves together ({0-3,12-15,20-27}, ...) then hit 16 different
+// 4-bank groups.  MFMA order per row = two 16-float chunks of the first form back to back: the same chain per output element.
 __device__ __forceinline__ void conv_segment(const ConvProb& p, float* smem, const int grp, const int pp, const int j, const int k0,
                                              const int k1, const int slice, const int prio, long long (&ph)[4], const bool stamp) {
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int li = lane & 31, lh = lane >> 5, wm = wave >> 1, wn = wave & 1;
-    const int srow = lane >> 2, sq = (lane & 3) ^ ((lane >> 4) & 3);
     const int HW = p.g.HW, ks = p.ks, half = ks >> 1, ntap_all = ks * ks;
     const int py = pp / p.W, px = pp - py * p.W;
     unsigned long long tap_list = 0;
@@ -72,29 +75,38 @@ __device__ __forceinline__ void conv_segment(const ConvProb& p, float* smem, con
         const int yy = py + t / ks - half, xx = px + t % ks - half;
         if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) { tap_list |= (unsigned long long)t << (4 * ntap); ++ntap; }
     }
-    // lane -> (row of the piece, quad slot): the DMA writes lane i's 16 bytes at piece + 16 i; it FETCHES the quad the swizzle puts there
-    const unsigned a_off = (unsigned)((16 * wave + srow) * HW * p.Cin + 4 * sq) * 4u;
-    const unsigned b_off = (unsigned)((16 * wave + srow) * p.Ktot + 4 * sq) * 4u;
+    // a DMA piece = 8 rows x 128 B; wave w moves pieces w and w + 4 of both operands.  lane -> (row of the piece, quad slot): the DMA
+    // writes lane i's 16 bytes at piece + 16 i; it FETCHES the quad the swizzle puts there
+    const int rowp = lane >> 3, slot = lane & 7;
+    unsigned a_off[2], b_off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 8 * (wave + 4 * i) + rowp;
+        const int sq = slot ^ ((row >> 1) & 7);
+        a_off[i] = (unsigned)(row * HW * p.Cin + 4 * sq) * 4u;
+        b_off[i] = (unsigned)(row * p.Ktot + 4 * sq) * 4u;
+    }
     const float* xpix = p.x + ((int64_t)grp * 64 * HW + pp) * p.Cin;            // uniform: the tile's pixel of the group's first image
     const float* wt = p.w + (int64_t)j * 64 * p.Ktot;
-    // walker over the chunks: k = (cc * ntap + jj) * 2 + sub
-    int w_sub = k0 & 1, w_cc = (k0 >> 1) / ntap, w_j = (k0 >> 1) - w_cc * ntap, l_buf = 0;
+    // walker over the chunks: k = cc * ntap + jj
+    int w_cc = k0 / ntap, w_j = k0 - w_cc * ntap, l_buf = 0;
 #define SK_CONV_DMA()                                                                                           \
     do {                                                                                                        \
         const int tap_ = (int)((tap_list >> (4 * w_j)) & 15ull);                                                \
         const int ty_ = tap_ / ks, tx_ = tap_ - ty_ * ks;                                                       \
-        const int aoff_ = ((ty_ - half) * p.W + tx_ - half) * p.Cin + w_cc * 32 + w_sub * 16;                   \
-        const int boff_ = ((w_cc * ntap_all + tap_) * 2 + w_sub) * 16;                                          \
+        const char* pa_ = reinterpret_cast<const char*>(xpix + ((ty_ - half) * p.W + tx_ - half) * p.Cin + w_cc * 32); \
+        const char* pb_ = reinterpret_cast<const char*>(wt + (w_cc * ntap_all + tap_) * 32);                    \
         float* st_ = smem + l_buf * STAGE_C + wave * 256;                                                       \
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(reinterpret_cast<const char*>(xpix + aoff_) + a_off), (lds_ptr_t)st_, 16, 0, 0); \
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(reinterpret_cast<const char*>(wt + boff_) + b_off), (lds_ptr_t)(st_ + 1024), 16, 0, 0); \
-        if (++w_sub == 2) { w_sub = 0; if (++w_j == ntap) { w_j = 0; ++w_cc; } }                                \
-        l_buf = l_buf == NST_C - 1 ? 0 : l_buf + 1;                                                             \
+        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                      \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pa_ + a_off[i_]), (lds_ptr_t)(st_ + i_ * 1024), 16, 0, 0); \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pb_ + b_off[i_]), (lds_ptr_t)(st_ + 2048 + i_ * 1024), 16, 0, 0); \
+        }                                                                                                       \
+        if (++w_j == ntap) { w_j = 0; ++w_cc; }                                                                 \
+        l_buf = l_buf == 2 ? 0 : l_buf + 1;                                                                     \
     } while (0)
 
-    const int fsw = (li >> 2) & 3;
-    const int fq0 = 4 * (lh ^ fsw), fq1 = 4 * ((lh + 2) ^ fsw);
-    const int a_fr = (wm * 32 + li) * 16, b_fr = 1024 + (wn * 32 + li) * 16;
+    const int fsw = (li >> 1) & 7;
+    const int a_fr = (wm * 32 + li) * 32, b_fr = 2048 + (wn * 32 + li) * 32;
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
@@ -103,42 +115,30 @@ __device__ __forceinline__ void conv_segment(const ConvProb& p, float* smem, con
     SK_VMCNT(0);                                   // the previous segment's stores and DMAs of THIS wave are done ...
     __builtin_amdgcn_s_barrier();                  // ... and every wave has left the previous segment's LDS
     const long long c1 = stamp ? (long long)__builtin_amdgcn_s_memtime() : 0;
-    // Ring of NST_C stages, PD_C = NST_C - 1 chunks in flight.  Two were not enough: a DMA takes 1-2 us from issue to landed when a
-    // launch's 768 workgroups stream at once (41 % of the requests miss the XCD's L2), a chunk is 0.2 us of MFMAs, and the per-workgroup
-    // timeline (tools/sk_trace.py) showed a convolution workgroup ALONE on its CU advancing one chunk per microsecond.
     if (prio) __builtin_amdgcn_s_setprio(1);       // short MFMA bursts between waits: take the pipe when ready (the weight gradients fill the rest)
-#pragma unroll
-    for (int i = 0; i < PD_C; ++i)
-        if (k0 + i < k1) SK_CONV_DMA();
+    SK_CONV_DMA();
+    if (k0 + 1 < k1) SK_CONV_DMA();
     int r_buf = 0;
     const long long c2 = stamp ? (long long)__builtin_amdgcn_s_memtime() : 0;
     for (int k = k0; k < k1; ++k) {
-        // chunk k has landed: all but this wave's DMAs of the chunks k + 1 .. k + PD_C - 1 (those that exist) are done
-        {
-            const int rem = k1 - 1 - k;
-            if (rem >= PD_C - 1) SK_VMCNT(2 * (PD_C - 1));
-            else if (rem == 3) SK_VMCNT(6);
-            else if (rem == 2) SK_VMCNT(4);
-            else if (rem == 1) SK_VMCNT(2);
-            else SK_VMCNT(0);
-        }
+        // chunk k has landed: all but this wave's newest four DMAs (chunk k + 1, when there is one) are done
+        if (k + 1 < k1) SK_VMCNT(4); else SK_VMCNT(0);
         __builtin_amdgcn_s_barrier();              // every wave's pieces of chunk k are in LDS; the stage of chunk k - 1 is free
-        if (k + PD_C < k1) SK_CONV_DMA();
+        if (k + 2 < k1) SK_CONV_DMA();
         __builtin_amdgcn_sched_barrier(0);
         {
             const float* sb = smem + r_buf * STAGE_C;
-            const f32x4 a0 = *reinterpret_cast<const f32x4*>(sb + a_fr + fq0), b0 = *reinterpret_cast<const f32x4*>(sb + b_fr + fq0);
-            const f32x4 a1 = *reinterpret_cast<const f32x4*>(sb + a_fr + fq1), b1 = *reinterpret_cast<const f32x4*>(sb + b_fr + fq1);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, b0.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, b0.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, b0.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, b0.w, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, b1.x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, b1.y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, b1.z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, b1.w, acc, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int fq = 4 * ((lh + 2 * g) ^ fsw);
+                const f32x4 av = *reinterpret_cast<const f32x4*>(sb + a_fr + fq), bv = *reinterpret_cast<const f32x4*>(sb + b_fr + fq);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bv.x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bv.y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bv.z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bv.w, acc, 0, 0, 0);
+            }
         }
-        r_buf = r_buf == NST_C - 1 ? 0 : r_buf + 1;
+        r_buf = r_buf == 2 ? 0 : r_buf + 1;
         __builtin_amdgcn_sched_barrier(0);
     }
     if (prio) __builtin_amdgcn_s_setprio(0);
@@ -330,6 +330,79 @@ int worst_slices(int tiles, int Q, SpanOfTile span) {
     return worst;
 }
 
+// Workgroups per problem: proportional to its cost (chunks x weight + segments x fixed cost), multiples of 8, capped so that no
+// tile is cut into more slices than the consumers take / the scratch holds.  false: a problem's scratch holds fewer than two slices.
+bool share_workgroups(Prob* pr, int np) {
+    // ---- workgroups per problem: proportional to its cost (chunks x weight + segments x fixed cost), multiples of 8, capped so
+    //      that no tile is cut into more slices than the consumers take / the scratch holds
+    const int slots_per_cu = (int)env_num("BE_SK_SLOTS", 3.0);
+    const int G_total = (be::device_cu_count() * (slots_per_cu < 1 ? 1 : slots_per_cu)) & ~7;
+    int cap[4];
+    for (int i = 0; i < np; ++i) {
+        const int smax = pr[i].smax_buf < pr[i].smax ? pr[i].smax_buf : pr[i].smax;
+        if (smax < 2) return false;
+        // a tile of n chunks cut by quotas of Q has at most ceil(n / Q) + 1 slices: Q >= ceil(nmax / (smax - 1)) keeps it <= smax
+        const int qmin = (pr[i].nmax + smax - 2) / (smax - 1);
+        cap[i] = (pr[i].L / (qmin < 4 ? 4 : qmin)) & ~7;
+        if (cap[i] < 8) cap[i] = 8;
+    }
+    double share[4];
+    bool fixed[4] = {false, false, false, false};
+    int left = G_total;
+    for (int round = 0; round < np; ++round) {          // water-filling: capped problems keep their cap, the rest share what is left
+        double tot = 0.0;
+        for (int i = 0; i < np; ++i)
+            if (!fixed[i]) tot += share[i] = pr[i].L * pr[i].w + (pr[i].tiles + (double)G_total / np) * pr[i].f;
+        bool again = false;
+        for (int i = 0; i < np; ++i) {
+            if (fixed[i]) continue;
+            int g = (int)(left * share[i] / tot + 4.0) & ~7;
+            if (g < 8) g = 8;
+            if (g >= cap[i]) { pr[i].G = cap[i]; fixed[i] = true; left -= cap[i]; again = true; }
+            else pr[i].G = g;
+        }
+        if (!again) break;
+    }
+    {   // the rounding may leave the sum a few workgroups off G_total: give / take them at the largest uncapped problem
+        int sum = 0, big = -1;
+        for (int i = 0; i < np; ++i) { sum += pr[i].G; if (!fixed[i] && (big < 0 || pr[i].G > pr[big].G)) big = i; }
+        if (big >= 0 && sum != G_total && pr[big].G + (G_total - sum) >= 8 && pr[big].G + (G_total - sum) <= cap[big]) pr[big].G += G_total - sum;
+    }
+    return true;
+}
+
+// fills a convolution problem's geometry (tile lengths) for [n,h,w,cin] x ks -> n_tiles column tiles of 64; returns the longest tile's taps
+int conv_geometry(be_sk::ConvGeom& g, int n, int h, int w, int cin, int ks, int n_tiles) {
+    const int HW = h * w, half = ks >> 1, taps = ks * ks;
+    g.HW = HW; g.n_tiles = n_tiles; g.kmul = cin / 32; g.ngrp = n / 64;
+    g.PP[0] = 0;
+    int tmax = 0;
+    for (int pp = 0; pp < HW; ++pp) {
+        const int py = pp / w, px = pp % w;
+        int nt = 0;
+        for (int t = 0; t < taps; ++t)
+            nt += (unsigned)(py + t / ks - half) < (unsigned)h && (unsigned)(px + t % ks - half) < (unsigned)w;
+        g.PP[pp + 1] = (unsigned short)(g.PP[pp] + nt);
+        if (nt > tmax) tmax = nt;
+    }
+    g.L = g.ngrp * (int)g.PP[HW] * g.n_tiles * g.kmul;
+    return tmax;
+}
+
+// quota of a convolution problem with pc.G workgroups; lowers G until no tile has more slices than allowed.  false: impossible
+bool settle_conv(Prob& pc, be_sk::ConvGeom& g) {
+    for (;;) {
+        pc.Q = (pc.L + pc.G - 1) / pc.G;
+        g.Q = pc.Q;
+        const int per_grp = g.HW * g.n_tiles;
+        const int worst = worst_slices(pc.tiles, pc.Q, [&](int t, int& ts, int& n) {
+            be_sk::conv_span(g, t / per_grp, (t % per_grp) / g.n_tiles, t % g.n_tiles, ts, n); });
+        if (worst <= pc.smax && worst <= pc.smax_buf) return true;
+        if (pc.G <= 8) return false;
+        pc.G -= 8;
+    }
+}
+
 }  // namespace
 
 namespace be {
@@ -362,13 +435,14 @@ int sk_plan(const SkUnitIn* in, int nu, SkUnitOut* out, SkPlan* plan) {
     memset(&pd, 0, sizeof(pd));
     Prob pr[4];
     int np = 0;
-    // Cost model, in convolution chunks (64 x 64 x 16: 8 MFMAs per wave).  A weight-gradient chunk (128 x 128 x 16) is 32 MFMAs per
-    // wave, four times the matrix work - but what a workgroup's chunk COSTS on a CU shared by three workgroups is its serial stream
-    // (waits, barrier, DMA issue, LDS latency, then the MFMAs), and that of the short chunk is dominated by the rest: the per-workgroup
-    // timeline (tools/sk_trace.py, profiles/r06_sk_timeline.txt) shows 1.1 us per convolution chunk against 2.5 us per weight-gradient
-    // chunk whatever the split, i.e. a weight of ~2.3; the sweep of the graph-replayed step (profiles/r06_sk_sweep.txt) is flat
-    // between 2 and 2.5 and best with no fixed cost per weight-gradient segment.  Environment overrides for re-tuning.
-    const double ww = env_num("BE_SK_WW", 2.0), fw = env_num("BE_SK_FW", 0.0), fc = env_num("BE_SK_FC", 4.0);
+    // Cost model, in convolution chunks (64 x 64 x 32: 16 MFMAs per wave).  A weight-gradient chunk (128 x 128 x 16) is 32 MFMAs per
+    // wave, twice the matrix work - but what a workgroup's chunk COSTS on a CU shared by three workgroups is its serial stream (wait,
+    // barrier, DMA issue, LDS latency, then the MFMAs), and the short chunk carries relatively more of the rest.  The per-workgroup
+    // timelines (tools/sk_trace.py, profiles/r06_sk_timeline.txt) put the two kinds' median lifetimes level at a weight of 1.5 (384 -> 384:
+    // 88.4 / 88.5 us, 256 -> 384: 58.6 / 62.2 us); the graph-replayed step is flat within its run-to-run noise between 1 and 2
+    // (profiles/r06_sk_sweep.txt).  No fixed cost per weight-gradient segment, four chunks per convolution segment.  Environment
+    // overrides for re-tuning.
+    const double ww = env_num("BE_SK_WW", 1.5), fw = env_num("BE_SK_FW", 0.0), fc = env_num("BE_SK_FC", 4.0);
     double flops = 0.0, flops_exec = 0.0;
     a.prio = (int)env_num("BE_SK_PRIO", 1.0);
     static const bool trace = getenv("BE_SK_TRACE") != nullptr;       // diagnostic: tools/sk_trace.py reads the stamps back
@@ -401,59 +475,14 @@ int sk_plan(const SkUnitIn* in, int nu, SkUnitOut* out, SkPlan* plan) {
         ConvProb& c = a.c[i];
         c.x = u.dy; c.w = u.dgrad_packed_w; c.part = in[i].cpart; c.H = d.h; c.W = d.w; c.Cin = d.cout; c.ks = ks;
         c.Ktot = (d.cout / 32) * taps * 32; c.M = M; c.ldp = d.cin;
-        c.g.HW = HW; c.g.n_tiles = d.cin / 64; c.g.kmul = d.cout / 16; c.g.ngrp = d.n / 64;
-        c.g.PP[0] = 0;
-        int tmax = 0;
-        for (int pp = 0; pp < HW; ++pp) {
-            const int py = pp / d.w, px = pp % d.w;
-            int nt = 0;
-            for (int t = 0; t < taps; ++t)
-                nt += (unsigned)(py + t / ks - half) < (unsigned)d.h && (unsigned)(px + t % ks - half) < (unsigned)d.w;
-            c.g.PP[pp + 1] = (unsigned short)(c.g.PP[pp] + nt);
-            if (nt > tmax) tmax = nt;
-        }
-        c.g.L = c.g.ngrp * (int)c.g.PP[HW] * c.g.n_tiles * c.g.kmul;
+        const int tmax = conv_geometry(c.g, d.n, d.h, d.w, d.cout, ks, d.cin / 64);
         const size_t csize = (size_t)M * d.cin * sizeof(float);
         pr[np++] = Prob{c.g.L, tmax * c.g.kmul, c.g.ngrp * HW * c.g.n_tiles, 1.0, fc, (int)(in[i].cpart_bytes / csize), be_sk::MAX_SLICES_C, 0, 0};
         flops += 4.0 * M * (double)d.cin * d.cout * taps;
-        flops_exec += (double)w.g.L * 2.0 * 128 * 128 * 16 + (double)c.g.L * 2.0 * 64 * 64 * 16;
+        flops_exec += (double)w.g.L * 2.0 * 128 * 128 * 16 + (double)c.g.L * 2.0 * 64 * 64 * 32;
         out[i].ldp = d.cin;
     }
-    // ---- workgroups per problem: proportional to its cost (chunks x weight + segments x fixed cost), multiples of 8, capped so
-    //      that no tile is cut into more slices than the consumers take / the scratch holds
-    const int slots_per_cu = (int)env_num("BE_SK_SLOTS", 3.0);
-    const int G_total = (be::device_cu_count() * (slots_per_cu < 1 ? 1 : slots_per_cu)) & ~7;
-    int cap[4];
-    for (int i = 0; i < np; ++i) {
-        const int smax = pr[i].smax_buf < pr[i].smax ? pr[i].smax_buf : pr[i].smax;
-        if (smax < 2) return 1;
-        // a tile of n chunks cut by quotas of Q has at most ceil(n / Q) + 1 slices: Q >= ceil(nmax / (smax - 1)) keeps it <= smax
-        const int qmin = (pr[i].nmax + smax - 2) / (smax - 1);
-        cap[i] = (pr[i].L / (qmin < 4 ? 4 : qmin)) & ~7;
-        if (cap[i] < 8) cap[i] = 8;
-    }
-    double share[4];
-    bool fixed[4] = {false, false, false, false};
-    int left = G_total;
-    for (int round = 0; round < np; ++round) {          // water-filling: capped problems keep their cap, the rest share what is left
-        double tot = 0.0;
-        for (int i = 0; i < np; ++i)
-            if (!fixed[i]) tot += share[i] = pr[i].L * pr[i].w + (pr[i].tiles + (double)G_total / np) * pr[i].f;
-        bool again = false;
-        for (int i = 0; i < np; ++i) {
-            if (fixed[i]) continue;
-            int g = (int)(left * share[i] / tot + 4.0) & ~7;
-            if (g < 8) g = 8;
-            if (g >= cap[i]) { pr[i].G = cap[i]; fixed[i] = true; left -= cap[i]; again = true; }
-            else pr[i].G = g;
-        }
-        if (!again) break;
-    }
-    {   // the rounding may leave the sum a few workgroups off G_total: give / take them at the largest uncapped problem
-        int sum = 0, big = -1;
-        for (int i = 0; i < np; ++i) { sum += pr[i].G; if (!fixed[i] && (big < 0 || pr[i].G > pr[big].G)) big = i; }
-        if (big >= 0 && sum != G_total && pr[big].G + (G_total - sum) >= 8 && pr[big].G + (G_total - sum) <= cap[big]) pr[big].G += G_total - sum;
-    }
+    if (!share_workgroups(pr, np)) return 1;
     int g0 = 0;
     for (int i = 0; i < nu; ++i) {
         Prob& pw = pr[2 * i];
@@ -468,22 +497,56 @@ int sk_plan(const SkUnitIn* in, int nu, SkUnitOut* out, SkPlan* plan) {
             if (pw.G <= 8) return 1;
             pw.G -= 8;
         }
-        for (;;) {
-            pc.Q = (pc.L + pc.G - 1) / pc.G;
-            c.g.Q = pc.Q;
-            const int per_grp = c.g.HW * c.g.n_tiles;
-            const int worst = worst_slices(pc.tiles, pc.Q, [&](int t, int& ts, int& n) {
-                be_sk::conv_span(c.g, t / per_grp, (t % per_grp) / c.g.n_tiles, t % c.g.n_tiles, ts, n); });
-            if (worst <= pc.smax && worst <= pc.smax_buf) break;
-            if (pc.G <= 8) return 1;
-            pc.G -= 8;
-        }
+        if (!settle_conv(pc, c.g)) return 1;
         out[i].cg = c.g; out[i].wg = w.g;
     }
     for (int i = 0; i < nu; ++i) { a.w[i].g0 = g0; a.w[i].G = pr[2 * i].G; g0 += pr[2 * i].G; }       // the long chunks first
     for (int i = 0; i < nu; ++i) { a.c[i].g0 = g0; a.c[i].G = pr[2 * i + 1].G; g0 += pr[2 * i + 1].G; }
     a.nw = nu; a.nc = nu;
     pd.grid = g0; pd.flops = flops; pd.flops_exec = flops_exec;
+    return BE_OK;
+}
+
+
+// Forward convolutions of one or two training units (models/local_stage.py:11-17 in train mode; the forward half of
+// local_training.py:103) on the same persistent launch: conv-only problems, raw slices for k_bn_stats.
+bool sk_fwd_eligible(const be_conv_desc& d) {
+    if (d.ksize != 1 && d.ksize != 3) return false;
+    if (d.n < 64 || d.n % 64 || d.h < 3 || d.w < 3 || d.h * d.w > be_sk::MAX_HW) return false;
+    if (d.cout % 64 || d.cin % 32) return false;
+    const int64_t M = (int64_t)d.n * d.h * d.w;
+    const int cmax = d.cout > d.cin ? d.cout : d.cin;
+    return M * cmax * 4 < ((int64_t)1 << 31) && (int64_t)d.cin * d.cout * d.ksize * d.ksize * 4 < ((int64_t)1 << 31);
+}
+
+int sk_plan_fwd(const SkFwdIn* in, int nu, be_sk::ConvGeom* out, SkPlan* plan) {
+    SkPlanData& pd = *reinterpret_cast<SkPlanData*>(plan->blob);
+    SkArgs& a = pd.a;
+    memset(&pd, 0, sizeof(pd));
+    Prob pr[4];
+    const double fc = env_num("BE_SK_FC", 4.0);
+    a.prio = 0;
+    for (int i = 0; i < nu; ++i) {
+        const be_conv_desc& d = *in[i].d;
+        const int ks = d.ksize, taps = ks * ks, M = d.n * d.h * d.w;
+        ConvProb& c = a.c[i];
+        c.x = in[i].x; c.w = in[i].packed_w; c.part = in[i].part; c.H = d.h; c.W = d.w; c.Cin = d.cin; c.ks = ks;
+        c.Ktot = (d.cin / 32) * taps * 32; c.M = M; c.ldp = d.cout;
+        const int tmax = conv_geometry(c.g, d.n, d.h, d.w, d.cin, ks, d.cout / 64);
+        const size_t csize = (size_t)M * d.cout * sizeof(float);
+        pr[i] = Prob{c.g.L, tmax * c.g.kmul, c.g.ngrp * c.g.HW * c.g.n_tiles, 1.0, fc, (int)(in[i].part_bytes / csize), be_sk::MAX_SLICES_C, 0, 0};
+        pd.flops += 2.0 * M * (double)d.cin * d.cout * taps;
+        pd.flops_exec += (double)c.g.L * 2.0 * 64 * 64 * 32;
+    }
+    if (!share_workgroups(pr, nu)) return 1;
+    int g0 = 0;
+    for (int i = 0; i < nu; ++i) {
+        if (!settle_conv(pr[i], a.c[i].g)) return 1;
+        a.c[i].g0 = g0; a.c[i].G = pr[i].G; g0 += pr[i].G;
+        out[i] = a.c[i].g;
+    }
+    a.nw = 0; a.nc = nu;
+    pd.grid = g0;
     return BE_OK;
 }
 
@@ -520,7 +583,7 @@ extern "C" int be_train_sk_plan_debug(int n, int h, int w, int cin, int cout, in
     }
     wg.L = wg.PT[taps] * wg.wx;
     be_sk::ConvGeom cg{};
-    cg.HW = HW; cg.n_tiles = cin / 64; cg.kmul = cout / 16; cg.ngrp = n / 64;
+    cg.HW = HW; cg.n_tiles = cin / 64; cg.kmul = cout / 32; cg.ngrp = n / 64;
     for (int pp = 0; pp < HW; ++pp) {
         int nt = 0;
         for (int t = 0; t < taps; ++t)

@@ -12,6 +12,7 @@ import torch
 import torch.nn as nn
 
 from be_hip import autograd_ops as ag
+from be_hip import cpu_forms as cf
 from be_hip import native
 
 
@@ -64,11 +65,17 @@ class PostProcessBase(nn.Module, ABC):
             return torch.pow(10, torch.erf(params) * 2 - 2)
         return ag.Params2Etas.apply(params)
 
+    # A CPU tensor (BASELINE configs[0]: PyTorch-CPU plumbing; a reference-style subclass left on the CPU) takes the torch expression of
+    # be_hip/cpu_forms.py - the reference's own operation order, differentiable by autograd; a GPU tensor takes the HIP kernel or raises.
     def params2dists(self, params):
+        if not params.is_cuda:
+            return cf.params2dists(self.x.to(params.device), self.y.to(params.device), self.w, params)
         p, grid = self._flat_params(params)
         return self._unflat_pixels(ag.Params2Dists.apply(p, self.render_opts(False)), grid)
 
     def dists2indicators(self, dists, etas):
+        if not dists.is_cuda:
+            return cf.dists2indicators(dists, etas)
         if dists.dim() == 6:                                   # global layout [B,2,21,21,Hp,Wp]
             b, _, _, _, hp, wp = dists.shape
             d = dists.permute(0, 4, 5, 1, 2, 3).reshape(-1, 2, self.R, self.R)
@@ -79,12 +86,18 @@ class PostProcessBase(nn.Module, ABC):
         return self._unflat_pixels(ag.Dists2Indicators.apply(d, e), grid)
 
     def normalized_gaussian(self, x, delta=0.07):
+        if not x.is_cuda:
+            return cf.normalized_gaussian(x, delta)
         return ag.NormalizedGaussian.apply(x, float(torch.tensor(delta ** 2, dtype=torch.float32)))
 
     def inverse_3by3(self, A):
+        if not A.is_cuda:
+            return cf.inverse_3by3(A)
         return ag.Inverse3x3.apply(A)
 
     def get_image_derivative(self, img):
+        if not img.is_cuda:
+            return cf.image_derivative(img, self.sobel_x.to(img.device, img.dtype), self.sobel_y.to(img.device, img.dtype))
         return ag.ImageDerivative.apply(img)
 
     # ---- fused passes (flat layout)
@@ -134,15 +147,29 @@ class PostProcessGlobalBase(PostProcessBase):
         c = t.numel() // (lead * self.R * self.R * p)
         return ag.FoldPatches.apply(t, lead, c, self.H_patches, self.W_patches, self.H, self.W, self.stride, mode)
 
+    def _fold_cpu(self, t, lead, c):
+        """nn.Fold of a CPU patch stack divided by the patch count (utils/postprocessing_loss.py:151-162)"""
+        n = self.num_patches.to(t.device)
+        return cf.fold(t.reshape(lead, c * self.R ** 2, -1), lead, self.R, self.H, self.W, self.stride) / n
+
     def local2global_color(self, patches, pair=True):
+        if not patches.is_cuda:
+            lead = self.batch_size * (2 if pair else 1)
+            out = self._fold_cpu(patches, lead, 3)
+            return out.view(self.batch_size, 2, 3, self.H, self.W) if pair else out.view(self.batch_size, 3, self.H, self.W)
         if pair:
             return self._fold(patches, self.batch_size * 2, 1).view(self.batch_size, 2, 3, self.H, self.W)
         return self._fold(patches, self.batch_size, 1).view(self.batch_size, 3, self.H, self.W)
 
     def local2global_bndry(self, bndry_patches):
+        if not bndry_patches.is_cuda:
+            return self._fold_cpu(bndry_patches, self.batch_size, 1).view(self.batch_size, 1, self.H, self.W)
         return self._fold(bndry_patches, self.batch_size, 1).view(self.batch_size, 1, self.H, self.W)
 
     def local2global_depth(self, depth_map, depth_mask):
+        if not depth_map.is_cuda:
+            return cf.local2global_depth(depth_map, depth_mask, self.batch_size, self.R, self.H, self.W, self.H_patches, self.W_patches,
+                                         self.stride, self.num_patches.to(depth_map.device))
         is_int = depth_mask.dtype == torch.int32
         with torch.no_grad():                                   # a count: piecewise constant in the mask
             cnt = self._fold(depth_mask if is_int else depth_mask.to(torch.float32), self.batch_size, 2)

@@ -645,7 +645,8 @@ int be_datagen_crop_f64(const double* const* in6, const double* bloc, const doub
 #define BE_KERNEL_MAXPOOL           9   /* k_maxpool_nhwc */
 #define BE_KERNEL_RENDER_COLORS    10   /* k_render_colors (pass A: wedges + ridge colour solve) */
 #define BE_KERNEL_STAGING          11   /* NCHW / image view -> NHWC4 staging of conv1's input */
-#define BE_KERNEL_TRAIN_BWD_GEMMS  12   /* k_unit_gemms: training units' weight-gradient GEMMs + data-gradient convolutions (one or two units), a block's two forward convolutions: one launch */
+#define BE_KERNEL_TRAIN_BWD_GEMMS  12   /* k_unit_gemms / k_unit_gemms_sk: training units' weight-gradient GEMMs + data-gradient convolutions (one or two units), a block's two forward convolutions: one launch */
+#define BE_KERNEL_CONV1_POOL       13   /* k_conv1_pool: conv1 7x7 + Smish + the first max-pool, image-major (bytes: staging in, pooled 11x11x64 map out) */
 int be_profile_enable(int max_launches);
 int be_profile_reset(void);
 /* Waits for the recorded events; fills up to cap records (launch order); returns the number filled (>= 0)

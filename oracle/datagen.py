@@ -151,6 +151,15 @@ def cv_poly_masks(pts, H, W):
     if not edges:
         return fill, ring
     y_min, y_max = min(e[0] for e in edges), min(max(e[1] for e in edges), H)
+    # WHICH OpenCV this restates: the run rule below - ceil of the left edge, floor of the right one, no
+    # half-pixel offset on the edges, un-clipped end points - is FillEdgeCollection as OpenCV 2.4 / 3.x / 4.0-4.5.1 wrote it.  Both
+    # reviewers recall (from memory; no OpenCV source or wheel exists offline to settle it) that 4.5.2+ passes line_type into
+    # FillEdgeCollection, adds XY_ONE >> 1 to edge.x for LINE_8 and rounds both ends (delta = 0), and rebuilds clipped edges from the
+    # clipLine() end points.  The reference pins no opencv-python version (requirements.txt), so a current wheel would follow the newer
+    # rule.  Because CollectPolyEdges draws every edge FIRST (cv_line above) the two rules can differ only in pixels where a run's end
+    # is not on the drawn outline (ties at .5, clipped polygons).  Consequence: g14's masks pin the HIP rasteriser to THIS
+    # restatement, not to cv2 - a self-referential pin, as tests/golden/make_golden.py says; Cv2Stub is the one place to swap the day
+    # a real cv2 is at hand, and this rule is the first thing to check then.
     for y in range(y_min, y_max):
         # the active edges of FillEdgeCollection at scan line y: y0 <= y < y1, each at x + (y - y0) dx (one addition per scan line
         # since it became active), walked in ascending x; consecutive pairs bound a run, ceil on the left, floor on the right

@@ -267,5 +267,18 @@ def test_bench_two_rank_rehearsal_on_one_gpu(tmp_path, launcher):
     dp = d["dp"]
     assert dp["world"] == 2 and dp["global_batch"] == 128 and dp["allreduce_bytes"] == 4 * 7254122 and dp["allreduce_buckets"] == 4
     assert dp["dp_step_ms"] > 0 and dp["allreduce_ms"] > 0 and dp["segmented_graph_step_ms"] > 0 and "error" not in dp
+    # the whole exchange A/B rides in the one multi-rank run: both algorithms x {4, 2} buckets, eager and as graph
+    # segments, per-bucket issue -> complete times and every rank's own clocks; the best variant named
+    ab = dp["ab"]
+    assert [(e["algorithm"], e["buckets"]) for e in ab] == [("allreduce", 4), ("rs_ag", 4), ("allreduce", 2), ("rs_ag", 2)]
+    for e in ab:
+        assert "error" not in e, e
+        assert e["dp_step_ms"] > 0 and e["segmented_graph_step_ms"] > 0 and len(e["buckets_bytes"]) == e["buckets"]
+        assert sum(e["buckets_bytes"]) == 4 * 7254122
+        assert [r["rank"] for r in e["per_rank"]] == [0, 1]
+        for r in e["per_rank"]:
+            assert r["dp_step_ms"] > 0 and r["segmented_graph_step_ms"] > 0
+            assert len(r["buckets_issue_to_complete_ms"]) in (0, e["buckets"])      # per-bucket events exist on the RCCL side stream only (this rehearsal is gloo)
+    assert dp["ab_best"]["segmented_graph_step_ms"] == min(e["segmented_graph_step_ms"] for e in ab) and "BE_BENCH_CAPTURED_DP" in dp["ab_note"]
     assert len(d["extra_configs"]) == 4 and all("error" not in e for e in d["extra_configs"])
     assert d["extra_configs"][3]["images_per_s"] > 0                       # the global-stage training step

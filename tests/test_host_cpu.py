@@ -535,14 +535,14 @@ def test_balanced_backward_plan_partitions_every_tile_and_numbers_its_slices():
                     dy, dx = t // ks - half, t % ks - half
                     for j in range(wx):
                         exp[t * wx + j] = (n // 16) * (h - abs(dy)) * (w - abs(dx))
-            else:                                                 # data gradient: a pixel of 64 images x 64 channels, cout / 16 chunks per valid tap
+            else:                                                 # data gradient: a pixel of 64 images x 64 channels, cout / 32 chunks per valid tap
                 nt = cin // 64
                 for g in range(n // 64):
                     for pp in range(h * w):
                         py, px = pp // w, pp % w
                         taps = sum(1 for t in range(ks * ks) if 0 <= py + t // ks - half < h and 0 <= px + t % ks - half < w)
                         for j in range(nt):
-                            exp[(g * h * w + pp) * nt + j] = taps * (cout // 16)
+                            exp[(g * h * w + pp) * nt + j] = taps * (cout // 32)
             assert set(tiles) == set(exp), (prob, len(tiles), len(exp))
             for t, segs in tiles.items():
                 segs.sort()

@@ -980,23 +980,33 @@ def test_unit_pair_launches_equal_two_single_unit_calls_bit_for_bit(binding, mon
         ds_a2, ds_b2, dx_2 = train._unit_pair_bwd(x, ua, ub)
         torch.cuda.synchronize()
         same = lambda a, b: (a is None and b is None) or (a.numel() == 0 and b is None) or (b.numel() == 0 and a is None) or torch.equal(a, b)
-        assert same(out_a1, out_a2) and same(out_b1, out_b2), (n, cin, cout)
+        # Round 6: shapes the balanced persistent launch takes (csrc/be_train_sk.h) - forward: cout % 64 == 0, cin % 32 == 0; backward:
+        # both channel counts multiples of 128; whole 64-image groups, maps of at most 11 x 11.  Where a tile's K loop is cut depends
+        # on how the launch's workgroups are shared between its problems, i.e. on whether one unit or two are in it: those
+        # results agree to the rounding of an fp32 sum regrouped (measured 1-4e-7), and whatever is computed FROM them (the backward
+        # reads the forward's y) to the same level; every other shape stays bit for bit.
+        sk_on = not os.environ.get("BE_NO_TRAIN_SK") and n % 64 == 0
+        fwd_bal = sk_on and not os.environ.get("BE_NO_TRAIN_SK_FWD") and cout % 64 == 0 and cin % 32 == 0
+        bwd_bal = sk_on and cin % 128 == 0 and cout % 128 == 0
+        rel = lambda p, q: float((p - q).norm() / q.norm().clamp_min(1e-30))
+
+        def eq(p, q, loose, tol=2e-6):
+            if p is None or q is None or p.numel() == 0 or q.numel() == 0:
+                return same(p, q)
+            return rel(p, q) <= tol if loose else torch.equal(p, q)
+        assert eq(out_a1, out_a2, fwd_bal) and eq(out_b1, out_b2, fwd_bal), (n, cin, cout)
         for s1, s2 in ((sv_a1, sv_a2), (sv_b1, sv_b2)):
-            assert all(same(p, q) for p, q in zip(s1, s2)), (n, cin, cout)
-        # Round 6: the units with channel counts that are multiples of 128 run their backward GEMMs as ONE balanced launch
-        # (csrc/be_train_sk.h): where a tile's K loop is cut depends on how the launch's workgroups are shared between the
-        # problems, i.e. on whether one unit or two are in it - the weight gradient and the input gradient of those shapes agree
-        # to the rounding of an fp32 sum regrouped (measured 2-4e-7), everything else stays bit for bit
-        balanced = cin % 128 == 0 and cout % 128 == 0 and n % 64 == 0 and not os.environ.get("BE_NO_TRAIN_SK")
-        close = lambda p, q: float((p - q).norm() / q.norm().clamp_min(1e-30)) <= 2e-6
+            assert all(eq(p, q, fwd_bal) for p, q in zip(s1, s2)), (n, cin, cout)
         for wi in (0, 6):
-            assert all(torch.equal(p, q) for p, q in zip(st1[wi], st2[wi])), (n, cin, cout, wi)
+            assert all(eq(p, q, fwd_bal) for p, q in zip(st1[wi], st2[wi])), (n, cin, cout, wi)
             dgam1, dbet1, dw1, db1 = g1[wi]
             dgam2, dbet2, dw2, db2 = g2[wi]
-            assert torch.equal(dgam1, dgam2) and torch.equal(dbet1, dbet2) and torch.equal(db1, db2), (n, cin, cout, wi)
-            assert (close(dw1, dw2) if balanced else torch.equal(dw1, dw2)), (n, cin, cout, wi)
-        assert torch.equal(ds_a1, ds_a2) and torch.equal(ds_b1, ds_b2), (n, cin, cout)
-        assert (close(dx_1, dx_2) if balanced else torch.equal(dx_1, dx_2)), (n, cin, cout)
+            assert eq(dgam1, dgam2, fwd_bal, 1e-5) and eq(dbet1, dbet2, fwd_bal, 1e-5), (n, cin, cout, wi)
+            # the conv bias gradient is rounding noise around 0 (BatchNorm removes the mean of dy): absolute scale of a column sum
+            assert (float((db1 - db2).abs().max()) <= 1e-5 * float(par[wi]["dout"].abs().max()) * n) if fwd_bal else torch.equal(db1, db2), (n, cin, cout, wi)
+            assert eq(dw1, dw2, fwd_bal or bwd_bal, 5e-6), (n, cin, cout, wi, rel(dw1, dw2))
+        assert eq(ds_a1, ds_a2, fwd_bal) and eq(ds_b1, ds_b2, fwd_bal), (n, cin, cout)
+        assert eq(dx_1, dx_2, fwd_bal or bwd_bal, 5e-6), (n, cin, cout, rel(dx_1, dx_2))
         if n == 512:
             # ... and the same calls captured into a hipGraph on a side stream: a launch on the null stream would end the capture
             st3, g3 = stats(), grads()
