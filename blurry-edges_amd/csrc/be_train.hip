@@ -1013,7 +1013,7 @@ __device__ __forceinline__ void post_job(const PostJob& a, const int b, const be
                 if (i < plane) {
                     // balanced launch: the slices of THIS element's 128 x 128 tile, tap by tap (be_train_sk.h)
                     int tile_j = 0;
-                    if (wg) { const int cin = wg->cin_tiles * 128, co = (int)(i / cin), ci = (int)(i - (int64_t)co * cin); tile_j = (co >> 7) * wg->cin_tiles + (ci >> 7); }
+                    if (wg) { const int co = (int)(i / wg->cin), ci = (int)(i - (int64_t)co * wg->cin); tile_j = (co / wg->tm) * wg->cin_tiles + ci / wg->tn; }
                     for (int t = 0; t < a.wtaps; ++t) {
                         int nS = a.wS;
                         if (wg) { int ts, n; be_sk::w_span(*wg, t, tile_j, ts, n); nS = be_sk::slices_of(ts, n, wg->Q); }
@@ -1485,7 +1485,7 @@ int fwd_bn_launches(const be_train_unit_fwd* const* u, int nu, const int* S, con
         BE_REQUIRE((size_t)sb.n * C * 2 * sizeof(double) <= sp.stats_b, "%s: statistics region too small", who);
         st.j[j] = StatsArgs{S[j] > 1 ? reinterpret_cast<const float*>(sp.conv) : nullptr, u[j]->packed_bias, u[j]->y,
                             reinterpret_cast<double*>(sp.stats), S[j] > 1 ? S[j] : 0, M, C, ldp[j], sb.rows, 0, {}};
-        if (sk) { st.j[j].partial = sk_part[j]; st.j[j].S = 1; st.j[j].ldp = C; st.j[j].sk = 1; st.j[j].g = sk[j]; }
+        if (sk) { st.j[j].partial = sk_part[j]; st.j[j].S = 1; st.j[j].ldp = (C + 63) / 64 * 64; st.j[j].sk = 1; st.j[j].g = sk[j]; }
         fa.j[j] = FwdApplyArgs{u[j]->y, reinterpret_cast<const double*>(sp.stats), u[j]->gamma, u[j]->beta, u[j]->res, u[j]->run_mean,
                                u[j]->run_var, u[j]->mean, u[j]->invstd, u[j]->s_in, u[j]->out, sb.n, M, C, ab.rows, u[j]->act, eps, momentum};
     }

@@ -26,10 +26,11 @@ struct ConvGeom {
     int Q, L;                                   // quota per workgroup, total chunks
     unsigned short PP[MAX_HW + 1];              // PP[pp] = taps inside the image summed over the pixels < pp
 };
-// A weight gradient's tiles: 128 cout x 128 cin of ONE tap; K chunks = one valid output pixel of 16 consecutive images.
-// Tile (tap, j): j = cout tile * cin_tiles + cin tile.
+// A weight gradient's tiles: tm cout x tn cin of ONE tap (tm, tn = 128, or 64 for channel counts that are not multiples of 128);
+// K chunks = one valid output pixel of 16 consecutive images.  Tile (tap, j): j = cout tile * cin_tiles + cin tile.
 struct WGeom {
     int wx, cin_tiles, ntaps;
+    int tm, tn, cin;
     int Q, L;
     int PT[10];                                 // PT[t] = chunks of one tile of the taps < t
 };

@@ -32,6 +32,7 @@ struct ConvProb {
     const float* w;        // packed [Cout_pad][Ktot] (be_conv_pack_dgrad_f32)
     float* part;           // [slices][M][ldp]
     int H, W, Cin, Ktot, ks, M, ldp, g0, G;
+    int rows_w;            // rows of the pack (output channels rounded up to 32): a column tile's rows past them re-read row 0, never used
     be_sk::ConvGeom g;
 };
 struct WProb {
@@ -84,10 +85,11 @@ __device__ __forceinline__ void conv_segment(const ConvProb& p, float* smem, con
         const int row = 8 * (wave + 4 * i) + rowp;
         const int sq = slot ^ ((row >> 1) & 7);
         a_off[i] = (unsigned)(row * HW * p.Cin + 4 * sq) * 4u;
-        b_off[i] = (unsigned)(row * p.Ktot + 4 * sq) * 4u;
+        const int wrow = j * 64 + row < p.rows_w ? j * 64 + row : 0;            // the empty half of a 96-channel layer's second tile
+        b_off[i] = (unsigned)(wrow * p.Ktot + 4 * sq) * 4u;
     }
     const float* xpix = p.x + ((int64_t)grp * 64 * HW + pp) * p.Cin;            // uniform: the tile's pixel of the group's first image
-    const float* wt = p.w + (int64_t)j * 64 * p.Ktot;
+    const float* wt = p.w;
     // walker over the chunks: k = cc * ntap + jj
     int w_cc = k0 / ntap, w_j = k0 - w_cc * ntap, l_buf = 0;
 #define SK_CONV_DMA()                                                                                           \
@@ -157,8 +159,17 @@ __device__ __forceinline__ void conv_segment(const ConvProb& p, float* smem, con
 }
 
 // ---- one segment of a weight-gradient tile: valid pixels [v0, v1) of tile (tap, j) -> slice `slice` ----------------------------
+// Tile TM cout x TN cin, TM, TN in {128, 64} (128 wherever the channel count is a multiple of 128; 64 for layer0's 64 / 96 channels
+// and layer1's 96 inputs: the second tile of a 96-channel side is half empty - its waves move their share of the operands and
+// issue no MFMA).  A wave owns (TM / 2) x (TN / 2): with 64 rows / columns lane li holds channels 2 li and 2 li + 1 (one ds_read_b64
+// feeds two MFMA tiles), with 32 it holds channel li.  Lanes whose channels lie past the tensor's last channel re-read its last
+// quad (never stored): no access leaves the tensor.
+template <int TM, int TN>
 __device__ __forceinline__ void wgrad_segment(const WProb& p, float* smem, const int tap, const int j, const int v0, const int v1,
                                               const int slice) {
+    constexpr int MI = TM / 64, NI = TN / 64;                  // MFMA tiles per wave along cout / cin
+    constexpr int PA = TM / 16, PB = TN / 16, NPW = (PA + PB) / 4;   // 1-KB DMA pieces of dy / x per chunk; pieces per wave
+    constexpr int RA = 256 / TM, RB = 256 / TN;                // image rows per piece
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int li = lane & 31, lh = lane >> 5, wm = wave >> 1, wn = wave & 1;
@@ -166,40 +177,42 @@ __device__ __forceinline__ void wgrad_segment(const WProb& p, float* smem, const
     const int tdy = tap / p.ks - half, tdx = tap % p.ks - half;
     int y0, hv, x0, wv;
     be_sk::tap_rect(p.H, p.W, tdy, tdx, y0, hv, x0, wv);
-    const int co0 = (j / p.g.cin_tiles) * 128, ci0 = (j % p.g.cin_tiles) * 128;
-    // a DMA piece = 2 pixels-rows (images) x 128 channels; wave w moves pieces w and w + 4 of both operands
-    const int rr = lane >> 5, q = lane & 31;
-    unsigned a_vo[2], b_vo[2];
+    const int co0 = (j / p.g.cin_tiles) * TM, ci0 = (j % p.g.cin_tiles) * TN;
+    const bool live = co0 + wm * (TM / 2) < p.Cout && ci0 + wn * (TN / 2) < p.Cin;
+    // piece pi = wave + 4 i: the first PA pieces are dy's (PA is a multiple of 4: a given i is the same operand for every wave)
+    unsigned vo[NPW];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = 2 * (wave + 4 * i) + rr;   // image of the chunk's 16
-        a_vo[i] = (unsigned)(row * HW * p.Cout + 4 * q) * 4u;
-        b_vo[i] = (unsigned)(row * HW * p.Cin + 4 * q) * 4u;
+    for (int i = 0; i < NPW; ++i) {
+        const int pi = wave + 4 * i;
+        if (pi < PA) {
+            const int row = RA * pi + lane / (TM / 4), c = min(co0 + 4 * (lane % (TM / 4)), p.Cout - 4);
+            vo[i] = (unsigned)(row * HW * p.Cout + c) * 4u;
+        } else {
+            const int row = RB * (pi - PA) + lane / (TN / 4), c = min(ci0 + 4 * (lane % (TN / 4)), p.Cin - 4);
+            vo[i] = (unsigned)(row * HW * p.Cin + c) * 4u;
+        }
     }
-    const float* dyb = p.dy + co0;
-    const float* xb = p.x + (int64_t)(tdy * p.W + tdx) * p.Cin + ci0;
+    const float* xb = p.x + (int64_t)(tdy * p.W + tdx) * p.Cin;
     // walker: v = (ic * hv + ry) * wv + rx
     int w_ic = v0 / (hv * wv), w_ry, w_rx, l_buf = 0;
     { const int rem = v0 - w_ic * hv * wv; w_ry = rem / wv; w_rx = rem - w_ry * wv; }
 #define SK_W_DMA()                                                                                              \
     do {                                                                                                        \
         const int64_t m0_ = (int64_t)w_ic * 16 * HW + (y0 + w_ry) * p.W + x0 + w_rx;                            \
-        const char* pa_ = reinterpret_cast<const char*>(dyb + m0_ * p.Cout);                                    \
+        const char* pa_ = reinterpret_cast<const char*>(p.dy + m0_ * p.Cout);                                   \
         const char* pb_ = reinterpret_cast<const char*>(xb + m0_ * p.Cin);                                      \
         float* st_ = smem + l_buf * STAGE_W + wave * 256;                                                       \
-        _Pragma("unroll") for (int i_ = 0; i_ < 2; ++i_) {                                                      \
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pa_ + a_vo[i_]), (lds_ptr_t)(st_ + i_ * 1024), 16, 0, 0); \
-            __builtin_amdgcn_global_load_lds((glb_ptr_t)(pb_ + b_vo[i_]), (lds_ptr_t)(st_ + 2048 + i_ * 1024), 16, 0, 0); \
-        }                                                                                                       \
+        _Pragma("unroll") for (int i_ = 0; i_ < NPW; ++i_)                                                      \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t)((4 * i_ < PA ? pa_ : pb_) + vo[i_]), (lds_ptr_t)(st_ + i_ * 1024), 16, 0, 0); \
         if (++w_rx == wv) { w_rx = 0; if (++w_ry == hv) { w_ry = 0; ++w_ic; } }                                 \
         l_buf = l_buf == 2 ? 0 : l_buf + 1;                                                                     \
     } while (0)
 
-    f32x16 acc[2][2];
+    f32x16 acc[MI][NI];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int jj = 0; jj < 2; ++jj)
+        for (int jj = 0; jj < NI; ++jj)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][jj][r] = 0.f;
 
@@ -208,39 +221,49 @@ __device__ __forceinline__ void wgrad_segment(const WProb& p, float* smem, const
     SK_W_DMA();
     if (v0 + 1 < v1) SK_W_DMA();
     int r_buf = 0;
-    const int a_fr = wm * 64 + 2 * li, b_fr = 2048 + wn * 64 + 2 * li;
+    // stage image: dy [16][TM] at 0, x [16][TN] at 16 TM (pieces in order: the DMA of piece pi lands at 256 pi floats)
+    const int a_fr = wm * (TM / 2) + MI * li, b_fr = 16 * TM + wn * (TN / 2) + NI * li;
     for (int v = v0; v < v1; ++v) {
-        if (v + 1 < v1) SK_VMCNT(4); else SK_VMCNT(0);
+        if (v + 1 < v1) SK_VMCNT(NPW); else SK_VMCNT(0);
         __builtin_amdgcn_s_barrier();
         if (v + 2 < v1) SK_W_DMA();
         __builtin_amdgcn_sched_barrier(0);
-        {
+        if (live) {
             const float* sb = smem + r_buf * STAGE_W;
 #pragma unroll
             for (int s2 = 0; s2 < 8; ++s2) {
-                const f32x2 av = *reinterpret_cast<const f32x2*>(sb + (2 * s2 + lh) * 128 + a_fr);
-                const f32x2 bv = *reinterpret_cast<const f32x2*>(sb + (2 * s2 + lh) * 128 + b_fr);
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[0], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[0], bv[1], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv[0], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[1], bv[1], acc[1][1], 0, 0, 0);
+                float av[MI], bv[NI];
+                if (MI == 2) { const f32x2 t = *reinterpret_cast<const f32x2*>(sb + (2 * s2 + lh) * TM + a_fr); av[0] = t[0]; av[MI - 1] = t[1]; }
+                else av[0] = sb[(2 * s2 + lh) * TM + a_fr];
+                if (NI == 2) { const f32x2 t = *reinterpret_cast<const f32x2*>(sb + (2 * s2 + lh) * TN + b_fr); bv[0] = t[0]; bv[NI - 1] = t[1]; }
+                else bv[0] = sb[(2 * s2 + lh) * TN + b_fr];
+#pragma unroll
+                for (int i = 0; i < MI; ++i)
+#pragma unroll
+                    for (int jj = 0; jj < NI; ++jj) acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[jj], acc[i][jj], 0, 0, 0);
             }
         }
         r_buf = r_buf == 2 ? 0 : r_buf + 1;
         __builtin_amdgcn_sched_barrier(0);
     }
 #undef SK_W_DMA
-    // D tile (i, jj): row (e & 3) + 8 (e >> 2) + 4 lh = position ii of the wave's interleaved rows -> co = co0 + wm 64 + 2 ii + i;
-    // column li -> ci = ci0 + wn 64 + 2 li + jj: the pair jj = 0, 1 is one 8-byte store
-    float* out = p.part + ((int64_t)slice * p.g.ntaps + tap) * p.Cout * p.Cin + (int64_t)(co0 + wm * 64 + 8 * lh) * p.Cin + ci0 + wn * 64 + 2 * li;
+    if (!live) return;
+    // D tile (i, jj): row (e & 3) + 8 (e >> 2) + 4 lh = position ii of the wave's rows -> co = co0 + wm TM/2 + MI ii + i; column li ->
+    // ci = ci0 + wn TN/2 + NI li + jj (NI = 2: the pair jj = 0, 1 is one 8-byte store)
+    const int co_w = co0 + wm * (TM / 2) + MI * 4 * lh, ci_l = ci0 + wn * (TN / 2) + NI * li;
+    float* out = p.part + ((int64_t)slice * p.g.ntaps + tap) * p.Cout * p.Cin + (int64_t)co_w * p.Cin + ci_l;
+    if (ci_l < p.Cin) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int ro = 2 * ((e & 3) + 8 * (e >> 2)) + i;
-            f32x2 v = {acc[i][0][e], acc[i][1][e]};
-            *reinterpret_cast<f32x2*>(out + (int64_t)ro * p.Cin) = v;
-        }
+            for (int e = 0; e < 16; ++e) {
+                const int ro = MI * ((e & 3) + 8 * (e >> 2)) + i;
+                if (co_w + ro < p.Cout) {
+                    if (NI == 2) { f32x2 v = {acc[i][0][e], acc[i][NI - 1][e]}; *reinterpret_cast<f32x2*>(out + (int64_t)ro * p.Cin) = v; }
+                    else out[(int64_t)ro * p.Cin] = acc[i][0][e];
+                }
+            }
+    }
 }
 
 // workgroup -> (problem, position g on the problem's axis).  Ids congruent mod 8 share an XCD (speed only): the workgroups of
@@ -273,7 +296,9 @@ void k_unit_gemms_sk(SkArgs a) {
             int ts, n;
             be_sk::w_span(p.g, tap, j, ts, n);
             const int v0 = pos - ts, v1 = min(n, end - ts);
-            wgrad_segment(p, smem, tap, j, v0, v1, pos / p.g.Q - ts / p.g.Q);
+            const int sl = pos / p.g.Q - ts / p.g.Q;
+            if (p.g.tm == 128) { if (p.g.tn == 128) wgrad_segment<128, 128>(p, smem, tap, j, v0, v1, sl); else wgrad_segment<128, 64>(p, smem, tap, j, v0, v1, sl); }
+            else { if (p.g.tn == 128) wgrad_segment<64, 128>(p, smem, tap, j, v0, v1, sl); else wgrad_segment<64, 64>(p, smem, tap, j, v0, v1, sl); }
             pos = ts + v1;
             ++n_seg;
             if (++j == p.g.wx) { j = 0; ++tap; }
@@ -412,13 +437,14 @@ bool sk_enabled() {
     return !off;
 }
 
-// Units this launch takes: 1x1 / 3x3 convolutions of whole 64-image groups on maps of at most 11 x 11 with channel counts that are
-// multiples of 128 (layers 1-3 of LocalStage: 77 % of the backward's matrix time), input gradient wanted.
+// Units this launch takes: 1x1 / 3x3 convolutions of whole 64-image groups on maps of at most 11 x 11, channel counts multiples of
+// 32 and at least 64 (every unit of LocalStage's layers 0-3; not conv1 - 3 input channels - and not fc.1, whose weight gradient is
+// stored in the (C,H,W) column order), input gradient wanted.
 bool sk_eligible(const be_train_unit_bwd& u) {
     const be_conv_desc& d = u.desc;
     if (d.ksize != 1 && d.ksize != 3) return false;
-    if (d.n < 64 || d.n % 64 || d.h < 3 || d.w < 3 || d.h * d.w > be_sk::MAX_HW) return false;
-    if (d.cout % 128 || d.cin % 128 || u.layout_chw_hw || !u.dx || !u.dgrad_packed_w) return false;
+    if (d.n < 64 || d.n % 64 || d.h * d.w > be_sk::MAX_HW || (d.ksize == 3 && (d.h < 3 || d.w < 3))) return false;
+    if (d.cout % 32 || d.cin % 32 || d.cout < 64 || d.cin < 64 || u.layout_chw_hw || !u.dx || !u.dgrad_packed_w) return false;
     const int64_t M = (int64_t)d.n * d.h * d.w;
     const int cmax = d.cout > d.cin ? d.cout : d.cin;
     if (M * cmax * 4 >= ((int64_t)1 << 31) || (int64_t)d.cin * d.cout * d.ksize * d.ksize * 4 >= ((int64_t)1 << 31)) return false;
@@ -458,7 +484,8 @@ int sk_plan(const SkUnitIn* in, int nu, SkUnitOut* out, SkPlan* plan) {
         // weight gradient
         WProb& w = a.w[i];
         w.x = u.x; w.dy = u.dy; w.part = in[i].wpart; w.H = d.h; w.W = d.w; w.Cin = d.cin; w.Cout = d.cout; w.ks = ks;
-        w.g.cin_tiles = d.cin / 128; w.g.wx = (d.cout / 128) * (d.cin / 128); w.g.ntaps = taps;
+        w.g.tm = d.cout % 128 == 0 ? 128 : 64; w.g.tn = d.cin % 128 == 0 ? 128 : 64; w.g.cin = d.cin;
+        w.g.cin_tiles = (d.cin + w.g.tn - 1) / w.g.tn; w.g.wx = ((d.cout + w.g.tm - 1) / w.g.tm) * w.g.cin_tiles; w.g.ntaps = taps;
         w.g.PT[0] = 0;
         int nmax = 0;
         for (int t = 0; t < taps; ++t) {
@@ -470,17 +497,19 @@ int sk_plan(const SkUnitIn* in, int nu, SkUnitOut* out, SkPlan* plan) {
         }
         w.g.L = w.g.PT[taps] * w.g.wx;
         const size_t wsize = (size_t)d.cout * d.cin * taps * sizeof(float);
-        pr[np++] = Prob{w.g.L, nmax, w.g.wx * taps, ww, fw, (int)((in[i].wpart_bytes - (i == nu - 1 ? w_reserve : 0)) / wsize), be_sk::MAX_SLICES_W, 0, 0};
+        // a chunk of a tm x tn tile is tm tn / 16384 of the 128 x 128 chunk's MFMAs; the small tiles carry relatively more of the rest
+        const double wtile = ww * (w.g.tm * w.g.tn == 16384 ? 1.0 : (w.g.tm * w.g.tn == 8192 ? 0.6 : 0.4));
+        pr[np++] = Prob{w.g.L, nmax, w.g.wx * taps, wtile, fw, (int)((in[i].wpart_bytes - (i == nu - 1 ? w_reserve : 0)) / wsize), be_sk::MAX_SLICES_W, 0, 0};
         // data gradient: a convolution of dy [M, Cout] with the transposed, tap-mirrored pack -> [M, Cin]
         ConvProb& c = a.c[i];
         c.x = u.dy; c.w = u.dgrad_packed_w; c.part = in[i].cpart; c.H = d.h; c.W = d.w; c.Cin = d.cout; c.ks = ks;
-        c.Ktot = (d.cout / 32) * taps * 32; c.M = M; c.ldp = d.cin;
-        const int tmax = conv_geometry(c.g, d.n, d.h, d.w, d.cout, ks, d.cin / 64);
-        const size_t csize = (size_t)M * d.cin * sizeof(float);
+        c.Ktot = (d.cout / 32) * taps * 32; c.M = M; c.ldp = (d.cin + 63) / 64 * 64; c.rows_w = (d.cin + 31) / 32 * 32;
+        const int tmax = conv_geometry(c.g, d.n, d.h, d.w, d.cout, ks, (d.cin + 63) / 64);
+        const size_t csize = (size_t)M * c.ldp * sizeof(float);
         pr[np++] = Prob{c.g.L, tmax * c.g.kmul, c.g.ngrp * HW * c.g.n_tiles, 1.0, fc, (int)(in[i].cpart_bytes / csize), be_sk::MAX_SLICES_C, 0, 0};
         flops += 4.0 * M * (double)d.cin * d.cout * taps;
-        flops_exec += (double)w.g.L * 2.0 * 128 * 128 * 16 + (double)c.g.L * 2.0 * 64 * 64 * 32;
-        out[i].ldp = d.cin;
+        flops_exec += (double)w.g.L * 2.0 * w.g.tm * w.g.tn * 16 + (double)c.g.L * 2.0 * 64 * 64 * 32;
+        out[i].ldp = c.ldp;
     }
     if (!share_workgroups(pr, np)) return 1;
     int g0 = 0;
@@ -512,8 +541,10 @@ int sk_plan(const SkUnitIn* in, int nu, SkUnitOut* out, SkPlan* plan) {
 // local_training.py:103) on the same persistent launch: conv-only problems, raw slices for k_bn_stats.
 bool sk_fwd_eligible(const be_conv_desc& d) {
     if (d.ksize != 1 && d.ksize != 3) return false;
-    if (d.n < 64 || d.n % 64 || d.h < 3 || d.w < 3 || d.h * d.w > be_sk::MAX_HW) return false;
-    if (d.cout % 64 || d.cin % 32) return false;
+    // a 3x3 kernel needs a map of at least 3 x 3 (every tap then has a pixel: no empty tile on the axis); a 1x1 takes any map,
+    // h = w = 1 included: fc.1 (64 rows x 2304 -> 1024: sixteen tiles of 72 chunks that no equal-slice grid fills)
+    if (d.n < 64 || d.n % 64 || d.h * d.w > be_sk::MAX_HW || (d.ksize == 3 && (d.h < 3 || d.w < 3))) return false;
+    if (d.cout % 32 || d.cout < 64 || d.cin % 32) return false;    // 96 outputs: two column tiles, the second half empty
     const int64_t M = (int64_t)d.n * d.h * d.w;
     const int cmax = d.cout > d.cin ? d.cout : d.cin;
     return M * cmax * 4 < ((int64_t)1 << 31) && (int64_t)d.cin * d.cout * d.ksize * d.ksize * 4 < ((int64_t)1 << 31);
@@ -531,9 +562,9 @@ int sk_plan_fwd(const SkFwdIn* in, int nu, be_sk::ConvGeom* out, SkPlan* plan) {
         const int ks = d.ksize, taps = ks * ks, M = d.n * d.h * d.w;
         ConvProb& c = a.c[i];
         c.x = in[i].x; c.w = in[i].packed_w; c.part = in[i].part; c.H = d.h; c.W = d.w; c.Cin = d.cin; c.ks = ks;
-        c.Ktot = (d.cin / 32) * taps * 32; c.M = M; c.ldp = d.cout;
-        const int tmax = conv_geometry(c.g, d.n, d.h, d.w, d.cin, ks, d.cout / 64);
-        const size_t csize = (size_t)M * d.cout * sizeof(float);
+        c.Ktot = (d.cin / 32) * taps * 32; c.M = M; c.ldp = (d.cout + 63) / 64 * 64; c.rows_w = (d.cout + 31) / 32 * 32;
+        const int tmax = conv_geometry(c.g, d.n, d.h, d.w, d.cin, ks, (d.cout + 63) / 64);
+        const size_t csize = (size_t)M * c.ldp * sizeof(float);
         pr[i] = Prob{c.g.L, tmax * c.g.kmul, c.g.ngrp * c.g.HW * c.g.n_tiles, 1.0, fc, (int)(in[i].part_bytes / csize), be_sk::MAX_SLICES_C, 0, 0};
         pd.flops += 2.0 * M * (double)d.cin * d.cout * taps;
         pd.flops_exec += (double)c.g.L * 2.0 * 64 * 64 * 32;
@@ -575,7 +606,7 @@ extern "C" int be_train_sk_plan_debug(int n, int h, int w, int cin, int cout, in
                cin % 128 == 0 && cout % 128 == 0 && workgroups >= 16 && w_share > 0.0 && w_share < 1.0, "be_train_sk_plan_debug: bad arguments");
     const int ks = ksize, half = ks >> 1, taps = ks * ks, HW = h * w;
     be_sk::WGeom wg{};
-    wg.cin_tiles = cin / 128; wg.wx = (cout / 128) * (cin / 128); wg.ntaps = taps;
+    wg.tm = wg.tn = 128; wg.cin = cin; wg.cin_tiles = cin / 128; wg.wx = (cout / 128) * (cin / 128); wg.ntaps = taps;
     for (int t = 0; t < taps; ++t) {
         int y0, hv, x0, wv;
         be_sk::tap_rect(h, w, t / ks - half, t % ks - half, y0, hv, x0, wv);

@@ -980,14 +980,16 @@ def test_unit_pair_launches_equal_two_single_unit_calls_bit_for_bit(binding, mon
         ds_a2, ds_b2, dx_2 = train._unit_pair_bwd(x, ua, ub)
         torch.cuda.synchronize()
         same = lambda a, b: (a is None and b is None) or (a.numel() == 0 and b is None) or (b.numel() == 0 and a is None) or torch.equal(a, b)
-        # Round 6: shapes the balanced persistent launch takes (csrc/be_train_sk.h) - forward: cout % 64 == 0, cin % 32 == 0; backward:
-        # both channel counts multiples of 128; whole 64-image groups, maps of at most 11 x 11.  Where a tile's K loop is cut depends
+        # Round 6: shapes the balanced persistent launch takes (csrc/be_train_sk.h) - channel counts multiples of 32 (at least 64 for every
+        # side that is tiled); whole 64-image groups, maps of at most 11 x 11: every block of LocalStage at batch 64.  Where a tile's K loop is cut depends
         # on how the launch's workgroups are shared between its problems, i.e. on whether one unit or two are in it: those
         # results agree to the rounding of an fp32 sum regrouped (measured 1-4e-7), and whatever is computed FROM them (the backward
         # reads the forward's y) to the same level; every other shape stays bit for bit.
-        sk_on = not os.environ.get("BE_NO_TRAIN_SK") and n % 64 == 0
-        fwd_bal = sk_on and not os.environ.get("BE_NO_TRAIN_SK_FWD") and cout % 64 == 0 and cin % 32 == 0
-        bwd_bal = sk_on and cin % 128 == 0 and cout % 128 == 0
+        # (n = 512: whole 64-image groups too, but one slice of its 61 952-row maps does not fit the scratch twice - the plan says
+        #  "not mine" and rounds 3-5's launches run, bit for bit)
+        sk_on = not os.environ.get("BE_NO_TRAIN_SK") and n == 64
+        fwd_bal = sk_on and not os.environ.get("BE_NO_TRAIN_SK_FWD") and cout % 32 == 0 and cout >= 64 and cin % 32 == 0
+        bwd_bal = sk_on and cin % 32 == 0 and cout % 32 == 0 and cin >= 64 and cout >= 64
         rel = lambda p, q: float((p - q).norm() / q.norm().clamp_min(1e-30))
 
         def eq(p, q, loose, tol=2e-6):

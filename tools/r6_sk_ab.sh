@@ -5,6 +5,6 @@ timeout -k 10 900 python -m pytest tests/test_train_gpu.py -x -q -k "training_un
 cd blurry-edges_amd
 for i in 1 2; do
 timeout -k 10 200 python3 -m be_hip.train_local --steps 400 --graph 2>/dev/null | tail -1 | cut -c1-140
-BE_NO_TRAIN_SK_FWD=1 timeout -k 10 200 python3 -m be_hip.train_local --steps 400 --graph 2>/dev/null | tail -1 | cut -c1-140
 done
 BE_NO_TRAIN_SK=1 timeout -k 10 200 python3 -m be_hip.train_local --steps 400 --graph 2>/dev/null | tail -1 | cut -c1-140
+cd .. && bash tools/train_trace.sh r6/trace_sk3 > gpurun_out/r6/trace_sk3.log 2>&1; grep "k_unit_gemms\|k_conv_igemm\|launches" gpurun_out/r6/trace_sk3/step_sequence.txt | cut -c1-100
