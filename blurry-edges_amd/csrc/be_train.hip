@@ -943,6 +943,8 @@ void k_bn_bwd_apply(Two<BwdApplyArgs> two) {
 struct PostJob {              // one unit's parameter-gradient roles
     const float* wpart; float* dw; int64_t wsize; int wS; int conv1_map, cout1;   // conv1_map: slices are [cout][7][8 px][4 ch]
     int wtaps;                // > 0: slices are [S][tap][cout][cin] (k_wgrad128), transposed here
+    int chw;                  // > 0 (wtaps == 1, balanced launch): the slices' columns run (hw, c) - our activations' order - and dW is
+                              //      stored in the reference's (c, hw) column order, hw < chw (fc.1: models/local_stage.py:44-46)
     const double* dbpart; float* db; int nb_rows, C;
     int nb_w, nb_b;
 };
@@ -957,7 +959,7 @@ struct PostArgs {             // up to two units (a residual block's conv1 and d
     be_sk::ConvGeom xsk[2];
 };
 
-__device__ __forceinline__ void post_job(const PostJob& a, const int b, const be_sk::WGeom* wg) {
+__device__ __forceinline__ void post_job(const PostJob& a, const int b, const be_sk::WGeom& wgeo, const bool sk) {
     if (b < a.nb_w) {
         if (a.conv1_map) {                                  // dW[co][ci][kh][kw] <- slice[co][kh][kw][ci] of a 224-column row
             const int64_t total = (int64_t)a.cout1 * 147;
@@ -1002,6 +1004,23 @@ __device__ __forceinline__ void post_job(const PostJob& a, const int b, const be
             }
             return;
         }
+        if (a.chw > 0 && sk) {
+            // fc.1 on the balanced launch (one tap): the slices' columns run (hw, c) - our activations' order - and dW is stored in the
+            // reference's (c, hw) column order (models/local_stage.py:44-46: Flatten of [C,H,W]).  A branch of its own: with the column
+            // map inside the general loop below the compiler spilled that loop (every k_bwd_post of the step 45 us slower)
+            const int cin = wgeo.cin, cpl = cin / a.chw;
+            const int64_t plane = a.wsize;
+            for (int64_t i = (int64_t)b * 256 + threadIdx.x; i < plane; i += (int64_t)a.nb_w * 256) {
+                const int co = (int)(i / cin), ci = (int)(i - (int64_t)co * cin);
+                int ts, n;
+                be_sk::w_span(wgeo, 0, (co / wgeo.tm) * wgeo.cin_tiles + ci / wgeo.tn, ts, n);
+                const int nS = be_sk::slices_of(ts, n, wgeo.Q);
+                float s = 0.f;
+                for (int k = 0; k < nS; ++k) s += a.wpart[(int64_t)k * plane + i];
+                a.dw[(int64_t)co * cin + (ci % cpl) * a.chw + ci / cpl] = s;
+            }
+            return;
+        }
         if (a.wtaps) {                                      // k_wgrad128's slices [S][tap][cout*cin] -> dW[cout][cin][tap]
             // a workgroup sums 256 consecutive (cout, cin) positions for every tap (coalesced reads of each slice plane), parks
             // the 256 x taps results in LDS and writes them out as ONE contiguous run (the transposed stores straight from
@@ -1013,10 +1032,10 @@ __device__ __forceinline__ void post_job(const PostJob& a, const int b, const be
                 if (i < plane) {
                     // balanced launch: the slices of THIS element's 128 x 128 tile, tap by tap (be_train_sk.h)
                     int tile_j = 0;
-                    if (wg) { const int co = (int)(i / wg->cin), ci = (int)(i - (int64_t)co * wg->cin); tile_j = (co / wg->tm) * wg->cin_tiles + ci / wg->tn; }
+                    if (sk) { const int co = (int)(i / wgeo.cin), ci = (int)(i - (int64_t)co * wgeo.cin); tile_j = (co / wgeo.tm) * wgeo.cin_tiles + ci / wgeo.tn; }
                     for (int t = 0; t < a.wtaps; ++t) {
                         int nS = a.wS;
-                        if (wg) { int ts, n; be_sk::w_span(*wg, t, tile_j, ts, n); nS = be_sk::slices_of(ts, n, wg->Q); }
+                        if (sk) { int ts, n; be_sk::w_span(wgeo, t, tile_j, ts, n); nS = be_sk::slices_of(ts, n, wgeo.Q); }
                         float s = 0.f;
                         for (int k0 = 0; k0 < nS; k0 += 8) {            // eight slices in flight, added in slice order
                             float p[8];
@@ -1077,9 +1096,9 @@ void k_bwd_post(PostArgs g) {
     int b = blockIdx.x;
     const int n_j0 = g.j[0].nb_w + g.j[0].nb_b, n_j1 = g.nj > 1 ? g.j[1].nb_w + g.j[1].nb_b : 0;
     if (b < n_j0) {
-        post_job(g.j[0], b, g.sk ? &g.wsk[0] : nullptr);
+        post_job(g.j[0], b, g.wsk[0], g.sk != 0);
     } else if (b < n_j0 + n_j1) {
-        post_job(g.j[1], b - n_j0, g.sk ? &g.wsk[1] : nullptr);
+        post_job(g.j[1], b - n_j0, g.wsk[1], g.sk != 0);
     } else {
         const PostArgs& a = g;
         const int bx = b - n_j0 - n_j1, nb_x = gridDim.x - n_j0 - n_j1;
@@ -1693,7 +1712,7 @@ void sk_post_roles(const be_train_unit_bwd& u, const be::SkUnitIn& in, const be:
     const int taps = d->ksize * d->ksize;
     PostJob& pj = pa->j[j];
     pj.wpart = in.wpart; pj.dw = u.dw; pj.wsize = (int64_t)d->cout * d->cin * taps; pj.wS = 1; pj.conv1_map = 0; pj.cout1 = d->cout;
-    pj.wtaps = taps;
+    pj.wtaps = taps; pj.chw = u.layout_chw_hw;
     pj.nb_w = (int)cap_grid(pj.wsize / taps, 256, 1024);
     pa->sk = 1;
     pa->wsk[j] = out.wg;

@@ -438,13 +438,16 @@ bool sk_enabled() {
 }
 
 // Units this launch takes: 1x1 / 3x3 convolutions of whole 64-image groups on maps of at most 11 x 11, channel counts multiples of
-// 32 and at least 64 (every unit of LocalStage's layers 0-3; not conv1 - 3 input channels - and not fc.1, whose weight gradient is
-// stored in the (C,H,W) column order), input gradient wanted.
+// 32 and at least 64 (every unit of LocalStage's layers 0-3 and fc.1; not conv1: 3 input channels, no input gradient), input
+// gradient wanted.
 bool sk_eligible(const be_train_unit_bwd& u) {
     const be_conv_desc& d = u.desc;
     if (d.ksize != 1 && d.ksize != 3) return false;
     if (d.n < 64 || d.n % 64 || d.h * d.w > be_sk::MAX_HW || (d.ksize == 3 && (d.h < 3 || d.w < 3))) return false;
-    if (d.cout % 32 || d.cin % 32 || d.cout < 64 || d.cin < 64 || u.layout_chw_hw || !u.dx || !u.dgrad_packed_w) return false;
+    if (d.cout % 32 || d.cin % 32 || d.cout < 64 || d.cin < 64 || !u.dx || !u.dgrad_packed_w) return false;
+    // fc.1 (a linear on flattened (h, w, c) features whose weight is stored in (c, h, w) column order): rows are images, k_bwd_post
+    // permutes the columns while it sums the slices
+    if (u.layout_chw_hw && !(d.ksize == 1 && d.h * d.w == 1 && d.cin % u.layout_chw_hw == 0)) return false;
     const int64_t M = (int64_t)d.n * d.h * d.w;
     const int cmax = d.cout > d.cin ? d.cout : d.cin;
     if (M * cmax * 4 >= ((int64_t)1 << 31) || (int64_t)d.cin * d.cout * d.ksize * d.ksize * 4 >= ((int64_t)1 << 31)) return false;

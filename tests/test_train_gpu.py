@@ -50,45 +50,14 @@ def test_twenty_training_steps_teacher_forced_against_the_fp64_oracle():
     W = dict(loss=0.0, logits=0.0, dest_same=0.0, cnn=0.0, cnn_name="", chain=0.0, chain_name="", chain_norm=0.0, cnn_event=0.0,
              cnn_name_event="", chain_event=0.0, chain_name_event="", chain_norm_event=0.0, e2e_hip=0.0, e2e_f32=0.0,
              norm=0.0, run=0.0, upd_ulp=0.0, upd_name="", dead=0.0)
-    cnn_all, hip_curve, ora_curve, events, event_steps = [], [], [], [], []
+    cnn_all, hip_curve, ora_curve, events, event_steps, loss_steps = [], [], [], [], [], []
 
     def loss_of(est, cb):
         return orr.local_loss(est, cb["img_gt"], cb["img_gt"], cb["bndry_dist"], cb["deri"], args.beta_bndry_loc,
                               args.beta_smthns, inverse="solve")[0]
     rel = lambda a, r: float((a - r).norm() / r.norm())
 
-    def pool_winner_flips(state, x_gpu):
-        """The three max-pools of one training forward from `state`: which windows does the HIP forward give to a different
-        element than the float64 oracle, and how far apart are the two candidates in float64 (relative to the map's largest value)?
-        -> {pool: (windows whose winner differs, largest float64 gap between the two candidates)}"""
-        import torch.nn.functional as F
-        from be_hip import train
-        probe = models.LocalStage().to(DEV)
-        probe.load_state_dict(state)
-        _, S = train.forward_train(x_gpu.to(torch.float32).contiguous(), [v.detach() for v in probe._tensor_list()])
-        taps = {}
-        sdd = {k: (v.double() if v.is_floating_point() else v) for k, v in state.items()}
-        with torch.no_grad():
-            ols.local_stage_forward(sdd, x_gpu.cpu().double(), training=True, taps=taps)
-        out = {}
-        for pool, src, k, st, pd in (("pool1", "conv1", 3, 2, 1), ("pool2", "layer0", 3, 2, 1), ("pool3", "layer3", 2, 2, 0)):
-            v = taps[src]                                                    # [n,c,h,w] float64
-            n_, c_, h_, w_ = v.shape
-            _, oi = F.max_pool2d(v, k, st, pd, return_indices=True)          # flat y*w + x per [n,c,oh,ow]
-            idx = S[pool][0].permute(0, 3, 1, 2).cpu().long()               # HIP: dy*k + dx of the winner, -> [n,c,oh,ow]
-            oh, ow = idx.shape[2], idx.shape[3]
-            oy = torch.arange(oh).view(1, 1, oh, 1) * st - pd
-            ox = torch.arange(ow).view(1, 1, 1, ow) * st - pd
-            hi = (oy + idx // k) * w_ + (ox + idx % k)
-            diff = hi != oi
-            gap = 0.0
-            if diff.any():
-                flat = v.flatten(2)
-                a_ = torch.gather(flat, 2, oi.flatten(2)).view_as(oi)[diff]
-                b_ = torch.gather(flat, 2, hi.flatten(2)).view_as(hi)[diff]
-                gap = float((a_ - b_).abs().max() / v.abs().max())
-            out[pool] = (int(diff.sum()), gap)
-        return out
+    from pool_flips import pool_winner_flips          # max-pool windows whose HIP winner differs from the float64 oracle's (near-ties)
     for it in range(steps):
         t = it + 1
         sd_cpu = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
@@ -124,13 +93,20 @@ def test_twenty_training_steps_teacher_forced_against_the_fp64_oracle():
             if dt == torch.float64:
                 go = dict(zip(names, torch.autograd.grad(lo, P, retain_graph=True)))
                 e_same = est.detach().cpu().double().requires_grad_(True)
-                dest_same, = torch.autograd.grad(loss_of(e_same, cb), e_same)
+                l_same = loss_of(e_same, cb)
+                loss_same_val = float(l_same.detach())           # the float64 loss AT the HIP logits
+                dest_same, = torch.autograd.grad(l_same, e_same)
                 gb = dict(zip(names, torch.autograd.grad(esto, P, grad_outputs=dest_h, retain_graph=True)))
                 gc = dict(zip(names, torch.autograd.grad(esto, P, grad_outputs=dest_same.detach())))
                 logits_o = esto.detach()
         o = res[torch.float64]
         ora_curve.append(o["loss"])
         W["loss"] = max(W["loss"], abs(hip_curve[-1] - o["loss"]) / abs(o["loss"]))                          # (1)
+        # (1') the same loss split in two: the LOSS KERNEL alone (the float64 oracle loss evaluated at the HIP logits), and what the
+        # reference's own float32 arithmetic from the same state does to the loss (its CNN rounds differently from ours AND from
+        # float64; a patch whose edge is far sharper than the pixel pitch turns a 2e-6 logit difference into a larger loss difference)
+        W["loss_same"] = max(W.get("loss_same", 0.0), abs(hip_curve[-1] - loss_same_val) / abs(o["loss"]))
+        loss_steps.append((abs(hip_curve[-1] - o["loss"]) / abs(o["loss"]), abs(res[torch.float32]["loss"] - o["loss"]) / abs(o["loss"])))
         W["dest_same"] = max(W["dest_same"], rel(dest_h, dest_same))                                           # (2)
         step_err = {k: rel(gh[k], gb[k]) for k in live}                                                        # (3)
         hot = [k for k in live if step_err[k] > 3e-4]
@@ -196,7 +172,14 @@ def test_twenty_training_steps_teacher_forced_against_the_fp64_oracle():
     print("oracle (forced)", ["%.6f" % v for v in ora_curve])
     print("teacher-forced, worst over %d steps: %s  cnn median %.2e" % (steps, W, cnn_med))
     # tolerances written from the measurement on MI355X quoted next to each (about 3x margin)
-    assert W["loss"] <= 3e-6                 # measured 8.9e-7
+    # (1) Round 6: the forward convolutions run on the balanced launch (csrc/be_train_sk.h), whose K cuts regroup the fp32 partial
+    # sums: the train-mode logits moved by ~1e-6 (still 2-4e-6 of float64, bound 1e-5 below) and with them the visited states.  The
+    # loss kernel itself is held to 1e-6 at EQUAL logits (measured 1e-7); end to end the loss is held, step by step, to 3e-6 or
+    # to three times what the reference's own float32 run from the same state loses against float64, whichever is larger (an
+    # ill-conditioned batch - round 3 met one at 7e-6 with another tiling - moves both), and to 2e-5 whatever the reference does.
+    print("loss per step, hip vs f64 | reference f32 vs f64:", ["%.1e|%.1e" % t for t in loss_steps])
+    assert W["loss_same"] <= 1e-6
+    assert all(eh <= max(3e-6, 3.0 * ef) for eh, ef in loss_steps) and W["loss"] <= 2e-5, loss_steps   # rounds 3-5 measured 8.9e-7 worst
     assert W["dest_same"] <= 1.5e-6          # measured 4.2e-7
     # Per-tensor CNN gradients, 20 steps x 46 tensors.  The HIP run follows ITS OWN trajectory (the oracle is re-seated on the HIP state
     # every step), so which near-ties it meets changes with any rounding-level change in any kernel: the bounds are therefore split.
