@@ -466,12 +466,15 @@ int sk_plan(const SkUnitIn* in, int nu, SkUnitOut* out, SkPlan* plan) {
     int np = 0;
     // Cost model, in convolution chunks (64 x 64 x 32: 16 MFMAs per wave).  A weight-gradient chunk (128 x 128 x 16) is 32 MFMAs per
     // wave, twice the matrix work - but what a workgroup's chunk COSTS on a CU shared by three workgroups is its serial stream (wait,
-    // barrier, DMA issue, LDS latency, then the MFMAs), and the short chunk carries relatively more of the rest.  The per-workgroup
-    // timelines (tools/sk_trace.py, profiles/r06_sk_timeline.txt) put the two kinds' median lifetimes level at a weight of 1.5 (384 -> 384:
-    // 88.4 / 88.5 us, 256 -> 384: 58.6 / 62.2 us); the graph-replayed step is flat within its run-to-run noise between 1 and 2
-    // (profiles/r06_sk_sweep.txt).  No fixed cost per weight-gradient segment, four chunks per convolution segment.  Environment
-    // overrides for re-tuning.
-    const double ww = env_num("BE_SK_WW", 1.5), fw = env_num("BE_SK_FW", 0.0), fc = env_num("BE_SK_FC", 4.0);
+    // barrier, DMA issue, LDS latency, then the MFMAs), and the short chunk carries relatively more of the rest: the per-workgroup
+    // timelines (tools/sk_trace.py, profiles/r06_sk_timeline.txt) put the two kinds' median lifetimes level between 1 and 1.5.
+    // Within that range the step time is set by WHERE the quotas cut the tiles (how many tiles end up in two slices), not by the
+    // balance: the sweeps of the graph-replayed step (profiles/r06_sk_sweep.txt, two boxes, repeated) are flat within +-12 us from
+    // 1 to 2.5 except for one sharp, repeatable optimum at weight 1 with no fixed cost per segment (1.315 ms against 1.335-1.36),
+    // which is the default.  (Snapping every problem's quota to a divisor of its longest tile - fewer tiles in two slices - was built
+    // and measured: 1.356-1.388 ms against 1.320-1.360 without, because tile STARTS stay unaligned in the natural tile order and the
+    // snapped counts leave slots empty; removed.)  Environment overrides for re-tuning.
+    const double ww = env_num("BE_SK_WW", 1.0), fw = env_num("BE_SK_FW", 0.0), fc = env_num("BE_SK_FC", 0.0);
     double flops = 0.0, flops_exec = 0.0;
     a.prio = (int)env_num("BE_SK_PRIO", 1.0);
     static const bool trace = getenv("BE_SK_TRACE") != nullptr;       // diagnostic: tools/sk_trace.py reads the stamps back
@@ -501,7 +504,7 @@ int sk_plan(const SkUnitIn* in, int nu, SkUnitOut* out, SkPlan* plan) {
         w.g.L = w.g.PT[taps] * w.g.wx;
         const size_t wsize = (size_t)d.cout * d.cin * taps * sizeof(float);
         // a chunk of a tm x tn tile is tm tn / 16384 of the 128 x 128 chunk's MFMAs; the small tiles carry relatively more of the rest
-        const double wtile = ww * (w.g.tm * w.g.tn == 16384 ? 1.0 : (w.g.tm * w.g.tn == 8192 ? 0.6 : 0.4));
+        const double wtile = ww * (w.g.tm * w.g.tn == 16384 ? 1.0 : (w.g.tm * w.g.tn == 8192 ? env_num("BE_SK_W8K", 0.6) : env_num("BE_SK_W4K", 0.4)));
         pr[np++] = Prob{w.g.L, nmax, w.g.wx * taps, wtile, fw, (int)((in[i].wpart_bytes - (i == nu - 1 ? w_reserve : 0)) / wsize), be_sk::MAX_SLICES_W, 0, 0};
         // data gradient: a convolution of dy [M, Cout] with the transposed, tap-mirrored pack -> [M, Cin]
         ConvProb& c = a.c[i];
@@ -558,7 +561,7 @@ int sk_plan_fwd(const SkFwdIn* in, int nu, be_sk::ConvGeom* out, SkPlan* plan) {
     SkArgs& a = pd.a;
     memset(&pd, 0, sizeof(pd));
     Prob pr[4];
-    const double fc = env_num("BE_SK_FC", 4.0);
+    const double fc = env_num("BE_SK_FC", 0.0);
     a.prio = 0;
     for (int i = 0; i < nu; ++i) {
         const be_conv_desc& d = *in[i].d;
