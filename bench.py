@@ -55,7 +55,8 @@ CPU_REPEATS = 3                       # 3 repeats, median: ~25 s of CPU work (th
 # cout FLOPs they execute; the same layer as a direct 3x3 convolution on a 6x6 map is 2 x 36 x 9 x n x cin x cout.
 # positions x tiles per map = 40 x 2 (8x5 tiles, be_wino_tile_rows() = 6) or 25 x 4 (5x5 tiles): filled in main()
 ALGO_OVER_HOOK = {}
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_traffic.json")
+TRAFFIC_FILE = next((f for f in (os.path.join(ROOT, "profiles", n) for n in ("r06_pmc_traffic.json", "r05_pmc_traffic.json")) if os.path.exists(f)),
+                    os.path.join(ROOT, "profiles", "r06_pmc_traffic.json"))       # the newest counter record of the dominant kernel
 
 
 def cpu_baseline(x_np, sd_np):
