@@ -854,8 +854,13 @@ def test_training_unit_matches_the_single_purpose_kernels():
     import ctypes as C
     g = torch.Generator(device="cpu").manual_seed(11)
     rel = lambda a, b: float((a - b).norm() / b.norm().clamp_min(1e-30))
+    # round 6 adds the shapes that exercise the balanced launch's corners: two image groups (n = 128: tiles of the second group sit
+    # further along the axis), layer0's 11 x 11 maps with 64 / 96 channels (64-wide weight-gradient tiles, half-empty second tiles,
+    # column tiles past the pack), and a 3 x 3 unit on the smallest map it takes
     for (n, hw, cin, cout, ks, act, with_res) in ((64, 6, 256, 384, 3, True, True), (64, 6, 96, 256, 1, False, False),
-                                                  (64, 21, 3, 64, 7, True, False)):
+                                                  (64, 21, 3, 64, 7, True, False), (128, 6, 256, 256, 3, True, False),
+                                                  (64, 11, 64, 96, 3, True, False), (64, 11, 96, 96, 3, False, True),
+                                                  (64, 3, 128, 128, 3, True, False)):
         w = (torch.randn(cout, cin, ks, ks, generator=g) * (1.0 / (cin * ks * ks) ** 0.5)).to(DEV)
         b = (torch.randn(cout, generator=g) * 0.1).to(DEV)
         gamma, beta = (1 + 0.1 * torch.randn(cout, generator=g)).to(DEV), (0.1 * torch.randn(cout, generator=g)).to(DEV)

@@ -15,8 +15,9 @@ echo "code tree: $T"
 cd $T/blurry-edges_amd
 STAGE=${STAGE:-local}
 df -h /tmp | tail -n 1; free -g | sed -n 2p
-D=/tmp/be_conv; mkdir -p $D $R/gpurun_out/r05_converged
-O=$R/gpurun_out/r05_converged
+RUN=${RUN:-r05_converged}    # round 6: RUN=r06_converged (the HEAD generator, the balanced training launches)
+D=/tmp/be_conv; mkdir -p $D $R/gpurun_out/$RUN
+O=$R/gpurun_out/$RUN
 NT=${NT:-8000}; NV=${NV:-2000}
 t() { date +%s.%N; }
 if [ $STAGE != eval ] && [ ! -f $D/data/images_ny_val.npy ]; then
