@@ -273,6 +273,7 @@ void k_unit_gemms_sk(SkArgs a) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int b = blockIdx.x;
     const long long t_start = a.trace ? (long long)__builtin_amdgcn_s_memrealtime() : 0;
+    const long long c_start = a.trace ? (long long)__builtin_amdgcn_s_memtime() : 0;     // shader cycles: with t_start / t_end the workgroup's own clock
     int n_seg = 0;
     long long ph[4] = {0, 0, 0, 0};
 #define SK_TRACE_END(PROB, G_)                                                                                  \
@@ -280,7 +281,7 @@ void k_unit_gemms_sk(SkArgs a) {
         a.trace[8 * b] = t_start; a.trace[8 * b + 1] = (long long)__builtin_amdgcn_s_memrealtime();             \
         a.trace[8 * b + 2] = (PROB) | ((long long)(G_) << 8) | ((long long)n_seg << 32);                        \
         unsigned xcc_; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc_));                      \
-        a.trace[8 * b + 3] = xcc_;                                                                              \
+        a.trace[8 * b + 3] = (long long)(xcc_ & 15u) | (((long long)__builtin_amdgcn_s_memtime() - c_start) << 8);   \
         for (int q_ = 0; q_ < 4; ++q_) a.trace[8 * b + 4 + q_] = ph[q_];                                        \
     }
     for (int i = 0; i < a.nw; ++i) {
@@ -467,11 +468,13 @@ int sk_plan(const SkUnitIn* in, int nu, SkUnitOut* out, SkPlan* plan) {
     // Cost model, in convolution chunks (64 x 64 x 32: 16 MFMAs per wave).  A weight-gradient chunk (128 x 128 x 16) is 32 MFMAs per
     // wave, twice the matrix work - but what a workgroup's chunk COSTS on a CU shared by three workgroups is its serial stream (wait,
     // barrier, DMA issue, LDS latency, then the MFMAs), and the short chunk carries relatively more of the rest: the per-workgroup
-    // timelines (tools/sk_trace.py, profiles/r06_sk_timeline.txt) put the two kinds' median lifetimes level between 1 and 1.5.
+    // timelines (tools/sk_trace.py, profiles/r06_sk_timeline.txt) put the two kinds' median lifetimes level between 1.5 and 2.
     // Within that range the step time is set by WHERE the quotas cut the tiles (how many tiles end up in two slices), not by the
     // balance: the sweeps of the graph-replayed step (profiles/r06_sk_sweep.txt, two boxes, repeated) are flat within +-12 us from
     // 1 to 2.5 except for one sharp, repeatable optimum at weight 1 with no fixed cost per segment (1.315 ms against 1.335-1.36),
-    // which is the default.  (Snapping every problem's quota to a divisor of its longest tile - fewer tiles in two slices - was built
+    // which is the default: there a 3x3 unit with equal channel counts splits its workgroups 256 / 512, which makes BOTH quotas 36
+    // chunks at 384 channels (16 at 256) - a divisor of the interior pixels' tiles (108, 72) and of the centre tap's (144): 1.03 /
+    // 1.2 segments per workgroup, almost no tile cut twice.  (Snapping every problem's quota to a divisor of its longest tile - fewer tiles in two slices - was built
     // and measured: 1.356-1.388 ms against 1.320-1.360 without, because tile STARTS stay unaligned in the natural tile order and the
     // snapped counts leave slots empty; removed.)  Environment overrides for re-tuning.
     const double ww = env_num("BE_SK_WW", 1.0), fw = env_num("BE_SK_FW", 0.0), fc = env_num("BE_SK_FC", 0.0);

@@ -68,6 +68,10 @@ def report(tag, tr):
     pts = np.linspace(0, span, 11)[1:-1]
     st, en = (live[:, 0] - t0) / 100.0, (live[:, 1] - t0) / 100.0
     print("   alive at 10%..90% of the span:", " ".join(f"{int(((st <= q) & (en > q)).sum()):4d}" for q in pts))
+    # the shader clock each workgroup saw: its own s_memtime delta (shader cycles) over its own s_memrealtime delta (100 MHz)
+    cyc = (live[:, 3] >> 8).astype(np.float64)
+    ghz = cyc / ((live[:, 1] - live[:, 0]).astype(np.float64) * 10.0)
+    print("   shader clock over the workgroups' lifetimes: median %.3f GHz (min %.3f, max %.3f)" % (np.median(ghz), ghz.min(), ghz.max()))
     xcc = live[:, 3] & 15
     print("   workgroups per XCC:", np.bincount(xcc.astype(int), minlength=8).tolist())
 
