@@ -1,3 +1,6 @@
+"""Diagnostic (GPU box): the train-mode forward / backward of golden batch g2 against the reference's gradients, tensor by tensor, and
+the max-pool windows whose HIP winner differs from the float64 oracle's (tests/pool_flips.py explains the near-ties).  Run it with
+BE_NO_TRAIN_SK=1 / BE_NO_TRAIN_SK_FWD=1 to see which forward flips which window.  usage: python tools/g2_probe.py"""
 import os, sys
 ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path[:0] = [ROOT, os.path.join(ROOT, "blurry-edges_amd"), os.path.join(ROOT, "tests")]
